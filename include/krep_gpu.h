@@ -1,0 +1,206 @@
+/* krep_gpu.h — C-ABI of the MI355X-native literal-scan backend for krep.
+ *
+ * This header is the drop-in boundary.  Everything here is plain C (pointers + sizes, no C++ and
+ * no torch types).  It sits exactly where krep's own algorithm functions sit: behind the uniform
+ * operator signature `search_func_t` (reference krep.h:98-101), which search_chunk_thread()
+ * (krep.c:1950) and search_string() (krep.c:2169) call, and which select_search_algorithm()
+ * (krep.c:1771) returns.  The structs below are layout-identical to the reference's
+ * (krep.h:49-60 match_position_t / match_result_t, krep.h:65-94 search_params_t) so a caller built
+ * against krep.h can pass its own objects straight through.  If krep.h was included first its
+ * definitions are used and ours are skipped.
+ *
+ * Error behaviour mirrors the reference: the search_func_t-shaped entry points have no in-band
+ * error channel (the reference's do not either: they print to stderr and return a partial count,
+ * e.g. krep.c:1359-1362); on a device/launch failure they print "krep-gpu: ..." to stderr, set
+ * krep_gpu_last_error() and return 0.  search_buffer() returns 0 match / 1 no match / 2 error
+ * exactly like search_file()/search_string() (krep.h:159,168).  There is NO CPU fallback inside this
+ * library: if no gfx950 device / code object is available every entry point fails loudly.
+ */
+#ifndef KREP_GPU_H
+#define KREP_GPU_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef KREP_H /* ---- ABI twins of the reference types (krep.h:49-101) ---- */
+typedef struct
+{
+    size_t start_offset; /* first byte of the match, relative to text_start           */
+    size_t end_offset;   /* one past the last byte (exclusive)                         */
+} match_position_t;      /* 16 bytes — also the record format the kernels write in HBM */
+
+typedef struct match_result_t
+{
+    match_position_t *positions; /* malloc-family block: match_result_free() (krep.c:244) frees it */
+    uint64_t count;
+    uint64_t capacity;
+} match_result_t;
+
+struct ac_trie;
+typedef struct ac_trie ac_trie_t;
+
+typedef struct search_params
+{
+    const char *pattern; /* valid when num_patterns == 1 (krep.c:3736-3740) */
+    size_t pattern_len;
+    const char **patterns;
+    size_t *pattern_lens;
+    size_t num_patterns;
+    bool case_sensitive;
+    bool use_regex;
+    bool count_lines_mode;
+    bool count_matches_mode;
+    bool track_positions;
+    bool whole_word;
+    const void *compiled_regex; /* const regex_t* in krep.h; never dereferenced here */
+    ac_trie_t *ac_trie;         /* opaque; only tested against NULL (aho_corasick.c:306) */
+    size_t max_count;
+} search_params_t;
+
+typedef uint64_t (*search_func_t)(const search_params_t *params, const char *text_start,
+                                  size_t text_len, match_result_t *result);
+#endif /* KREP_H */
+
+/* ------------------------------------------------------------------------------------------------
+ * Which reference build are we a drop-in for?  The reference picks its algorithm — and with it the
+ * match-set family (all occurrences vs. greedy non-overlapping) — from compile-time SIMD macros
+ * (krep.c:47-74, :1798-1869) and three file-static globals that no external backend can see
+ * (krep.c:117-120).  They are made explicit here.  Defaults: AVX2 build, no overrides.
+ * ---------------------------------------------------------------------------------------------- */
+enum krep_ref_simd
+{
+    KREP_REF_SCALAR = 0, /* no -msse4.2: BMH / KMP / memchr only                   */
+    KREP_REF_SSE42 = 1,  /* Makefile:40                                            */
+    KREP_REF_AVX2 = 2,   /* Makefile:37                                            */
+    KREP_REF_AVX512 = 3, /* Makefile:35                                            */
+    KREP_REF_NEON = 4    /* Makefile:44-48 (arm64)                                 */
+};
+enum krep_ref_algo_override
+{
+    KREP_ALGO_AUTO = 0,
+    KREP_ALGO_BM = 1, /* --algo=bm  (krep.c:1788) */
+    KREP_ALGO_KMP = 2 /* --algo=kmp (krep.c:1790) */
+};
+/* The reference algorithm whose exact output (count, positions, order, max_count quirks) a scan
+ * reproduces.  krep_gpu_mirror_select() is the twin of select_search_algorithm() incl. the
+ * delegation chain AVX-512 -> AVX2 -> SSE4.2 -> BMH (krep.c:4708-4712, :4883-4896, :5114-5126). */
+enum krep_ref_algo
+{
+    KREP_RA_NONE = 0,
+    KREP_RA_BMH = 1,          /* boyer_moore_search   krep.c:1260 */
+    KREP_RA_KMP = 2,          /* kmp_search           krep.c:1628 */
+    KREP_RA_MEMCHR = 3,       /* memchr_search        krep.c:3891 */
+    KREP_RA_MEMCHR_SHORT = 4, /* memchr_short_search  krep.c:4371 */
+    KREP_RA_SSE42 = 5,        /* simd_sse42_search    krep.c:4702 */
+    KREP_RA_AVX2 = 6,         /* simd_avx2_search     krep.c:4877 (17..32 B body) */
+    KREP_RA_AVX512 = 7,       /* simd_avx512_search   krep.c:5108 (33..64 B body) */
+    KREP_RA_NEON = 8,         /* neon_search          krep.c:4506 */
+    KREP_RA_AHO_CORASICK = 9, /* aho_corasick_search  aho_corasick.c:299 */
+    KREP_RA_REGEX = 10        /* regex_search — out of scope, never executed here */
+};
+
+void krep_gpu_set_reference_simd(int krep_ref_simd_level);   /* compile-time SIMD macros, krep.c:47-74 */
+void krep_gpu_set_only_matching(int on);                     /* static only_matching,   krep.c:117   */
+void krep_gpu_set_force_no_simd(int on);                     /* static force_no_simd,   krep.c:118   */
+void krep_gpu_set_algo_override(int krep_ref_algo_override); /* static algo_override,   krep.c:120   */
+int krep_gpu_get_reference_simd(void);
+/* Twin of select_search_algorithm() (krep.c:1771): the algorithm the reference build would END UP
+ * executing for `params` on a text of `text_len` bytes (text_len matters: the SIMD functions fall back
+ * to BMH when text_len < pattern_len, and so on). */
+int krep_gpu_mirror_select(const search_params_t *params, size_t text_len);
+const char *krep_gpu_algorithm_name(int krep_ref_algo); /* twin of get_algorithm_name(), krep.c:1964 */
+
+/* ------------------------------------------------------------------------------------------------
+ * Operator-level entry points (search_func_t-compatible).  `text_start` is a HOST pointer, exactly
+ * as in the reference; the bytes are staged to HBM through pinned buffers, scanned by the HIP
+ * kernels, and the results appended to `result` with the match_result_add() contract
+ * (krep.c:175-241: malloc/realloc'd block, offsets relative to text_start, end exclusive).
+ * Return value = match count, or distinct-line count when params->count_lines_mode.
+ * ---------------------------------------------------------------------------------------------- */
+uint64_t krep_gpu_literal_search(const search_params_t *params, const char *text_start,
+                                 size_t text_len, match_result_t *result);
+uint64_t krep_gpu_aho_corasick_search(const search_params_t *params, const char *text_start,
+                                      size_t text_len, match_result_t *result);
+/* Drop-in for select_search_algorithm(): returns one of the two functions above, or NULL when the
+ * reference would pick regex_search (not accelerated; the caller keeps the CPU function). */
+search_func_t krep_gpu_select_search_algorithm(const search_params_t *params);
+
+/* The in-memory twin of search_file()/search_string() that BASELINE.json calls search_buffer():
+ * validation as krep.c:2013-2049 (no patterns -> 2; empty pattern among several -> 2; pattern
+ * longer than 1024 -> 2), algorithm selection as krep.c:2166, single-chunk semantics, clamp to
+ * max_count as krep.c:2176-2184.  Nothing is printed.  num_gpus > 1 shards the buffer by contiguous
+ * chunk across that many devices of this process with start-offset ownership.
+ * Returns 0 = match found, 1 = none, 2 = error. */
+int search_buffer(const search_params_t *params, const char *buf, size_t len, int only_matching,
+                  int num_gpus, match_result_t *out /* nullable */, uint64_t *count_out /* nullable */);
+
+/* match_result_t helpers with the reference's allocation contract (krep.c:139-251), exported so a
+ * caller without krep.c can own the results. */
+match_result_t *krep_gpu_match_result_init(uint64_t initial_capacity);
+void krep_gpu_match_result_free(match_result_t *r);
+
+/* ------------------------------------------------------------------------------------------------
+ * Device-resident path (the one the roofline number is measured on): the haystack already lives
+ * in HBM.  A plan holds the compiled pattern set (pattern words / Aho-Corasick filter + trie
+ * tables) on one device; a scan runs it over a device buffer.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct krep_gpu_plan krep_gpu_plan_t;
+
+/* per-scan output; counters are exact even when the position buffer is too small */
+typedef struct krep_gpu_scan_out
+{
+    uint64_t count;          /* what the reference function would RETURN for this shard           */
+    uint64_t stored;         /* number of match_position_t records written to d_positions         */
+    uint64_t total_matches;  /* uncapped number of emitted matches (before max_count)             */
+    uint64_t line_count;     /* distinct lines holding a match start (count_lines_mode), shard-local */
+    uint8_t head_line_hit;   /* a match starts before the first '\n' of the owned window           */
+    uint8_t tail_line_hit;   /* a match starts after the last '\n' of the owned window             */
+    uint8_t has_newline;     /* the owned window contains at least one '\n'                        */
+    uint8_t overflow;        /* 1: more matches than position capacity (re-run with more)          */
+    float kernel_ms;         /* hipEvent time of the scan kernels on `stream` (0 if not timed)     */
+} krep_gpu_scan_out_t;
+
+krep_gpu_plan_t *krep_gpu_plan_create(const search_params_t *params, int only_matching, int device);
+void krep_gpu_plan_destroy(krep_gpu_plan_t *plan);
+int krep_gpu_plan_ref_algo(const krep_gpu_plan_t *plan); /* enum krep_ref_algo this plan reproduces */
+
+/* Scan d_text[0 .. text_len) and report the matches whose START lies in [own_lo, own_hi)
+ * (start-offset ownership; bytes outside the window are context: the tail halo completes matches
+ * that begin inside, the byte before own_lo serves -w and line bookkeeping).  Offsets written are
+ * (offset within d_text) + global_base.  d_positions may be NULL (count only) and receives at most
+ * `position_capacity` records, in the reference's emission order.  `stream` is a hipStream_t (NULL =
+ * default stream); with time_it != 0 the kernels are bracketed by hipEvents on that stream and the
+ * call synchronises.  Returns 0 on success, non-zero on error (krep_gpu_last_error()). */
+int krep_gpu_scan_device(krep_gpu_plan_t *plan, const void *d_text, size_t text_len, size_t own_lo,
+                         size_t own_hi, size_t global_base, match_position_t *d_positions,
+                         uint64_t position_capacity, void *stream, int time_it,
+                         krep_gpu_scan_out_t *out);
+
+/* Deterministic synthetic haystacks, generated directly in HBM by a counter-based
+ * PRNG so that any [global_off, global_off+len) slice is reproducible on any rank.
+ * kind: 2 = background a-z/space/newline + planted 8-byte literal every `period` bytes (cfg 2/5),
+ *       3 = background + target byte with probability 1/100 (cfg 3),
+ *       4 = background + planted dictionary words (cfg 4; `plant`/`plant_len` = packed patterns). */
+int krep_gpu_generate(void *d_dst, size_t len, size_t global_off, int kind, uint64_t seed,
+                      const void *plant, size_t plant_len, uint64_t period, void *stream);
+/* Host twin of the generator (same bytes), for parity tests and the CPU baseline. */
+void krep_gpu_generate_host(void *dst, size_t len, size_t global_off, int kind, uint64_t seed,
+                            const void *plant, size_t plant_len, uint64_t period);
+
+/* Combine per-shard line bookkeeping left-to-right (the one "exchange step" of the multi-GPU path):
+ * returns the global distinct-line count given shard outputs in shard order. */
+uint64_t krep_gpu_combine_line_counts(const krep_gpu_scan_out_t *shards, int n);
+
+int krep_gpu_device_count(void);
+const char *krep_gpu_last_error(void);
+const char *krep_gpu_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KREP_GPU_H */

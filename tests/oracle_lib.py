@@ -1,0 +1,219 @@
+"""Test-side loaders for the parity checkers (oracle/ restatement and oracle/_ref compiled reference).
+
+TEST INFRASTRUCTURE: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from krep_amd import abi  # noqa: E402
+
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+REF_DIR = os.path.join(ORACLE_DIR, "_ref")
+
+_SF_ARGS = [C.POINTER(abi.SearchParams), C.c_void_p, C.c_size_t, C.POINTER(abi.MatchResult)]
+
+
+def _cpu_flags() -> set:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    return set(line.split(":", 1)[1].split())
+    except OSError:
+        pass
+    return set()
+
+
+def build_oracle() -> None:
+    """Compile oracle/liboracle_krep.so (and oracle/_ref when /root/reference is present)."""
+    subprocess.run(["make", "-C", ORACLE_DIR, "all"], check=True, stdout=subprocess.DEVNULL)
+
+
+class TextBuf:
+    """Keeps a haystack alive and hands out a raw pointer (bytes or uint8 ndarray, zero-copy)."""
+
+    def __init__(self, data):
+        if isinstance(data, np.ndarray):
+            assert data.dtype == np.uint8
+            self.arr = np.ascontiguousarray(data)
+            self.ptr = C.c_void_p(self.arr.ctypes.data)
+            self.n = self.arr.size
+        else:
+            self.raw = bytes(data)
+            self._cp = C.c_char_p(self.raw)
+            self.ptr = C.cast(self._cp, C.c_void_p)
+            self.n = len(self.raw)
+
+
+class _Engine:
+    """Uniform face over a library exporting krep's search_func_t operators."""
+
+    name = "?"
+    lib = None
+    fn = {}
+    init_name = add_name = free_name = None
+    ac_build = ac_free = None
+
+    def _setup(self):
+        L = self.lib
+        for f in self.fn.values():
+            g = getattr(L, f)
+            g.restype = C.c_uint64
+            g.argtypes = _SF_ARGS
+        init = getattr(L, self.init_name)
+        init.restype = C.POINTER(abi.MatchResult)
+        init.argtypes = [C.c_uint64]
+        free = getattr(L, self.free_name)
+        free.restype = None
+        free.argtypes = [C.POINTER(abi.MatchResult)]
+        self._init, self._free = init, free
+        b = getattr(L, self.ac_build)
+        b.restype = C.c_void_p
+        b.argtypes = [C.POINTER(abi.SearchParams)]
+        fr = getattr(L, self.ac_free)
+        fr.restype = None
+        fr.argtypes = [C.c_void_p]
+        self._acb, self._acf = b, fr
+
+    def has(self, algo: int) -> bool:
+        return algo in self.fn
+
+    def call(self, algo: int, params: abi.Params, text, want_result=True):
+        """-> (returned count, positions[(n,2) uint64] or None).  Single chunk, whole buffer."""
+        tb = text if isinstance(text, TextBuf) else TextBuf(text)
+        trie = None
+        if algo == abi.RA_AHO_CORASICK:
+            trie = self._acb(params.ref)
+            params.s.ac_trie = trie
+        res = self._init(16) if want_result else None
+        try:
+            ret = getattr(self.lib, self.fn[algo])(params.ref, tb.ptr, tb.n, res)
+            pos = abi.result_positions(res) if res else None
+        finally:
+            if res:
+                self._free(res)
+            if trie:
+                self._acf(trie)
+                params.s.ac_trie = None
+        return int(ret), pos
+
+
+class OracleEngine(_Engine):
+    name = "oracle"
+    fn = {abi.RA_BMH: "ko_boyer_moore_search", abi.RA_KMP: "ko_kmp_search",
+          abi.RA_MEMCHR: "ko_memchr_search", abi.RA_MEMCHR_SHORT: "ko_memchr_short_search",
+          abi.RA_SSE42: "ko_sse42_search", abi.RA_AVX2: "ko_avx2_search",
+          abi.RA_AVX512: "ko_avx512_search", abi.RA_AHO_CORASICK: "ko_aho_corasick_search"}
+    init_name, free_name = "ko_result_init", "ko_result_free"
+    ac_build, ac_free = "ko_ac_trie_build", "ko_ac_trie_free"
+
+    def __init__(self):
+        path = os.path.join(ORACLE_DIR, "liboracle_krep.so")
+        if not os.path.exists(path):
+            subprocess.run(["make", "-C", ORACLE_DIR, "liboracle_krep.so"], check=True,
+                           stdout=subprocess.DEVNULL)
+        self.lib = C.CDLL(path)
+        self._setup()
+        self.lib.ko_select.restype = C.c_int
+        self.lib.ko_select.argtypes = [C.POINTER(abi.SearchParams), C.c_int]
+        self.lib.ko_set_only_matching.argtypes = [C.c_int]
+        self.lib.ko_set_force_no_simd.argtypes = [C.c_int]
+        self.lib.ko_set_algo_override.argtypes = [C.c_int]
+        self.lib.ko_chunked_search.restype = C.c_uint64
+        self.lib.ko_chunked_search.argtypes = [C.c_int, C.POINTER(abi.SearchParams), C.c_void_p,
+                                               C.c_size_t, C.c_int]
+        self.lib.ko_ac_num_states.restype = C.c_uint64
+        self.lib.ko_ac_num_states.argtypes = [C.c_void_p]
+
+    def select(self, params: abi.Params, simd: int) -> int:
+        return int(self.lib.ko_select(params.ref, simd))
+
+    def set_only_matching(self, on: bool):
+        self.lib.ko_set_only_matching(int(on))
+
+    def chunked(self, algo, params, text: TextBuf, threads: int) -> int:
+        trie = None
+        if algo == abi.RA_AHO_CORASICK:
+            trie = self._acb(params.ref)
+            params.s.ac_trie = trie
+        try:
+            return int(self.lib.ko_chunked_search(algo, params.ref, text.ptr, text.n, threads))
+        finally:
+            if trie:
+                self._acf(trie)
+                params.s.ac_trie = None
+
+
+_REF_FILES = {abi.REF_SCALAR: "libkrep_ref_scalar.so", abi.REF_SSE42: "libkrep_ref_sse42.so",
+              abi.REF_AVX2: "libkrep_ref_avx2.so", abi.REF_AVX512: "libkrep_ref_avx512.so"}
+_REF_NEEDS = {abi.REF_SCALAR: set(), abi.REF_SSE42: {"sse4_2"}, abi.REF_AVX2: {"avx2", "sse4_2"},
+              abi.REF_AVX512: {"avx512f", "avx512bw", "avx2"}}
+
+
+class RefEngine(_Engine):
+    """The unmodified reference, compiled by oracle/Makefile into oracle/_ref/."""
+
+    init_name, free_name = "match_result_init", "match_result_free"
+    ac_build, ac_free = "ac_trie_build", "ac_trie_free"
+
+    def __init__(self, level: int):
+        self.level = level
+        self.name = "ref:" + _REF_FILES[level]
+        self.lib = C.CDLL(os.path.join(REF_DIR, _REF_FILES[level]))
+        fn = {abi.RA_BMH: "boyer_moore_search", abi.RA_KMP: "kmp_search",
+              abi.RA_MEMCHR: "memchr_search", abi.RA_MEMCHR_SHORT: "memchr_short_search",
+              abi.RA_AHO_CORASICK: "aho_corasick_search"}
+        if level >= abi.REF_SSE42:
+            fn[abi.RA_SSE42] = "simd_sse42_search"
+        if level >= abi.REF_AVX2:
+            fn[abi.RA_AVX2] = "simd_avx2_search"
+        if level >= abi.REF_AVX512:
+            fn[abi.RA_AVX512] = "simd_avx512_search"
+        self.fn = fn
+        self._setup()
+        self.lib.select_search_algorithm.restype = C.c_void_p
+        self.lib.select_search_algorithm.argtypes = [C.POINTER(abi.SearchParams)]
+        self.lib.get_algorithm_name.restype = C.c_char_p
+        self.lib.get_algorithm_name.argtypes = [C.c_void_p]
+
+    def select(self, params: abi.Params) -> int:
+        """enum krep_ref_algo of the pointer select_search_algorithm() returns."""
+        p = self.lib.select_search_algorithm(params.ref)
+        for algo, name in self.fn.items():
+            if C.cast(getattr(self.lib, name), C.c_void_p).value == p:
+                return algo
+        return abi.RA_REGEX if params.s.use_regex else abi.RA_NONE
+
+
+def ref_available(level: int) -> bool:
+    return os.path.exists(os.path.join(REF_DIR, _REF_FILES[level])) and _REF_NEEDS[level] <= _cpu_flags()
+
+
+_cache = {}
+
+
+def oracle() -> OracleEngine:
+    if "o" not in _cache:
+        _cache["o"] = OracleEngine()
+    return _cache["o"]
+
+
+def ref(level: int):
+    if not ref_available(level):
+        return None
+    if level not in _cache:
+        _cache[level] = RefEngine(level)
+    return _cache[level]
+
+
+def ref_cli() -> str | None:
+    p = os.path.join(REF_DIR, "krep")
+    return p if os.path.exists(p) and {"avx2", "sse4_2"} <= _cpu_flags() else None
