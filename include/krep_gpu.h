@@ -109,6 +109,8 @@ void krep_gpu_set_only_matching(int on);                     /* static only_matc
 void krep_gpu_set_force_no_simd(int on);                     /* static force_no_simd,   krep.c:118   */
 void krep_gpu_set_algo_override(int krep_ref_algo_override); /* static algo_override,   krep.c:120   */
 int krep_gpu_get_reference_simd(void);
+/* test hook: force the kernel tile shape (0 = auto, 1 = 32 KiB tiles, 4 = 128 KiB tiles) */
+void krep_gpu_debug_force_rounds(int rounds);
 /* Twin of select_search_algorithm() (krep.c:1771): the algorithm the reference build would END UP
  * executing for `params` on a text of `text_len` bytes (text_len matters: the SIMD functions fall back
  * to BMH when text_len < pattern_len, and so on). */
@@ -197,7 +199,8 @@ void krep_gpu_generate_host(void *dst, size_t len, size_t global_off, int kind, 
 uint64_t krep_gpu_combine_line_counts(const krep_gpu_scan_out_t *shards, int n);
 
 int krep_gpu_device_count(void);
-const char *krep_gpu_last_error(void);
+const char *krep_gpu_last_error(void); /* "" when the last call on this thread succeeded */
+void krep_gpu_clear_error(void);
 const char *krep_gpu_version(void);
 
 #ifdef __cplusplus

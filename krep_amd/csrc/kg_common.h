@@ -1,0 +1,75 @@
+// kg_common.h — shared host/device definitions of the krep-gpu scan engine (gfx950 only).
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+namespace kg {
+
+// ---- tile geometry ------------------------------------------------------------------------
+// A workgroup = 256 threads = 4 wave64.  One "cell" = what one wave reads with ONE
+// global_load_dwordx4: 64 lanes x 16 B = 1 KiB contiguous (fully coalesced).  A wave owns
+// CELLS consecutive cells (all loads issued back-to-back => CELLS x 16 B in flight per lane),
+// = one 8 KiB load ROUND.  A chain UNIT is what one wave scans before it publishes its aggregate:
+// `rounds` rounds (1 for small inputs, kRoundsBig = 4 -> 32 KiB otherwise), hit masks kept in
+// registers.  A workgroup TILE = 4 units (128 KiB) and is what one ticket hands out, so the single
+// ticket word sees 32 GiB / 128 KiB = 262144 fetch-adds per scan (~46/us at 6 TB/s; one word
+// saturates at ~88/us, MI355X_MICROARCH.md "dequeue").
+constexpr int      kWave        = 64;
+constexpr int      kBlock       = 256;
+constexpr int      kWavesPerBlk = kBlock / kWave;
+constexpr int      kCells       = 8;
+constexpr uint32_t kCellBytes   = kWave * 16;                               // 1 KiB
+constexpr uint32_t kSegBytes    = kCellBytes * kCells;                      // per wave: 8 KiB
+constexpr int      kRoundsBig   = 4;                                        // 32 KiB per wave unit, 128 KiB per tile
+
+// ---- decoupled look-back status word (ONE aligned 8-byte granule, written by one relaxed
+// agent-scope atomic store: the payload is the flag — guide G16 "R2") ---------------------------
+//   [63:62] state  0 = not ready (zeroed by hipMemsetAsync before every launch)
+//                  1 = AGGREGATE (this tile only)   2 = PREFIX (inclusive, all tiles <= this)
+//   [61]    has_nl : window contains a '\n'
+//   [60]    head   : a match starts before the first '\n' (== any match when !has_nl)
+//   [59]    tail   : a match starts after the last '\n'   (== any match when !has_nl)
+//   [58:0]  value  : number of matches (aggregate or inclusive prefix)
+constexpr uint64_t kStAgg = 1ull << 62, kStPre = 2ull << 62, kStMask = 3ull << 62;
+constexpr uint64_t kLnNl = 1ull << 61, kLnHead = 1ull << 60, kLnTail = 1ull << 59;
+constexpr uint64_t kValMask = (1ull << 59) - 1;
+
+// flags
+enum : uint32_t {
+    F_CI        = 1u << 0,   // fold A-Z (C-locale lower_table, krep.c:125-134)
+    F_WW        = 1u << 1,   // -w: is_whole_word_match (krep.h:312-319)
+    F_POS       = 1u << 2,   // write ordered match_position_t records
+    F_LINES     = 1u << 3,   // line bookkeeping (count distinct lines holding a match start)
+};
+
+// Counters block in device memory (zeroed before each launch, read back after).
+struct Counters {
+    unsigned long long total;        // matches (after -w / ownership filtering)
+    unsigned long long lines;        // distinct lines with a match start (F_LINES)
+    unsigned long long ticket;       // dynamic tile id dispenser
+    unsigned long long summary;      // final look-back word of the last tile (line bits + total)
+    unsigned long long spin_fail;    // look-back watchdog tripped (never expected)
+    unsigned long long pad[3];
+};
+
+// Parameters of a literal scan launch.
+struct LitArgs {
+    const uint8_t *text;          // device pointer to byte 0 of the buffer
+    uint64_t text_len;            // readable bytes
+    uint64_t own_lo, own_hi;      // matches are reported iff own_lo <= start < own_hi
+    uint64_t anchor;              // tile grid origin (<= own_lo, 16-byte aligned)
+    uint64_t num_tiles;           // workgroup tiles of 4 x rounds x 8 KiB
+    uint32_t rounds;              // 1 or kRoundsBig
+    uint64_t global_base;         // added to reported offsets
+    uint64_t ww_exempt_left;      // a start offset whose LEFT neighbour test is skipped (AVX tail quirk) or ~0
+    uint32_t m;                   // pattern length (1..1024)
+    uint32_t flags;
+    uint32_t p0, p1, k0, k1;      // first <=8 pattern bytes (folded when F_CI) and their byte masks
+    const uint8_t *pat;           // device copy of the (folded) pattern, for m > 8
+    unsigned long long *status;   // [num_tiles * 4] look-back words, one per wave unit (F_POS | F_LINES)
+    Counters *ctr;
+    uint64_t *positions;          // match_position_t records (2 x u64) or nullptr
+    uint64_t pos_cap;             // min(capacity, max_count)
+};
+
+} // namespace kg

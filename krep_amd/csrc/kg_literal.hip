@@ -1,0 +1,553 @@
+// kg_literal.hip — single-literal scan kernel for gfx950 (CDNA4, wave64).
+//
+// Replaces, behind krep's search_func_t boundary, the hot loops of boyer_moore_search
+// (krep.c:1294-1382), memchr_search (:3918-4023), memchr_short_search (:4396-4500) and the
+// SIMD literal scans (:4737-4866, :4914-5056, :5145-5257): it produces the set of ALL occurrences
+// of one literal (optionally case-folded, optionally -w filtered) whose START lies in the owned
+// window, their exact count, their ordered match_position_t list and the line bookkeeping of -c.
+//
+// Design (HBM-bound byte scan, no MFMA):
+//  * every haystack byte is read exactly once with coalesced 16-byte-per-lane loads
+//    (global_load_dwordx4, 1 KiB per wave instruction), kCells loads in flight per lane;
+//  * all 16 candidate positions of a lane are tested in registers: v_alignbyte_b32 builds the 20
+//    unaligned dwords of the lane's 24-byte window (16 own + 8 from the next lane), which are
+//    compared with the first 4 (+4) pattern bytes; the per-position lane masks live in SGPR pairs
+//    (v_cmp -> s_or / s_bcnt1), so a cell without a candidate costs no further vector work;
+//  * longer patterns (> 8 B) use those 8 bytes as the filter and verify the rest on the (rare)
+//    candidate lanes only; m == 1 uses an exact SWAR byte compare (memchr path, 1 % hit rate);
+//  * ordered output in ONE pass: per-lane 16-bit hit masks -> wave prefix (ballot bit-planes +
+//    v_mbcnt) -> workgroup prefix (LDS) -> chained decoupled look-back across tiles, whose status
+//    word is a single 8-byte {state, line bits, count} granule published with one relaxed
+//    agent-scope atomic store (per-XCD L2s are not coherent: guide G16, form R2);
+//  * tiles are handed out by an atomic ticket, so a tile's predecessors are always owned by
+//    running workgroups (no dispatch-order assumption, look-back cannot deadlock; every spin is
+//    bounded by a watchdog).
+#include <hip/hip_runtime.h>
+#include "kg_common.h"
+
+namespace kg {
+
+using u32 = uint32_t;
+using u64 = unsigned long long;
+
+__device__ __forceinline__ u32 lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+// popcount(mask & lanes_below_me)
+__device__ __forceinline__ u32 mbcnt64(u64 m) { return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)); }
+__device__ __forceinline__ u64 rfl64(u64 v)
+{
+    u32 lo = __builtin_amdgcn_readfirstlane((u32)v), hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
+    return ((u64)hi << 32) | lo;
+}
+
+// C-locale tolower on 4 packed bytes: 'A'..'Z' -> +0x20, everything else untouched
+__device__ __forceinline__ u32 fold4(u32 x)
+{
+    u32 t = x & 0x7f7f7f7fu;
+    u32 ge = t + 0x3f3f3f3fu; // bit7 <=> t >= 'A'
+    u32 gt = t + 0x25252525u; // bit7 <=> t >  'Z'
+    return x | ((ge & ~gt & ~x & 0x80808080u) >> 2);
+}
+// 0x80 in every byte of x that equals the byte replicated in c4 (exact, no false positives)
+__device__ __forceinline__ u32 eq_bytes(u32 x, u32 c4)
+{
+    u32 y = x ^ c4;
+    u32 t = (y & 0x7f7f7f7fu) + 0x7f7f7f7fu;
+    return ~(t | y | 0x7f7f7f7fu);
+}
+// gather the four 0x80 flags of a dword into a 4-bit mask
+__device__ __forceinline__ u32 movemask4(u32 t) { return (((t >> 7) * 0x00204081u) >> 21) & 0xfu; }
+
+__device__ __forceinline__ bool is_wordc(u32 c)
+{
+    return (c - '0' < 10u) || ((c | 0x20u) - 'a' < 26u) || c == '_';
+}
+
+// ---- line bookkeeping monoid: a window summarised as (cnt, has_nl, head, tail) -------------
+struct LS { u32 cnt; bool nl, head, tail; };
+__device__ __forceinline__ LS ls_combine(const LS &a, const LS &b)
+{
+    LS r;
+    r.cnt = a.cnt + b.cnt - ((a.tail && b.head) ? 1u : 0u);
+    r.nl = a.nl || b.nl;
+    r.head = a.nl ? a.head : (a.head || b.head);
+    r.tail = b.nl ? b.tail : (a.tail || b.tail);
+    return r;
+}
+__device__ __forceinline__ u64 ls_bits(const LS &s) { return (s.nl ? kLnNl : 0) | (s.head ? kLnHead : 0) | (s.tail ? kLnTail : 0); }
+
+// wave sum of a small per-lane value (< 32) through ballot bit-planes: SALU only
+__device__ __forceinline__ u32 wave_sum5(u32 v)
+{
+    u32 s = 0;
+#pragma unroll
+    for (int b = 0; b < 5; ++b)
+        s += (u32)__popcll(__ballot((v >> b) & 1u)) << b;
+    return s;
+}
+// exclusive prefix over lanes of a small per-lane value (< 32)
+__device__ __forceinline__ u32 wave_excl5(u32 v)
+{
+    u32 s = 0;
+#pragma unroll
+    for (int b = 0; b < 5; ++b)
+        s += mbcnt64(__ballot((v >> b) & 1u)) << b;
+    return s;
+}
+
+// guarded 24-byte window for the (at most two) tiles that touch the end of the buffer
+struct W6 { u32 v[6]; };
+__device__ __noinline__ W6 load_window_guarded(const uint8_t *text, u64 text_len, u64 off)
+{
+    W6 r;
+#pragma unroll
+    for (int w = 0; w < 6; ++w)
+    {
+        u32 v = 0;
+        for (int b = 0; b < 4; ++b)
+        {
+            u64 o = off + (u64)(w * 4 + b);
+            if (o < text_len)
+                v |= (u32)text[o] << (8 * b);
+        }
+        r.v[w] = v;
+    }
+    return r;
+}
+
+// Decoupled look-back by one wave.  Returns the exclusive prefix {line summary, count} of tile t and
+// publishes this tile's AGGREGATE then PREFIX word.  `mine` = this tile's aggregate.
+__device__ __forceinline__ void lookback(u64 *status, u64 t, const LS &mine, u64 mine_cnt, LS &excl, u64 &excl_cnt,
+                                         Counters *ctr)
+{
+    const u32 lane = lane_id();
+    excl = LS{0, false, false, false};
+    excl_cnt = 0;
+    if (t == 0)
+    {
+        if (lane == 0)
+            __hip_atomic_store(&status[0], kStPre | ls_bits(mine) | (mine_cnt & kValMask), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    if (lane == 0)
+        __hip_atomic_store(&status[t], kStAgg | ls_bits(mine) | (mine_cnt & kValMask), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    long long base = (long long)t - 1;
+    u32 spins = 0;
+    for (;;)
+    {
+        long long idx = base - (long long)lane;
+        u64 w = kStPre; // virtual "prefix = 0" in front of tile 0
+        if (idx >= 0)
+            w = __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const u32 st = (u32)(w >> 62);
+        const u64 pre = __ballot(st == 2u);
+        const u64 need = pre ? ((2ull << __builtin_ctzll(pre)) - 1ull) : ~0ull; // lanes 0..first prefix
+        const u64 notready = __ballot(st == 0u) & need;
+        if (notready)
+        {
+            if (++spins > (1u << 22))
+            { // watchdog: never expected; makes a protocol bug visible instead of hanging the GPU
+                if (lane == 0)
+                    atomicAdd(&ctr->spin_fail, 1ull);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+            continue;
+        }
+        const bool in = (need >> lane) & 1ull;
+        // counts: 64-bit wave sum over the needed lanes
+        u64 v = in ? (w & kValMask) : 0ull;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1)
+            v += __shfl_xor(v, o);
+        // line summary of the sequence [lane fp (oldest) ... lane 0 (newest)]
+        const u64 nlm = __ballot(in && (w & kLnNl));
+        const u64 hdm = __ballot(in && (w & kLnHead));
+        const u64 tlm = __ballot(in && (w & kLnTail));
+        LS seg;
+        seg.cnt = 0;
+        seg.nl = nlm != 0;
+        if (seg.nl)
+        {
+            const int newest = __builtin_ctzll(nlm), oldest = 63 - __builtin_clzll(nlm);
+            seg.tail = (tlm & ((2ull << newest) - 1ull)) != 0;   // lanes <= newest newline holder
+            seg.head = (hdm & ~((1ull << oldest) - 1ull)) != 0;  // lanes >= oldest newline holder
+        }
+        else
+            seg.head = seg.tail = (hdm | tlm) != 0;
+        excl = ls_combine(seg, excl); // seg is older than what we accumulated so far
+        excl_cnt += v;
+        if (pre)
+            break;
+        base -= 64;
+    }
+    excl.cnt = 0;
+    const LS incl = ls_combine(excl, mine);
+    if (lane == 0)
+        __hip_atomic_store(&status[t], kStPre | ls_bits(incl) | ((excl_cnt + mine_cnt) & kValMask), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// KIND: 1 -> m == 1 (SWAR), 4 -> 2..4 bytes (one word), 8 -> 5..8 bytes (two words), 9 -> m > 8 (filter+verify)
+// MASKED: the last compared word is partial (m = 2,3 or 5,6,7), so its compare needs the byte mask.
+// R: load rounds per chain unit.  A workgroup draws ONE ticket per tile (4 waves x R x 8 KiB); each
+// wave scans its own contiguous R x 8 KiB quarter (the chain UNIT), keeps the R x 8 per-lane hit
+// masks in registers, publishes the unit's aggregate, looks back, and emits.  The ticket for the
+// next tile is fetched while the current one is scanned.  One barrier per tile (ticket broadcast).
+template <int KIND, bool MASKED, bool CI, bool LINES, int R>
+__global__ __launch_bounds__(kBlock) void lit_scan(const LitArgs a)
+{
+    __shared__ u64 s_ticket[2];
+    const u32 lane = lane_id();
+    const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool want_pos = (a.flags & F_POS) != 0;
+    const bool ww = (a.flags & F_WW) != 0;
+    const bool chain = want_pos || LINES;
+    const u64 hi_match = (a.own_hi < a.text_len - a.m + 1) ? a.own_hi : (a.text_len - a.m + 1); // exclusive start bound
+    constexpr u64 kUnitBytes = (u64)R * kSegBytes;
+    const u64 last_unit = a.num_tiles * kWavesPerBlk - 1;
+
+    u64 acc_total = 0, acc_lines = 0; // wave-uniform accumulators
+    u64 next_ticket = 0;
+    if (threadIdx.x == 0)
+        next_ticket = __hip_atomic_fetch_add(&a.ctr->ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+    for (u32 it = 0;; ++it)
+    {
+        if (threadIdx.x == 0)
+            s_ticket[it & 1u] = next_ticket;
+        __syncthreads();
+        const u64 tile = rfl64(s_ticket[it & 1u]);
+        if (tile >= a.num_tiles)
+            break;
+        if (threadIdx.x == 0) // prefetch: consumed at the top of the next iteration
+            next_ticket = __hip_atomic_fetch_add(&a.ctr->ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+        const u64 unit = tile * kWavesPerBlk + wave;
+        const u64 ubase = a.anchor + unit * kUnitBytes;
+
+        u32 M[R][kCells]; // per-lane 16-bit hit masks of the whole unit
+        u32 wcnt = 0;     // unit total (uniform)
+        LS wls{0, false, false, false};
+
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+        {
+            const u64 seg = ubase + (u64)r * kSegBytes;
+            const bool fast = seg + kSegBytes + 8 <= a.text_len;
+            const bool interior = seg >= a.own_lo && seg + kSegBytes <= hi_match;
+
+            uint4 d[kCells];
+            uint2 after = make_uint2(0u, 0u);
+            if (fast)
+            {
+                const uint4 *src = reinterpret_cast<const uint4 *>(a.text + seg) + lane;
+#pragma unroll
+                for (int j = 0; j < kCells; ++j)
+                    d[j] = src[j * kWave];
+                after = *reinterpret_cast<const uint2 *>(a.text + seg + kSegBytes);
+            }
+
+#pragma unroll
+            for (int j = 0; j < kCells; ++j)
+            {
+                const u64 lbase = seg + (u64)j * kCellBytes + (u64)lane * 16u; // this lane's first byte
+                u32 D[6];
+                if (fast)
+                {
+                    D[0] = d[j].x; D[1] = d[j].y; D[2] = d[j].z; D[3] = d[j].w;
+                    if (KIND != 1)
+                    {
+                        const u32 n0 = __shfl_down(D[0], 1), n1 = __shfl_down(D[1], 1);
+                        u32 e0, e1;
+                        if (j + 1 < kCells)
+                        {
+                            e0 = __builtin_amdgcn_readfirstlane(d[(j + 1 < kCells) ? j + 1 : j].x);
+                            e1 = __builtin_amdgcn_readfirstlane(d[(j + 1 < kCells) ? j + 1 : j].y);
+                        }
+                        else
+                        {
+                            e0 = after.x;
+                            e1 = after.y;
+                        }
+                        D[4] = (lane == 63u) ? e0 : n0;
+                        D[5] = (lane == 63u) ? e1 : n1;
+                    }
+                }
+                else
+                {
+                    const W6 g = load_window_guarded(a.text, a.text_len, lbase);
+#pragma unroll
+                    for (int w = 0; w < 6; ++w)
+                        D[w] = g.v[w];
+                }
+
+                // newline mask before folding (folding never touches '\n')
+                u32 NL = 0;
+                if (LINES)
+                {
+#pragma unroll
+                    for (int w = 0; w < 4; ++w)
+                        NL |= movemask4(eq_bytes(D[w], 0x0a0a0a0au)) << (4 * w);
+                }
+                if (CI)
+                {
+#pragma unroll
+                    for (int w = 0; w < (KIND == 1 ? 4 : 6); ++w)
+                        D[w] = fold4(D[w]);
+                }
+
+                u32 m16 = 0;
+                if (KIND == 1)
+                {
+#pragma unroll
+                    for (int w = 0; w < 4; ++w)
+                        m16 |= movemask4(eq_bytes(D[w], a.p0)) << (4 * w);
+                }
+                else
+                {
+                    // unaligned dwords of the 24-byte window: A(k) = bytes [k, k+4)
+                    auto A = [&](int k) -> u32 {
+                        return ((k & 3) == 0) ? D[k >> 2] : __builtin_amdgcn_alignbyte(D[(k >> 2) + 1], D[k >> 2], (u32)(k & 3));
+                    };
+                    u32 A0[16];
+                    bool c[16];
+                    u64 any = 0;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k)
+                    {
+                        A0[k] = A(k);
+                        c[k] = (KIND == 4 && MASKED) ? (((A0[k] ^ a.p0) & a.k0) == 0u) : (A0[k] == a.p0);
+                        any |= __ballot(c[k]);
+                    }
+                    if (any) // wave-uniform: almost never taken for a selective 4-byte prefix
+                    {
+#pragma unroll
+                        for (int k = 0; k < 16; ++k)
+                        {
+                            bool h = c[k];
+                            if (KIND >= 8)
+                            {
+                                const u32 a4 = (k < 12) ? A0[k + 4] : A(k + 4);
+                                h = h && ((KIND == 8 && MASKED) ? (((a4 ^ a.p1) & a.k1) == 0u) : (a4 == a.p1));
+                            }
+                            m16 |= h ? (1u << k) : 0u;
+                        }
+                    }
+                }
+
+                // window limits (boundary segments only)
+                u32 nlm = NL;
+                if (!interior)
+                {
+                    auto clip = [&](u64 lo, u64 hi) -> u32 { // bit mask of k with lo <= lbase+k < hi
+                        u32 klo = lo > lbase ? (u32)((lo - lbase) < 16 ? (lo - lbase) : 16) : 0u;
+                        u32 khi = hi > lbase ? (u32)((hi - lbase) < 16 ? (hi - lbase) : 16) : 0u;
+                        return khi > klo ? (((1u << khi) - 1u) & ~((1u << klo) - 1u)) : 0u;
+                    };
+                    m16 &= clip(a.own_lo, hi_match);
+                    if (LINES)
+                        nlm &= clip(a.own_lo, a.own_hi);
+                }
+
+                // rare refinement on candidate lanes: verify the pattern tail (m > 8) and -w
+                if ((KIND == 9 || ww) && __ballot(m16 != 0u))
+                {
+                    u32 rest = m16;
+                    while (rest)
+                    {
+                        const u32 k = __builtin_ctz(rest);
+                        rest &= rest - 1u;
+                        const u64 p = lbase + k;
+                        bool ok = true;
+                        if (KIND == 9)
+                        {
+                            for (u32 q = 8; q < a.m; ++q)
+                            {
+                                u32 tc = a.text[p + q];
+                                if (CI && (tc - 'A' < 26u))
+                                    tc += 32u;
+                                if (tc != a.pat[q])
+                                {
+                                    ok = false;
+                                    break;
+                                }
+                            }
+                        }
+                        if (ok && ww)
+                        {
+                            if (p > 0 && p != a.ww_exempt_left && is_wordc(a.text[p - 1]))
+                                ok = false;
+                            else if (p + a.m < a.text_len && is_wordc(a.text[p + a.m]))
+                                ok = false;
+                        }
+                        if (!ok)
+                            m16 &= ~(1u << k);
+                    }
+                }
+
+                M[r][j] = m16;
+                const u64 anyhit = __ballot(m16 != 0u);
+                u32 ccnt = 0;
+                if (anyhit)
+                    ccnt = wave_sum5(__popc(m16));
+                wcnt += ccnt;
+
+                if (LINES)
+                {
+                    // per-lane summary of its 16 bytes
+                    const u32 H = m16, N = nlm;
+                    const bool l_nl = N != 0u;
+                    const u64 B_nl = __ballot(l_nl);
+                    LS cell{0, B_nl != 0, false, false};
+                    if (anyhit)
+                    {
+                        // first hit of every newline-delimited segment: see DESIGN.md (line bookkeeping)
+                        const u32 S = ((N << 1) | 1u) & 0xffffu, Hs = H | N;
+                        const u32 firsts = H & Hs & ~(Hs - S);
+                        bool l_head, l_tail;
+                        if (l_nl)
+                        {
+                            const u32 lo_nl = N & (0u - N);
+                            l_head = (H & (lo_nl | (lo_nl - 1u))) != 0u;
+                            l_tail = (H >> (32 - __builtin_clz(N))) != 0u;
+                        }
+                        else
+                            l_head = l_tail = H != 0u;
+                        const u64 B_any = anyhit, B_tail = __ballot(l_tail), B_head = __ballot(l_head);
+                        // is the line that enters this lane already holding a match (within the cell)?
+                        const u64 lt = (1ull << lane) - 1ull;
+                        const u64 nl_below = B_nl & lt;
+                        bool open;
+                        if (nl_below)
+                        {
+                            const int q = 63 - __builtin_clzll(nl_below);
+                            open = ((B_tail >> q) & 1ull) || (B_any & lt & ~((2ull << q) - 1ull)) != 0;
+                        }
+                        else
+                            open = (B_any & lt) != 0;
+                        const u32 lc = __popc(firsts) - ((open && l_head) ? 1u : 0u);
+                        cell.cnt = wave_sum5(lc);
+                        if (cell.nl)
+                        {
+                            const int f = __builtin_ctzll(B_nl), l = 63 - __builtin_clzll(B_nl);
+                            cell.head = (B_any & ((1ull << f) - 1ull)) != 0 || ((B_head >> f) & 1ull);
+                            cell.tail = (l < 63 && (B_any >> (l + 1)) != 0) || ((B_tail >> l) & 1ull);
+                        }
+                        else
+                            cell.head = cell.tail = true;
+                    }
+                    wls = ls_combine(wls, cell);
+                }
+            }
+
+        }
+
+        if (!chain)
+        {
+            acc_total += wcnt;
+            continue;
+        }
+
+        // ---- chain this unit into the global order ------------------------------------------------
+        LS tl = wls;
+        if (!LINES)
+            tl.head = tl.tail = wcnt != 0;
+        LS ex;
+        u64 excnt;
+        lookback(a.status, unit, tl, wcnt, ex, excnt, a.ctr);
+        if (LINES)
+            acc_lines += tl.cnt - ((ex.tail && tl.head) ? 1u : 0u);
+        if (unit == last_unit && lane == 0)
+        {
+            const LS incl = ls_combine(ex, tl);
+            a.ctr->total = excnt + wcnt;
+            a.ctr->summary = ls_bits(incl);
+        }
+
+        // ---- ordered emission ------------------------------------------------------------------------
+        if (want_pos && wcnt)
+        {
+            u64 out = excnt;
+            if (out < a.pos_cap)
+            {
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                {
+#pragma unroll
+                    for (int j = 0; j < kCells; ++j)
+                    {
+                        u32 m16 = M[r][j];
+                        const u64 anyhit = __ballot(m16 != 0u);
+                        if (!anyhit)
+                            continue;
+                        const u32 c = __popc(m16);
+                        u64 idx = out + wave_excl5(c);
+                        out += wave_sum5(c);
+                        const u64 lb = ubase + (u64)(r * kCells + j) * kCellBytes + (u64)lane * 16u + a.global_base;
+                        while (m16)
+                        {
+                            const u32 k = __builtin_ctz(m16);
+                            m16 &= m16 - 1u;
+                            if (idx < a.pos_cap)
+                            {
+                                const u64 s = lb + k, e = s + a.m;
+                                uint4 rec = make_uint4((u32)s, (u32)(s >> 32), (u32)e, (u32)(e >> 32));
+                                *reinterpret_cast<uint4 *>(a.positions + 2 * idx) = rec;
+                            }
+                            ++idx;
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    if (lane == 0)
+    {
+        if (!chain && acc_total)
+            atomicAdd(&a.ctr->total, acc_total);
+        if (LINES && acc_lines)
+            atomicAdd(&a.ctr->lines, acc_lines);
+    }
+}
+
+// ---- launcher ----------------------------------------------------------------------------------
+template <int KIND, bool MASKED, bool CI, int R>
+static hipError_t launch3(const LitArgs &a, u32 grid, hipStream_t st)
+{
+    if (a.flags & F_LINES)
+        hipLaunchKernelGGL((lit_scan<KIND, MASKED, CI, true, R>), dim3(grid), dim3(kBlock), 0, st, a);
+    else
+        hipLaunchKernelGGL((lit_scan<KIND, MASKED, CI, false, R>), dim3(grid), dim3(kBlock), 0, st, a);
+    return hipGetLastError();
+}
+template <int KIND, bool MASKED, bool CI>
+static hipError_t launch2(const LitArgs &a, u32 grid, hipStream_t st)
+{
+    return a.rounds == kRoundsBig ? launch3<KIND, MASKED, CI, kRoundsBig>(a, grid, st) : launch3<KIND, MASKED, CI, 1>(a, grid, st);
+}
+template <int KIND, bool MASKED>
+static hipError_t launch1(const LitArgs &a, u32 grid, hipStream_t st)
+{
+    return (a.flags & F_CI) ? launch2<KIND, MASKED, true>(a, grid, st) : launch2<KIND, MASKED, false>(a, grid, st);
+}
+
+// a.num_tiles counts workgroup tiles of 4 x a.rounds x 8 KiB; a.rounds is 1 or kRoundsBig
+hipError_t launch_literal(const LitArgs &a, u32 grid, hipStream_t st)
+{
+    if (a.m == 1)
+        return launch1<1, false>(a, grid, st);
+    if (a.m < 4)
+        return launch1<4, true>(a, grid, st);
+    if (a.m == 4)
+        return launch1<4, false>(a, grid, st);
+    if (a.m < 8)
+        return launch1<8, true>(a, grid, st);
+    if (a.m == 8)
+        return launch1<8, false>(a, grid, st);
+    return launch1<9, false>(a, grid, st);
+}
+
+} // namespace kg

@@ -1,0 +1,200 @@
+"""ctypes binding of include/krep_gpu.h.  Plumbing only — every search runs in libkrep_gpu.so."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libkrep_gpu.so")
+
+
+class KrepGpuError(RuntimeError):
+    pass
+
+
+class Engine:
+    """Thin face over the C-ABI.  Host-buffer operators mirror krep's search_func_t; the device path
+    takes raw device pointers (e.g. torch tensors' data_ptr())."""
+
+    def __init__(self, path: str = LIB_PATH):
+        if not os.path.exists(path):
+            raise KrepGpuError(f"{path} is missing: build it with `python -m krep_amd.build` "
+                               "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        L = self.lib = C.CDLL(path)
+        sf = [C.POINTER(abi.SearchParams), C.c_void_p, C.c_size_t, C.POINTER(abi.MatchResult)]
+        for n in ("krep_gpu_literal_search", "krep_gpu_aho_corasick_search"):
+            getattr(L, n).restype = C.c_uint64
+            getattr(L, n).argtypes = sf
+        L.krep_gpu_select_search_algorithm.restype = C.c_void_p
+        L.krep_gpu_select_search_algorithm.argtypes = [C.POINTER(abi.SearchParams)]
+        L.search_buffer.restype = C.c_int
+        L.search_buffer.argtypes = [C.POINTER(abi.SearchParams), C.c_void_p, C.c_size_t, C.c_int, C.c_int,
+                                    C.POINTER(abi.MatchResult), C.POINTER(C.c_uint64)]
+        L.krep_gpu_match_result_init.restype = C.POINTER(abi.MatchResult)
+        L.krep_gpu_match_result_init.argtypes = [C.c_uint64]
+        L.krep_gpu_match_result_free.restype = None
+        L.krep_gpu_match_result_free.argtypes = [C.POINTER(abi.MatchResult)]
+        L.krep_gpu_plan_create.restype = C.c_void_p
+        L.krep_gpu_plan_create.argtypes = [C.POINTER(abi.SearchParams), C.c_int, C.c_int]
+        L.krep_gpu_plan_destroy.restype = None
+        L.krep_gpu_plan_destroy.argtypes = [C.c_void_p]
+        L.krep_gpu_plan_ref_algo.restype = C.c_int
+        L.krep_gpu_plan_ref_algo.argtypes = [C.c_void_p]
+        L.krep_gpu_scan_device.restype = C.c_int
+        L.krep_gpu_scan_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t,
+                                           C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.POINTER(abi.ScanOut)]
+        L.krep_gpu_generate.restype = C.c_int
+        L.krep_gpu_generate.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_uint64, C.c_void_p,
+                                        C.c_size_t, C.c_uint64, C.c_void_p]
+        L.krep_gpu_generate_host.restype = None
+        L.krep_gpu_generate_host.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_uint64, C.c_void_p,
+                                             C.c_size_t, C.c_uint64]
+        L.krep_gpu_combine_line_counts.restype = C.c_uint64
+        L.krep_gpu_combine_line_counts.argtypes = [C.POINTER(abi.ScanOut), C.c_int]
+        L.krep_gpu_mirror_select.restype = C.c_int
+        L.krep_gpu_mirror_select.argtypes = [C.POINTER(abi.SearchParams), C.c_size_t]
+        L.krep_gpu_algorithm_name.restype = C.c_char_p
+        L.krep_gpu_algorithm_name.argtypes = [C.c_int]
+        for n in ("krep_gpu_set_reference_simd", "krep_gpu_set_only_matching", "krep_gpu_set_force_no_simd",
+                  "krep_gpu_set_algo_override", "krep_gpu_debug_force_rounds"):
+            getattr(L, n).restype = None
+            getattr(L, n).argtypes = [C.c_int]
+        L.krep_gpu_get_reference_simd.restype = C.c_int
+        L.krep_gpu_device_count.restype = C.c_int
+        L.krep_gpu_last_error.restype = C.c_char_p
+        L.krep_gpu_clear_error.restype = None
+        L.krep_gpu_version.restype = C.c_char_p
+
+    # ---- configuration of the reference mirror ----
+    def set_reference_simd(self, level: int):
+        self.lib.krep_gpu_set_reference_simd(level)
+
+    def set_only_matching(self, on: bool):
+        self.lib.krep_gpu_set_only_matching(int(on))
+
+    def set_force_no_simd(self, on: bool):
+        self.lib.krep_gpu_set_force_no_simd(int(on))
+
+    def set_algo_override(self, a: int):
+        self.lib.krep_gpu_set_algo_override(a)
+
+    def force_rounds(self, r: int):
+        self.lib.krep_gpu_debug_force_rounds(r)
+
+    def mirror_select(self, params: abi.Params, text_len: int) -> int:
+        return int(self.lib.krep_gpu_mirror_select(params.ref, text_len))
+
+    def last_error(self) -> str:
+        return (self.lib.krep_gpu_last_error() or b"").decode()
+
+    def device_count(self) -> int:
+        return int(self.lib.krep_gpu_device_count())
+
+    # ---- search_func_t-shaped operators on host buffers ----
+    def _ptr(self, text):
+        if isinstance(text, np.ndarray):
+            assert text.dtype == np.uint8 and text.flags["C_CONTIGUOUS"]
+            return C.c_void_p(text.ctypes.data), text.size, text
+        raw = bytes(text)
+        cp = C.c_char_p(raw)
+        return C.cast(cp, C.c_void_p), len(raw), (raw, cp)
+
+    def search(self, params: abi.Params, text, want_result=True):
+        """krep_gpu_select_search_algorithm(params)(params, text, len, result) -> (ret, positions)."""
+        ptr, n, keep = self._ptr(text)
+        fn = self.lib.krep_gpu_aho_corasick_search if params.s.num_patterns > 1 else self.lib.krep_gpu_literal_search
+        res = self.lib.krep_gpu_match_result_init(16) if want_result else None
+        dummy = C.c_int(0)
+        if params.s.num_patterns > 1 and not params.s.ac_trie:
+            params.s.ac_trie = C.cast(C.pointer(dummy), C.c_void_p)  # "caller pre-built the trie" (krep.c:2528)
+        try:
+            self.lib.krep_gpu_clear_error()
+            ret = fn(params.ref, ptr, n, res)
+            if self.last_error():
+                raise KrepGpuError(self.last_error())
+            pos = abi.result_positions(res) if res else None
+        finally:
+            if res:
+                self.lib.krep_gpu_match_result_free(res)
+            params.s.ac_trie = None
+        del keep
+        return int(ret), pos
+
+    def search_buffer(self, params: abi.Params, text, only_matching=False, num_gpus=1, want_result=True):
+        ptr, n, keep = self._ptr(text)
+        res = self.lib.krep_gpu_match_result_init(16) if want_result else None
+        cnt = C.c_uint64(0)
+        try:
+            rc = self.lib.search_buffer(params.ref, ptr, n, int(only_matching), num_gpus, res, C.byref(cnt))
+            pos = abi.result_positions(res) if res else None
+        finally:
+            if res:
+                self.lib.krep_gpu_match_result_free(res)
+        del keep
+        return int(rc), int(cnt.value), pos
+
+    # ---- device-resident path ----
+    def plan(self, params: abi.Params, only_matching=False, device=0) -> "Plan":
+        h = self.lib.krep_gpu_plan_create(params.ref, int(only_matching), device)
+        if not h:
+            raise KrepGpuError("krep_gpu_plan_create failed: " + self.last_error())
+        return Plan(self, h, params)
+
+    def generate(self, d_ptr: int, length: int, global_off: int, kind: int, seed: int, plant: bytes = b"",
+                 period: int = 0, stream: int = 0):
+        rc = self.lib.krep_gpu_generate(C.c_void_p(d_ptr), length, global_off, kind, seed, plant, len(plant), period,
+                                        C.c_void_p(stream))
+        if rc:
+            raise KrepGpuError("krep_gpu_generate failed: " + self.last_error())
+
+    def generate_host(self, length: int, global_off: int, kind: int, seed: int, plant: bytes = b"",
+                      period: int = 0) -> np.ndarray:
+        out = np.empty(length, dtype=np.uint8)
+        self.lib.krep_gpu_generate_host(C.c_void_p(out.ctypes.data), length, global_off, kind, seed, plant, len(plant),
+                                        period)
+        return out
+
+
+class Plan:
+    def __init__(self, eng: Engine, handle, params):
+        self.eng, self.h, self.params = eng, handle, params
+
+    @property
+    def ref_algo(self) -> int:
+        return int(self.eng.lib.krep_gpu_plan_ref_algo(self.h))
+
+    def scan(self, d_text: int, text_len: int, own_lo=0, own_hi=None, global_base=0, d_positions: int = 0,
+             capacity: int = 0, stream: int = 0, time_it=False) -> abi.ScanOut:
+        out = abi.ScanOut()
+        rc = self.eng.lib.krep_gpu_scan_device(self.h, C.c_void_p(d_text), text_len, own_lo,
+                                               text_len if own_hi is None else own_hi, global_base,
+                                               C.c_void_p(d_positions) if d_positions else None, capacity,
+                                               C.c_void_p(stream) if stream else None, int(time_it), C.byref(out))
+        if rc:
+            raise KrepGpuError("krep_gpu_scan_device failed: " + self.eng.last_error())
+        return out
+
+    def close(self):
+        if self.h:
+            self.eng.lib.krep_gpu_plan_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_engine = None
+
+
+def load() -> Engine:
+    global _engine
+    if _engine is None:
+        _engine = Engine()
+    return _engine

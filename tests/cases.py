@@ -1,0 +1,67 @@
+"""Seeded parity cases shared by the GPU tests and the golden-vector generator."""
+from __future__ import annotations
+
+import random
+
+import numpy as np
+
+from krep_amd import abi
+
+ALPHAS = {
+    "ab": b"ab",
+    "abn": b"ab\n",
+    "mixed": b"abAB \n",
+    "word": b"abc_ \n-",
+    "text": bytes(range(97, 123)) + b"  \n",
+}
+# lengths around every geometry edge of the kernel: 16 B lane, 1 KiB cell, 8 KiB wave segment,
+# 32 KiB tile, and a few tiles
+EDGE_SIZES = [0, 1, 2, 7, 8, 9, 15, 16, 17, 23, 24, 31, 32, 33, 63, 64, 65, 127, 128, 1000, 1023, 1024, 1025,
+              1031, 2048, 8191, 8192, 8193, 8200, 16384, 32767, 32768, 32769, 32776, 40000, 65536, 65537, 98304 + 5,
+              200003]
+
+
+def rand_text(rng: np.random.RandomState, n: int, alpha: bytes) -> np.ndarray:
+    a = np.frombuffer(alpha, dtype=np.uint8)
+    return a[rng.randint(0, len(a), size=n)].astype(np.uint8) if n else np.zeros(0, dtype=np.uint8)
+
+
+def pick_pattern(rng: np.random.RandomState, text: np.ndarray, m: int, alpha: bytes) -> bytes:
+    n = text.size
+    if n >= m and rng.rand() < 0.75:
+        s = rng.randint(0, n - m + 1)
+        return text[s:s + m].tobytes()
+    return rand_text(rng, m, alpha).tobytes()
+
+
+def literal_cases(seed: int, count: int, sizes=None, lens=None, big=False):
+    """Yields (text ndarray, pattern bytes, kwargs for abi.Params)."""
+    rng = np.random.RandomState(seed)
+    pyr = random.Random(seed)
+    sizes = sizes or EDGE_SIZES
+    lens = lens or [1, 2, 3, 4, 5, 7, 8, 9, 12, 16, 17, 31, 32, 33, 64, 65, 200]
+    for _ in range(count):
+        alpha = ALPHAS[pyr.choice(list(ALPHAS))]
+        n = pyr.choice(sizes)
+        m = pyr.choice(lens)
+        text = rand_text(rng, n, alpha)
+        if m > 8 and n > m and rng.rand() < 0.6:
+            # long patterns: plant a few copies so that verification is exercised
+            pat = rand_text(rng, m, alpha).tobytes()
+            for _k in range(pyr.choice([1, 2, 5])):
+                s = rng.randint(0, n - m + 1)
+                text[s:s + m] = np.frombuffer(pat, dtype=np.uint8)
+        else:
+            pat = pick_pattern(rng, text, m, alpha)
+        kw = dict(case_sensitive=pyr.random() < 0.6, whole_word=pyr.random() < 0.25,
+                  max_count=pyr.choice([abi.SIZE_MAX] * 4 + [0, 1, 2, 3, 7, 100]))
+        mode = pyr.choice(["pos", "pos", "lines", "count"])
+        if mode == "lines":
+            kw.update(count_lines=True)
+        elif mode == "count":
+            kw.update(count_lines=True, only_match=True)
+        yield text, pat, kw
+
+
+def has_border(p: bytes) -> bool:
+    return any(p[:len(p) - k] == p[k:] for k in range(1, len(p)))

@@ -1,0 +1,92 @@
+"""GPU parity: the HIP literal scan, called through the C-ABI, against the oracle restatement of the
+reference function that select_search_algorithm() would have executed (bit-exact count + offsets)."""
+import numpy as np
+import pytest
+
+import cases
+import oracle_lib as ol
+from krep_amd import abi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", params=[1, 4], ids=["tile32k", "tile128k"])
+def gpu(request):
+    """Every test runs with both kernel tile shapes (1 round = 32 KiB tiles, 4 rounds = 128 KiB tiles)."""
+    import krep_amd
+    e = krep_amd.load()
+    assert e.device_count() >= 1, "no MI355X visible"
+    e.force_rounds(request.param)
+    yield e
+    e.force_rounds(0)
+
+
+def _check(gpu, o, text, pat, kw, level):
+    gpu.set_reference_simd(level)
+    p = abi.Params([pat], **kw)
+    algo = gpu.mirror_select(p, text.size)
+    want = o.call(algo, abi.Params([pat], **kw), text)
+    got = gpu.search(p, text)
+    assert got[0] == want[0], (abi.RA_NAMES[algo], pat, kw, text.size, got[0], want[0])
+    assert np.array_equal(got[1], want[1]), (abi.RA_NAMES[algo], pat, kw, text.size, got[1][:8], want[1][:8])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_all_occurrence_family(gpu, oracle_engine, seed):
+    """Scalar reference build: BMH / memchr / memchr_short (family O) and KMP for repetitive 4..7 B."""
+    n = 0
+    for text, pat, kw in cases.literal_cases(100 + seed, 120):
+        gpu.set_reference_simd(abi.REF_SCALAR)
+        p = abi.Params([pat], **kw)
+        algo = gpu.mirror_select(p, text.size)
+        if algo == abi.RA_KMP and cases.has_border(pat if kw["case_sensitive"] else pat.lower()):
+            continue  # greedy family with a bordered pattern: covered in test_gpu_greedy.py
+        _check(gpu, oracle_engine, text, pat, kw, abi.REF_SCALAR)
+        n += 1
+    assert n > 60
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_simd_builds_border_free(gpu, oracle_engine, seed):
+    """AVX2 / AVX-512 reference builds: SSE4.2 (<=16 B), AVX2 (17..32), AVX-512 (33..64) bodies."""
+    n = 0
+    for text, pat, kw in cases.literal_cases(200 + seed, 120):
+        level = [abi.REF_SSE42, abi.REF_AVX2, abi.REF_AVX512][seed % 3]
+        if kw.get("count_lines") and not kw.get("only_match") and len(pat) > 16 and kw["case_sensitive"]:
+            continue  # block-structured -c skipping of the AVX bodies: canonical semantics only
+        gpu.set_reference_simd(level)
+        p = abi.Params([pat], **kw)
+        algo = gpu.mirror_select(p, text.size)
+        folded = pat if kw["case_sensitive"] else pat.lower()
+        if algo in (abi.RA_SSE42, abi.RA_KMP) and cases.has_border(folded):
+            continue
+        if algo == abi.RA_AVX512 and len(pat) > 32:
+            continue  # the unexamined-last-block bug of krep.c:5171 is covered in test_gpu_quirks.py
+        _check(gpu, oracle_engine, text, pat, kw, level)
+        n += 1
+    assert n > 50
+
+
+def test_headline_literal_small(gpu, oracle_engine):
+    """'Sherlock' planted in background text, every alignment of a match against 16 B / 1 KiB / 32 KiB edges."""
+    rng = np.random.RandomState(3)
+    text = cases.rand_text(rng, 3 * 32768 + 100, cases.ALPHAS["text"])
+    pat = b"Sherlock"
+    spots = [0, 9, 1017, 2044, 8185, 16380, 32761, 32769, 65530, 65539, text.size - 8]
+    for s in spots:
+        text[s:s + 8] = np.frombuffer(pat, dtype=np.uint8)
+    for level in (abi.REF_SCALAR, abi.REF_AVX2):
+        for kw in (dict(), dict(count_lines=True), dict(whole_word=True), dict(case_sensitive=False),
+                   dict(max_count=5), dict(count_lines=True, only_match=True)):
+            _check(gpu, oracle_engine, text, pat, kw, level)
+    got = gpu.search(abi.Params([pat]), text)
+    assert got[0] == len(spots) and got[1][:, 0].tolist() == sorted(spots)
+
+
+def test_dense_single_byte(gpu, oracle_engine):
+    rng = np.random.RandomState(4)
+    text = cases.rand_text(rng, 300_000, b"#abcdefghij \n")
+    for kw in (dict(), dict(count_lines=True), dict(max_count=4096), dict(max_count=8192), dict(max_count=4097),
+               dict(whole_word=True), dict(case_sensitive=False)):
+        _check(gpu, oracle_engine, text, b"#", kw, abi.REF_AVX2)
+    _check(gpu, oracle_engine, text, b"A", dict(case_sensitive=False), abi.REF_AVX2)
