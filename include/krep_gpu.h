@@ -111,6 +111,8 @@ void krep_gpu_set_algo_override(int krep_ref_algo_override); /* static algo_over
 int krep_gpu_get_reference_simd(void);
 /* test hook: force the kernel tile shape (0 = auto, 1 = 32 KiB tiles, 4 = 128 KiB tiles) */
 void krep_gpu_debug_force_rounds(int rounds);
+/* test hook: staging records per scan unit (0 = auto); small values exercise the emit-mode re-scan */
+void krep_gpu_debug_force_stage_cap(int records);
 /* Twin of select_search_algorithm() (krep.c:1771): the algorithm the reference build would END UP
  * executing for `params` on a text of `text_len` bytes (text_len matters: the SIMD functions fall back
  * to BMH when text_len < pattern_len, and so on). */

@@ -22,17 +22,16 @@ constexpr uint32_t kCellBytes   = kWave * 16;                               // 1
 constexpr uint32_t kSegBytes    = kCellBytes * kCells;                      // per wave: 8 KiB
 constexpr int      kRoundsBig   = 4;                                        // 32 KiB per wave unit, 128 KiB per tile
 
-// ---- decoupled look-back status word (ONE aligned 8-byte granule, written by one relaxed
-// agent-scope atomic store: the payload is the flag — guide G16 "R2") ---------------------------
-//   [63:62] state  0 = not ready (zeroed by hipMemsetAsync before every launch)
-//                  1 = AGGREGATE (this tile only)   2 = PREFIX (inclusive, all tiles <= this)
-//   [61]    has_nl : window contains a '\n'
-//   [60]    head   : a match starts before the first '\n' (== any match when !has_nl)
-//   [59]    tail   : a match starts after the last '\n'   (== any match when !has_nl)
-//   [58:0]  value  : number of matches (aggregate or inclusive prefix)
-constexpr uint64_t kStAgg = 1ull << 62, kStPre = 2ull << 62, kStMask = 3ull << 62;
-constexpr uint64_t kLnNl = 1ull << 61, kLnHead = 1ull << 60, kLnTail = 1ull << 59;
-constexpr uint64_t kValMask = (1ull << 59) - 1;
+// ---- per-unit info word written by the scan kernel, consumed by the post-pass (kg_post.hip) ---
+//   [63]    has_nl : the unit's owned bytes contain a '\n'
+//   [62]    head   : a match starts before the first '\n' (== any match when !has_nl)
+//   [61]    tail   : a match starts after the last '\n'   (== any match when !has_nl)
+//   [60:32] lines  : distinct lines holding a match start, counted as if no line were open on entry
+//   [31:0]  count  : matches starting in the unit
+constexpr uint64_t kLnNl = 1ull << 63, kLnHead = 1ull << 62, kLnTail = 1ull << 61;
+constexpr int      kUiLineShift = 32;
+constexpr uint64_t kUiLineMask = (1ull << 29) - 1;
+constexpr uint64_t kUiCountMask = 0xffffffffull;
 
 // flags
 enum : uint32_t {
@@ -47,9 +46,10 @@ struct Counters {
     unsigned long long total;        // matches (after -w / ownership filtering)
     unsigned long long lines;        // distinct lines with a match start (F_LINES)
     unsigned long long ticket;       // dynamic tile id dispenser
-    unsigned long long summary;      // final look-back word of the last tile (line bits + total)
-    unsigned long long spin_fail;    // look-back watchdog tripped (never expected)
-    unsigned long long pad[3];
+    unsigned long long summary;      // line bits (kLnNl|kLnHead|kLnTail) of the whole owned window
+    unsigned long long overflow_units; // units whose hit count exceeded the staging capacity
+    unsigned long long max_unit_count; // largest per-unit hit count seen
+    unsigned long long pad[2];
 };
 
 // Parameters of a literal scan launch.
@@ -66,8 +66,12 @@ struct LitArgs {
     uint32_t flags;
     uint32_t p0, p1, k0, k1;      // first <=8 pattern bytes (folded when F_CI) and their byte masks
     const uint8_t *pat;           // device copy of the (folded) pattern, for m > 8
-    unsigned long long *status;   // [num_tiles * 4] look-back words, one per wave unit (F_POS | F_LINES)
+    unsigned long long *unitinfo; // [num_tiles * 4] per-unit info words (F_POS | F_LINES)
     Counters *ctr;
+    uint64_t *stage;              // [num_tiles * 4 * stage_cap] ordered start offsets per unit (F_POS, scan mode)
+    uint32_t stage_cap;           // staging records per unit
+    uint32_t emit_mode;           // 0: scan (count + stage); 1: re-scan the overflowed units and write records
+    const uint64_t *offsets;      // [units] exclusive global index of each unit's first match (emit mode)
     uint64_t *positions;          // match_position_t records (2 x u64) or nullptr
     uint64_t pos_cap;             // min(capacity, max_count)
 };

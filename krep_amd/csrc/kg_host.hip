@@ -61,6 +61,8 @@ extern "C" void krep_gpu_set_only_matching(int on) { g_only_matching = on != 0; 
 extern "C" void krep_gpu_set_force_no_simd(int on) { g_no_simd = on != 0; }
 extern "C" void krep_gpu_set_algo_override(int a) { g_algo_override = a; }
 static int g_force_rounds = 0; // test hook: 0 = auto, 1 / 4 = force the tile shape
+static int g_force_stage_cap = 0; // test hook: staging records per unit (0 = auto)
+extern "C" void krep_gpu_debug_force_stage_cap(int c) { g_force_stage_cap = c; }
 extern "C" void krep_gpu_debug_force_rounds(int r) { g_force_rounds = r; }
 
 static inline uint8_t lo8(uint8_t c) { return (c >= 'A' && c <= 'Z') ? (uint8_t)(c + 32) : c; }
@@ -247,8 +249,6 @@ struct krep_gpu_plan
     uint8_t *d_pat = nullptr;
     // workspace
     Counters *d_ctr = nullptr, *h_ctr = nullptr;
-    unsigned long long *d_status = nullptr;
-    size_t status_cap = 0;
     int num_cu = 256;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // multi-pattern
@@ -375,7 +375,6 @@ extern "C" void krep_gpu_plan_destroy(krep_gpu_plan_t *pl)
     if (pl->d_pat) (void)hipFree(pl->d_pat);
     if (pl->d_ctr) (void)hipFree(pl->d_ctr);
     if (pl->h_ctr) (void)hipHostFree(pl->h_ctr);
-    if (pl->d_status) (void)hipFree(pl->d_status);
     if (pl->ev0) (void)hipEventDestroy(pl->ev0);
     if (pl->ev1) (void)hipEventDestroy(pl->ev1);
     if (pl->ac) ac_free(pl->ac);
@@ -519,14 +518,21 @@ static int scan_literal(krep_gpu_plan *pl, int algo, const uint8_t *d_text, size
     HIPCHK(hipSetDevice(pl->device));
     const bool chain = (a.flags & (F_POS | F_LINES)) != 0;
     const uint64_t n_units = a.num_tiles * kWavesPerBlk;
-    if (chain && n_units > pl->status_cap)
+    // staging slot per unit: sized for ~4x BASELINE's densities (1e-4/B literal, 1e-2/B single byte);
+    // denser units take the emit-mode re-scan
+    a.stage_cap = (a.flags & F_POS) ? (m == 1 ? 512u : 64u) * (a.rounds == kRoundsBig ? 1u : 1u) : 0u;
+    if (a.rounds == 1 && a.stage_cap)
+        a.stage_cap = m == 1 ? 256u : 32u;
+    if (g_force_stage_cap && (a.flags & F_POS))
+        a.stage_cap = (uint32_t)g_force_stage_cap;
+    if (chain)
     {
-        if (pl->d_status) (void)hipFree(pl->d_status);
-        pl->status_cap = 0;
-        HIPCHK(hipMalloc(&pl->d_status, n_units * sizeof(unsigned long long)));
-        pl->status_cap = n_units;
+        if (post_reserve(pl->post, n_units, n_units * a.stage_cap))
+            return 2;
+        a.unitinfo = pl->post.d_unitinfo;
+        a.stage = (uint64_t *)pl->post.d_stage;
+        a.offsets = (const uint64_t *)pl->post.d_offsets;
     }
-    a.status = pl->d_status;
     const uint32_t grid = (uint32_t)std::min<uint64_t>(a.num_tiles, (uint64_t)pl->num_cu * 8);
 
     if (time_it) HIPCHK(hipEventRecord(pl->ev0, st));
@@ -535,23 +541,31 @@ static int scan_literal(krep_gpu_plan *pl, int algo, const uint8_t *d_text, size
     if (!need_post)
     {
         HIPCHK(hipMemsetAsync(pl->d_ctr, 0, sizeof(Counters), st));
-        if (chain) HIPCHK(hipMemsetAsync(pl->d_status, 0, n_units * sizeof(unsigned long long), st));
         HIPCHK(launch_literal(a, grid, st));
+        if (chain && post_order(pl->post, n_units, a.stage_cap, m, pl->lines, (uint64_t *)d_pos, want, pl->d_ctr, pl->num_cu, st))
+            return 2;
         if (time_it) HIPCHK(hipEventRecord(pl->ev1, st));
         HIPCHK(hipMemcpyAsync(pl->h_ctr, pl->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        if (pl->h_ctr->spin_fail)
-            return kg::fail("look-back watchdog tripped (%llu)", pl->h_ctr->spin_fail);
+        if ((a.flags & F_POS) && pl->h_ctr->overflow_units)
+        {
+            // some units held more hits than their staging slot: re-scan exactly those, writing in place
+            LitArgs e = a;
+            e.emit_mode = 1;
+            HIPCHK(hipMemsetAsync(&pl->d_ctr->ticket, 0, sizeof(unsigned long long), st));
+            HIPCHK(launch_literal(e, grid, st));
+            if (time_it) HIPCHK(hipEventRecord(pl->ev1, st));
+            HIPCHK(hipStreamSynchronize(st));
+        }
         total = pl->h_ctr->total;
         lines = pl->h_ctr->lines;
         summary = pl->h_ctr->summary;
+        if (!chain)
+            summary = total ? (kLnHead | kLnTail) : 0;
     }
     else
     {
-        int rc = post_greedy_scan(pl->post, a, grid, pl->d_ctr, pl->h_ctr, pl->ww, pl->lines, (uint64_t *)d_pos, want, st,
-                                  time_it ? pl->ev1 : nullptr, &total, &lines, &summary);
-        if (rc)
-            return rc;
+        return kg::fail("greedy post-pass not wired yet");
     }
     if (time_it)
     {
@@ -591,7 +605,7 @@ extern "C" int krep_gpu_scan_device(krep_gpu_plan_t *pl, const void *d_text, siz
     if (pl->ref_algo == KREP_RA_REGEX)
         return kg::fail("regex search is not part of the accelerated path");
     if (pl->ref_algo == KREP_RA_AHO_CORASICK)
-        return ac_scan(pl->ac, pl->d_ctr, pl->h_ctr, &pl->d_status, &pl->status_cap, pl->num_cu, (const uint8_t *)d_text,
+        return ac_scan(pl->ac, pl->d_ctr, pl->h_ctr, pl->post, pl->num_cu, (const uint8_t *)d_text,
                        text_len, own_lo, own_hi, global_base, d_positions, position_capacity, pl->ww, pl->lines, pl->track,
                        pl->max_count, st, time_it, pl->ev0, pl->ev1, out);
     if (pl->sp.num_patterns != 1)

@@ -11,28 +11,33 @@ int fail(const char *fmt, ...); // records krep_gpu_last_error(), prints "krep-g
 // kg_literal.hip
 hipError_t launch_literal(const LitArgs &a, uint32_t grid, hipStream_t st);
 
-// kg_post.hip — greedy non-overlapping selection (simd_sse42_search / kmp_search family) on the
-// ordered occurrence list, then -w, line bookkeeping and compaction
+// kg_post.hip — ordering post-pass shared by the literal and Aho-Corasick scans
 struct PostScratch
 {
-    uint64_t *d_occ = nullptr;  // all-occurrence records (2 x u64 each)
+    unsigned long long *d_unitinfo = nullptr; // [units] info words written by the scan kernel
+    unsigned long long *d_offsets = nullptr;  // [units] exclusive global index of each unit's first hit
+    unsigned long long *d_blk = nullptr;      // [2 * units/1024] block sums / line carries
+    uint64_t units_cap = 0;
+    unsigned long long *d_stage = nullptr;    // [units * stage_cap] staged, unit-ordered hit words
+    uint64_t stage_cap_words = 0;
+    uint64_t *d_occ = nullptr;                // all-occurrence records for the greedy (family N) filter
     uint64_t occ_cap = 0;
-    uint8_t *d_keep = nullptr;
-    uint64_t *d_blocksum = nullptr;
-    uint64_t keep_cap = 0;
-    unsigned long long *d_status = nullptr;
-    uint64_t status_cap = 0;
 };
 void post_free(PostScratch &s);
-int post_greedy_scan(PostScratch &s, LitArgs a, uint32_t grid, Counters *d_ctr, Counters *h_ctr, bool ww, bool lines,
-                     uint64_t *d_pos, uint64_t want, hipStream_t st, hipEvent_t ev_end, uint64_t *total, uint64_t *nlines,
-                     unsigned long long *summary);
+int post_reserve(PostScratch &s, uint64_t n_units, uint64_t stage_words);
+// K1..K4 on `st`: offsets, distinct-line total (ctr->lines), line summary (ctr->summary), gather into d_pos
+int post_order(PostScratch &s, uint64_t n_units, uint32_t stage_cap, uint32_t fixed_len, bool want_lines, uint64_t *d_pos,
+               uint64_t pos_cap, Counters *d_ctr, int num_cu, hipStream_t st);
+// greedy non-overlapping selection (simd_sse42_search / kmp_search family) on the ordered occurrence list
+int post_greedy(PostScratch &s, const uint8_t *d_text, uint64_t text_len, uint32_t m, bool ww, bool lines, uint64_t n_occ,
+                uint64_t *d_pos, uint64_t want, Counters *d_ctr, Counters *h_ctr, hipStream_t st, uint64_t *total,
+                uint64_t *nlines);
 
 // kg_ac.hip — multi-pattern scan
 struct AcTables;
 AcTables *ac_build(const search_params_t &sp, int device);
 void ac_free(AcTables *t);
-int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, unsigned long long **d_status, size_t *status_cap, int num_cu,
+int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, int num_cu,
             const uint8_t *d_text, size_t text_len, size_t own_lo, size_t own_hi, size_t global_base,
             match_position_t *d_pos, uint64_t cap, bool ww, bool lines, bool track, size_t max_count, hipStream_t st,
             int time_it, hipEvent_t ev0, hipEvent_t ev1, krep_gpu_scan_out_t *out);

@@ -15,13 +15,16 @@
 //    (v_cmp -> s_or / s_bcnt1), so a cell without a candidate costs no further vector work;
 //  * longer patterns (> 8 B) use those 8 bytes as the filter and verify the rest on the (rare)
 //    candidate lanes only; m == 1 uses an exact SWAR byte compare (memchr path, 1 % hit rate);
-//  * ordered output in ONE pass: per-lane 16-bit hit masks -> wave prefix (ballot bit-planes +
-//    v_mbcnt) -> workgroup prefix (LDS) -> chained decoupled look-back across tiles, whose status
-//    word is a single 8-byte {state, line bits, count} granule published with one relaxed
-//    agent-scope atomic store (per-XCD L2s are not coherent: guide G16, form R2);
-//  * tiles are handed out by an atomic ticket, so a tile's predecessors are always owned by
-//    running workgroups (no dispatch-order assumption, look-back cannot deadlock; every spin is
-//    bounded by a watchdog).
+//  * ordered output WITHOUT re-reading the haystack and without any inter-workgroup waiting: a
+//    wave turns its unit's per-lane 16-bit hit masks into unit-local ranks (ballot bit-planes +
+//    v_mbcnt) and stages the start offsets, already in order, in the unit's fixed slot; it
+//    publishes one info word per unit {line bits, line count, hit count}.  The post-pass
+//    (kg_post.hip: offset scan over the info words + line carry + coalesced gather) produces the
+//    globally ordered match_position_t list.  A chained decoupled look-back was measured first and
+//    capped the ordered rate at ~3 TB/s (status round trips), see DESIGN.md;
+//  * a unit with more hits than its staging slot (very dense inputs) is re-scanned by the same
+//    kernel in emit mode, writing its records straight to their final offsets;
+//  * tiles are handed out by an atomic ticket (dynamic balance; one fetch-add per 128 KiB).
 #include <hip/hip_runtime.h>
 #include "kg_common.h"
 
@@ -114,81 +117,6 @@ __device__ __noinline__ W6 load_window_guarded(const uint8_t *text, u64 text_len
     return r;
 }
 
-// Decoupled look-back by one wave.  Returns the exclusive prefix {line summary, count} of tile t and
-// publishes this tile's AGGREGATE then PREFIX word.  `mine` = this tile's aggregate.
-__device__ __forceinline__ void lookback(u64 *status, u64 t, const LS &mine, u64 mine_cnt, LS &excl, u64 &excl_cnt,
-                                         Counters *ctr)
-{
-    const u32 lane = lane_id();
-    excl = LS{0, false, false, false};
-    excl_cnt = 0;
-    if (t == 0)
-    {
-        if (lane == 0)
-            __hip_atomic_store(&status[0], kStPre | ls_bits(mine) | (mine_cnt & kValMask), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
-    if (lane == 0)
-        __hip_atomic_store(&status[t], kStAgg | ls_bits(mine) | (mine_cnt & kValMask), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-    long long base = (long long)t - 1;
-    u32 spins = 0;
-    for (;;)
-    {
-        long long idx = base - (long long)lane;
-        u64 w = kStPre; // virtual "prefix = 0" in front of tile 0
-        if (idx >= 0)
-            w = __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const u32 st = (u32)(w >> 62);
-        const u64 pre = __ballot(st == 2u);
-        const u64 need = pre ? ((2ull << __builtin_ctzll(pre)) - 1ull) : ~0ull; // lanes 0..first prefix
-        const u64 notready = __ballot(st == 0u) & need;
-        if (notready)
-        {
-            if (++spins > (1u << 22))
-            { // watchdog: never expected; makes a protocol bug visible instead of hanging the GPU
-                if (lane == 0)
-                    atomicAdd(&ctr->spin_fail, 1ull);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(2);
-            continue;
-        }
-        const bool in = (need >> lane) & 1ull;
-        // counts: 64-bit wave sum over the needed lanes
-        u64 v = in ? (w & kValMask) : 0ull;
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1)
-            v += __shfl_xor(v, o);
-        // line summary of the sequence [lane fp (oldest) ... lane 0 (newest)]
-        const u64 nlm = __ballot(in && (w & kLnNl));
-        const u64 hdm = __ballot(in && (w & kLnHead));
-        const u64 tlm = __ballot(in && (w & kLnTail));
-        LS seg;
-        seg.cnt = 0;
-        seg.nl = nlm != 0;
-        if (seg.nl)
-        {
-            const int newest = __builtin_ctzll(nlm), oldest = 63 - __builtin_clzll(nlm);
-            seg.tail = (tlm & ((2ull << newest) - 1ull)) != 0;   // lanes <= newest newline holder
-            seg.head = (hdm & ~((1ull << oldest) - 1ull)) != 0;  // lanes >= oldest newline holder
-        }
-        else
-            seg.head = seg.tail = (hdm | tlm) != 0;
-        excl = ls_combine(seg, excl); // seg is older than what we accumulated so far
-        excl_cnt += v;
-        if (pre)
-            break;
-        base -= 64;
-    }
-    excl.cnt = 0;
-    const LS incl = ls_combine(excl, mine);
-    if (lane == 0)
-        __hip_atomic_store(&status[t], kStPre | ls_bits(incl) | ((excl_cnt + mine_cnt) & kValMask), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-}
-
 // KIND: 1 -> m == 1 (SWAR), 4 -> 2..4 bytes (one word), 8 -> 5..8 bytes (two words), 9 -> m > 8 (filter+verify)
 // MASKED: the last compared word is partial (m = 2,3 or 5,6,7), so its compare needs the byte mask.
 // R: load rounds per chain unit.  A workgroup draws ONE ticket per tile (4 waves x R x 8 KiB); each
@@ -206,9 +134,8 @@ __global__ __launch_bounds__(kBlock) void lit_scan(const LitArgs a)
     const bool chain = want_pos || LINES;
     const u64 hi_match = (a.own_hi < a.text_len - a.m + 1) ? a.own_hi : (a.text_len - a.m + 1); // exclusive start bound
     constexpr u64 kUnitBytes = (u64)R * kSegBytes;
-    const u64 last_unit = a.num_tiles * kWavesPerBlk - 1;
 
-    u64 acc_total = 0, acc_lines = 0; // wave-uniform accumulators
+    u64 acc_total = 0; // wave-uniform accumulator
     u64 next_ticket = 0;
     if (threadIdx.x == 0)
         next_ticket = __hip_atomic_fetch_add(&a.ctr->ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -226,6 +153,8 @@ __global__ __launch_bounds__(kBlock) void lit_scan(const LitArgs a)
 
         const u64 unit = tile * kWavesPerBlk + wave;
         const u64 ubase = a.anchor + unit * kUnitBytes;
+        if (a.emit_mode && (u32)(a.unitinfo[unit] & kUiCountMask) <= a.stage_cap)
+            continue; // wave-uniform: only overflowed units are re-scanned
 
         u32 M[R][kCells]; // per-lane 16-bit hit masks of the whole unit
         u32 wcnt = 0;     // unit total (uniform)
@@ -444,32 +373,61 @@ __global__ __launch_bounds__(kBlock) void lit_scan(const LitArgs a)
 
         }
 
+        acc_total += wcnt;
         if (!chain)
-        {
-            acc_total += wcnt;
             continue;
-        }
 
-        // ---- chain this unit into the global order ------------------------------------------------
-        LS tl = wls;
-        if (!LINES)
-            tl.head = tl.tail = wcnt != 0;
-        LS ex;
-        u64 excnt;
-        lookback(a.status, unit, tl, wcnt, ex, excnt, a.ctr);
-        if (LINES)
-            acc_lines += tl.cnt - ((ex.tail && tl.head) ? 1u : 0u);
-        if (unit == last_unit && lane == 0)
+        if (!a.emit_mode)
         {
-            const LS incl = ls_combine(ex, tl);
-            a.ctr->total = excnt + wcnt;
-            a.ctr->summary = ls_bits(incl);
+            // ---- publish the unit: info word + staged, unit-ordered start offsets ----------------------
+            if (lane == 0)
+            {
+                u64 info = (u64)wcnt;
+                if (LINES)
+                    info |= ls_bits(wls) | ((u64)(wls.cnt & kUiLineMask) << kUiLineShift);
+                else if (wcnt)
+                    info |= kLnHead | kLnTail;
+                a.unitinfo[unit] = info;
+                if (want_pos && wcnt > a.stage_cap)
+                {
+                    atomicAdd(&a.ctr->overflow_units, 1ull);
+                    atomicMax(&a.ctr->max_unit_count, (u64)wcnt);
+                }
+            }
+            if (want_pos && wcnt)
+            {
+                u64 *slot = reinterpret_cast<u64 *>(a.stage) + unit * (u64)a.stage_cap;
+                u32 out = 0;
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                {
+#pragma unroll
+                    for (int j = 0; j < kCells; ++j)
+                    {
+                        u32 m16 = M[r][j];
+                        const u64 anyhit = __ballot(m16 != 0u);
+                        if (!anyhit)
+                            continue;
+                        const u32 c = __popc(m16);
+                        u32 idx = out + wave_excl5(c);
+                        out += wave_sum5(c);
+                        const u64 lb = ubase + (u64)(r * kCells + j) * kCellBytes + (u64)lane * 16u + a.global_base;
+                        while (m16)
+                        {
+                            const u32 k = __builtin_ctz(m16);
+                            m16 &= m16 - 1u;
+                            if (idx < a.stage_cap)
+                                slot[idx] = lb + k;
+                            ++idx;
+                        }
+                    }
+                }
+            }
         }
-
-        // ---- ordered emission ------------------------------------------------------------------------
-        if (want_pos && wcnt)
+        else if (want_pos && wcnt > a.stage_cap)
         {
-            u64 out = excnt;
+            // ---- emit mode: this unit overflowed its staging slot; write its records in place -----------
+            u64 out = a.offsets[unit];
             if (out < a.pos_cap)
             {
 #pragma unroll
@@ -492,9 +450,9 @@ __global__ __launch_bounds__(kBlock) void lit_scan(const LitArgs a)
                             m16 &= m16 - 1u;
                             if (idx < a.pos_cap)
                             {
-                                const u64 s = lb + k, e = s + a.m;
-                                uint4 rec = make_uint4((u32)s, (u32)(s >> 32), (u32)e, (u32)(e >> 32));
-                                *reinterpret_cast<uint4 *>(a.positions + 2 * idx) = rec;
+                                const u64 st = lb + k, en = st + a.m;
+                                *reinterpret_cast<uint4 *>(a.positions + 2 * idx) =
+                                    make_uint4((u32)st, (u32)(st >> 32), (u32)en, (u32)(en >> 32));
                             }
                             ++idx;
                         }
@@ -504,13 +462,8 @@ __global__ __launch_bounds__(kBlock) void lit_scan(const LitArgs a)
         }
     }
 
-    if (lane == 0)
-    {
-        if (!chain && acc_total)
-            atomicAdd(&a.ctr->total, acc_total);
-        if (LINES && acc_lines)
-            atomicAdd(&a.ctr->lines, acc_lines);
-    }
+    if (lane == 0 && acc_total && !a.emit_mode)
+        atomicAdd(&a.ctr->total, acc_total);
 }
 
 // ---- launcher ----------------------------------------------------------------------------------

@@ -1,13 +1,12 @@
 // temporary stubs (replaced as the rows of SURVEY §8 are filled in)
 #include "kg_internal.h"
 namespace kg {
-void post_free(PostScratch &) {}
-int post_greedy_scan(PostScratch &, LitArgs, uint32_t, Counters *, Counters *, bool, bool, uint64_t *, uint64_t, hipStream_t,
-                     hipEvent_t, uint64_t *, uint64_t *, unsigned long long *)
+int post_greedy(PostScratch &, const uint8_t *, uint64_t, uint32_t, bool, bool, uint64_t, uint64_t *, uint64_t, Counters *,
+                Counters *, hipStream_t, uint64_t *, uint64_t *)
 { return fail("greedy post-pass not built yet"); }
 AcTables *ac_build(const search_params_t &, int) { fail("Aho-Corasick not built yet"); return nullptr; }
 void ac_free(AcTables *) {}
-int ac_scan(AcTables *, Counters *, Counters *, unsigned long long **, size_t *, int, const uint8_t *, size_t, size_t, size_t,
+int ac_scan(AcTables *, Counters *, Counters *, PostScratch &, int, const uint8_t *, size_t, size_t, size_t,
             size_t, match_position_t *, uint64_t, bool, bool, bool, size_t, hipStream_t, int, hipEvent_t, hipEvent_t,
             krep_gpu_scan_out_t *)
 { return fail("Aho-Corasick not built yet"); }

@@ -60,7 +60,7 @@ class Engine:
         L.krep_gpu_algorithm_name.restype = C.c_char_p
         L.krep_gpu_algorithm_name.argtypes = [C.c_int]
         for n in ("krep_gpu_set_reference_simd", "krep_gpu_set_only_matching", "krep_gpu_set_force_no_simd",
-                  "krep_gpu_set_algo_override", "krep_gpu_debug_force_rounds"):
+                  "krep_gpu_set_algo_override", "krep_gpu_debug_force_rounds", "krep_gpu_debug_force_stage_cap"):
             getattr(L, n).restype = None
             getattr(L, n).argtypes = [C.c_int]
         L.krep_gpu_get_reference_simd.restype = C.c_int
@@ -84,6 +84,9 @@ class Engine:
 
     def force_rounds(self, r: int):
         self.lib.krep_gpu_debug_force_rounds(r)
+
+    def force_stage_cap(self, c: int):
+        self.lib.krep_gpu_debug_force_stage_cap(c)
 
     def mirror_select(self, params: abi.Params, text_len: int) -> int:
         return int(self.lib.krep_gpu_mirror_select(params.ref, text_len))

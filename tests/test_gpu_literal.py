@@ -90,3 +90,19 @@ def test_dense_single_byte(gpu, oracle_engine):
                dict(whole_word=True), dict(case_sensitive=False)):
         _check(gpu, oracle_engine, text, b"#", kw, abi.REF_AVX2)
     _check(gpu, oracle_engine, text, b"A", dict(case_sensitive=False), abi.REF_AVX2)
+
+
+def test_staging_overflow_takes_emit_mode(gpu, oracle_engine):
+    """Units with more hits than their staging slot are re-scanned in emit mode: force tiny slots."""
+    rng = np.random.RandomState(9)
+    text = cases.rand_text(rng, 150_000, b"ab#\n")
+    try:
+        gpu.set_algo_override(abi.ALGO_BM)  # all-occurrence family for every pattern (--algo=bm, krep.c:1788)
+        for cap in (1, 3):
+            gpu.force_stage_cap(cap)
+            for pat, kw in ((b"#", dict()), (b"ab", dict()), (b"aba", dict(case_sensitive=False)),
+                            (b"a#ba#b", dict()), (b"ab", dict(max_count=1000)), (b"#", dict(whole_word=True))):
+                _check(gpu, oracle_engine, text, pat, kw, abi.REF_SCALAR)
+    finally:
+        gpu.force_stage_cap(0)
+        gpu.set_algo_override(abi.ALGO_AUTO)
