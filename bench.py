@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py — the measurement contract.
+
+A step = one pass of krep's literal-scan hot path over one synthetic haystack already resident in
+HBM: the HIP scan of the 8-byte case-sensitive literal 'Sherlock' (BASELINE.json configs[1]: 32 GiB,
+~1e-4 matches/byte, match offsets produced) + for N > 1 the single RCCL all-reduce of the per-GPU
+counts.  One process per GPU (torch.distributed, backend nccl == RCCL); the buffer is sharded by
+contiguous 32 GiB chunk per rank (weak scaling), each rank generates its own shard in HBM with the
+counter-based generator at global offset rank*shard.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+PATTERN = b"Sherlock"
+PERIOD = 10000
+SEED = 20260925
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+WORKLOADS = {
+    # name: (generator kind, patterns, params kwargs, plant, period)
+    "literal8": dict(kind=2, patterns=[PATTERN], kw=dict(), plant=PATTERN, period=PERIOD,
+                     desc="8-byte case-sensitive literal 'Sherlock', ~1e-4 matches/byte, offsets tracked"),
+    "memchr1": dict(kind=3, patterns=[b"#"], kw=dict(), plant=b"#", period=0,
+                    desc="single byte '#', ~1% hit rate, offsets tracked (worst-case compaction)"),
+}
+
+
+def cpu_baseline(eng, wl, sample_bytes, d_buf):
+    """krep's own CPU path on this host's cores, on a bounded sample of the same workload."""
+    import ctypes as C
+    import threading
+    import numpy as np
+    import torch
+    import oracle_lib as ol
+    from krep_amd import abi
+
+    n = sample_bytes
+    host = torch.empty(n, dtype=torch.uint8, pin_memory=True)
+    host.copy_(d_buf[:n])
+    torch.cuda.synchronize()
+    text = host.numpy()
+    cores = os.cpu_count() or 1
+    threads = cores
+    flags = ol._cpu_flags()
+    level = abi.REF_AVX512 if {"avx512f", "avx512bw"} <= flags else abi.REF_AVX2 if "avx2" in flags else abi.REF_SSE42
+    ref = None
+    for lv in (level, abi.REF_AVX2, abi.REF_SSE42, abi.REF_SCALAR):
+        if lv <= level and ol.ref_available(lv):
+            ref = ol.ref(lv)
+            break
+    p = abi.Params(wl["patterns"], count_lines=True, only_match=True, **wl["kw"])  # -c -o: count matches
+    m = max(len(x) for x in wl["patterns"])
+    chunk = (n + threads - 1) // threads
+    if ref is not None:
+        kind = "reference"
+        algo = ref.select(p)
+        fn = getattr(ref.lib, ref.fn[algo])
+        name = f"oracle/_ref/{ol._REF_FILES[ref.level]}:{ref.fn[algo]}"
+    else:
+        kind = "port"
+        o = ol.oracle()
+        algo = o.select(p, abi.REF_SCALAR)
+        fn = getattr(o.lib, o.fn[algo])
+        name = f"oracle/liboracle_krep.so:{o.fn[algo]}"
+    counts = [0] * threads
+    base = text.ctypes.data
+
+    def work(i):  # search_chunk_thread(): one search_func_t call per chunk, overlap = m-1 (krep.c:2851-2905)
+        b = i * chunk
+        if b >= n:
+            return
+        ln = min(chunk + (m - 1 if i != threads - 1 else 0), n - b)
+        counts[i] = fn(p.ref, C.c_void_p(base + b), ln, None)
+
+    best = None
+    t_all = time.time()
+    reps = 0
+    while reps < 3 or (time.time() - t_all < 10 and reps < 20):
+        ths = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
+        t0 = time.time()
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        dt = time.time() - t0
+        best = dt if best is None else min(best, dt)
+        reps += 1
+    return dict(value=round(n / best / 1e9, 3), unit="GB/s", cores=threads, kind=kind,
+                sample=f"{n / 2**30:.1f} GiB slice of the same haystack, {threads} threads x {name}, "
+                       f"chunk+overlap as krep.c:2851-2905, best of {reps}, count={sum(counts)}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="literal8", choices=sorted(WORKLOADS))
+    ap.add_argument("--gib", type=float, default=32.0, help="haystack GiB per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-gib", type=float, default=4.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import krep_amd
+    from krep_amd import abi
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 or world > 1:
+        assert world == args.gpus, f"launch with torchrun --nproc-per-node {args.gpus}"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    wl = WORKLOADS[args.workload]
+    eng = krep_amd.load()
+    n = int(args.gib * (1 << 30))
+    shard_off = rank * n                      # contiguous chunk per rank
+    halo = 64                                 # >= pattern_len-1 bytes of the next shard (start-ownership)
+    buf = torch.empty(n + halo, dtype=torch.uint8, device=dev)
+    eng.generate(buf.data_ptr(), n + halo, shard_off, wl["kind"], SEED, wl["plant"], wl["period"])
+    last = rank == world - 1
+    text_len = n if last else n + halo        # the global text ends with the last shard
+    params = abi.Params(wl["patterns"], **wl["kw"])
+    plan = eng.plan(params, device=local)
+    density = 1.0 / 100 if wl["kind"] == 3 else 1.0 / wl["period"]
+    cap = int(n * density * 1.25) + 4096
+    pos = torch.empty(cap * 2, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    counts = torch.zeros(2, dtype=torch.int64, device=dev)
+
+    def step():
+        out = plan.scan(buf.data_ptr(), text_len, 0, n, shard_off, pos.data_ptr(), cap, stream, True)
+        if world > 1:
+            counts[0] = out.count
+            counts[1] = out.total_matches
+            dist.all_reduce(counts)           # the one RCCL all-reduce of the per-GPU counts
+        return out
+
+    for _ in range(args.warmup):
+        out = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    k_ms = 0.0
+    for _ in range(args.steps):
+        out = step()
+        k_ms += out.kernel_ms
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        total_matches = int(counts[1].item())
+    else:
+        total_matches = int(out.total_matches)
+    assert not out.overflow, "position buffer too small"
+
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        total_bytes = n * world
+        value = total_bytes / (dt / args.steps) / 1e9
+        k_avg_ms = k_ms / args.steps
+        achieved = n / (k_avg_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(args.workload, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "GB/s scanned (literal scan, match offsets produced), haystack resident in HBM",
+            "value": round(value, 1), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {wl['desc']}; {args.gib:g} GiB per GPU "
+                                   f"(BASELINE.json configs[1]{' x' + str(world) + ' shards = configs[4] shape' if world > 1 else ''})",
+                       "pattern": wl["patterns"][0].decode("latin-1"), "bytes_per_gpu": n, "matches": total_matches,
+                       "matches_per_s": round(total_matches / (dt / args.steps), 1),
+                       "parallelism": f"contiguous shards x{world}, start-offset ownership, 1 RCCL all-reduce of counts"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": "kg::lit_scan + post-pass, hipEvent-timed on the launch stream",
+                         "kernel_ms": round(k_avg_ms, 4), "algorithmic_bytes_per_launch": n},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(eng, wl, min(n, int(args.cpu_sample_gib * (1 << 30))), buf)
+            except Exception as e:  # the baseline is reported, never required
+                line["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": os.cpu_count(), "kind": "port",
+                                        "sample": f"failed: {e}"}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -104,23 +104,37 @@ __global__ __launch_bounds__(kPostBlock) void post_reduce(const u64 *__restrict_
     }
 }
 
-// sequential walk over the block records (n_blocks = units/1024: 1024 for a 32 GiB shard)
-__global__ void post_carry(u64 n_blocks, u64 *__restrict__ blk_sum, u64 *__restrict__ blk_bits, Counters *ctr)
+// one wave scans the block records 64 at a time (n_blocks = units/1024: 1024 for a 32 GiB shard)
+__global__ __launch_bounds__(64) void post_carry(u64 n_blocks, u64 *__restrict__ blk_sum, u64 *__restrict__ blk_bits, Counters *ctr)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0)
-        return;
-    u64 run = 0;
-    Bits c{false, false, false};
-    for (u64 b = 0; b < n_blocks; ++b)
+    const u32 lane = plane_id();
+    u64 run = 0;                 // hits in all earlier blocks (uniform)
+    Bits c{false, false, false}; // composition of all earlier blocks (uniform)
+    for (u64 b0 = 0; b0 < n_blocks; b0 += 64)
     {
-        const u64 s = blk_sum[b];
-        const Bits bb = bits_of(blk_bits[b]);
-        blk_sum[b] = run;                           // exclusive offset of the block
-        blk_bits[b] = c.tail ? 1ull : 0ull;         // a matched line is open on entry to the block
-        run += s;
-        c = compose(c, bb);
+        const u64 b = b0 + lane;
+        const bool live = b < n_blocks;
+        const u64 s = live ? blk_sum[b] : 0ull;
+        const Bits mine = live ? bits_of(blk_bits[b]) : Bits{false, false, false};
+        u64 incl = s;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1)
+        {
+            const u64 v = __shfl_up(incl, o);
+            if (lane >= (u32)o)
+                incl += v;
+        }
+        const bool open = wave_open_in(mine, c.tail, lane);
+        if (live)
+        {
+            blk_sum[b] = run + (incl - s);      // exclusive offset of the block
+            blk_bits[b] = open ? 1ull : 0ull;   // a matched line is open on entry to the block
+        }
+        run += __shfl(incl, 63);
+        c = compose(c, wave_compose(mine));
     }
-    ctr->summary = word_of(c);
+    if (lane == 0)
+        ctr->summary = word_of(c);
 }
 
 __global__ __launch_bounds__(kPostBlock) void post_offsets(const u64 *__restrict__ info, u64 n_units,
