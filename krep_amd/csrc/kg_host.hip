@@ -454,9 +454,13 @@ static int scan_literal(krep_gpu_plan *pl, int algo, const uint8_t *d_text, size
         else if (algo == KREP_RA_MEMCHR_SHORT)
             return kg::fail("memchr_short_search with -o (krep.c:4495 skips after failed candidates) is not supported");
     }
-    const bool need_post = greedy && pl->has_border && m > 1;
+    bool need_post = greedy && pl->has_border && m > 1;
     if (need_post && pl->has_newline && pl->lines)
         return kg::fail("greedy (SSE4.2/KMP) line counting with a pattern containing a newline is not supported");
+    // without -w a line holds a greedy hit iff it holds any occurrence (a line's first occurrence heads a
+    // cluster), so plain -c needs no selection pass
+    if (need_post && pl->lines && !pl->ww)
+        need_post = false;
 
     LitArgs a{};
     a.text = d_text;
@@ -565,7 +569,46 @@ static int scan_literal(krep_gpu_plan *pl, int algo, const uint8_t *d_text, size
     }
     else
     {
-        return kg::fail("greedy post-pass not wired yet");
+        // family N with a bordered pattern: all occurrences first, then the greedy selection (kg_greedy.hip)
+        const bool ww_first = pl->ww && algo == KREP_RA_BMH; // BMH -o: a -w rejected hit does not consume (krep.c:1323-1329)
+        if (ww_first) a.flags |= F_WW;
+        HIPCHK(hipMemsetAsync(pl->d_ctr, 0, sizeof(Counters), st));
+        HIPCHK(launch_literal(a, grid, st));
+        if (post_offsets_pass(pl->post, n_units, false, pl->d_ctr, st))
+            return 2;
+        HIPCHK(hipMemcpyAsync(pl->h_ctr, pl->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        const uint64_t n_occ = pl->h_ctr->total;
+        if (n_occ > pl->post.occ_cap)
+        {
+            if (pl->post.d_occ) (void)hipFree(pl->post.d_occ);
+            pl->post.d_occ = nullptr;
+            pl->post.occ_cap = 0;
+            HIPCHK(hipMalloc(&pl->post.d_occ, n_occ * 2 * sizeof(uint64_t)));
+            pl->post.occ_cap = n_occ;
+        }
+        if (n_occ)
+        {
+            if (post_gather_pass(pl->post, n_units, a.stage_cap, m, pl->post.d_occ, n_occ, pl->num_cu, st))
+                return 2;
+            if (pl->h_ctr->overflow_units)
+            {
+                LitArgs e = a;
+                e.emit_mode = 1;
+                e.positions = pl->post.d_occ;
+                e.pos_cap = n_occ;
+                HIPCHK(hipMemsetAsync(&pl->d_ctr->ticket, 0, sizeof(unsigned long long), st));
+                HIPCHK(launch_literal(e, grid, st));
+            }
+            HIPCHK(hipMemsetAsync(pl->d_ctr, 0, sizeof(Counters), st));
+            int rc = post_greedy(pl->post, d_text, text_len, global_base, m, pl->ww && !ww_first, pl->lines, n_occ,
+                                 (uint64_t *)d_pos, want, pl->d_ctr, pl->h_ctr, st, &total, &lines);
+            if (rc)
+                return rc;
+        }
+        if (time_it) HIPCHK(hipEventRecord(pl->ev1, st));
+        HIPCHK(hipStreamSynchronize(st));
+        summary = total ? (kLnHead | kLnTail) : 0; // shard line bits are not produced on this path
     }
     if (time_it)
     {

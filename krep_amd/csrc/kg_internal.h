@@ -21,17 +21,24 @@ struct PostScratch
     unsigned long long *d_stage = nullptr;    // [units * stage_cap] staged, unit-ordered hit words
     uint64_t stage_cap_words = 0;
     uint64_t *d_occ = nullptr;                // all-occurrence records for the greedy (family N) filter
-    uint64_t occ_cap = 0;
+    uint64_t occ_cap = 0;                     // in records
+    uint8_t *d_keep = nullptr;                // greedy survivor flags
+    unsigned long long *d_gblk = nullptr;     // compaction block counts
+    unsigned long long *d_surv = nullptr;     // compacted survivors (line counting)
+    uint64_t keep_cap = 0;
 };
 void post_free(PostScratch &s);
 int post_reserve(PostScratch &s, uint64_t n_units, uint64_t stage_words);
 // K1..K4 on `st`: offsets, distinct-line total (ctr->lines), line summary (ctr->summary), gather into d_pos
 int post_order(PostScratch &s, uint64_t n_units, uint32_t stage_cap, uint32_t fixed_len, bool want_lines, uint64_t *d_pos,
                uint64_t pos_cap, Counters *d_ctr, int num_cu, hipStream_t st);
+int post_offsets_pass(PostScratch &s, uint64_t n_units, bool want_lines, Counters *d_ctr, hipStream_t st);
+int post_gather_pass(PostScratch &s, uint64_t n_units, uint32_t stage_cap, uint32_t fixed_len, uint64_t *d_pos,
+                     uint64_t pos_cap, int num_cu, hipStream_t st);
 // greedy non-overlapping selection (simd_sse42_search / kmp_search family) on the ordered occurrence list
-int post_greedy(PostScratch &s, const uint8_t *d_text, uint64_t text_len, uint32_t m, bool ww, bool lines, uint64_t n_occ,
-                uint64_t *d_pos, uint64_t want, Counters *d_ctr, Counters *h_ctr, hipStream_t st, uint64_t *total,
-                uint64_t *nlines);
+int post_greedy(PostScratch &s, const uint8_t *d_text, uint64_t text_len, uint64_t global_base, uint32_t m, bool ww,
+                bool lines, uint64_t n_occ, uint64_t *d_pos, uint64_t want, Counters *d_ctr, Counters *h_ctr, hipStream_t st,
+                uint64_t *total, uint64_t *nlines);
 
 // kg_ac.hip — multi-pattern scan
 struct AcTables;

@@ -284,6 +284,9 @@ void post_free(PostScratch &s)
     if (s.d_blk) (void)hipFree(s.d_blk);
     if (s.d_stage) (void)hipFree(s.d_stage);
     if (s.d_occ) (void)hipFree(s.d_occ);
+    if (s.d_keep) (void)hipFree(s.d_keep);
+    if (s.d_gblk) (void)hipFree(s.d_gblk);
+    if (s.d_surv) (void)hipFree(s.d_surv);
     s = PostScratch{};
 }
 
@@ -319,8 +322,7 @@ int post_reserve(PostScratch &s, uint64_t n_units, uint64_t stage_words)
     return 0;
 }
 
-int post_order(PostScratch &s, uint64_t n_units, uint32_t stage_cap, uint32_t fixed_len, bool want_lines, uint64_t *d_pos,
-               uint64_t pos_cap, Counters *d_ctr, int num_cu, hipStream_t st)
+int post_offsets_pass(PostScratch &s, uint64_t n_units, bool want_lines, Counters *d_ctr, hipStream_t st)
 {
     const uint64_t nb = (n_units + kPostUnitsPerBlock - 1) / kPostUnitsPerBlock;
     u64 *blk_sum = (u64 *)s.d_blk, *blk_bits = (u64 *)s.d_blk + nb;
@@ -329,15 +331,29 @@ int post_order(PostScratch &s, uint64_t n_units, uint32_t stage_cap, uint32_t fi
     hipLaunchKernelGGL(post_carry, dim3(1), dim3(64), 0, st, (u64)nb, blk_sum, blk_bits, d_ctr);
     hipLaunchKernelGGL(post_offsets, dim3((u32)nb), dim3(kPostBlock), 0, st, (const u64 *)s.d_unitinfo, (u64)n_units,
                        (const u64 *)blk_sum, (const u64 *)blk_bits, (u64 *)s.d_offsets, d_ctr, want_lines ? 1 : 0);
-    if (d_pos && pos_cap)
-    {
-        const uint64_t groups = (n_units + 63) / 64;
-        const u32 grid = (u32)std::min<uint64_t>((groups + 3) / 4, (uint64_t)num_cu * 16);
-        hipLaunchKernelGGL(post_gather, dim3(grid ? grid : 1), dim3(kPostBlock), 0, st, (const u64 *)s.d_unitinfo, (u64)n_units,
-                           (const u64 *)s.d_offsets, (const u64 *)s.d_stage, stage_cap, fixed_len, (u64 *)d_pos, (u64)pos_cap);
-    }
     PCHK(hipGetLastError());
     return 0;
+}
+
+int post_gather_pass(PostScratch &s, uint64_t n_units, uint32_t stage_cap, uint32_t fixed_len, uint64_t *d_pos,
+                     uint64_t pos_cap, int num_cu, hipStream_t st)
+{
+    if (!d_pos || !pos_cap)
+        return 0;
+    const uint64_t groups = (n_units + 63) / 64;
+    const u32 grid = (u32)std::min<uint64_t>((groups + 3) / 4, (uint64_t)num_cu * 16);
+    hipLaunchKernelGGL(post_gather, dim3(grid ? grid : 1), dim3(kPostBlock), 0, st, (const u64 *)s.d_unitinfo, (u64)n_units,
+                       (const u64 *)s.d_offsets, (const u64 *)s.d_stage, stage_cap, fixed_len, (u64 *)d_pos, (u64)pos_cap);
+    PCHK(hipGetLastError());
+    return 0;
+}
+
+int post_order(PostScratch &s, uint64_t n_units, uint32_t stage_cap, uint32_t fixed_len, bool want_lines, uint64_t *d_pos,
+               uint64_t pos_cap, Counters *d_ctr, int num_cu, hipStream_t st)
+{
+    if (post_offsets_pass(s, n_units, want_lines, d_ctr, st))
+        return 2;
+    return post_gather_pass(s, n_units, stage_cap, fixed_len, d_pos, pos_cap, num_cu, st);
 }
 
 } // namespace kg

@@ -1,9 +1,6 @@
 // temporary stubs (replaced as the rows of SURVEY §8 are filled in)
 #include "kg_internal.h"
 namespace kg {
-int post_greedy(PostScratch &, const uint8_t *, uint64_t, uint32_t, bool, bool, uint64_t, uint64_t *, uint64_t, Counters *,
-                Counters *, hipStream_t, uint64_t *, uint64_t *)
-{ return fail("greedy post-pass not built yet"); }
 AcTables *ac_build(const search_params_t &, int) { fail("Aho-Corasick not built yet"); return nullptr; }
 void ac_free(AcTables *) {}
 int ac_scan(AcTables *, Counters *, Counters *, PostScratch &, int, const uint8_t *, size_t, size_t, size_t,

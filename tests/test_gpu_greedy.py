@@ -1,0 +1,85 @@
+"""GPU parity for the greedy non-overlapping family (simd_sse42_search / kmp_search) with BORDERED
+patterns, where the all-occurrence set and the reference's set differ (test/test_krep.c:444-477)."""
+import numpy as np
+import pytest
+
+import cases
+import oracle_lib as ol
+from krep_amd import abi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import krep_amd
+    e = krep_amd.load()
+    assert e.device_count() >= 1
+    return e
+
+
+def _check(gpu, o, text, pat, kw, level):
+    gpu.set_reference_simd(level)
+    p = abi.Params([pat], **kw)
+    algo = gpu.mirror_select(p, text.size)
+    want = o.call(algo, abi.Params([pat], **kw), text)
+    got = gpu.search(p, text)
+    assert got[0] == want[0], (abi.RA_NAMES[algo], pat, kw, text.size, got[0], want[0])
+    assert np.array_equal(got[1], want[1]), (abi.RA_NAMES[algo], pat, kw, text.size, got[1][:8], want[1][:8])
+    return algo
+
+
+def test_reference_overlap_vectors(gpu, oracle_engine):
+    # 'aba' in 'abababa': BM 3, KMP/SSE4.2 2; 'aa' in 'aaaaa': BM 4, KMP/SSE4.2 2 (test_krep.c:444-477)
+    for text, pat, n_o, n_n in ((b"abababa", b"aba", 3, 2), (b"aaaaa", b"aa", 4, 2)):
+        t = np.frombuffer(text, dtype=np.uint8)
+        gpu.set_reference_simd(abi.REF_AVX2)
+        assert gpu.search(abi.Params([pat]), t)[0] == n_n          # SSE4.2 path of an AVX2 build
+        gpu.set_reference_simd(abi.REF_SCALAR)
+        gpu.set_algo_override(abi.ALGO_BM)
+        assert gpu.search(abi.Params([pat]), t)[0] == n_o
+        gpu.set_algo_override(abi.ALGO_KMP)
+        assert gpu.search(abi.Params([pat]), t)[0] == n_n
+        gpu.set_algo_override(abi.ALGO_AUTO)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_bordered_patterns(gpu, oracle_engine, seed):
+    rng = np.random.RandomState(300 + seed)
+    pats = [b"aa", b"aba", b"abab", b"aaaa", b"abaab", b"a-a", b"ab\nab", b"aabaa", b"abcabcab", b"a" * 16, b"ab" * 8]
+    seen = set()
+    for i in range(60):
+        alpha = [b"ab", b"ab\n", b"ab-\n ", b"abc"][i % 4]
+        n = [5, 40, 1000, 8192, 8200, 33000, 70000][rng.randint(0, 7)]
+        text = cases.rand_text(rng, n, alpha)
+        pat = pats[rng.randint(0, len(pats))]
+        kw = dict(whole_word=bool(rng.rand() < 0.3), max_count=[abi.SIZE_MAX, abi.SIZE_MAX, 1, 3, 50][rng.randint(0, 5)])
+        mode = ["pos", "lines", "count"][rng.randint(0, 3)]
+        if mode == "lines":
+            if b"\n" in pat:
+                continue
+            kw.update(count_lines=True)
+        elif mode == "count":
+            kw.update(count_lines=True, only_match=True)
+        level = [abi.REF_AVX2, abi.REF_SSE42, abi.REF_AVX512][i % 3]
+        seen.add(_check(gpu, oracle_engine, text, pat, kw, level))
+    assert abi.RA_SSE42 in seen
+
+
+def test_kmp_selection_and_extra_record(gpu, oracle_engine):
+    """Scalar build: repetitive 4..7-byte patterns go to kmp_search (krep.c:1860-1865), which also stores
+    the (max_count+1)-th match before breaking (krep.c:1717-1724)."""
+    rng = np.random.RandomState(11)
+    text = cases.rand_text(rng, 50000, b"ab")
+    for pat in (b"abab", b"aaaa", b"ababab", b"aabaab"):
+        for kw in (dict(), dict(max_count=5), dict(count_lines=True, only_match=True), dict(whole_word=True),
+                   dict(case_sensitive=False, max_count=2)):
+            algo = _check(gpu, oracle_engine, text, pat, kw, abi.REF_SCALAR)
+            assert algo == abi.RA_KMP
+
+
+def test_giant_cluster(gpu, oracle_engine):
+    text = np.full(300_000, ord("a"), dtype=np.uint8)
+    for pat in (b"aa", b"aaa", b"aaaaaaa"):
+        _check(gpu, oracle_engine, text, pat, dict(), abi.REF_AVX2)
+        _check(gpu, oracle_engine, text, pat, dict(max_count=1000), abi.REF_AVX2)
