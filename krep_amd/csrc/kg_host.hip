@@ -62,7 +62,8 @@ extern "C" void krep_gpu_set_force_no_simd(int on) { g_no_simd = on != 0; }
 extern "C" void krep_gpu_set_algo_override(int a) { g_algo_override = a; }
 static int g_force_rounds = 0; // test hook: 0 = auto, 1 / 4 = force the tile shape
 static int g_force_stage_cap = 0; // test hook: staging records per unit (0 = auto)
-extern "C" void krep_gpu_debug_force_stage_cap(int c) { g_force_stage_cap = c; }
+namespace kg { extern int g_ac_force_stage_cap; }
+extern "C" void krep_gpu_debug_force_stage_cap(int c) { g_force_stage_cap = c; kg::g_ac_force_stage_cap = c; }
 extern "C" void krep_gpu_debug_force_rounds(int r) { g_force_rounds = r; }
 
 static inline uint8_t lo8(uint8_t c) { return (c >= 'A' && c <= 'Z') ? (uint8_t)(c + 32) : c; }

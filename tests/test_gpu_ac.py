@@ -1,0 +1,91 @@
+"""GPU parity for the multi-pattern scan against the oracle restatement of aho_corasick_search
+(count, every (start,end) record, and the reference's emission order: end ascending, longest first)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import cases
+from krep_amd import abi
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import krep_amd
+    e = krep_amd.load()
+    assert e.device_count() >= 1
+    return e
+
+
+def _check(gpu, o, text, pats, kw):
+    want = o.call(abi.RA_AHO_CORASICK, abi.Params(pats, **kw), text)
+    got = gpu.search(abi.Params(pats, **kw), text)
+    assert got[0] == want[0], (pats[:6], kw, len(text), got[0], want[0])
+    assert np.array_equal(got[1], want[1]), (pats[:6], kw, got[1][:8], want[1][:8])
+
+
+def test_reference_vectors(gpu, oracle_engine):
+    kat = [v for v in json.load(open(os.path.join(HERE, "golden", "reference_kat.json"))) if v["algos"] == ["ac"]]
+    assert len(kat) >= 10
+    for v in kat:
+        kw = dict(case_sensitive=v["case_sensitive"], max_count=abi.SIZE_MAX if v["max_count"] is None else v["max_count"],
+                  track_positions=bool(v["track_positions"]))
+        p = abi.Params([s.encode() for s in v["patterns"]], **kw)
+        ret, pos = gpu.search(p, v["text"].encode())
+        assert ret == v["expect"], v["src"]
+        if v["expect_result_count"] is not None:
+            assert len(pos) == v["expect_result_count"], v["src"]
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_random_pattern_sets(gpu, oracle_engine, seed):
+    rng = np.random.RandomState(500 + seed)
+    for it in range(40):
+        alpha = [b"ab", b"abc\n", b"abAB -\n", bytes(range(97, 105)) + b" \n"][it % 4]
+        n = [0, 3, 17, 500, 8192, 8195, 40000, 140000][rng.randint(0, 8)]
+        text = cases.rand_text(rng, n, alpha)
+        k = [2, 3, 5, 9, 40][rng.randint(0, 5)]
+        lens = [[1, 2, 3], [2, 3, 4, 6], [4, 5, 8, 16], [1, 4, 9, 30], [3, 3, 3]][rng.randint(0, 5)]
+        pats = [cases.pick_pattern(rng, text, lens[rng.randint(0, len(lens))], alpha) for _ in range(k)]
+        if rng.rand() < 0.3:
+            pats.append(pats[0])  # duplicate pattern: the reference emits it twice
+        kw = dict(case_sensitive=bool(rng.rand() < 0.6), whole_word=bool(rng.rand() < 0.25),
+                  max_count=[abi.SIZE_MAX, abi.SIZE_MAX, abi.SIZE_MAX, 0, 1, 4, 77][rng.randint(0, 7)])
+        mode = ["pos", "pos", "lines", "count"][rng.randint(0, 4)]
+        if mode == "lines":
+            if any(b"\n" in p for p in pats):
+                continue
+            kw.update(count_lines=True)
+        elif mode == "count":
+            kw.update(count_lines=True, only_match=True)
+        _check(gpu, oracle_engine, text, pats, kw)
+
+
+def test_thousand_patterns(gpu, oracle_engine):
+    """BASELINE config 4 in miniature: 1000 patterns of length 4..16 over a-z, planted + chance hits."""
+    rng = np.random.RandomState(1234)
+    az = bytes(range(97, 123))
+    pats = [cases.rand_text(rng, rng.randint(4, 17), az).tobytes() for _ in range(1000)]
+    text = cases.rand_text(rng, 1 << 21, az + b"  \n")
+    for _ in range(3000):
+        p = np.frombuffer(pats[rng.randint(0, 1000)], dtype=np.uint8)
+        s = rng.randint(0, text.size - p.size)
+        text[s:s + p.size] = p
+    _check(gpu, oracle_engine, text, pats, dict())
+    _check(gpu, oracle_engine, text, pats, dict(count_lines=True))
+    _check(gpu, oracle_engine, text, pats, dict(max_count=1000))
+    _check(gpu, oracle_engine, text, pats, dict(case_sensitive=False, whole_word=True))
+
+
+def test_dense_nested(gpu, oracle_engine):
+    text = np.frombuffer(b"abc" * 20000, dtype=np.uint8)
+    _check(gpu, oracle_engine, text, [b"a", b"b", b"c", b"ab", b"bc", b"abc", b"cab", b"abcabc"], dict())
+    try:
+        gpu.force_stage_cap(4)
+        _check(gpu, oracle_engine, text, [b"a", b"ab", b"abc", b"bca"], dict())
+    finally:
+        gpu.force_stage_cap(0)
