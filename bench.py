@@ -25,12 +25,33 @@ PERIOD = 10000
 SEED = 20260925
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
+def ac_patterns(n=1000, seed=1234):
+    """BASELINE configs[3]: 1000 literal patterns, lengths uniform 4..16 over a-z (SURVEY.md §8d cfg 4)."""
+    import random
+    rng = random.Random(seed)
+    return [bytes(rng.randrange(97, 123) for _ in range(rng.randint(4, 16))) for _ in range(n)]
+
+
+def pack_dict(pats):
+    import struct
+    head = struct.pack("<I", len(pats))
+    off = 4 + 8 * len(pats)
+    body = b""
+    for p in pats:
+        head += struct.pack("<II", off + len(body), len(p))
+        body += p
+    return head + body
+
+
 WORKLOADS = {
     # name: (generator kind, patterns, params kwargs, plant, period)
     "literal8": dict(kind=2, patterns=[PATTERN], kw=dict(), plant=PATTERN, period=PERIOD,
                      desc="8-byte case-sensitive literal 'Sherlock', ~1e-4 matches/byte, offsets tracked"),
     "memchr1": dict(kind=3, patterns=[b"#"], kw=dict(), plant=b"#", period=0,
                     desc="single byte '#', ~1% hit rate, offsets tracked (worst-case compaction)"),
+    "ac1000": dict(kind=4, patterns=None, kw=dict(), plant=None, period=4096,
+                   desc="Aho-Corasick replacement: 1000 literal patterns (len 4-16, a-z), one planted per 4 KiB + "
+                        "chance hits, offsets tracked in the reference's (end, longest-first) order"),
 }
 
 
@@ -59,18 +80,23 @@ def cpu_baseline(eng, wl, sample_bytes, d_buf):
             break
     p = abi.Params(wl["patterns"], count_lines=True, only_match=True, **wl["kw"])  # -c -o: count matches
     m = max(len(x) for x in wl["patterns"])
+    multi = len(wl["patterns"]) > 1
     chunk = (n + threads - 1) // threads
     if ref is not None:
         kind = "reference"
         algo = ref.select(p)
         fn = getattr(ref.lib, ref.fn[algo])
         name = f"oracle/_ref/{ol._REF_FILES[ref.level]}:{ref.fn[algo]}"
+        if multi:
+            p.s.ac_trie = ref._acb(p.ref)      # the caller builds the trie once (krep.c:2528-2535)
     else:
         kind = "port"
         o = ol.oracle()
         algo = o.select(p, abi.REF_SCALAR)
         fn = getattr(o.lib, o.fn[algo])
         name = f"oracle/liboracle_krep.so:{o.fn[algo]}"
+        if multi:
+            p.s.ac_trie = o._acb(p.ref)
     counts = [0] * threads
     base = text.ctypes.data
 
@@ -125,7 +151,10 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    wl = WORKLOADS[args.workload]
+    wl = dict(WORKLOADS[args.workload])
+    if wl["patterns"] is None:
+        wl["patterns"] = ac_patterns()
+        wl["plant"] = pack_dict(wl["patterns"])
     eng = krep_amd.load()
     n = int(args.gib * (1 << 30))
     shard_off = rank * n                      # contiguous chunk per rank
@@ -136,7 +165,7 @@ def main():
     text_len = n if last else n + halo        # the global text ends with the last shard
     params = abi.Params(wl["patterns"], **wl["kw"])
     plan = eng.plan(params, device=local)
-    density = 1.0 / 100 if wl["kind"] == 3 else 1.0 / wl["period"]
+    density = 1.0 / 100 if wl["kind"] == 3 else 1.0 / wl["period"] + (2.5e-4 if wl["kind"] == 4 else 0)
     cap = int(n * density * 1.25) + 4096
     pos = torch.empty(cap * 2, dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
@@ -193,12 +222,14 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {wl['desc']}; {args.gib:g} GiB per GPU "
                                    f"(BASELINE.json configs[1]{' x' + str(world) + ' shards = configs[4] shape' if world > 1 else ''})",
-                       "pattern": wl["patterns"][0].decode("latin-1"), "bytes_per_gpu": n, "matches": total_matches,
+                       "pattern": wl["patterns"][0].decode("latin-1") if len(wl["patterns"]) == 1
+                       else f"{len(wl['patterns'])} patterns", "bytes_per_gpu": n, "matches": total_matches,
                        "matches_per_s": round(total_matches / (dt / args.steps), 1),
                        "parallelism": f"contiguous shards x{world}, start-offset ownership, 1 RCCL all-reduce of counts"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "kg::lit_scan + post-pass, hipEvent-timed on the launch stream",
+                         "kernel": ("kg::ac_scan_kernel" if len(wl["patterns"]) > 1 else "kg::lit_scan")
+                         + " + post-pass, hipEvent-timed on the launch stream",
                          "kernel_ms": round(k_avg_ms, 4), "algorithmic_bytes_per_launch": n},
         }
         if world == 1 and not args.no_cpu_baseline:

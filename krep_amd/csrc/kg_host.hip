@@ -58,6 +58,7 @@ static int g_simd = KREP_REF_AVX2, g_only_matching = 0, g_no_simd = 0, g_algo_ov
 extern "C" void krep_gpu_set_reference_simd(int l) { g_simd = l; }
 extern "C" int krep_gpu_get_reference_simd(void) { return g_simd; }
 extern "C" void krep_gpu_set_only_matching(int on) { g_only_matching = on != 0; }
+namespace kg { int current_only_matching() { return g_only_matching; } }
 extern "C" void krep_gpu_set_force_no_simd(int on) { g_no_simd = on != 0; }
 extern "C" void krep_gpu_set_algo_override(int a) { g_algo_override = a; }
 static int g_force_rounds = 0; // test hook: 0 = auto, 1 / 4 = force the tile shape

@@ -1,0 +1,95 @@
+"""search_buffer() and the sharded path: N logical shards (start-offset ownership) must reproduce the
+single-chunk oracle exactly — unlike the reference's own chunking.  On a 1-GPU box the
+shards share device 0; the sharding, halo and merge logic is identical."""
+import numpy as np
+import pytest
+
+import cases
+from krep_amd import abi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import krep_amd
+    e = krep_amd.load()
+    assert e.device_count() >= 1
+    return e
+
+
+def _oracle(o, gpu, pats, kw, text):
+    p = abi.Params(pats, **kw)
+    algo = abi.RA_AHO_CORASICK if len(pats) > 1 else gpu.mirror_select(p, text.size)
+    return o.call(algo, abi.Params(pats, **kw), text)
+
+
+def _verdict(want_ret, want_pos, kw):
+    """search_string()'s clamp + exit code (krep.c:2176-2199)."""
+    maxc = kw.get("max_count", abi.SIZE_MAX)
+    n = min(want_ret, maxc)
+    cnt = min(len(want_pos), maxc)
+    counting = kw.get("count_lines", False)
+    if counting:
+        return (0 if n > 0 else 1), n, cnt
+    return (0 if cnt > 0 else 1), (cnt if cnt > 0 else n), cnt
+
+
+@pytest.mark.parametrize("shards", [1, 2, 3, 8])
+def test_search_buffer_sharded(gpu, oracle_engine, shards):
+    rng = np.random.RandomState(40 + shards)
+    gpu.set_reference_simd(abi.REF_AVX2)
+    text = cases.rand_text(rng, 100_003, b"abcd \n")
+    jobs = [([b"abcd"], dict()), ([b"d"], dict(count_lines=True)), ([b"ab"], dict(whole_word=True)),
+            ([b"abc", b"cd", b"d ab", b"a"], dict()), ([b"abc", b"bcd"], dict(count_lines=True)),
+            ([b"ab cd"], dict(count_lines=True, only_match=True)), ([b"cab"], dict(max_count=10)),
+            ([b"abab"], dict()), ([b"ca", b"a"], dict(max_count=50, whole_word=True)),
+            ([b"a\nb"], dict()), ([b"dab"], dict(case_sensitive=False, count_lines=True))]
+    for pats, kw in jobs:
+        want_ret, want_pos = _oracle(oracle_engine, gpu, pats, kw, text)
+        rc, n, pos = gpu.search_buffer(abi.Params(pats, **kw), text, num_gpus=shards)
+        erc, en, ecnt = _verdict(want_ret, want_pos, kw)
+        assert rc == erc and n == en, (pats, kw, shards, rc, n, erc, en)
+        track = not (kw.get("count_lines") and not kw.get("only_match"))
+        if track:
+            assert np.array_equal(pos, want_pos[:ecnt]), (pats, kw, shards)
+
+
+def test_search_buffer_validation(gpu):
+    t = np.frombuffer(b"hello world", dtype=np.uint8)
+    assert gpu.search_buffer(abi.Params([]), t)[0] == 2                      # krep.c:2013
+    assert gpu.search_buffer(abi.Params([b"a", b""]), t)[0] == 2             # krep.c:2035
+    assert gpu.search_buffer(abi.Params([b"x" * 1025]), t)[0] == 2           # krep.c:2042
+    assert gpu.search_buffer(abi.Params([b"zzz"]), t)[0] == 1
+    assert gpu.search_buffer(abi.Params([b"world"]), t)[:2] == (0, 1)
+
+
+def test_device_windows_concatenate(gpu, oracle_engine):
+    """krep_gpu_scan_device with ownership windows: per-window lists concatenate to the single-chunk list and
+    the line bookkeeping combines across windows."""
+    import torch
+    rng = np.random.RandomState(77)
+    text = cases.rand_text(rng, 300_000, b"ab \n")
+    d = torch.from_numpy(text).cuda()
+    for pats, kw in (([b"ab a"], dict()), ([b"b"], dict(count_lines=True)), ([b"ab", b"b a", b"a"], dict()),
+                     ([b"ba", b"ab"], dict(count_lines=True))):
+        want_ret, want_pos = _oracle(oracle_engine, gpu, pats, kw, text)
+        p = abi.Params(pats, **kw)
+        plan = gpu.plan(p)
+        cuts = [0, 1, 4097, 100_000, 100_001, 250_000, text.size]
+        outs, recs = [], []
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            posbuf = torch.zeros(2 * 400_000, dtype=torch.int64, device="cuda")
+            o = plan.scan(d.data_ptr(), text.size, lo, hi, 0, posbuf.data_ptr(), 400_000)
+            outs.append(o)
+            recs.append(posbuf[: 2 * o.stored].cpu().numpy().astype(np.uint64).reshape(-1, 2))
+        plan.close()
+        if kw.get("count_lines"):
+            arr = (abi.ScanOut * len(outs))(*outs)
+            assert gpu.lib.krep_gpu_combine_line_counts(arr, len(outs)) == want_ret, (pats, kw)
+        else:
+            got = np.concatenate(recs)
+            if len(pats) > 1:  # per-window lists are (end,start)-ordered; the global order needs the merge
+                got = got[np.lexsort((got[:, 0], got[:, 1]))]
+            assert sum(o.total_matches for o in outs) == want_ret
+            assert np.array_equal(got, want_pos), (pats, kw)
