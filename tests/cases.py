@@ -65,3 +65,49 @@ def literal_cases(seed: int, count: int, sizes=None, lens=None, big=False):
 
 def has_border(p: bytes) -> bool:
     return any(p[:len(p) - k] == p[k:] for k in range(1, len(p)))
+
+
+def golden_cases():
+    """The fixed case list behind tests/golden/ref_vectors.json: (id, text, patterns, kwargs, algo, simd level).
+    Inputs are regenerated from seeds (numpy RandomState is a frozen stream); the OUTPUTS stored in the JSON were
+    produced by the unmodified reference (oracle/_ref) via tests/golden/gen_ref_vectors.py."""
+    out = []
+    rng = np.random.RandomState(424242)
+    pyr = random.Random(424242)
+    single = [(abi.RA_BMH, abi.REF_SCALAR, [1, 2, 4, 8, 9, 17, 40, 100]), (abi.RA_KMP, abi.REF_SCALAR, [2, 4, 6]),
+              (abi.RA_MEMCHR, abi.REF_SCALAR, [1]), (abi.RA_MEMCHR_SHORT, abi.REF_SCALAR, [2, 3]),
+              (abi.RA_SSE42, abi.REF_SSE42, [2, 4, 8, 16]), (abi.RA_AVX2, abi.REF_AVX2, [17, 24, 32]),
+              (abi.RA_AVX512, abi.REF_AVX512, [33, 48, 64])]
+    cid = 0
+    for algo, level, lens in single:
+        for rep in range(14):
+            alpha = ALPHAS[pyr.choice(list(ALPHAS))]
+            m = pyr.choice(lens)
+            n = max(pyr.choice([64, 777, 8192, 8200, 33000, 70001]), 2 * m)
+            text = rand_text(rng, n, alpha)
+            pat = pick_pattern(rng, text, m, alpha)
+            if m > 8:
+                for _k in range(3):
+                    s = rng.randint(0, n - m + 1)
+                    text[s:s + m] = np.frombuffer(pat, dtype=np.uint8)
+            kw = dict(case_sensitive=True if algo in (abi.RA_SSE42, abi.RA_AVX2, abi.RA_AVX512) else pyr.random() < 0.6,
+                      whole_word=pyr.random() < 0.2, max_count=pyr.choice([abi.SIZE_MAX] * 3 + [2, 9]))
+            mode = pyr.choice(["pos", "pos", "lines", "count"])
+            if mode == "lines":
+                kw.update(count_lines=True)
+            elif mode == "count":
+                kw.update(count_lines=True, only_match=True)
+            out.append((cid, text, [pat], kw, algo, level))
+            cid += 1
+    for rep in range(24):
+        alpha = [b"ab", b"abc\n", b"abAB -\n", bytes(range(97, 105)) + b" \n"][rep % 4]
+        n = pyr.choice([100, 8195, 40000, 90000])
+        text = rand_text(rng, n, alpha)
+        pats = [pick_pattern(rng, text, pyr.choice([1, 2, 3, 4, 6, 9]), alpha) for _ in range(pyr.choice([2, 4, 9]))]
+        kw = dict(case_sensitive=pyr.random() < 0.6, whole_word=pyr.random() < 0.2,
+                  max_count=pyr.choice([abi.SIZE_MAX] * 3 + [5]))
+        if pyr.random() < 0.3 and not any(b"\n" in p for p in pats):
+            kw.update(count_lines=True)
+        out.append((cid, text, pats, kw, abi.RA_AHO_CORASICK, abi.REF_SCALAR))
+        cid += 1
+    return out

@@ -1,0 +1,88 @@
+"""CPU-side checks of the drop-in boundary: libkrep_gpu.so builds for gfx950, loads, exports every entry
+point include/krep_gpu.h declares, keeps the reference's struct layouts, and fails LOUDLY without a GPU
+(no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from krep_amd import abi, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return C.CDLL(build.build())
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "krep_gpu.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"\b([a-z_][a-z0-9_]*)\s*\([^;{]*\)\s*;", src)
+    return sorted({n for n in names if n.startswith("krep_gpu_") or n == "search_buffer"})
+
+
+def test_every_declared_symbol_is_exported(lib):
+    fns = declared_functions()
+    assert len(fns) >= 20 and "search_buffer" in fns and "krep_gpu_literal_search" in fns
+    for n in fns:
+        assert hasattr(lib, n), n
+
+
+def test_struct_layouts_match_reference_header():
+    # krep.h:49-94 on LP64: match_position_t 16 B, match_result_t 24 B, search_params_t 72 B
+    assert C.sizeof(abi.MatchPosition) == 16 and C.sizeof(abi.MatchResult) == 24 and C.sizeof(abi.SearchParams) == 72
+    assert abi.SearchParams.case_sensitive.offset == 40 and abi.SearchParams.whole_word.offset == 45
+    assert abi.SearchParams.compiled_regex.offset == 48 and abi.SearchParams.max_count.offset == 64
+
+
+def test_mirror_of_select_search_algorithm_matches_oracle(lib):
+    import krep_amd
+    import oracle_lib as ol
+    e = krep_amd.load()
+    o = ol.oracle()
+    pats = [b"a", b"ab", b"abc", b"abab", b"aaaa", b"abcabc", b"Sherlock", b"x" * 16, b"y" * 17, b"z" * 32, b"q" * 33,
+            b"w" * 64, b"e" * 65, b"aabaab"]
+    top = {abi.RA_AVX512: abi.RA_AVX512, abi.RA_AVX2: abi.RA_AVX2}
+    for lvl in (abi.REF_SCALAR, abi.REF_SSE42, abi.REF_AVX2, abi.REF_AVX512):
+        e.set_reference_simd(lvl)
+        for pat in pats:
+            for cs in (True, False):
+                p = abi.Params([pat], case_sensitive=cs)
+                sel = o.select(p, lvl)
+                eff = e.mirror_select(p, 1000)
+                # the effective algorithm is the selected one after the reference's internal delegation
+                m = len(pat)
+                if sel == abi.RA_AVX512:
+                    want = abi.RA_AVX512 if m > 32 else (abi.RA_AVX2 if m > 16 else abi.RA_SSE42)
+                elif sel == abi.RA_AVX2:
+                    want = abi.RA_BMH if not cs else (abi.RA_AVX2 if m > 16 else abi.RA_SSE42)
+                else:
+                    want = sel
+                assert eff == want, (lvl, pat, cs, sel, eff)
+    e.set_reference_simd(abi.REF_AVX2)
+
+
+def test_fails_loudly_without_gpu():
+    import krep_amd
+    e = krep_amd.load()
+    if e.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(krep_amd.KrepGpuError):
+        e.search(abi.Params([b"x"]), b"xxx")
+    rc, n, _ = e.search_buffer(abi.Params([b"x"]), b"xxx")
+    assert rc == 2  # error, like search_file()/search_string() (krep.h:159,168)
+
+
+def test_host_generator_is_deterministic_and_sliceable():
+    import krep_amd
+    e = krep_amd.load()
+    a = e.generate_host(5000, 0, 2, 42, b"Sherlock", 1000)
+    b = e.generate_host(3000, 1500, 2, 42, b"Sherlock", 1000)
+    assert np.array_equal(a[1500:4500], b)
+    assert bytes(a).count(b"Sherlock") == 5
+    c = e.generate_host(200_000, 0, 3, 7, b"#", 0)
+    assert 1500 < int((c == ord("#")).sum()) < 2500
