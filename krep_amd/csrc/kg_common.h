@@ -61,6 +61,7 @@ struct LitArgs {
     uint64_t num_tiles;           // workgroup tiles of 4 x rounds x 8 KiB
     uint32_t rounds;              // 1 or kRoundsBig
     uint64_t global_base;         // added to reported offsets
+    uint64_t excl_lo, excl_hi;    // starts in [excl_lo, excl_hi) are NOT reported (simd_avx512_search's unexamined block)
     uint64_t ww_exempt_left;      // a start offset whose LEFT neighbour test is skipped (AVX tail quirk) or ~0
     uint32_t m;                   // pattern length (1..1024)
     uint32_t flags;

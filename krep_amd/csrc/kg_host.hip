@@ -481,6 +481,12 @@ static int scan_literal(krep_gpu_plan *pl, int algo, const uint8_t *d_text, size
     }
     a.global_base = global_base;
     a.ww_exempt_left = ~0ull;
+    a.excl_lo = a.excl_hi = 0; // empty
+    if (algo == KREP_RA_AVX512 && !pl->lines && text_len >= 64 && (text_len % 64) < (uint64_t)m - 1)
+    { // krep.c:5171: the last full 64-byte block is stepped over unexamined when remaining < (m-1)+64
+        a.excl_hi = text_len - text_len % 64;
+        a.excl_lo = a.excl_hi - 64;
+    }
     if (pl->ww && !pl->lines)
     { // the BMH tail call of the AVX paths sees the tail as its own text: no left context at its first byte
         if (algo == KREP_RA_AVX2 && (text_len % 32) >= m)

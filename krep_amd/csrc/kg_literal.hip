@@ -165,7 +165,8 @@ __global__ __launch_bounds__(kBlock) void lit_scan(const LitArgs a)
         {
             const u64 seg = ubase + (u64)r * kSegBytes;
             const bool fast = seg + kSegBytes + 8 <= a.text_len;
-            const bool interior = seg >= a.own_lo && seg + kSegBytes <= hi_match;
+            const bool interior = seg >= a.own_lo && seg + kSegBytes <= hi_match &&
+                                  (seg + kSegBytes <= a.excl_lo || seg >= a.excl_hi);
 
             uint4 d[kCells];
             uint2 after = make_uint2(0u, 0u);
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(kBlock) void lit_scan(const LitArgs a)
                         u32 khi = hi > lbase ? (u32)((hi - lbase) < 16 ? (hi - lbase) : 16) : 0u;
                         return khi > klo ? (((1u << khi) - 1u) & ~((1u << klo) - 1u)) : 0u;
                     };
-                    m16 &= clip(a.own_lo, hi_match);
+                    m16 &= clip(a.own_lo, hi_match) & ~clip(a.excl_lo, a.excl_hi);
                     if (LINES)
                         nlm &= clip(a.own_lo, a.own_hi);
                 }

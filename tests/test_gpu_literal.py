@@ -60,8 +60,6 @@ def test_simd_builds_border_free(gpu, oracle_engine, seed):
         folded = pat if kw["case_sensitive"] else pat.lower()
         if algo in (abi.RA_SSE42, abi.RA_KMP) and cases.has_border(folded):
             continue
-        if algo == abi.RA_AVX512 and len(pat) > 32:
-            continue  # the unexamined-last-block bug of krep.c:5171 is covered in test_gpu_quirks.py
         _check(gpu, oracle_engine, text, pat, kw, level)
         n += 1
     assert n > 50
@@ -106,3 +104,18 @@ def test_staging_overflow_takes_emit_mode(gpu, oracle_engine):
     finally:
         gpu.force_stage_cap(0)
         gpu.set_algo_override(abi.ALGO_AUTO)
+
+
+def test_avx512_unexamined_block_is_reproduced(gpu, oracle_engine):
+    """simd_avx512_search steps over its last full 64-byte block when fewer than (m-1)+64 bytes remain
+    (krep.c:5171): matches starting there are lost by the reference, hence by its drop-in."""
+    rng = np.random.RandomState(12)
+    pat = b"0123456789abcdefghijklmnopqrstuvwxyzABCDEFGH"  # 44 bytes -> AVX-512 body on an AVX-512 build
+    for n in (64 * 5 + 10, 64 * 5 + 42, 64 * 5 + 43, 64 * 5 + 63, 64 * 200 + 3):
+        text = cases.rand_text(rng, n, b"xyz \n")
+        b = n - n % 64
+        for s in (b - 64, b - 50, b - 130, 3):
+            if 0 <= s and s + len(pat) <= n:
+                text[s:s + len(pat)] = np.frombuffer(pat, dtype=np.uint8)
+        for kw in (dict(), dict(count_lines=True, only_match=True), dict(max_count=1)):
+            _check(gpu, oracle_engine, text, pat, kw, abi.REF_AVX512)
