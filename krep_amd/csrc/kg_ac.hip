@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <unordered_map>
 #include <vector>
@@ -56,6 +57,15 @@ struct AcArgs
     const uint2 *edges;          // open addressing: {key = node << 8 | byte, val = child | has_out << 31}
     u32 emask;
     const u32 *copies;           // per node: number of patterns equal to the node's string
+    u64 unit_base;               // global index of this launch's first unit (chunked filter -> verify pipeline)
+    u32 *cand;                   // [units * cand_cap] candidate end offsets (relative to the unit), split pipeline
+    u32 *candcnt;                // [units] number of candidates, or kAcFlooded
+    u32 cand_cap;
+    const uint4 *sfx;            // whole-pattern table, 2 x uint4 per entry: {bytes right-aligned in 16}, {len, copies, 0, 0}
+    const unsigned long long *tags; // per slot: (suffix hash << 32) | (copies << 8) | len, 0 = empty
+    u32 sfxmask, lenmask;        // entries-1; bit L set <=> some pattern has length L (1..16)
+    const uint2 *gram4;          // exact last-4-bytes -> {key, depth-4 node | has_out << 31} (val 0 = empty)
+    u32 g4mask;
     unsigned long long *unitinfo;
     Counters *ctr;
     u64 *stage;
@@ -92,34 +102,62 @@ __device__ __forceinline__ LS2 ls2_combine(const LS2 &a, const LS2 &b)
 }
 
 // Walk the reversed trie from end index i.  EMIT == false: returns the number of matches ending at i
-// (after ownership and -w).  EMIT == true: additionally writes them, longest first, at slot[base ...].
-template <bool CI, bool EMIT, typename Put>
+// (after ownership and -w).  EMIT == true: additionally hands them to `put`, longest first.
+// Deliberately NOT inlined per call site: the scan loop keeps one copy of each instantiation.
+template <bool CI, bool EMIT, bool JUMP, typename Put>
 __device__ __forceinline__ u32 ac_walk(const AcArgs &a, u64 i, u32 total, Put put)
 {
     u32 node = 0, seen = 0;
     const bool ww = (a.flags & F_WW) != 0, lines = (a.flags & F_LINES) != 0;
     const u64 maxd = (i + 1 < (u64)a.lmax) ? i + 1 : (u64)a.lmax;
-    for (u64 d = 1; d <= maxd; ++d)
+    u64 d = 1;
+    u32 child = 0xffffffffu;
+    if (JUMP && i >= 3)
     {
-        u32 c = a.text[i + 1 - d];
-        if (CI && (c - 'A' < 26u))
-            c += 32u;
-        const u32 key = (node << 8) | c;
-        u32 h = (key * kHashMul) >> 7;
-        u32 child = 0xffffffffu;
-        for (;; ++h)
+        // every pattern has >= 4 bytes: resolve trie levels 1..4 with ONE probe keyed by the exact last 4 bytes
+        struct __attribute__((packed)) U32p { u32 v; };
+        u32 E = reinterpret_cast<const U32p *>(a.text + (i - 3))->v; // one unaligned dword load
+        if (CI)
+            E = ac_fold4(E);
+        for (u32 h = (E * kHashMul) >> 9;; ++h)
         {
-            const uint2 e = a.edges[h & a.emask];
-            if (e.x == key)
+            const uint2 e = a.gram4[h & a.g4mask];
+            if (e.y == 0u)
+                return 0u; // not a suffix of any pattern
+            if (e.x == E)
             {
                 child = e.y;
                 break;
             }
-            if (e.x == 0xffffffffu)
+        }
+        d = 4;
+    }
+    else if (JUMP)
+        return 0u; // fewer than 4 bytes before i: no pattern of length >= 4 can end here
+    for (; d <= maxd; ++d)
+    {
+        if (!(JUMP && d == 4))
+        {
+            u32 c = a.text[i + 1 - d];
+            if (CI && (c - 'A' < 26u))
+                c += 32u;
+            const u32 key = (node << 8) | c;
+            u32 h = (key * kHashMul) >> 7;
+            child = 0xffffffffu;
+            for (;; ++h)
+            {
+                const uint2 e = a.edges[h & a.emask];
+                if (e.x == key)
+                {
+                    child = e.y;
+                    break;
+                }
+                if (e.x == 0xffffffffu)
+                    break;
+            }
+            if (child == 0xffffffffu)
                 break;
         }
-        if (child == 0xffffffffu)
-            break;
         node = child & 0x7fffffffu;
         if (child & 0x80000000u)
         {
@@ -145,67 +183,89 @@ __device__ __forceinline__ u32 ac_walk(const AcArgs &a, u64 i, u32 total, Put pu
     return seen;
 }
 
-template <bool CI, bool LINES>
+constexpr u32 kAcUnitsPerTicket = 8;   // 64 KiB of haystack per wave ticket
+constexpr u32 kAcQueue = 512;          // candidate queue entries per wave (u32 each)
+constexpr u32 kAcBitmapWords = 256;    // 8192 end positions of a unit, one bit each (LINES)
+
+// bit of table `base` at hash h
+__device__ __forceinline__ u32 ac_tbit(const u32 *tab, u32 base, u32 h) { return (tab[base + (h >> 5)] >> (h & 31u)) & 1u; }
+
+// CLS: bit 0/1/2/3 = 1-/2-/3-/>=4-byte patterns present.  CLS == 8 is the common case (all >= 4).
+template <bool CI, bool LINES, int CLS>
 __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) u32 s_filter[]; // filter tables, then 2 ticket words
+    extern __shared__ __attribute__((aligned(16))) u32 s_mem[]; // filter | tickets | per-wave queue (+ bitmap)
     const u32 lane = ac_lane();
     const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (u32 w = threadIdx.x; w < a.filter_words; w += kAcBlock)
-        s_filter[w] = a.filter[w];
-    u64 *s_ticket = reinterpret_cast<u64 *>(s_filter + ((a.filter_words + 3u) & ~3u));
+        s_mem[w] = a.filter[w];
+    const u32 fw = (a.filter_words + 3u) & ~3u;
+    constexpr u32 kPerWave = kAcQueue + (LINES ? kAcBitmapWords : 0u);
+    u32 *queue = s_mem + fw + 4u + wave * kPerWave;
+    u32 *bitmap = queue + kAcQueue;
+    if (LINES)
+        for (u32 w = lane; w < kAcBitmapWords; w += 64)
+            bitmap[w] = 0u;
     const bool want_pos = (a.flags & F_POS) != 0;
     const bool chain = want_pos || LINES;
+    const bool emit_final = a.emit_mode != 0;
 
     u64 acc_total = 0;
-    u64 next_ticket = 0;
-    if (threadIdx.x == 0)
-        next_ticket = __hip_atomic_fetch_add(&a.ctr->ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads(); // filter tables are in LDS from here on; the waves never synchronise again
 
-    for (u32 it = 0;; ++it)
+    // Waves are autonomous: each draws its own ticket for kAcUnitsPerTicket consecutive 8-KiB units (64 KiB:
+    // <= ~50 fetch-adds/us on the single ticket word at 3 TB/s).  A per-tile workgroup barrier (one block
+    // per CU because of the 64 KiB table) made every wave wait for the slowest verifier of its tile.
+    for (;;)
     {
-        if (threadIdx.x == 0)
-            s_ticket[it & 1u] = next_ticket;
-        __syncthreads(); // also orders the filter-table fill before its first use
-        const u64 tile = ac_rfl64(s_ticket[it & 1u]);
-        if (tile >= a.num_tiles)
+        u64 tk = 0;
+        if (lane == 0)
+            tk = __hip_atomic_fetch_add(&a.ctr->ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tk = ac_rfl64(tk);
+        const u64 u_begin = tk * (u64)kAcUnitsPerTicket;
+        if (u_begin >= a.num_tiles)
             break;
-        if (threadIdx.x == 0)
-            next_ticket = __hip_atomic_fetch_add(&a.ctr->ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-
-        const u64 unit = tile * kAcWaves + wave;
+        const u64 u_end = (u_begin + kAcUnitsPerTicket < a.num_tiles) ? u_begin + kAcUnitsPerTicket : a.num_tiles;
+      for (u64 unit = u_begin; unit < u_end; ++unit)
+      {
         const u64 seg = a.anchor + unit * (u64)kSegBytes;
-        if (a.emit_mode && (u32)(a.unitinfo[unit] & kUiCountMask) <= a.stage_cap)
+        if (emit_final && (u32)(a.unitinfo[unit] & kUiCountMask) <= a.stage_cap)
             continue;
-        const bool fast = seg + kSegBytes <= a.text_len;
+        const bool fast_now = seg + kSegBytes <= a.text_len;
         const bool interior = seg >= a.end_lo && seg + kSegBytes <= a.end_hi;
 
         uint4 d[kCells];
         u32 before = 0; // the 4 bytes in front of the segment
-        if (fast)
+        if (fast_now)
         {
             const uint4 *src = reinterpret_cast<const uint4 *>(a.text + seg) + lane;
 #pragma unroll
             for (int j = 0; j < kCells; ++j)
                 d[j] = src[j * kWave];
         }
-        if (seg >= 4 && seg - 4 + 4 <= a.text_len)
+        if (seg >= 4 && seg <= a.text_len)
             before = *reinterpret_cast<const u32 *>(a.text + seg - 4);
         else
             for (u32 b = 0; b < 4; ++b)
                 if (seg + b >= 4 && seg + b - 4 < a.text_len)
                     before |= (u32)a.text[seg + b - 4] << (8 * b);
 
-        u32 CM[kCells]; // per lane: low 16 bits = end positions with >= 1 match, high 16 = matches of the lane
-        u32 wcnt = 0;
-        LS2 wls{0, false, false, false};
+        u64 *slot = reinterpret_cast<u64 *>(a.stage) + unit * (u64)a.stage_cap;
+        const bool do_final = emit_final && want_pos;
+        const bool do_stage = !emit_final && want_pos;
+        const u64 fbase = do_final ? a.offsets[unit] : 0ull;
+        u32 wcnt = 0; // matches of the unit so far == rank of the next one (uniform)
+        u32 qn = 0;   // queued candidates (uniform)
 
+        bool flooded = false; // the candidate queue overflowed (uniform)
+
+        u32 NLm[kCells];
 #pragma unroll
         for (int j = 0; j < kCells; ++j)
         {
             const u64 lbase = seg + (u64)j * kCellBytes + (u64)lane * 16u;
             u32 W[5]; // W[0] = the 4 bytes before the lane, W[1..4] = the lane's 16 bytes
-            if (fast)
+            if (fast_now)
             {
                 W[1] = d[j].x; W[2] = d[j].y; W[3] = d[j].z; W[4] = d[j].w;
                 const u32 up = __shfl_up(W[4], 1);
@@ -214,7 +274,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
             }
             else
             {
-#pragma unroll
+#pragma unroll 1
                 for (int w = 0; w < 5; ++w)
                 {
                     u32 v = 0;
@@ -241,7 +301,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                     W[w] = ac_fold4(W[w]);
             }
 
-            // ---- filter: which of my 16 end positions can end a pattern? -----------------------------
+            // ---- filter: which of my 16 end positions can end a pattern?  (branch-free) ----------------
             u32 cand = 0;
 #pragma unroll
             for (int k = 0; k < 16; ++k)
@@ -249,28 +309,16 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 // E = bytes [k-3, k] of the lane (little endian: the byte at k is the top byte)
                 const int o = k + 1;
                 const u32 E = ((o & 3) == 0) ? W[o >> 2] : __builtin_amdgcn_alignbyte(W[(o >> 2) + 1], W[o >> 2], (u32)(o & 3));
-                bool hit = false;
-                if (a.has4)
-                {
-                    const u32 h = (E * kHashMul) >> (32 - kT4Bits);
-                    hit = (s_filter[a.off4 + (h >> 5)] >> (h & 31u)) & 1u;
-                }
-                if (a.has3)
-                {
-                    const u32 h = ((E >> 8) * kHashMul) >> (32 - kT3Bits);
-                    hit = hit || ((s_filter[a.off3 + (h >> 5)] >> (h & 31u)) & 1u);
-                }
-                if (a.has2)
-                {
-                    const u32 h = E >> 16;
-                    hit = hit || ((s_filter[a.off2 + (h >> 5)] >> (h & 31u)) & 1u);
-                }
-                if (a.has1)
-                {
-                    const u32 h = E >> 24;
-                    hit = hit || ((s_filter[h >> 5] >> (h & 31u)) & 1u);
-                }
-                cand |= hit ? (1u << k) : 0u;
+                u32 hit = 0;
+                if (CLS & 8)
+                    hit |= ac_tbit(s_mem, a.off4, (E * kHashMul) >> (32 - kT4Bits));
+                if (CLS & 4)
+                    hit |= ac_tbit(s_mem, a.off3, ((E >> 8) * kHashMul) >> (32 - kT3Bits));
+                if (CLS & 2)
+                    hit |= ac_tbit(s_mem, a.off2, E >> 16);
+                if (CLS & 1)
+                    hit |= ac_tbit(s_mem, 0u, E >> 24);
+                cand |= hit << k;
             }
             u32 nlm = NL;
             if (!interior)
@@ -284,38 +332,100 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 if (LINES)
                     nlm &= clip(a.own_lo, a.own_hi);
             }
+            NLm[j] = nlm;
+            if (a.flags & (1u << 31)) // ablation hook (KREP_GPU_AC_NOVERIFY): filter cost only
+                cand = 0;
 
-            // ---- verify the candidates --------------------------------------------------------------
-            u32 hits = 0, lcnt = 0;
-            if (__ballot(cand != 0u))
+            // ---- queue the candidates in position order -------------------------------------------------
+            if (!flooded && __ballot(cand != 0u))
             {
-                u32 rest = cand;
-                while (rest)
+                const u32 c = __popc(cand);
+                u32 tot = 0, ex = 0;
+#pragma unroll
+                for (int b = 0; b < 5; ++b)
                 {
-                    const u32 k = __builtin_ctz(rest);
-                    rest &= rest - 1u;
-                    const u32 c = ac_walk<CI, false>(a, lbase + k, 0u, [](u32, u64, u32) {});
-                    if (c)
+                    const u64 m = __ballot((c >> b) & 1u);
+                    tot += (u32)__popcll(m) << b;
+                    ex += (u32)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)) << b;
+                }
+                if (qn + tot > kAcQueue)
+                    flooded = true; // > 6 % of the unit's positions are candidates: verify every position instead
+                else
+                {
+                    u32 at = qn + ex, rest = cand;
+                    const u32 rel0 = (u32)j * kCellBytes + lane * 16u;
+                    while (rest)
                     {
-                        hits |= 1u << k;
-                        lcnt += c;
+                        const u32 k = __builtin_ctz(rest);
+                        rest &= rest - 1u;
+                        queue[at++] = rel0 + k;
                     }
+                    qn += tot;
                 }
             }
-            CM[j] = hits | (lcnt << 16);
-            const u64 anyhit = __ballot(hits != 0u);
-            if (anyhit)
-            {
-                u32 v = lcnt;
-#pragma unroll
-                for (int o = 32; o >= 1; o >>= 1)
-                    v += __shfl_xor(v, o);
-                wcnt += v;
-            }
+        }
 
-            if (LINES)
+        // ---- verify (and stage/emit) the candidates, 64 at a time, one per lane; a flooded unit walks
+        //      every end position of the unit instead (exact, slow, pathological inputs only) ------------
+        {
+            const u32 n = flooded ? kSegBytes : qn;
+            for (u32 b0 = 0; b0 < n; b0 += 64)
             {
-                const u32 H = hits, N = nlm;
+                const u32 qi = b0 + lane;
+                bool live = qi < n;
+                const u32 rel = flooded ? qi : (live ? queue[qi] : 0u);
+                const u64 pos = seg + rel;
+                if (flooded)
+                    live = pos >= a.end_lo && pos < a.end_hi;
+                u32 c = 0;
+                if (live)
+                    c = ac_walk<CI, false, CLS == 8>(a, pos, 0u, [](u32, u64, u32) {});
+                u32 incl = c;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1)
+                {
+                    const u32 t = __shfl_up(incl, o);
+                    if (lane >= (u32)o)
+                        incl += t;
+                }
+                const u32 rank0 = wcnt + incl - c;
+                wcnt += __shfl(incl, 63);
+                if (c)
+                {
+                    if (LINES)
+                        atomicOr(&bitmap[rel >> 5], 1u << (rel & 31u));
+                    if (do_stage || do_final)
+                        ac_walk<CI, true, CLS == 8>(a, pos, c, [&](u32 r, u64 s, u32 len) {
+                            const u32 at = rank0 + r;
+                            if (do_stage)
+                            {
+                                if (at < a.stage_cap)
+                                    slot[at] = ((s + a.global_base) << 11) | len;
+                            }
+                            else
+                            {
+                                const u64 g = fbase + at;
+                                if (g < a.pos_cap)
+                                {
+                                    const u64 st = s + a.global_base, en = st + len;
+                                    *reinterpret_cast<uint4 *>(a.positions + 2 * g) =
+                                        make_uint4((u32)st, (u32)(st >> 32), (u32)en, (u32)(en >> 32));
+                                }
+                            }
+                        });
+                }
+            }
+        }
+
+        LS2 wls{0, false, false, false};
+        if (LINES)
+        {
+#pragma unroll
+            for (int j = 0; j < kCells; ++j)
+            {
+                const u32 bitoff = (u32)j * kCellBytes + lane * 16u;
+                const u32 H = (bitmap[bitoff >> 5] >> (bitoff & 31u)) & 0xffffu, N = NLm[j];
+                const u64 anyhit = __ballot(H != 0u);
                 const bool l_nl = N != 0u;
                 const u64 B_nl = __ballot(l_nl);
                 LS2 cell{0, B_nl != 0, false, false};
@@ -359,15 +469,12 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 }
                 wls = ls2_combine(wls, cell);
             }
+            for (u32 w = lane; w < kAcBitmapWords; w += 64)
+                bitmap[w] = 0u;
         }
 
         acc_total += wcnt;
-        if (!chain)
-            continue;
-
-        // ---- publish / emit ----------------------------------------------------------------------------
-        const bool emit_final = a.emit_mode != 0;
-        if (!emit_final && lane == 0)
+        if (chain && !emit_final && lane == 0)
         {
             u64 info = (u64)wcnt;
             if (LINES)
@@ -382,62 +489,468 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 atomicMax(&a.ctr->max_unit_count, (u64)wcnt);
             }
         }
-        const bool do_stage = !emit_final && want_pos && wcnt != 0;
-        const bool do_final = emit_final && want_pos && wcnt > a.stage_cap;
-        if (do_stage || do_final)
+      }
+    }
+    if (lane == 0 && acc_total && !a.emit_mode)
+        atomicAdd(&a.ctr->total, acc_total);
+}
+
+// ================================================================================================
+// Split pipeline (positions / counts): FILTER kernel -> candidate lists -> VERIFY kernel.
+// The trie walk is a chain of dependent L2 accesses (2-3 us each under a saturated HBM stream); inside
+// the streaming kernel (128 VGPRs, 16 waves/CU) it cost 17 us per 8 KiB unit and capped the scan at
+// ~1.2 TB/s.  Split, the filter keeps streaming and the verifier runs as a small-footprint kernel whose
+// latency is hidden by occupancy.
+// ================================================================================================
+constexpr u32 kAcFlooded = 0xffffffffu;
+
+template <bool CI, int CLS>
+__global__ __launch_bounds__(kAcBlock) void ac_filter_kernel(const AcArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) u32 s_mem[]; // filter tables
+    const u32 lane = ac_lane();
+    for (u32 w = threadIdx.x; w < a.filter_words; w += kAcBlock)
+        s_mem[w] = a.filter[w];
+    __syncthreads();
+    for (;;)
+    {
+        u64 tk = 0;
+        if (lane == 0)
+            tk = __hip_atomic_fetch_add(&a.ctr->ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tk = ac_rfl64(tk);
+        const u64 u_begin = tk * (u64)kAcUnitsPerTicket;
+        if (u_begin >= a.num_tiles)
+            break;
+        const u64 u_end = (u_begin + kAcUnitsPerTicket < a.num_tiles) ? u_begin + kAcUnitsPerTicket : a.num_tiles;
+        for (u64 unit = u_begin; unit < u_end; ++unit)
         {
-            u64 *slot = reinterpret_cast<u64 *>(a.stage) + unit * (u64)a.stage_cap;
-            const u64 fbase = do_final ? a.offsets[unit] : 0ull;
-            u32 out = 0;
+            const u64 seg = a.anchor + unit * (u64)kSegBytes;
+            const bool fast = seg + kSegBytes <= a.text_len;
+            const bool interior = seg >= a.end_lo && seg + kSegBytes <= a.end_hi;
+            uint4 d[kCells];
+            u32 before = 0;
+            if (fast)
+            {
+                const uint4 *src = reinterpret_cast<const uint4 *>(a.text + seg) + lane;
+#pragma unroll
+                for (int j = 0; j < kCells; ++j)
+                    d[j] = src[j * kWave];
+            }
+            if (seg >= 4 && seg <= a.text_len)
+                before = *reinterpret_cast<const u32 *>(a.text + seg - 4);
+            else
+                for (u32 b = 0; b < 4; ++b)
+                    if (seg + b >= 4 && seg + b - 4 < a.text_len)
+                        before |= (u32)a.text[seg + b - 4] << (8 * b);
+            u32 *out = a.cand + (a.unit_base + unit) * (u64)a.cand_cap;
+            u32 qn = 0;
+            bool flooded = false;
 #pragma unroll
             for (int j = 0; j < kCells; ++j)
             {
-                u32 hits = CM[j] & 0xffffu;
-                const u32 lcnt = CM[j] >> 16;
-                if (!__ballot(hits != 0u))
-                    continue;
-                // exclusive prefix of lcnt over lanes
-                u32 incl = lcnt;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1)
-                {
-                    const u32 t = __shfl_up(incl, o);
-                    if (lane >= (u32)o)
-                        incl += t;
-                }
-                u32 idx = out + incl - lcnt;
-                out += __shfl(incl, 63);
                 const u64 lbase = seg + (u64)j * kCellBytes + (u64)lane * 16u;
-                while (hits)
+                u32 W[5];
+                if (fast)
                 {
-                    const u32 k = __builtin_ctz(hits);
-                    hits &= hits - 1u;
-                    const u32 c = ac_walk<CI, false>(a, lbase + k, 0u, [](u32, u64, u32) {});
-                    const u32 base_i = idx;
-                    ac_walk<CI, true>(a, lbase + k, c, [&](u32 rank, u64 s, u32 len) {
-                        const u32 at = base_i + rank;
-                        if (do_stage)
-                        {
-                            if (at < a.stage_cap)
-                                slot[at] = ((s + a.global_base) << 11) | len;
-                        }
-                        else
-                        {
-                            const u64 g = fbase + at;
-                            if (g < a.pos_cap)
-                            {
-                                const u64 st = s + a.global_base, en = st + len;
-                                *reinterpret_cast<uint4 *>(a.positions + 2 * g) =
-                                    make_uint4((u32)st, (u32)(st >> 32), (u32)en, (u32)(en >> 32));
-                            }
-                        }
-                    });
-                    idx += c;
+                    W[1] = d[j].x; W[2] = d[j].y; W[3] = d[j].z; W[4] = d[j].w;
+                    const u32 up = __shfl_up(W[4], 1);
+                    const u32 edge = (j == 0) ? before : __builtin_amdgcn_readlane(d[j > 0 ? j - 1 : 0].w, 63);
+                    W[0] = (lane == 0u) ? edge : up;
                 }
+                else
+                {
+#pragma unroll 1
+                    for (int w = 0; w < 5; ++w)
+                    {
+                        u32 v = 0;
+                        for (int b = 0; b < 4; ++b)
+                        {
+                            const u64 o = lbase + (u64)(w * 4 + b);
+                            if (o >= 4 && o - 4 < a.text_len)
+                                v |= (u32)a.text[o - 4] << (8 * b);
+                        }
+                        W[w] = v;
+                    }
+                }
+                if (CI)
+                {
+#pragma unroll
+                    for (int w = 0; w < 5; ++w)
+                        W[w] = ac_fold4(W[w]);
+                }
+                u32 cand = 0;
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                {
+                    const int o = k + 1;
+                    const u32 E = ((o & 3) == 0) ? W[o >> 2] : __builtin_amdgcn_alignbyte(W[(o >> 2) + 1], W[o >> 2], (u32)(o & 3));
+                    u32 hit = 0;
+                    if (CLS & 8)
+                        hit |= ac_tbit(s_mem, a.off4, (E * kHashMul) >> (32 - kT4Bits));
+                    if (CLS & 4)
+                        hit |= ac_tbit(s_mem, a.off3, ((E >> 8) * kHashMul) >> (32 - kT3Bits));
+                    if (CLS & 2)
+                        hit |= ac_tbit(s_mem, a.off2, E >> 16);
+                    if (CLS & 1)
+                        hit |= ac_tbit(s_mem, 0u, E >> 24);
+                    cand |= hit << k;
+                }
+                if (!interior)
+                {
+                    const u64 lo = a.end_lo, hi = a.end_hi;
+                    const u32 klo = lo > lbase ? (u32)((lo - lbase) < 16 ? (lo - lbase) : 16) : 0u;
+                    const u32 khi = hi > lbase ? (u32)((hi - lbase) < 16 ? (hi - lbase) : 16) : 0u;
+                    cand &= khi > klo ? (((1u << khi) - 1u) & ~((1u << klo) - 1u)) : 0u;
+                }
+                if (a.flags & (1u << 31)) // ablation hook (KREP_GPU_AC_NOVERIFY)
+                    cand = 0;
+                if (!flooded && __ballot(cand != 0u))
+                {
+                    const u32 c = __popc(cand);
+                    u32 tot = 0, ex = 0;
+#pragma unroll
+                    for (int b = 0; b < 5; ++b)
+                    {
+                        const u64 m = __ballot((c >> b) & 1u);
+                        tot += (u32)__popcll(m) << b;
+                        ex += (u32)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)) << b;
+                    }
+                    if (qn + tot > a.cand_cap)
+                        flooded = true;
+                    else
+                    {
+                        u32 at = qn + ex, rest = cand;
+                        const u32 rel0 = (u32)j * kCellBytes + lane * 16u;
+                        while (rest)
+                        {
+                            const u32 k = __builtin_ctz(rest);
+                            rest &= rest - 1u;
+                            out[at++] = rel0 + k;
+                        }
+                        qn += tot;
+                    }
+                }
+            }
+            if (lane == 0)
+                a.candcnt[a.unit_base + unit] = flooded ? kAcFlooded : qn;
+        }
+    }
+}
+
+// one wave per unit: verify its candidates (or, for a flooded unit, every end position), rank, stage / emit
+template <bool CI, bool JUMP>
+__global__ __launch_bounds__(256) void ac_verify_kernel(const AcArgs a)
+{
+    const u32 lane = ac_lane();
+    const u64 n_waves = (u64)gridDim.x * 4, wid = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const bool want_pos = (a.flags & F_POS) != 0;
+    const bool emit_final = a.emit_mode != 0;
+    u64 acc_total = 0;
+    for (u64 lunit = wid; lunit < a.num_tiles; lunit += n_waves)
+    {
+        const u64 unit = a.unit_base + lunit; // global unit index (arrays); lunit addresses the chunk's text
+        if (emit_final && (u32)(a.unitinfo[unit] & kUiCountMask) <= a.stage_cap)
+            continue;
+        const u32 cc = a.candcnt[unit];
+        const bool flooded = cc == kAcFlooded;
+        const u32 n = flooded ? kSegBytes : cc;
+        const u64 seg = a.anchor + lunit * (u64)kSegBytes;
+        const u32 *cl = a.cand + unit * (u64)a.cand_cap;
+        u64 *slot = reinterpret_cast<u64 *>(a.stage) + unit * (u64)a.stage_cap;
+        const bool do_final = emit_final && want_pos, do_stage = !emit_final && want_pos;
+        const u64 fbase = do_final ? a.offsets[unit] : 0ull;
+        u32 wcnt = 0;
+        for (u32 b0 = 0; b0 < n; b0 += 64)
+        {
+            const u32 qi = b0 + lane;
+            bool live = qi < n;
+            const u32 rel = flooded ? qi : (live ? cl[qi] : 0u);
+            const u64 pos = seg + rel;
+            if (flooded)
+                live = pos >= a.end_lo && pos < a.end_hi;
+            u32 c = 0;
+            if (live)
+                c = ac_walk<CI, false, JUMP>(a, pos, 0u, [](u32, u64, u32) {});
+            if (!__ballot(c != 0u))
+                continue;
+            u32 incl = c;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1)
+            {
+                const u32 t = __shfl_up(incl, o);
+                if (lane >= (u32)o)
+                    incl += t;
+            }
+            const u32 rank0 = wcnt + incl - c;
+            wcnt += __shfl(incl, 63);
+            if (c && (do_stage || do_final))
+                ac_walk<CI, true, JUMP>(a, pos, c, [&](u32 r, u64 s, u32 len) {
+                    const u32 at = rank0 + r;
+                    if (do_stage)
+                    {
+                        if (at < a.stage_cap)
+                            slot[at] = ((s + a.global_base) << 11) | len;
+                    }
+                    else
+                    {
+                        const u64 g = fbase + at;
+                        if (g < a.pos_cap)
+                        {
+                            const u64 st = s + a.global_base, en = st + len;
+                            *reinterpret_cast<uint4 *>(a.positions + 2 * g) =
+                                make_uint4((u32)st, (u32)(st >> 32), (u32)en, (u32)(en >> 32));
+                        }
+                    }
+                });
+        }
+        acc_total += wcnt;
+        if (want_pos && !emit_final && lane == 0)
+        {
+            a.unitinfo[unit] = (u64)wcnt | (wcnt ? (kLnHead | kLnTail) : 0ull);
+            if (wcnt > a.stage_cap)
+            {
+                atomicAdd(&a.ctr->overflow_units, 1ull);
+                atomicMax(&a.ctr->max_unit_count, (u64)wcnt);
             }
         }
     }
-    if (lane == 0 && acc_total && !a.emit_mode)
+    if (lane == 0 && acc_total && !emit_final)
+        atomicAdd(&a.ctr->total, acc_total);
+}
+
+// ---- verify, fast form: every pattern is <= 16 bytes -------------------------------------------------
+// A trie walk costs two dependent memory accesses per matched byte and the reference order needs the total
+// before the first record (two walks): ~40 dependent accesses for a 10-byte match.  Here the 16 bytes ending at
+// the candidate are loaded once and each PRESENT pattern length L is resolved by ONE probe of a hash table of
+// whole patterns keyed by (L, suffix hash) — all probes independent, exact byte compare, results kept in
+// registers per length, emitted longest first.  Latency per candidate ~ 2 memory round trips, any match length.
+__device__ __forceinline__ u32 sfx_hash_step(u32 h, u32 byte) { return (h ^ byte) * 0x01000193u; } // FNV-1a over bytes i, i-1, ...
+__device__ __forceinline__ u32 sfx_slot(u32 h, u32 L) { return ((h ^ (L * 0x9E3779B1u)) * 0x85EBCA6Bu) >> 8; }
+
+template <bool CI>
+__global__ __launch_bounds__(256) void ac_verify16_kernel(const AcArgs a)
+{
+    const u32 lane = ac_lane();
+    const u64 n_waves = (u64)gridDim.x * 4, wid = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const bool want_pos = (a.flags & F_POS) != 0, ww = (a.flags & F_WW) != 0;
+    const bool emit_final = a.emit_mode != 0;
+    u64 acc_total = 0;
+    for (u64 lunit = wid; lunit < a.num_tiles; lunit += n_waves)
+    {
+        const u64 unit = a.unit_base + lunit;
+        if (emit_final && (u32)(a.unitinfo[unit] & kUiCountMask) <= a.stage_cap)
+            continue;
+        const u32 cc = a.candcnt[unit];
+        const bool flooded = cc == kAcFlooded;
+        const u32 n = flooded ? kSegBytes : cc;
+        const u64 seg = a.anchor + lunit * (u64)kSegBytes;
+        const u32 *cl = a.cand + unit * (u64)a.cand_cap;
+        u64 *slot = reinterpret_cast<u64 *>(a.stage) + unit * (u64)a.stage_cap;
+        const bool do_final = emit_final && want_pos, do_stage = !emit_final && want_pos;
+        const u64 fbase = do_final ? a.offsets[unit] : 0ull;
+        u32 wcnt = 0;
+        for (u32 b0 = 0; b0 < n; b0 += 64)
+        {
+            const u32 qi = b0 + lane;
+            bool live = qi < n;
+            const u32 rel = flooded ? qi : (live ? cl[qi] : 0u);
+            const u64 i = seg + rel; // END index
+            if (flooded)
+                live = i >= a.end_lo && i < a.end_hi;
+            // the 16 bytes ending at i: T[w] = bytes [i-15+4w, i-12+4w]
+            u32 T[4] = {0u, 0u, 0u, 0u};
+            if (live)
+            {
+                if (i >= 15)
+                {
+                    struct __attribute__((packed)) U32p { u32 v; };
+                    const U32p *q = reinterpret_cast<const U32p *>(a.text + (i - 15));
+                    T[0] = q[0].v; T[1] = q[1].v; T[2] = q[2].v; T[3] = q[3].v;
+                }
+                else
+                    for (u32 b = 0; b < 16; ++b)
+                        if (i + b >= 15)
+                            T[b >> 2] |= (u32)a.text[i + b - 15] << (8 * (b & 3));
+                if (CI)
+                {
+#pragma unroll
+                    for (int w = 0; w < 4; ++w)
+                        T[w] = ac_fold4(T[w]);
+                }
+            }
+            // gate: when every pattern has >= 4 bytes, a candidate whose exact last 4 bytes are no pattern suffix
+            // is a hash false positive of the LDS filter — one probe, then done
+            if (live && a.gram4 && a.lenmask >= (1u << 4) && !(a.lenmask & 0xeu))
+            {
+                bool any4 = false;
+                if (i >= 3)
+                    for (u32 hh = (T[3] * kHashMul) >> 9;; ++hh)
+                    {
+                        const uint2 e = a.gram4[hh & a.g4mask];
+                        if (e.y == 0u)
+                            break;
+                        if (e.x == T[3])
+                        {
+                            any4 = true;
+                            break;
+                        }
+                    }
+                live = any4;
+            }
+            // pass 1: suffix hashes of every length; ONE 8-byte tag load per PRESENT length, all in flight together
+            u64 tg[17];
+            u32 hs[17];
+            {
+                u32 h = 0x811C9DC5u;
+#pragma unroll
+                for (int L = 1; L <= 16; ++L)
+                {
+                    const int bi = 16 - L; // index of byte i-L+1 inside T
+                    h = sfx_hash_step(h, (T[bi >> 2] >> (8 * (bi & 3))) & 0xffu);
+                    hs[L] = h;
+                    tg[L] = 0;
+                    if ((a.lenmask >> L) & 1u) // uniform
+                        if (live)
+                            tg[L] = a.tags[sfx_slot(h, (u32)L) & a.sfxmask];
+                }
+            }
+            // pass 2: which lengths need a look?  tag hit -> exact compare; occupied slot with another key -> probe on
+            u32 look = 0;
+#pragma unroll
+            for (int L = 1; L <= 16; ++L)
+                if ((a.lenmask >> L) & 1u)
+                    look |= (tg[L] != 0ull && (u64)L <= i + 1) ? (1u << L) : 0u;
+            // rare part, longest first: resolve the looked-at lengths exactly (linear probing + 16-byte compare)
+            u32 c = 0, okmask = 0;
+            u64 cps = 0; // 4 bits of copies per validated length would not fit: copies are re-read at emission
+            for (u32 rest = look; rest;)
+            {
+                const u32 L = 31u - (u32)__builtin_clz(rest);
+                rest &= ~(1u << L);
+                const u32 bi = 16u - L;
+                u32 V[4];
+#pragma unroll
+                for (int w = 0; w < 4; ++w)
+                {
+                    const int lo = (int)bi - 4 * w;
+                    V[w] = lo <= 0 ? T[w] : lo >= 4 ? 0u : (T[w] & (0xffffffffu << (8 * lo)));
+                }
+                // recompute the hash of this length (hs[] is indexed statically only)
+                u32 h = 0x811C9DC5u;
+                for (u32 k = 0; k < L; ++k)
+                    h = sfx_hash_step(h, (T[(15 - k) >> 2] >> (8 * ((15 - k) & 3))) & 0xffu);
+                u32 copies = 0;
+                for (u32 sl = sfx_slot(h, L);; ++sl)
+                {
+                    const u64 tv = a.tags[sl & a.sfxmask];
+                    if (tv == 0ull)
+                        break;
+                    if ((u32)(tv >> 32) == h && (u32)(tv & 0xffu) == L)
+                    {
+                        const uint4 by = a.sfx[2 * (sl & a.sfxmask)];
+                        if (by.x == V[0] && by.y == V[1] && by.z == V[2] && by.w == V[3])
+                        {
+                            copies = (u32)(tv >> 8) & 0xffffffu;
+                            break;
+                        }
+                    }
+                }
+                if (copies)
+                {
+                    const u64 st = i + 1 - (u64)L;
+                    bool ok = st >= a.own_lo && st < a.own_hi;
+                    if (ok && ww)
+                    {
+                        if (st > 0 && ac_wordc(a.text[st - 1]))
+                            ok = false;
+                        else if (i + 1 < a.text_len && ac_wordc(a.text[i + 1]))
+                            ok = false;
+                    }
+                    if (ok)
+                    {
+                        c += copies;
+                        okmask |= 1u << L;
+                    }
+                }
+            }
+            (void)cps;
+            (void)hs;
+            if (!__ballot(c != 0u))
+                continue;
+            u32 incl = c;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1)
+            {
+                const u32 t = __shfl_up(incl, o);
+                if (lane >= (u32)o)
+                    incl += t;
+            }
+            u32 at = wcnt + incl - c;
+            wcnt += __shfl(incl, 63);
+            if (c && (do_stage || do_final))
+            {
+                for (u32 rest = okmask; rest;) // longest first (aho_corasick.c:353-431)
+                {
+                    const u32 L = 31u - (u32)__builtin_clz(rest);
+                    rest &= ~(1u << L);
+                    // copies of this (validated) pattern: find its slot again
+                    u32 h = 0x811C9DC5u;
+                    for (u32 k = 0; k < L; ++k)
+                        h = sfx_hash_step(h, (T[(15 - k) >> 2] >> (8 * ((15 - k) & 3))) & 0xffu);
+                    const u32 bi = 16u - L;
+                    u32 V[4];
+#pragma unroll
+                    for (int w = 0; w < 4; ++w)
+                    {
+                        const int lo = (int)bi - 4 * w;
+                        V[w] = lo <= 0 ? T[w] : lo >= 4 ? 0u : (T[w] & (0xffffffffu << (8 * lo)));
+                    }
+                    u32 copies = 0;
+                    for (u32 sl = sfx_slot(h, L);; ++sl)
+                    {
+                        const u64 tv = a.tags[sl & a.sfxmask];
+                        if (tv == 0ull)
+                            break;
+                        if ((u32)(tv >> 32) == h && (u32)(tv & 0xffu) == L)
+                        {
+                            const uint4 by = a.sfx[2 * (sl & a.sfxmask)];
+                            if (by.x == V[0] && by.y == V[1] && by.z == V[2] && by.w == V[3])
+                            {
+                                copies = (u32)(tv >> 8) & 0xffffffu;
+                                break;
+                            }
+                        }
+                    }
+                    for (u32 q = 0; q < copies; ++q, ++at)
+                    {
+                        const u64 st = i + 1 - (u64)L + a.global_base;
+                        if (do_stage)
+                        {
+                            if (at < a.stage_cap)
+                                slot[at] = (st << 11) | L;
+                        }
+                        else if (fbase + at < a.pos_cap)
+                        {
+                            const u64 en = st + (u64)L;
+                            *reinterpret_cast<uint4 *>(a.positions + 2 * (fbase + at)) =
+                                make_uint4((u32)st, (u32)(st >> 32), (u32)en, (u32)(en >> 32));
+                        }
+                    }
+                }
+            }
+        }
+        acc_total += wcnt;
+        if (want_pos && !emit_final && lane == 0)
+        {
+            a.unitinfo[unit] = (u64)wcnt | (wcnt ? (kLnHead | kLnTail) : 0ull);
+            if (wcnt > a.stage_cap)
+            {
+                atomicAdd(&a.ctr->overflow_units, 1ull);
+                atomicMax(&a.ctr->max_unit_count, (u64)wcnt);
+            }
+        }
+    }
+    if (lane == 0 && acc_total && !emit_final)
         atomicAdd(&a.ctr->total, acc_total);
 }
 
@@ -453,6 +966,13 @@ struct AcTables
     u32 emask = 0;
     u32 *d_copies = nullptr;
     u32 nnodes = 0;
+    uint2 *d_gram4 = nullptr;
+    u32 g4mask = 0;
+    uint4 *d_sfx = nullptr;      // whole-pattern table (lmax <= 16)
+    unsigned long long *d_tags = nullptr;
+    u32 sfxmask = 0, lenmask = 0;
+    u32 *d_cand = nullptr, *d_candcnt = nullptr; // split pipeline scratch
+    u64 cand_words = 0, candcnt_words = 0;
 };
 
 #define ACHK(x)                                                                                \
@@ -538,6 +1058,12 @@ AcTables *ac_build(const search_params_t &sp, int device)
             T4[h >> 5] |= 1u << (h & 31);
         }
     }
+    if (!(t->has4 && !t->has1 && !t->has2 && !t->has3))
+    { // the generic kernel variant tests all four tables: give the absent classes empty (all-zero) tables
+        if (T2.empty()) T2.assign(kT2Words, 0);
+        if (T3.empty()) T3.assign(kT3Words, 0);
+        if (T4.empty()) T4.assign(kT4Words, 0);
+    }
     std::vector<u32> filter(T1);
     t->off2 = (u32)filter.size(); filter.insert(filter.end(), T2.begin(), T2.end());
     t->off3 = (u32)filter.size(); filter.insert(filter.end(), T3.begin(), T3.end());
@@ -584,8 +1110,95 @@ AcTables *ac_build(const search_params_t &sp, int device)
             ++h;
         tab[h & t->emask] = make_uint2(kv.first, kv.second | (copies[kv.second] ? 0x80000000u : 0u));
     }
+    // exact 4-gram -> depth-4 node (used when every pattern has >= 4 bytes)
+    std::vector<uint2> g4;
+    {
+        struct Item { u32 node, depth, gram; };
+        std::vector<std::vector<std::pair<u32, u32>>> kids(t->nnodes); // node -> (byte, child)
+        for (auto &kv : edge)
+            kids[kv.first >> 8].push_back({kv.first & 255u, kv.second});
+        std::vector<Item> st{{0u, 0u, 0u}}, d4;
+        while (!st.empty())
+        {
+            Item it = st.back();
+            st.pop_back();
+            if (it.depth == 4)
+            {
+                d4.push_back(it);
+                continue;
+            }
+            for (auto &bc : kids[it.node])
+                // depth-1 byte is text[i] (top byte of E), depth-4 byte is text[i-3] (low byte)
+                st.push_back({bc.second, it.depth + 1, it.gram | (bc.first << (8 * (3 - it.depth)))});
+        }
+        u32 gcap = 1024;
+        while (gcap < d4.size() * 2 + 16)
+            gcap <<= 1;
+        t->g4mask = gcap - 1;
+        g4.assign(gcap, make_uint2(0u, 0u));
+        for (auto &it : d4)
+        {
+            u32 h = (it.gram * kHashMul) >> 9;
+            while (g4[h & t->g4mask].y != 0u)
+                ++h;
+            g4[h & t->g4mask] = make_uint2(it.gram, it.node | (copies[it.node] ? 0x80000000u : 0u));
+        }
+    }
+    // whole-pattern table for the fast verifier (all patterns <= 16 bytes)
+    std::vector<uint4> sfx;
+    std::vector<unsigned long long> tags;
+    if (t->lmax && t->lmax <= 16)
+    {
+        std::vector<std::pair<std::vector<uint8_t>, u32>> uniq; // distinct pattern -> copies
+        {
+            std::vector<std::vector<uint8_t>> sorted(pats);
+            std::sort(sorted.begin(), sorted.end());
+            for (size_t i = 0; i < sorted.size();)
+            {
+                size_t j = i;
+                while (j < sorted.size() && sorted[j] == sorted[i])
+                    ++j;
+                uniq.push_back({sorted[i], (u32)(j - i)});
+                i = j;
+            }
+        }
+        u32 scap = 1024;
+        while (scap < uniq.size() * 2 + 16)
+            scap <<= 1;
+        t->sfxmask = scap - 1;
+        sfx.assign(2 * (size_t)scap, make_uint4(0u, 0u, 0u, 0u));
+        tags.assign((size_t)scap, 0ull);
+        for (auto &pc : uniq)
+        {
+            const auto &p = pc.first;
+            const u32 L = (u32)p.size();
+            t->lenmask |= 1u << L;
+            uint8_t by[16] = {0};
+            memcpy(by + 16 - L, p.data(), L);
+            u32 h = 0x811C9DC5u;
+            for (u32 k = 0; k < L; ++k) // bytes i, i-1, ... = pattern bytes from the end
+                h = (h ^ p[L - 1 - k]) * 0x01000193u;
+            u32 sl = ((h ^ (L * 0x9E3779B1u)) * 0x85EBCA6Bu) >> 8;
+            while (sfx[2 * (size_t)(sl & t->sfxmask) + 1].x != 0u)
+                ++sl; // (tags[] is occupied exactly where sfx meta is)
+            uint4 b4;
+            memcpy(&b4, by, 16);
+            sfx[2 * (size_t)(sl & t->sfxmask)] = b4;
+            sfx[2 * (size_t)(sl & t->sfxmask) + 1] = make_uint4(L, pc.second, h, 0u);
+            tags[(size_t)(sl & t->sfxmask)] = ((unsigned long long)h << 32) | ((unsigned long long)(pc.second & 0xffffffu) << 8) | L;
+        }
+    }
     if (hipSetDevice(device) != hipSuccess)
         goto bad;
+    if (!sfx.empty())
+    {
+        ACHK(hipMalloc(&t->d_sfx, sfx.size() * sizeof(uint4)));
+        ACHK(hipMemcpy(t->d_sfx, sfx.data(), sfx.size() * sizeof(uint4), hipMemcpyHostToDevice));
+        ACHK(hipMalloc(&t->d_tags, tags.size() * sizeof(unsigned long long)));
+        ACHK(hipMemcpy(t->d_tags, tags.data(), tags.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+    }
+    ACHK(hipMalloc(&t->d_gram4, g4.size() * sizeof(uint2)));
+    ACHK(hipMemcpy(t->d_gram4, g4.data(), g4.size() * sizeof(uint2), hipMemcpyHostToDevice));
     ACHK(hipMalloc(&t->d_filter, filter.size() * sizeof(u32)));
     ACHK(hipMemcpy(t->d_filter, filter.data(), filter.size() * sizeof(u32), hipMemcpyHostToDevice));
     ACHK(hipMalloc(&t->d_edges, tab.size() * sizeof(uint2)));
@@ -606,6 +1219,11 @@ void ac_free(AcTables *t)
     if (t->d_filter) (void)hipFree(t->d_filter);
     if (t->d_edges) (void)hipFree(t->d_edges);
     if (t->d_copies) (void)hipFree(t->d_copies);
+    if (t->d_gram4) (void)hipFree(t->d_gram4);
+    if (t->d_sfx) (void)hipFree(t->d_sfx);
+    if (t->d_tags) (void)hipFree(t->d_tags);
+    if (t->d_cand) (void)hipFree(t->d_cand);
+    if (t->d_candcnt) (void)hipFree(t->d_candcnt);
     delete t;
 }
 
@@ -618,25 +1236,76 @@ void ac_free(AcTables *t)
     } while (0)
 
 int g_ac_force_stage_cap = 0; // test hook (krep_gpu_debug_force_stage_cap)
+static const int g_ac_split = getenv("KREP_GPU_AC_SPLIT") ? 1 : 0;
+static const int g_ac_force_walk = getenv("KREP_GPU_AC_FORCE_WALK") ? 1 : 0; // test hook: trie-walk verifier
+static const int g_ac_chunk_mib = getenv("KREP_GPU_AC_CHUNK_MIB") ? atoi(getenv("KREP_GPU_AC_CHUNK_MIB")) : 0;
 
-template <bool CI, bool LN>
-static void ac_allow_lds(u32 lds)
+static u32 ac_lds_bytes(u32 filter_words, bool lines)
+{
+    const u32 per_wave = kAcQueue + (lines ? kAcBitmapWords : 0u);
+    return (((filter_words + 3u) & ~3u) + 4u + kAcWaves * per_wave) * (u32)sizeof(u32);
+}
+
+template <bool CI, bool LN, int CLS>
+static hipError_t ac_launch3(const AcArgs &a, u32 grid, u32 lds, hipStream_t st)
 {
     // more than 64 KiB of dynamic LDS has to be requested explicitly
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ac_scan_kernel<CI, LN>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ac_scan_kernel<CI, LN, CLS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((ac_scan_kernel<CI, LN, CLS>), dim3(grid), dim3(kAcBlock), lds, st, a);
+    return hipGetLastError();
+}
+template <bool CI, bool LN>
+static hipError_t ac_launch2(const AcArgs &a, u32 grid, u32 lds, hipStream_t st)
+{
+    const bool only4 = a.has4 && !a.has1 && !a.has2 && !a.has3;
+    return only4 ? ac_launch3<CI, LN, 8>(a, grid, lds, st) : ac_launch3<CI, LN, 15>(a, grid, lds, st);
 }
 static hipError_t ac_launch(const AcArgs &a, u32 grid, u32 lds, hipStream_t st)
 {
     const bool ci = a.flags & F_CI, ln = a.flags & F_LINES;
-    if (ci && ln) ac_allow_lds<true, true>(lds);
-    else if (ci) ac_allow_lds<true, false>(lds);
-    else if (ln) ac_allow_lds<false, true>(lds);
-    else ac_allow_lds<false, false>(lds);
-    if (ci && ln) hipLaunchKernelGGL((ac_scan_kernel<true, true>), dim3(grid), dim3(kAcBlock), lds, st, a);
-    else if (ci) hipLaunchKernelGGL((ac_scan_kernel<true, false>), dim3(grid), dim3(kAcBlock), lds, st, a);
-    else if (ln) hipLaunchKernelGGL((ac_scan_kernel<false, true>), dim3(grid), dim3(kAcBlock), lds, st, a);
-    else hipLaunchKernelGGL((ac_scan_kernel<false, false>), dim3(grid), dim3(kAcBlock), lds, st, a);
+    if (ci && ln) return ac_launch2<true, true>(a, grid, lds, st);
+    if (ci) return ac_launch2<true, false>(a, grid, lds, st);
+    if (ln) return ac_launch2<false, true>(a, grid, lds, st);
+    return ac_launch2<false, false>(a, grid, lds, st);
+}
+
+template <bool CI, int CLS>
+static hipError_t ac_filter_launch2(const AcArgs &a, u32 grid, u32 lds, hipStream_t st)
+{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ac_filter_kernel<CI, CLS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess)
+    {
+        fail("hipFuncSetAttribute(ac_filter_kernel, %u B LDS) failed: %s", lds, hipGetErrorString(e));
+        return e;
+    }
+    hipLaunchKernelGGL((ac_filter_kernel<CI, CLS>), dim3(grid), dim3(kAcBlock), lds, st, a);
+    e = hipGetLastError();
+    if (e != hipSuccess)
+        fail("ac_filter_kernel<%d,%d> launch failed: %s (grid %u, lds %u)", (int)CI, CLS, hipGetErrorString(e), grid, lds);
+    return e;
+}
+static hipError_t ac_filter_launch(const AcArgs &a, u32 grid, u32 lds, hipStream_t st)
+{
+    const bool only4 = a.has4 && !a.has1 && !a.has2 && !a.has3;
+    if (a.flags & F_CI)
+        return only4 ? ac_filter_launch2<true, 8>(a, grid, lds, st) : ac_filter_launch2<true, 15>(a, grid, lds, st);
+    return only4 ? ac_filter_launch2<false, 8>(a, grid, lds, st) : ac_filter_launch2<false, 15>(a, grid, lds, st);
+}
+static hipError_t ac_verify_launch(const AcArgs &a, u32 grid, hipStream_t st)
+{
+    const bool only4 = a.has4 && !a.has1 && !a.has2 && !a.has3, ci = a.flags & F_CI;
+    if (a.sfx && !g_ac_force_walk)
+    { // every pattern <= 16 bytes: independent per-length probes instead of the trie walk
+        if (ci) hipLaunchKernelGGL((ac_verify16_kernel<true>), dim3(grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((ac_verify16_kernel<false>), dim3(grid), dim3(256), 0, st, a);
+        return hipGetLastError();
+    }
+    if (ci && only4) hipLaunchKernelGGL((ac_verify_kernel<true, true>), dim3(grid), dim3(256), 0, st, a);
+    else if (ci) hipLaunchKernelGGL((ac_verify_kernel<true, false>), dim3(grid), dim3(256), 0, st, a);
+    else if (only4) hipLaunchKernelGGL((ac_verify_kernel<false, true>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((ac_verify_kernel<false, false>), dim3(grid), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 
@@ -682,9 +1351,12 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
     a.end_lo = own_lo;
     a.end_hi = lines ? own_hi : std::min<u64>(text_len, (u64)own_hi + t->lmax - 1);
     a.anchor = own_lo & ~(u64)15;
-    const u64 tile_bytes = (u64)kSegBytes * kAcWaves;
-    a.num_tiles = (a.end_hi - a.anchor + tile_bytes - 1) / tile_bytes;
+    a.num_tiles = (a.end_hi - a.anchor + kSegBytes - 1) / kSegBytes; // 8-KiB units
     a.flags = (t->ci ? F_CI : 0) | (ww ? F_WW : 0) | (lines ? F_LINES : 0);
+    if (getenv("KREP_GPU_AC_NOVERIFY"))
+        a.flags |= 1u << 31;
+    if (getenv("KREP_GPU_AC_NOGATE"))
+        a.flags |= 1u << 30;
     a.lmax = t->lmax;
     a.has1 = t->has1; a.has2 = t->has2; a.has3 = t->has3; a.has4 = t->has4;
     a.filter = t->d_filter;
@@ -693,6 +1365,12 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
     a.edges = t->d_edges;
     a.emask = t->emask;
     a.copies = t->d_copies;
+    a.gram4 = t->d_gram4;
+    a.sfx = t->d_sfx;
+    a.tags = t->d_tags;
+    a.sfxmask = t->sfxmask;
+    a.lenmask = t->lenmask;
+    a.g4mask = t->g4mask;
     a.ctr = d_ctr;
     const u64 want = (d_pos && cap && !lines) ? std::min<u64>(cap, (u64)max_count) : 0;
     if (want)
@@ -700,7 +1378,7 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
     a.positions = (u64 *)d_pos;
     a.pos_cap = want;
     const bool chain = want || lines;
-    const u64 n_units = a.num_tiles * kAcWaves;
+    const u64 n_units = a.num_tiles;
     a.stage_cap = want ? (g_ac_force_stage_cap ? (u32)g_ac_force_stage_cap : 64u) : 0u;
     if (chain)
     {
@@ -710,24 +1388,103 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
         a.stage = (u64 *)post.d_stage;
         a.offsets = (const u64 *)post.d_offsets;
     }
-    const u32 lds = (((t->filter_words + 3u) & ~3u) + 4u) * sizeof(u32);
-    const u32 per_cu = lds <= 80 * 1024 ? 2u : 1u;
-    const u32 grid = (u32)std::min<u64>(a.num_tiles, (u64)num_cu * per_cu);
     SCHK(hipSetDevice(t->device));
+    // Default: the FUSED kernel (LDS filter + per-wave LDS candidate queue + dense in-kernel verify): 1.2 TB/s on
+    // BASELINE config 4.  The split pipelines (filter kernel -> candidate lists -> verify kernel) measured slower on
+    // MI355X and stay behind KREP_GPU_AC_SPLIT=1 as experiment switches (numbers in DESIGN.md §4.2); -c always
+    // uses the fused kernel (it needs the newline masks next to the hits).
+    const bool split = !lines && g_ac_split;
+    if (split)
+    {
+        a.cand_cap = g_ac_force_stage_cap ? 8u : 128u;
+        const u64 cw = n_units * a.cand_cap;
+        if (cw > t->cand_words)
+        {
+            if (t->d_cand) (void)hipFree(t->d_cand);
+            t->d_cand = nullptr; t->cand_words = 0;
+            SCHK(hipMalloc(&t->d_cand, cw * sizeof(u32)));
+            t->cand_words = cw;
+        }
+        if (n_units > t->candcnt_words)
+        {
+            if (t->d_candcnt) (void)hipFree(t->d_candcnt);
+            t->d_candcnt = nullptr; t->candcnt_words = 0;
+            SCHK(hipMalloc(&t->d_candcnt, n_units * sizeof(u32)));
+            t->candcnt_words = n_units;
+        }
+        a.cand = t->d_cand;
+        a.candcnt = t->d_candcnt;
+    }
+    const u32 lds = split ? (((t->filter_words + 3u) & ~3u) + 4u) * (u32)sizeof(u32) : ac_lds_bytes(t->filter_words, lines);
+    const u32 per_cu = lds <= 80 * 1024 ? 2u : 1u;
+    const u64 n_tickets = (a.num_tiles + kAcUnitsPerTicket - 1) / kAcUnitsPerTicket;
+    const u32 grid = (u32)std::min<u64>((n_tickets + kAcWaves - 1) / kAcWaves, (u64)num_cu * per_cu);
+    const u32 vgrid = (u32)std::min<u64>((n_units + 3) / 4, (u64)num_cu * 8);
     if (time_it) SCHK(hipEventRecord(ev0, st));
     SCHK(hipMemsetAsync(d_ctr, 0, sizeof(Counters), st));
-    SCHK(ac_launch(a, grid, lds, st));
+    // optional chunking of filter -> verify (KREP_GPU_AC_CHUNK_MIB): measured slower than one pass at every chunk
+    // size (the verifier is bound by dependent-access depth, not by HBM), kept as an experiment switch
+    const u64 chunk_units = split ? (g_ac_chunk_mib ? (u64)g_ac_chunk_mib * 1024 * 1024 / kSegBytes : n_units) : n_units;
+    auto run_split = [&](const AcArgs &base, bool filter) -> int {
+        for (u64 u0 = 0; u0 < n_units; u0 += chunk_units)
+        {
+            AcArgs c = base;
+            c.unit_base = u0;
+            c.anchor = base.anchor + u0 * (u64)kSegBytes;
+            c.num_tiles = std::min<u64>(chunk_units, n_units - u0);
+            const u64 ct = (c.num_tiles + kAcUnitsPerTicket - 1) / kAcUnitsPerTicket;
+            const u32 cgrid = (u32)std::min<u64>((ct + kAcWaves - 1) / kAcWaves, (u64)num_cu * per_cu);
+            const u32 cvgrid = (u32)std::min<u64>((c.num_tiles + 3) / 4, (u64)num_cu * 8);
+            if (filter)
+            {
+                SCHK(hipMemsetAsync(&d_ctr->ticket, 0, sizeof(unsigned long long), st));
+                SCHK(ac_filter_launch(c, cgrid, lds, st));
+            }
+            SCHK(ac_verify_launch(c, cvgrid, st));
+        }
+        return 0;
+    };
+    if (split)
+    {
+        if (run_split(a, true))
+            return 2;
+    }
+    else
+        SCHK(ac_launch(a, grid, lds, st));
     if (chain && post_order(post, n_units, a.stage_cap, 0, lines, (uint64_t *)d_pos, want, d_ctr, num_cu, st))
         return 2;
     if (time_it) SCHK(hipEventRecord(ev1, st));
     SCHK(hipMemcpyAsync(h_ctr, d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, st));
     SCHK(hipStreamSynchronize(st));
+    if (split && getenv("KREP_GPU_DEBUG"))
+    {
+        std::vector<u32> cc(n_units);
+        (void)hipMemcpy(cc.data(), t->d_candcnt, n_units * sizeof(u32), hipMemcpyDeviceToHost);
+        u64 sum = 0, fl = 0;
+        u32 mx = 0;
+        for (u32 v : cc)
+        {
+            if (v == kAcFlooded) { ++fl; continue; }
+            sum += v;
+            mx = std::max(mx, v);
+        }
+        fprintf(stderr, "krep-gpu: (debug) candidates: units=%llu mean=%.1f max=%u flooded=%llu\n", (unsigned long long)n_units,
+                (double)sum / (double)std::max<u64>(1, n_units - fl), mx, (unsigned long long)fl);
+    }
     if (want && h_ctr->overflow_units)
     {
         AcArgs e = a;
         e.emit_mode = 1;
-        SCHK(hipMemsetAsync(&d_ctr->ticket, 0, sizeof(unsigned long long), st));
-        SCHK(ac_launch(e, grid, lds, st));
+        if (split)
+        {
+            if (run_split(e, false))
+                return 2;
+        }
+        else
+        {
+            SCHK(hipMemsetAsync(&d_ctr->ticket, 0, sizeof(unsigned long long), st));
+            SCHK(ac_launch(e, grid, lds, st));
+        }
         if (time_it) SCHK(hipEventRecord(ev1, st));
         SCHK(hipStreamSynchronize(st));
     }

@@ -369,16 +369,23 @@ extern "C" krep_gpu_plan_t *krep_gpu_plan_create(const search_params_t *p, int o
     return pl;
 }
 
+#define DBGFREE(x)                                                                      \
+    do                                                                                  \
+    {                                                                                   \
+        hipError_t e_ = (x);                                                            \
+        if (e_ != hipSuccess && getenv("KREP_GPU_DEBUG"))                               \
+            fprintf(stderr, "krep-gpu: (debug) %s -> %s\n", #x, hipGetErrorString(e_)); \
+    } while (0)
 extern "C" void krep_gpu_plan_destroy(krep_gpu_plan_t *pl)
 {
     if (!pl)
         return;
     (void)hipSetDevice(pl->device);
-    if (pl->d_pat) (void)hipFree(pl->d_pat);
-    if (pl->d_ctr) (void)hipFree(pl->d_ctr);
-    if (pl->h_ctr) (void)hipHostFree(pl->h_ctr);
-    if (pl->ev0) (void)hipEventDestroy(pl->ev0);
-    if (pl->ev1) (void)hipEventDestroy(pl->ev1);
+    if (pl->d_pat) DBGFREE(hipFree(pl->d_pat));
+    if (pl->d_ctr) DBGFREE(hipFree(pl->d_ctr));
+    if (pl->h_ctr) DBGFREE(hipHostFree(pl->h_ctr));
+    if (pl->ev0) DBGFREE(hipEventDestroy(pl->ev0));
+    if (pl->ev1) DBGFREE(hipEventDestroy(pl->ev1));
     if (pl->ac) ac_free(pl->ac);
     post_free(pl->post);
     delete pl;
@@ -652,6 +659,13 @@ extern "C" int krep_gpu_scan_device(krep_gpu_plan_t *pl, const void *d_text, siz
     memset(out, 0, sizeof *out);
     if (!pl || (!d_text && text_len))
         return kg::fail("scan_device: bad arguments");
+    {
+        // hipGetLastError() is sticky per thread: an earlier, deliberately ignored failure (e.g. a hipFree in a
+        // destructor) must not be mistaken for a failure of the launches below
+        const hipError_t stale = hipGetLastError();
+        if (stale != hipSuccess && getenv("KREP_GPU_DEBUG"))
+            fprintf(stderr, "krep-gpu: (debug) cleared stale HIP error: %s\n", hipGetErrorString(stale));
+    }
     hipStream_t st = (hipStream_t)stream;
     if (pl->ref_algo == KREP_RA_REGEX)
         return kg::fail("regex search is not part of the accelerated path");
