@@ -1,0 +1,111 @@
+"""Full BASELINE sizes on the GPU (32 GiB literal, 8 GiB single byte): the oracle cannot scan these in seconds, so
+parity is established through size-independent properties — the closed-form match count of the synthetic
+generator, strict sortedness, every reported offset really holding the pattern — plus oracle comparisons on
+windows (incl. every GiB boundary plant)."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from krep_amd import abi
+
+pytestmark = pytest.mark.gpu
+
+SEED, PERIOD, PAT = 20260925, 10000, b"Sherlock"
+GIB = 1 << 30
+M64 = (1 << 64) - 1
+
+
+def splitmix64(x):
+    x = (x + np.uint64(0x9E3779B97F4A7C15)) & np.uint64(M64)
+    x = ((x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & np.uint64(M64)
+    x = ((x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & np.uint64(M64)
+    return x ^ (x >> np.uint64(31))
+
+
+def expected_kind2_starts(n, plen=8):
+    """Start offsets the generator plants (krep_amd/csrc/kg_synth.h, kind 2), closed form."""
+    with np.errstate(over="ignore"):
+        k = np.arange((n + PERIOD - 1) // PERIOD, dtype=np.uint64)
+        h = splitmix64(np.uint64(SEED) ^ np.uint64(0xA5A5A5A5DEADBEEF) ^ (k * np.uint64(0x9FB21C651E98DF25)))
+        s = k * np.uint64(PERIOD) + h % np.uint64(PERIOD - plen + 1)
+    s = s.astype(np.int64)
+    b = ((s + GIB // 2) // GIB) * GIB
+    near = (b != 0) & (s + 2 * plen + 3 > b) & (s < b + 2 * plen)
+    s = s[~near & (s + plen <= n)]
+    bp = np.arange(1, n // GIB + 2, dtype=np.int64) * GIB - 3
+    bp = bp[bp + plen <= n]
+    return np.sort(np.concatenate([s, bp]))
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import krep_amd
+    e = krep_amd.load()
+    assert e.device_count() >= 1
+    return e
+
+
+def test_literal_32gib_properties(gpu):
+    import torch
+    n = 32 * GIB
+    free, _ = torch.cuda.mem_get_info()
+    if free < n + (2 << 30):
+        pytest.skip("not enough free HBM for the 32 GiB haystack")
+    buf = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+    gpu.generate(buf.data_ptr(), n, 0, 2, SEED, PAT, PERIOD)
+    want = expected_kind2_starts(n)
+    cap = len(want) + 4096
+    pos = torch.empty(2 * cap, dtype=torch.int64, device="cuda")
+    plan = gpu.plan(abi.Params([PAT]))
+    out = plan.scan(buf.data_ptr(), n, 0, n, 0, pos.data_ptr(), cap)
+    assert not out.overflow
+    # (1) closed-form count, (2) the exact list
+    assert out.count == out.total_matches == len(want) == out.stored
+    rec = pos[: 2 * out.stored].view(-1, 2)
+    starts = rec[:, 0]
+    assert torch.equal(starts.cpu(), torch.from_numpy(want))
+    assert bool(torch.all(rec[:, 1] - rec[:, 0] == len(PAT)))
+    # (3) strict sortedness (size-independent), (4) every offset really holds the literal
+    assert bool(torch.all(starts[1:] > starts[:-1]))
+    idx = starts[:, None] + torch.arange(len(PAT), device="cuda")[None, :]
+    assert bool(torch.all(buf[idx] == torch.tensor(list(PAT), dtype=torch.uint8, device="cuda")[None, :]))
+    # (5) count-only and -c modes agree with the list (every planted line is distinct or not: check vs windows below)
+    cnt = gpu.plan(abi.Params([PAT], count_lines=True, only_match=True)).scan(buf.data_ptr(), n)
+    assert cnt.count == len(want)
+    # (6) oracle on windows: around every 4th GiB boundary plant and a few interior spots
+    o = ol.oracle()
+    spots = [0, n - (1 << 20)] + [j * GIB - (1 << 19) for j in range(1, 32, 4)] + [5 * GIB + 12345, 17 * GIB + 999]
+    for lo in spots:
+        hi = min(n, lo + (1 << 20))
+        win = buf[lo:hi].cpu().numpy()
+        _, wpos = o.call(abi.RA_BMH, abi.Params([PAT]), win)
+        inside = want[(want >= lo) & (want + len(PAT) <= hi)]
+        assert np.array_equal(wpos[:, 0].astype(np.int64) + lo, inside), lo
+        # distinct lines in the window through the sharded device API == oracle -c on the window
+        lines_want, _ = o.call(abi.RA_BMH, abi.Params([PAT], count_lines=True), win)
+        pl = gpu.plan(abi.Params([PAT], count_lines=True))
+        got = pl.scan(buf.data_ptr() + lo, hi - lo)
+        assert got.count == lines_want, lo
+    plan.close()
+
+
+def test_single_byte_8gib_checksum(gpu):
+    import torch
+    n = 8 * GIB
+    buf = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+    gpu.generate(buf.data_ptr(), n, 0, 3, SEED, b"#", 0)
+    truth = 0
+    csum = 0
+    chunk = 1 << 30
+    for lo in range(0, n, chunk):  # reference count and checksum of offsets, chunked to bound temporaries
+        nz = torch.nonzero(buf[lo:lo + chunk] == ord("#")).flatten()
+        truth += int(nz.numel())
+        csum += int(nz.sum().item()) + lo * int(nz.numel())
+    cap = truth + 4096
+    pos = torch.empty(2 * cap, dtype=torch.int64, device="cuda")
+    out = gpu.plan(abi.Params([b"#"])).scan(buf.data_ptr(), n, 0, n, 0, pos.data_ptr(), cap)
+    assert out.count == truth == out.stored and not out.overflow
+    starts = pos[: 2 * truth].view(-1, 2)[:, 0]
+    assert bool(torch.all(starts[1:] > starts[:-1]))
+    assert int(starts.sum().item()) == csum  # checksum of all offsets
+    assert bool(torch.all(buf[starts] == ord("#")))
