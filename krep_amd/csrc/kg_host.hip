@@ -723,6 +723,56 @@ int ensure(DevBuf &b, size_t n, int dev)
 }
 } // namespace
 
+// Host buffer -> HBM through two pinned staging buffers: the CPU copy of chunk k+1 overlaps the DMA of chunk k
+// (the reference mmaps with MAP_POPULATE, krep.c:2630-2726; a pageable hipMemcpy stages serially).
+// PCIe-bound by construction (<= ~55 GB/s); this rate is reported separately and is never the roofline number.
+namespace {
+struct Stager
+{
+    static constexpr size_t kChunk = 32u << 20;
+    uint8_t *pin[2] = {nullptr, nullptr};
+    hipStream_t st = nullptr;
+    hipEvent_t done[2] = {nullptr, nullptr};
+    int dev = -1;
+    int init(int device)
+    {
+        if (dev == device && pin[0])
+            return 0;
+        HIPCHK(hipSetDevice(device));
+        for (int i = 0; i < 2; ++i)
+        {
+            HIPCHK(hipHostMalloc(&pin[i], kChunk));
+            HIPCHK(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+        }
+        HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        dev = device;
+        return 0;
+    }
+    int copy(uint8_t *d_dst, const char *src, size_t len)
+    {
+        if (len < (4u << 20)) // small buffers: one synchronous copy is cheaper than the pipeline
+        {
+            HIPCHK(hipMemcpy(d_dst, src, len, hipMemcpyHostToDevice));
+            return 0;
+        }
+        size_t off = 0;
+        for (int k = 0; off < len; ++k, off += kChunk)
+        {
+            const int b = k & 1;
+            const size_t n = std::min(kChunk, len - off);
+            if (k >= 2)
+                HIPCHK(hipEventSynchronize(done[b])); // the DMA that last used this staging buffer
+            memcpy(pin[b], src + off, n);
+            HIPCHK(hipMemcpyAsync(d_dst + off, pin[b], n, hipMemcpyHostToDevice, st));
+            HIPCHK(hipEventRecord(done[b], st));
+        }
+        HIPCHK(hipStreamSynchronize(st));
+        return 0;
+    }
+};
+thread_local Stager tl_stager;
+} // namespace
+
 // memchr_search's final flush (krep.c:3976-3991 + :4026-4038): when max_count is a multiple of the
 // 4096-entry batch and more matches exist, the (max_count+1)-th record is stored FIRST (in front of
 // the last batch) and the max_count-th is dropped.
@@ -759,9 +809,10 @@ static uint64_t run_host_operator(const search_params_t *params, const char *tex
         }
         if (ensure(tl_text, text_len + 64, 0))
             break;
-        if (text_len && hipMemcpy(tl_text.p, text, text_len, hipMemcpyHostToDevice) != hipSuccess)
+        if (text_len && (tl_stager.init(0) || tl_stager.copy(tl_text.p, text, text_len)))
         {
-            kg::fail("H2D copy failed");
+            if (g_err.empty())
+                kg::fail("H2D copy failed");
             break;
         }
         const bool want_pos = params->track_positions && result != nullptr && !params->count_lines_mode;
