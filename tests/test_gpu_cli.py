@@ -1,0 +1,50 @@
+"""The reference CLI itself, built with the GPU backend wired in as INTEGRATION.md describes
+(integration/make_krep_gpu_cli.py -> oracle/_ref/krep_gpu_cli): with KREP_GPU=1 the scan runs on the MI355X,
+without it the unchanged CPU functions run.  Outputs must be byte-identical (CPU side pinned to one thread:
+krep's own multi-chunk path double-counts at chunk boundaries)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "oracle", "_ref", "krep_gpu_cli")
+
+
+def run(args, gpu):
+    env = dict(os.environ)
+    env.pop("KREP_GPU", None)
+    if gpu:
+        env["KREP_GPU"] = "1"
+    r = subprocess.run([CLI] + args, env=env, capture_output=True, timeout=300)
+    return r.returncode, r.stdout, r.stderr
+
+
+@pytest.mark.skipif(not os.path.exists(CLI), reason="oracle/_ref/krep_gpu_cli not built (needs /root/reference)")
+def test_cli_gpu_equals_cpu(tmp_path):
+    import krep_amd
+    e = krep_amd.load()
+    big = e.generate_host(12 << 20, 0, 2, 99, b"Sherlock", 5000)
+    big[1000:1008] = np.frombuffer(b"sherLOCK", dtype=np.uint8)
+    f_big = tmp_path / "big.txt"
+    f_big.write_bytes(big.tobytes())
+    f_small = tmp_path / "small.txt"
+    f_small.write_bytes(b"The quick brown fox\nSherlock Holmes and sherlock\nnothing here\nfoxSherlock fox\n")
+    cases = [
+        (["-c", "Sherlock"], f_big), (["-c", "-i", "sherlock"], f_big), (["-c", "-w", "Sherlock"], f_big),
+        (["-c", "-o", "Sherlock"], f_big), (["-c", "e"], f_big), (["-c", "-e", "Sherlock", "-e", "the", "-e", "qz"], f_big),
+        (["-c", "-m", "7", "Sherlock"], f_big), (["Sherlock"], f_small), (["-o", "fox"], f_small),
+        (["-i", "SHERLOCK"], f_small), (["-w", "fox"], f_small), (["-e", "fox", "-e", "Holmes"], f_small),
+        (["-c", "absent-pattern"], f_big),
+    ]
+    for args, path in cases:
+        cpu = run(["-t", "1", "--color=never"] + args + [str(path)], gpu=False)
+        gpu = run(["-t", "1", "--color=never"] + args + [str(path)], gpu=True)
+        assert b"krep-gpu:" not in gpu[2], gpu[2]
+        assert gpu[0] == cpu[0] and gpu[1] == cpu[1], (args, cpu[:2], gpu[:2])
+    # and the GPU path really ran: the algorithm is no CPU function -> no chunking, same answer with -t 8
+    multi = run(["-t", "8", "-c", "Sherlock", str(f_big)], gpu=True)
+    single = run(["-t", "1", "-c", "Sherlock", str(f_big)], gpu=False)
+    assert multi[1] == single[1]
