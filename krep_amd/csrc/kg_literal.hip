@@ -175,7 +175,11 @@ __global__ __launch_bounds__(kBlock) void lit_scan(const LitArgs a)
                 const uint4 *src = reinterpret_cast<const uint4 *>(a.text + seg) + lane;
 #pragma unroll
                 for (int j = 0; j < kCells; ++j)
-                    d[j] = src[j * kWave];
+                {
+                    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+                    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src + j * kWave));
+                    d[j] = make_uint4(v.x, v.y, v.z, v.w);
+                }
                 after = *reinterpret_cast<const uint2 *>(a.text + seg + kSegBytes);
             }
 
