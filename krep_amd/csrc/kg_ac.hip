@@ -1451,7 +1451,7 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
     }
     else
         SCHK(ac_launch(a, grid, lds, st));
-    if (chain && post_order(post, n_units, a.stage_cap, 0, lines, (uint64_t *)d_pos, want, d_ctr, num_cu, st))
+    if (chain && post_order(post, n_units, a.stage_cap, 0, 0, 0, lines, (uint64_t *)d_pos, want, d_ctr, num_cu, st))
         return 2;
     if (time_it) SCHK(hipEventRecord(ev1, st));
     SCHK(hipMemcpyAsync(h_ctr, d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, st));

@@ -546,7 +546,7 @@ static int scan_literal(krep_gpu_plan *pl, int algo, const uint8_t *d_text, size
         a.stage_cap = (uint32_t)g_force_stage_cap;
     if (chain)
     {
-        if (post_reserve(pl->post, n_units, n_units * a.stage_cap))
+        if (post_reserve(pl->post, n_units, (n_units * a.stage_cap + 3) / 4)) // 16-bit staging entries
             return 2;
         a.unitinfo = pl->post.d_unitinfo;
         a.stage = (uint64_t *)pl->post.d_stage;
@@ -561,7 +561,9 @@ static int scan_literal(krep_gpu_plan *pl, int algo, const uint8_t *d_text, size
     {
         HIPCHK(hipMemsetAsync(pl->d_ctr, 0, sizeof(Counters), st));
         HIPCHK(launch_literal(a, grid, st));
-        if (chain && post_order(pl->post, n_units, a.stage_cap, m, pl->lines, (uint64_t *)d_pos, want, pl->d_ctr, pl->num_cu, st))
+        const uint64_t unit_bytes = (uint64_t)a.rounds * kSegBytes, origin = a.anchor + global_base;
+        if (chain && post_order(pl->post, n_units, a.stage_cap, m, origin, unit_bytes, pl->lines, (uint64_t *)d_pos, want, pl->d_ctr,
+                                pl->num_cu, st))
             return 2;
         if (time_it) HIPCHK(hipEventRecord(pl->ev1, st));
         HIPCHK(hipMemcpyAsync(pl->h_ctr, pl->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, st));
@@ -604,7 +606,8 @@ static int scan_literal(krep_gpu_plan *pl, int algo, const uint8_t *d_text, size
         }
         if (n_occ)
         {
-            if (post_gather_pass(pl->post, n_units, a.stage_cap, m, pl->post.d_occ, n_occ, pl->num_cu, st))
+            if (post_gather_pass(pl->post, n_units, a.stage_cap, m, a.anchor + global_base, (uint64_t)a.rounds * kSegBytes,
+                                 pl->post.d_occ, n_occ, pl->num_cu, st))
                 return 2;
             if (pl->h_ctr->overflow_units)
             {

@@ -30,11 +30,12 @@ struct PostScratch
 void post_free(PostScratch &s);
 int post_reserve(PostScratch &s, uint64_t n_units, uint64_t stage_words);
 // K1..K4 on `st`: offsets, distinct-line total (ctr->lines), line summary (ctr->summary), gather into d_pos
-int post_order(PostScratch &s, uint64_t n_units, uint32_t stage_cap, uint32_t fixed_len, bool want_lines, uint64_t *d_pos,
-               uint64_t pos_cap, Counters *d_ctr, int num_cu, hipStream_t st);
+// fixed_len > 0: 16-bit unit-relative staging, record start = origin + unit * unit_bytes + offset
+int post_order(PostScratch &s, uint64_t n_units, uint32_t stage_cap, uint32_t fixed_len, uint64_t origin, uint64_t unit_bytes,
+               bool want_lines, uint64_t *d_pos, uint64_t pos_cap, Counters *d_ctr, int num_cu, hipStream_t st);
 int post_offsets_pass(PostScratch &s, uint64_t n_units, bool want_lines, Counters *d_ctr, hipStream_t st);
-int post_gather_pass(PostScratch &s, uint64_t n_units, uint32_t stage_cap, uint32_t fixed_len, uint64_t *d_pos,
-                     uint64_t pos_cap, int num_cu, hipStream_t st);
+int post_gather_pass(PostScratch &s, uint64_t n_units, uint32_t stage_cap, uint32_t fixed_len, uint64_t origin,
+                     uint64_t unit_bytes, uint64_t *d_pos, uint64_t pos_cap, int num_cu, hipStream_t st);
 // greedy non-overlapping selection (simd_sse42_search / kmp_search family) on the ordered occurrence list
 int post_greedy(PostScratch &s, const uint8_t *d_text, uint64_t text_len, uint64_t global_base, uint32_t m, bool ww,
                 bool lines, uint64_t n_occ, uint64_t *d_pos, uint64_t want, Counters *d_ctr, Counters *h_ctr, hipStream_t st,

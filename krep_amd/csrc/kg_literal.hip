@@ -124,7 +124,8 @@ __device__ __noinline__ W6 load_window_guarded(const uint8_t *text, u64 text_len
 // masks in registers, publishes the unit's aggregate, looks back, and emits.  The ticket for the
 // next tile is fetched while the current one is scanned.  One barrier per tile (ticket broadcast).
 template <int KIND, bool MASKED, bool CI, bool LINES, int R>
-__global__ __launch_bounds__(kBlock) void lit_scan(const LitArgs a)
+// >= 4 waves per SIMD (<= 128 VGPRs) for the plain variants: the allocator otherwise drifts to 137 and loses a wave
+__global__ __launch_bounds__(kBlock, (KIND <= 8 && !LINES) ? 4 : 1) void lit_scan(const LitArgs a)
 {
     __shared__ u64 s_ticket[2];
     const u32 lane = lane_id();
@@ -401,7 +402,8 @@ __global__ __launch_bounds__(kBlock) void lit_scan(const LitArgs a)
             }
             if (want_pos && wcnt)
             {
-                u64 *slot = reinterpret_cast<u64 *>(a.stage) + unit * (u64)a.stage_cap;
+                // unit-relative 16-bit offsets (a unit spans <= 32 KiB): 2 B staged per hit instead of 8
+                unsigned short *slot = reinterpret_cast<unsigned short *>(a.stage) + unit * (u64)a.stage_cap;
                 u32 out = 0;
 #pragma unroll
                 for (int r = 0; r < R; ++r)
@@ -414,15 +416,22 @@ __global__ __launch_bounds__(kBlock) void lit_scan(const LitArgs a)
                         if (!anyhit)
                             continue;
                         const u32 c = __popc(m16);
-                        u32 idx = out + wave_excl5(c);
-                        out += wave_sum5(c);
-                        const u64 lb = ubase + (u64)(r * kCells + j) * kCellBytes + (u64)lane * 16u + a.global_base;
+                        u32 idx = out, tot = 0;
+#pragma unroll
+                        for (int b = 0; b < 5; ++b) // exclusive lane prefix and wave total from the same ballots
+                        {
+                            const u64 bm = __ballot((c >> b) & 1u);
+                            idx += mbcnt64(bm) << b;
+                            tot += (u32)__popcll(bm) << b;
+                        }
+                        out += tot;
+                        const u32 rel0 = (u32)(r * kCells + j) * kCellBytes + lane * 16u;
                         while (m16)
                         {
                             const u32 k = __builtin_ctz(m16);
                             m16 &= m16 - 1u;
                             if (idx < a.stage_cap)
-                                slot[idx] = lb + k;
+                                slot[idx] = (unsigned short)(rel0 + k);
                             ++idx;
                         }
                     }

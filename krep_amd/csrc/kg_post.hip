@@ -216,12 +216,15 @@ __global__ __launch_bounds__(kPostBlock) void post_offsets(const u64 *__restrict
     }
 }
 
-// Staging -> final records.  fixed_len > 0: records are {start, start + fixed_len}; fixed_len == 0:
-// the staged word is (start << 11 | len) (Aho-Corasick, len <= 1024).
+// Staging -> final records.  fixed_len > 0 (single literal): the slot holds 16-bit offsets relative to the unit's
+// first byte, records are {unit_origin + rel, + fixed_len}; fixed_len == 0 (Aho-Corasick): the staged 64-bit word
+// is (start << 11 | len), len <= 1024.
 __global__ __launch_bounds__(kPostBlock) void post_gather(const u64 *__restrict__ info, u64 n_units,
                                                           const u64 *__restrict__ offsets, const u64 *__restrict__ stage,
-                                                          u32 stage_cap, u32 fixed_len, u64 *__restrict__ positions, u64 pos_cap)
+                                                          u32 stage_cap, u32 fixed_len, u64 origin, u64 unit_bytes,
+                                                          u64 *__restrict__ positions, u64 pos_cap)
 {
+    const unsigned short *stage16 = reinterpret_cast<const unsigned short *>(stage);
     const u32 lane = plane_id();
     const u64 n_waves = (u64)gridDim.x * (kPostBlock / 64);
     const u64 wid = (u64)blockIdx.x * (kPostBlock / 64) + (threadIdx.x >> 6);
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(kPostBlock) void post_gather(const u64 *__restrict_
         u64 s, e;
         if (fixed_len)
         {
-            s = word;
+            s = word; // already absolute: unit origin + 16-bit offset
             e = word + fixed_len;
         }
         else
@@ -254,10 +257,10 @@ __global__ __launch_bounds__(kPostBlock) void post_gather(const u64 *__restrict_
         // few records: the owning lane copies them itself
         if (cnt && cnt <= 4)
         {
-            const u64 *src = stage + u * (u64)stage_cap;
+            const u64 sbase = u * (u64)stage_cap, org = origin + u * unit_bytes;
             for (u32 i = 0; i < cnt; ++i)
                 if (off + i < pos_cap)
-                    put(off + i, src[i]);
+                    put(off + i, fixed_len ? org + stage16[sbase + i] : stage[sbase + i]);
             cnt = 0;
         }
         // many records: the whole wave copies one unit at a time (coalesced)
@@ -268,10 +271,10 @@ __global__ __launch_bounds__(kPostBlock) void post_gather(const u64 *__restrict_
             big &= big - 1;
             const u32 c = __shfl(cnt, l);
             const u64 o = __shfl(off, l);
-            const u64 *src = stage + (g + (u64)l) * (u64)stage_cap;
+            const u64 sbase = (g + (u64)l) * (u64)stage_cap, org = origin + (g + (u64)l) * unit_bytes;
             for (u32 i = lane; i < c; i += 64)
                 if (o + i < pos_cap)
-                    put(o + i, src[i]);
+                    put(o + i, fixed_len ? org + stage16[sbase + i] : stage[sbase + i]);
         }
     }
 }
@@ -335,25 +338,26 @@ int post_offsets_pass(PostScratch &s, uint64_t n_units, bool want_lines, Counter
     return 0;
 }
 
-int post_gather_pass(PostScratch &s, uint64_t n_units, uint32_t stage_cap, uint32_t fixed_len, uint64_t *d_pos,
-                     uint64_t pos_cap, int num_cu, hipStream_t st)
+int post_gather_pass(PostScratch &s, uint64_t n_units, uint32_t stage_cap, uint32_t fixed_len, uint64_t origin,
+                     uint64_t unit_bytes, uint64_t *d_pos, uint64_t pos_cap, int num_cu, hipStream_t st)
 {
     if (!d_pos || !pos_cap)
         return 0;
     const uint64_t groups = (n_units + 63) / 64;
     const u32 grid = (u32)std::min<uint64_t>((groups + 3) / 4, (uint64_t)num_cu * 16);
     hipLaunchKernelGGL(post_gather, dim3(grid ? grid : 1), dim3(kPostBlock), 0, st, (const u64 *)s.d_unitinfo, (u64)n_units,
-                       (const u64 *)s.d_offsets, (const u64 *)s.d_stage, stage_cap, fixed_len, (u64 *)d_pos, (u64)pos_cap);
+                       (const u64 *)s.d_offsets, (const u64 *)s.d_stage, stage_cap, fixed_len, (u64)origin, (u64)unit_bytes,
+                       (u64 *)d_pos, (u64)pos_cap);
     PCHK(hipGetLastError());
     return 0;
 }
 
-int post_order(PostScratch &s, uint64_t n_units, uint32_t stage_cap, uint32_t fixed_len, bool want_lines, uint64_t *d_pos,
-               uint64_t pos_cap, Counters *d_ctr, int num_cu, hipStream_t st)
+int post_order(PostScratch &s, uint64_t n_units, uint32_t stage_cap, uint32_t fixed_len, uint64_t origin, uint64_t unit_bytes,
+               bool want_lines, uint64_t *d_pos, uint64_t pos_cap, Counters *d_ctr, int num_cu, hipStream_t st)
 {
     if (post_offsets_pass(s, n_units, want_lines, d_ctr, st))
         return 2;
-    return post_gather_pass(s, n_units, stage_cap, fixed_len, d_pos, pos_cap, num_cu, st);
+    return post_gather_pass(s, n_units, stage_cap, fixed_len, origin, unit_bytes, d_pos, pos_cap, num_cu, st);
 }
 
 } // namespace kg
