@@ -183,6 +183,106 @@ __device__ __forceinline__ u32 ac_walk(const AcArgs &a, u64 i, u32 total, Put pu
     return seen;
 }
 
+// Fast verifier for pattern sets whose patterns all have >= 4 bytes (CLS == 8): ONE pass.
+//  * the 16 bytes ending at the candidate are loaded once (one unaligned 16-byte load) — the walk then needs one
+//    dependent access per level (the edge probe) instead of two (text byte + edge probe);
+//  * levels 1..4 are resolved by the exact 4-gram table;
+//  * the depths at which a pattern ends are remembered in a bit mask, so the longest-first emission needs no second
+//    walk (falls back to it when a pattern has duplicate copies or the set has patterns longer than 64 bytes).
+template <bool CI>
+__device__ __forceinline__ u32 ac_walk_fast(const AcArgs &a, u64 i, bool own_by_end, u64 &depthmask, bool &simple)
+{
+    depthmask = 0;
+    simple = true;
+    const bool ww = (a.flags & F_WW) != 0;
+    if (i < 15)
+    { // too close to the start of the text for the 16-byte window: generic walk
+        simple = false;
+        return ac_walk<CI, false, true>(a, i, 0u, [](u32, u64, u32) {});
+    }
+    struct __attribute__((packed)) U32p { u32 v; };
+    const U32p *q = reinterpret_cast<const U32p *>(a.text + (i - 15));
+    u32 T[4] = {q[0].v, q[1].v, q[2].v, q[3].v};
+    if (CI)
+    {
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+            T[w] = ac_fold4(T[w]);
+    }
+    u32 child = 0xffffffffu;
+    for (u32 h = (T[3] * kHashMul) >> 9;; ++h)
+    {
+        const uint2 e = a.gram4[h & a.g4mask];
+        if (e.y == 0u)
+            return 0u; // not a suffix of any pattern
+        if (e.x == T[3])
+        {
+            child = e.y;
+            break;
+        }
+    }
+    u32 node = 0, seen = 0;
+    const u64 maxd = (i + 1 < (u64)a.lmax) ? i + 1 : (u64)a.lmax;
+    for (u64 d = 4; d <= maxd; ++d)
+    {
+        if (d > 4)
+        {
+            u32 c;
+            if (d <= 16)
+            {
+                const u32 bi = 16u - (u32)d; // byte i-d+1 sits at index 16-d of the window
+                const u32 w = bi >> 2;
+                const u32 word = w == 0 ? T[0] : w == 1 ? T[1] : w == 2 ? T[2] : T[3];
+                c = (word >> (8 * (bi & 3u))) & 0xffu;
+            }
+            else
+            {
+                c = a.text[i + 1 - d];
+                if (CI && (c - 'A' < 26u))
+                    c += 32u;
+            }
+            const u32 key = (node << 8) | c;
+            child = 0xffffffffu;
+            for (u32 h = (key * kHashMul) >> 7;; ++h)
+            {
+                const uint2 e = a.edges[h & a.emask];
+                if (e.x == key)
+                {
+                    child = e.y;
+                    break;
+                }
+                if (e.x == 0xffffffffu)
+                    break;
+            }
+            if (child == 0xffffffffu)
+                break;
+        }
+        node = child & 0x7fffffffu;
+        if (child & 0x80000000u)
+        {
+            const u64 s = i + 1 - d;
+            bool ok = own_by_end ? true : (s >= a.own_lo && s < a.own_hi);
+            if (ok && ww)
+            {
+                if (s > 0 && ac_wordc(a.text[s - 1]))
+                    ok = false;
+                else if (i + 1 < a.text_len && ac_wordc(a.text[i + 1]))
+                    ok = false;
+            }
+            if (ok)
+            {
+                const u32 k = a.copies[node];
+                seen += k;
+                if (k != 1u || d > 63)
+                    simple = false;
+                else
+                    depthmask |= 1ull << d;
+            }
+        }
+    }
+    return seen;
+}
+
 constexpr u32 kAcUnitsPerTicket = 8;   // 64 KiB of haystack per wave ticket
 constexpr u32 kAcQueue = 512;          // candidate queue entries per wave (u32 each)
 constexpr u32 kAcBitmapWords = 256;    // 8192 end positions of a unit, one bit each (LINES)
@@ -378,8 +478,15 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 if (flooded)
                     live = pos >= a.end_lo && pos < a.end_hi;
                 u32 c = 0;
+                u64 depthmask = 0;
+                bool simple = false;
                 if (live)
-                    c = ac_walk<CI, false, CLS == 8>(a, pos, 0u, [](u32, u64, u32) {});
+                {
+                    if (CLS == 8)
+                        c = ac_walk_fast<CI>(a, pos, LINES, depthmask, simple);
+                    else
+                        c = ac_walk<CI, false, false>(a, pos, 0u, [](u32, u64, u32) {});
+                }
                 u32 incl = c;
 #pragma unroll
                 for (int o = 1; o < 64; o <<= 1)
@@ -395,24 +502,37 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                     if (LINES)
                         atomicOr(&bitmap[rel >> 5], 1u << (rel & 31u));
                     if (do_stage || do_final)
-                        ac_walk<CI, true, CLS == 8>(a, pos, c, [&](u32 r, u64 s, u32 len) {
-                            const u32 at = rank0 + r;
+                    {
+                        auto write = [&](u32 at, u64 s0, u32 len) {
                             if (do_stage)
                             {
                                 if (at < a.stage_cap)
-                                    slot[at] = ((s + a.global_base) << 11) | len;
+                                    slot[at] = ((s0 + a.global_base) << 11) | len;
                             }
                             else
                             {
                                 const u64 g = fbase + at;
                                 if (g < a.pos_cap)
                                 {
-                                    const u64 st = s + a.global_base, en = st + len;
+                                    const u64 st = s0 + a.global_base, en = st + len;
                                     *reinterpret_cast<uint4 *>(a.positions + 2 * g) =
                                         make_uint4((u32)st, (u32)(st >> 32), (u32)en, (u32)(en >> 32));
                                 }
                             }
-                        });
+                        };
+                        if (CLS == 8 && simple)
+                        {
+                            u32 at = rank0;
+                            for (u64 rest = depthmask; rest;) // longest first
+                            {
+                                const u32 d = 63u - (u32)__builtin_clzll(rest);
+                                rest &= ~(1ull << d);
+                                write(at++, pos + 1 - (u64)d, d);
+                            }
+                        }
+                        else
+                            ac_walk<CI, true, CLS == 8>(a, pos, c, [&](u32 r, u64 s2, u32 len) { write(rank0 + r, s2, len); });
+                    }
                 }
             }
         }
