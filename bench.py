@@ -134,6 +134,7 @@ def main():
     ap.add_argument("--gib", type=float, default=32.0, help="haystack GiB per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-gib", type=float, default=4.0)
+    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and all-reduce even with one rank (self-test)")
     args = ap.parse_args()
 
     import torch
@@ -144,12 +145,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 or world > 1:
-        assert world == args.gpus, f"launch with torchrun --nproc-per-node {args.gpus}"
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    use_dist = args.gpus > 1 or world > 1 or args.force_dist
+    if use_dist:
+        assert world == args.gpus, f"launch with torchrun --nproc-per-node {args.gpus}"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     wl = dict(WORKLOADS[args.workload])
     if wl["patterns"] is None:
@@ -170,18 +173,20 @@ def main():
     pos = torch.empty(cap * 2, dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     counts = torch.zeros(2, dtype=torch.int64, device=dev)
+    host_counts = torch.zeros(2, dtype=torch.int64).pin_memory()
 
     def step():
         out = plan.scan(buf.data_ptr(), text_len, 0, n, shard_off, pos.data_ptr(), cap, stream, True)
-        if world > 1:
-            counts[0] = out.count
-            counts[1] = out.total_matches
+        if use_dist:
+            host_counts[0] = out.count
+            host_counts[1] = out.total_matches
+            counts.copy_(host_counts, non_blocking=True)
             dist.all_reduce(counts)           # the one RCCL all-reduce of the per-GPU counts
         return out
 
     for _ in range(args.warmup):
         out = step()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -190,10 +195,10 @@ def main():
         out = step()
         k_ms += out.kernel_ms
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -239,7 +244,7 @@ def main():
                 line["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": os.cpu_count(), "kind": "port",
                                         "sample": f"failed: {e}"}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -119,3 +119,19 @@ def test_avx512_unexamined_block_is_reproduced(gpu, oracle_engine):
                 text[s:s + len(pat)] = np.frombuffer(pat, dtype=np.uint8)
         for kw in (dict(), dict(count_lines=True, only_match=True), dict(max_count=1)):
             _check(gpu, oracle_engine, text, pat, kw, abi.REF_AVX512)
+
+
+def test_maximum_pattern_length_and_dense_long_patterns(gpu, oracle_engine):
+    """MAX_PATTERN_LENGTH = 1024 (krep.c:77); and a long pattern whose every alignment is a candidate."""
+    rng = np.random.RandomState(21)
+    text = cases.rand_text(rng, 70_000, b"ab")
+    for m in (1023, 1024, 513):
+        pat = text[5000:5000 + m].tobytes()
+        text[40_000:40_000 + m] = np.frombuffer(pat, dtype=np.uint8)
+        for kw in (dict(), dict(count_lines=True, only_match=True), dict(case_sensitive=False)):
+            _check(gpu, oracle_engine, text, pat, kw, abi.REF_AVX2)
+    aaa = np.full(20_000, ord("a"), dtype=np.uint8)
+    aaa[7000] = ord("\n")
+    for m in (9, 100, 1024):
+        for kw in (dict(), dict(count_lines=True), dict(max_count=17)):
+            _check(gpu, oracle_engine, aaa, b"a" * m, kw, abi.REF_SCALAR if m < 33 else abi.REF_AVX2)
