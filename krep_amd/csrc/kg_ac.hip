@@ -283,9 +283,11 @@ __device__ __forceinline__ u32 ac_walk_fast(const AcArgs &a, u64 i, bool own_by_
     return seen;
 }
 
-constexpr u32 kAcUnitsPerTicket = 8;   // 64 KiB of haystack per wave ticket
+constexpr u32 kAcUnitsPerTicket = 4;   // 64 KiB of haystack per wave ticket
 constexpr u32 kAcQueue = 512;          // candidate queue entries per wave (u32 each)
-constexpr u32 kAcBitmapWords = 256;    // 8192 end positions of a unit, one bit each (LINES)
+constexpr int kAcRounds = 2;            // load rounds per unit: one candidate drain per 16 KiB (53 of 64 lanes busy)
+constexpr u32 kAcUnitBytes = kAcRounds * kSegBytes;
+constexpr u32 kAcBitmapWords = kAcUnitBytes / 32; // one bit per end position of a unit (LINES)
 
 // bit of table `base` at hash h
 __device__ __forceinline__ u32 ac_tbit(const u32 *tab, u32 base, u32 h) { return (tab[base + (h >> 5)] >> (h & 31u)) & 1u; }
@@ -328,14 +330,28 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
         const u64 u_end = (u_begin + kAcUnitsPerTicket < a.num_tiles) ? u_begin + kAcUnitsPerTicket : a.num_tiles;
       for (u64 unit = u_begin; unit < u_end; ++unit)
       {
-        const u64 seg = a.anchor + unit * (u64)kSegBytes;
+        const u64 useg = a.anchor + unit * (u64)kAcUnitBytes; // the unit = kAcRounds load rounds of 8 KiB
         if (emit_final && (u32)(a.unitinfo[unit] & kUiCountMask) <= a.stage_cap)
             continue;
+
+        u64 *slot = reinterpret_cast<u64 *>(a.stage) + unit * (u64)a.stage_cap;
+        const bool do_final = emit_final && want_pos;
+        const bool do_stage = !emit_final && want_pos;
+        const u64 fbase = do_final ? a.offsets[unit] : 0ull;
+        u32 wcnt = 0; // matches of the unit so far == rank of the next one (uniform)
+        u32 qn = 0;   // queued candidates (uniform)
+
+        bool flooded = false; // the candidate queue overflowed (uniform)
+
+        u32 NLm[kAcRounds][kCells];
+#pragma unroll
+        for (int r = 0; r < kAcRounds; ++r)
+        {
+        const u64 seg = useg + (u64)r * kSegBytes;
         const bool fast_now = seg + kSegBytes <= a.text_len;
         const bool interior = seg >= a.end_lo && seg + kSegBytes <= a.end_hi;
-
         uint4 d[kCells];
-        u32 before = 0; // the 4 bytes in front of the segment
+        u32 before = 0; // the 4 bytes in front of the round
         if (fast_now)
         {
             const uint4 *src = reinterpret_cast<const uint4 *>(a.text + seg) + lane;
@@ -349,17 +365,6 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
             for (u32 b = 0; b < 4; ++b)
                 if (seg + b >= 4 && seg + b - 4 < a.text_len)
                     before |= (u32)a.text[seg + b - 4] << (8 * b);
-
-        u64 *slot = reinterpret_cast<u64 *>(a.stage) + unit * (u64)a.stage_cap;
-        const bool do_final = emit_final && want_pos;
-        const bool do_stage = !emit_final && want_pos;
-        const u64 fbase = do_final ? a.offsets[unit] : 0ull;
-        u32 wcnt = 0; // matches of the unit so far == rank of the next one (uniform)
-        u32 qn = 0;   // queued candidates (uniform)
-
-        bool flooded = false; // the candidate queue overflowed (uniform)
-
-        u32 NLm[kCells];
 #pragma unroll
         for (int j = 0; j < kCells; ++j)
         {
@@ -432,7 +437,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 if (LINES)
                     nlm &= clip(a.own_lo, a.own_hi);
             }
-            NLm[j] = nlm;
+            NLm[r][j] = nlm;
             if (a.flags & (1u << 31)) // ablation hook (KREP_GPU_AC_NOVERIFY): filter cost only
                 cand = 0;
 
@@ -453,7 +458,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 else
                 {
                     u32 at = qn + ex, rest = cand;
-                    const u32 rel0 = (u32)j * kCellBytes + lane * 16u;
+                    const u32 rel0 = (u32)r * kSegBytes + (u32)j * kCellBytes + lane * 16u;
                     while (rest)
                     {
                         const u32 k = __builtin_ctz(rest);
@@ -465,16 +470,18 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
             }
         }
 
+        } // rounds
+
         // ---- verify (and stage/emit) the candidates, 64 at a time, one per lane; a flooded unit walks
         //      every end position of the unit instead (exact, slow, pathological inputs only) ------------
         {
-            const u32 n = flooded ? kSegBytes : qn;
+            const u32 n = flooded ? kAcUnitBytes : qn;
             for (u32 b0 = 0; b0 < n; b0 += 64)
             {
                 const u32 qi = b0 + lane;
                 bool live = qi < n;
                 const u32 rel = flooded ? qi : (live ? queue[qi] : 0u);
-                const u64 pos = seg + rel;
+                const u64 pos = useg + rel;
                 if (flooded)
                     live = pos >= a.end_lo && pos < a.end_hi;
                 u32 c = 0;
@@ -541,10 +548,12 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
         if (LINES)
         {
 #pragma unroll
+            for (int r = 0; r < kAcRounds; ++r)
+#pragma unroll
             for (int j = 0; j < kCells; ++j)
             {
-                const u32 bitoff = (u32)j * kCellBytes + lane * 16u;
-                const u32 H = (bitmap[bitoff >> 5] >> (bitoff & 31u)) & 0xffffu, N = NLm[j];
+                const u32 bitoff = (u32)r * kSegBytes + (u32)j * kCellBytes + lane * 16u;
+                const u32 H = (bitmap[bitoff >> 5] >> (bitoff & 31u)) & 0xffffu, N = NLm[r][j];
                 const u64 anyhit = __ballot(H != 0u);
                 const bool l_nl = N != 0u;
                 const u64 B_nl = __ballot(l_nl);
@@ -1471,7 +1480,9 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
     a.end_lo = own_lo;
     a.end_hi = lines ? own_hi : std::min<u64>(text_len, (u64)own_hi + t->lmax - 1);
     a.anchor = own_lo & ~(u64)15;
-    a.num_tiles = (a.end_hi - a.anchor + kSegBytes - 1) / kSegBytes; // 8-KiB units
+    const bool split = !lines && g_ac_split; // see below
+    const u64 unit_bytes = split ? (u64)kSegBytes : (u64)kAcUnitBytes;
+    a.num_tiles = (a.end_hi - a.anchor + unit_bytes - 1) / unit_bytes;
     a.flags = (t->ci ? F_CI : 0) | (ww ? F_WW : 0) | (lines ? F_LINES : 0);
     if (getenv("KREP_GPU_AC_NOVERIFY"))
         a.flags |= 1u << 31;
@@ -1509,11 +1520,10 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
         a.offsets = (const u64 *)post.d_offsets;
     }
     SCHK(hipSetDevice(t->device));
-    // Default: the FUSED kernel (LDS filter + per-wave LDS candidate queue + dense in-kernel verify): 1.2 TB/s on
+    // Default: the FUSED kernel (LDS filter + per-wave LDS candidate queue + dense in-kernel verify): 1.8 TB/s on
     // BASELINE config 4.  The split pipelines (filter kernel -> candidate lists -> verify kernel) measured slower on
     // MI355X and stay behind KREP_GPU_AC_SPLIT=1 as experiment switches (numbers in DESIGN.md §4.2); -c always
     // uses the fused kernel (it needs the newline masks next to the hits).
-    const bool split = !lines && g_ac_split;
     if (split)
     {
         a.cand_cap = g_ac_force_stage_cap ? 8u : 128u;
