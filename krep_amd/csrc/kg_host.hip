@@ -805,6 +805,57 @@ static void memchr_batch_quirk(match_position_t *recs, uint64_t have, size_t max
     recs[f] = extra;
 }
 
+// One cached plan per calling thread: the CLI calls the operator once per file (krep.c:1950) with the same params,
+// and building a plan costs device allocations + (multi-pattern) table construction.  Keyed by every field the scan
+// depends on, including the mirrored globals.
+namespace {
+struct PlanKey
+{
+    std::vector<std::vector<uint8_t>> pats;
+    bool cs, lines, track, ww;
+    size_t max_count;
+    int simd, only_matching, no_simd, algo;
+    bool operator==(const PlanKey &o) const
+    {
+        return pats == o.pats && cs == o.cs && lines == o.lines && track == o.track && ww == o.ww && max_count == o.max_count &&
+               simd == o.simd && only_matching == o.only_matching && no_simd == o.no_simd && algo == o.algo;
+    }
+};
+struct PlanCache
+{
+    PlanKey key;
+    krep_gpu_plan_t *plan = nullptr;
+    ~PlanCache()
+    {
+        // process teardown: the HIP runtime may already be gone, so the plan is deliberately not destroyed here
+    }
+};
+thread_local PlanCache tl_plan;
+} // namespace
+
+static krep_gpu_plan_t *cached_plan(const search_params_t *p)
+{
+    PlanKey k;
+    if (p->num_patterns >= 1 && p->patterns && p->pattern_lens)
+        for (size_t i = 0; i < p->num_patterns; ++i)
+            k.pats.emplace_back((const uint8_t *)p->patterns[i], (const uint8_t *)p->patterns[i] + p->pattern_lens[i]);
+    else if (p->pattern)
+        k.pats.emplace_back((const uint8_t *)p->pattern, (const uint8_t *)p->pattern + p->pattern_len);
+    k.cs = p->case_sensitive; k.lines = p->count_lines_mode; k.track = p->track_positions; k.ww = p->whole_word;
+    k.max_count = p->max_count;
+    k.simd = g_simd; k.only_matching = g_only_matching; k.no_simd = g_no_simd; k.algo = g_algo_override;
+    if (tl_plan.plan && tl_plan.key == k)
+        return tl_plan.plan;
+    if (tl_plan.plan)
+    {
+        krep_gpu_plan_destroy(tl_plan.plan);
+        tl_plan.plan = nullptr;
+    }
+    tl_plan.plan = krep_gpu_plan_create(p, g_only_matching, 0);
+    tl_plan.key = std::move(k);
+    return tl_plan.plan;
+}
+
 static uint64_t run_host_operator(const search_params_t *params, const char *text, size_t text_len, match_result_t *result,
                                   int *status)
 {
@@ -815,7 +866,7 @@ static uint64_t run_host_operator(const search_params_t *params, const char *tex
         kg::fail("NULL params/text");
         return 0;
     }
-    krep_gpu_plan_t *pl = krep_gpu_plan_create(params, g_only_matching, 0);
+    krep_gpu_plan_t *pl = cached_plan(params);
     if (!pl)
         return 0;
     uint64_t ret = 0;
@@ -890,8 +941,7 @@ static uint64_t run_host_operator(const search_params_t *params, const char *tex
         if (status)
             *status = 0;
     } while (0);
-    krep_gpu_plan_destroy(pl);
-    return ret;
+    return ret; // the plan stays in this thread's one-entry cache
 }
 
 extern "C" uint64_t krep_gpu_literal_search(const search_params_t *params, const char *text, size_t len, match_result_t *result)
