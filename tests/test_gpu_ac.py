@@ -89,3 +89,17 @@ def test_dense_nested(gpu, oracle_engine):
         _check(gpu, oracle_engine, text, [b"a", b"ab", b"abc", b"bca"], dict())
     finally:
         gpu.force_stage_cap(0)
+
+
+def test_binary_patterns_and_text(gpu, oracle_engine):
+    rng = np.random.RandomState(44)
+    text = rng.randint(0, 256, size=90_000).astype(np.uint8)
+    pats = []
+    for m in (1, 2, 3, 5, 9, 16, 17, 40):
+        s = rng.randint(0, text.size - m)
+        pats.append(text[s:s + m].tobytes())
+        for t in rng.randint(0, text.size - m, 5):
+            text[t:t + m] = np.frombuffer(pats[-1], dtype=np.uint8)
+    _check(gpu, oracle_engine, text, pats, dict())
+    _check(gpu, oracle_engine, text, pats, dict(case_sensitive=False, whole_word=True))
+    _check(gpu, oracle_engine, text, [p for p in pats if len(p) >= 4 and len(p) <= 16], dict(max_count=9))

@@ -135,3 +135,22 @@ def test_maximum_pattern_length_and_dense_long_patterns(gpu, oracle_engine):
     for m in (9, 100, 1024):
         for kw in (dict(), dict(count_lines=True), dict(max_count=17)):
             _check(gpu, oracle_engine, aaa, b"a" * m, kw, abi.REF_SCALAR if m < 33 else abi.REF_AVX2)
+
+
+def test_binary_haystack_all_byte_values(gpu, oracle_engine):
+    """Arbitrary bytes (NULs, 0x80-0xFF): nothing may be treated as a terminator, and -i folds ASCII A-Z only
+    (lower_table is built in the C locale, krep.c:125-134)."""
+    rng = np.random.RandomState(33)
+    text = rng.randint(0, 256, size=120_000).astype(np.uint8)
+    text[rng.randint(0, text.size, 3000)] = 0
+    for m in (1, 2, 3, 4, 8, 13, 16):
+        for _ in range(3):
+            s = rng.randint(0, text.size - m)
+            pat = text[s:s + m].tobytes()
+            for t in rng.randint(0, text.size - m, 4):
+                text[t:t + m] = np.frombuffer(pat, dtype=np.uint8)
+            for kw in (dict(), dict(case_sensitive=False), dict(whole_word=True), dict(count_lines=True)):
+                _check(gpu, oracle_engine, text, pat, kw, abi.REF_AVX2)
+    hi = np.frombuffer(bytes([0xC1, 0xE1, ord("A"), ord("a"), 0x41 + 0x80]) * 2000, dtype=np.uint8)
+    _check(gpu, oracle_engine, hi, bytes([0xE1, ord("a")]), dict(case_sensitive=False), abi.REF_SCALAR)
+    _check(gpu, oracle_engine, hi, b"A", dict(case_sensitive=False), abi.REF_SCALAR)
