@@ -52,8 +52,8 @@ struct AcArgs
     u32 flags;                   // F_CI | F_WW | F_POS | F_LINES
     u32 lmax;
     u32 has1, has2, has3, has4;  // which length classes exist
-    const u32 *filter;           // T1 | T2 | T3 | T4 (only the present ones, in this order)
-    u32 off2, off3, off4, filter_words;
+    const u32 *filter;           // T4 | T1 | T2 | T3 (T4/T2/T3 only when present)
+    u32 off1, off2, off3, filter_words; // word offsets of T1/T2/T3 in LDS; T4 (>= 4-byte class) is at offset 0
     const uint2 *edges;          // open addressing: {key = node << 8 | byte, val = child | has_out << 31}
     u32 emask;
     const u32 *copies;           // per node: number of patterns equal to the node's string
@@ -416,13 +416,18 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 const u32 E = ((o & 3) == 0) ? W[o >> 2] : __builtin_amdgcn_alignbyte(W[(o >> 2) + 1], W[o >> 2], (u32)(o & 3));
                 u32 hit = 0;
                 if (CLS & 8)
-                    hit |= ac_tbit(s_mem, a.off4, (E * kHashMul) >> (32 - kT4Bits));
+                    {
+                        // the >= 4-byte table sits at LDS byte 0: byte-addressed, no base add
+                        const u32 t = E * kHashMul;
+                        const u32 by = reinterpret_cast<const unsigned char *>(s_mem)[t >> (32 - kT4Bits + 3)];
+                        hit |= (by >> ((t >> (32 - kT4Bits)) & 7u)) & 1u;
+                    }
                 if (CLS & 4)
                     hit |= ac_tbit(s_mem, a.off3, ((E >> 8) * kHashMul) >> (32 - kT3Bits));
                 if (CLS & 2)
                     hit |= ac_tbit(s_mem, a.off2, E >> 16);
                 if (CLS & 1)
-                    hit |= ac_tbit(s_mem, 0u, E >> 24);
+                    hit |= ac_tbit(s_mem, a.off1, E >> 24);
                 cand |= hit << k;
             }
             u32 nlm = NL;
@@ -715,13 +720,18 @@ __global__ __launch_bounds__(kAcBlock) void ac_filter_kernel(const AcArgs a)
                     const u32 E = ((o & 3) == 0) ? W[o >> 2] : __builtin_amdgcn_alignbyte(W[(o >> 2) + 1], W[o >> 2], (u32)(o & 3));
                     u32 hit = 0;
                     if (CLS & 8)
-                        hit |= ac_tbit(s_mem, a.off4, (E * kHashMul) >> (32 - kT4Bits));
+                        {
+                        // the >= 4-byte table sits at LDS byte 0: byte-addressed, no base add
+                        const u32 t = E * kHashMul;
+                        const u32 by = reinterpret_cast<const unsigned char *>(s_mem)[t >> (32 - kT4Bits + 3)];
+                        hit |= (by >> ((t >> (32 - kT4Bits)) & 7u)) & 1u;
+                    }
                     if (CLS & 4)
                         hit |= ac_tbit(s_mem, a.off3, ((E >> 8) * kHashMul) >> (32 - kT3Bits));
                     if (CLS & 2)
                         hit |= ac_tbit(s_mem, a.off2, E >> 16);
                     if (CLS & 1)
-                        hit |= ac_tbit(s_mem, 0u, E >> 24);
+                        hit |= ac_tbit(s_mem, a.off1, E >> 24);
                     cand |= hit << k;
                 }
                 if (!interior)
@@ -1089,7 +1099,7 @@ struct AcTables
     int device = 0;
     u32 npat = 0, lmin = 0, lmax = 0;
     bool ci = false, has_nl = false, has_empty = false;
-    u32 has1 = 0, has2 = 0, has3 = 0, has4 = 0, off2 = 0, off3 = 0, off4 = 0, filter_words = 0;
+    u32 has1 = 0, has2 = 0, has3 = 0, has4 = 0, off1 = 0, off2 = 0, off3 = 0, filter_words = 0;
     u32 *d_filter = nullptr;
     uint2 *d_edges = nullptr;
     u32 emask = 0;
@@ -1193,10 +1203,10 @@ AcTables *ac_build(const search_params_t &sp, int device)
         if (T3.empty()) T3.assign(kT3Words, 0);
         if (T4.empty()) T4.assign(kT4Words, 0);
     }
-    std::vector<u32> filter(T1);
+    std::vector<u32> filter(T4); // the >= 4-byte table first: the kernels address it from LDS byte 0
+    t->off1 = (u32)filter.size(); filter.insert(filter.end(), T1.begin(), T1.end());
     t->off2 = (u32)filter.size(); filter.insert(filter.end(), T2.begin(), T2.end());
     t->off3 = (u32)filter.size(); filter.insert(filter.end(), T3.begin(), T3.end());
-    t->off4 = (u32)filter.size(); filter.insert(filter.end(), T4.begin(), T4.end());
     t->filter_words = (u32)filter.size();
     // ---- reversed trie ----
     std::unordered_map<u32, u32> edge; // key = node << 8 | byte
@@ -1491,7 +1501,7 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
     a.lmax = t->lmax;
     a.has1 = t->has1; a.has2 = t->has2; a.has3 = t->has3; a.has4 = t->has4;
     a.filter = t->d_filter;
-    a.off2 = t->off2; a.off3 = t->off3; a.off4 = t->off4;
+    a.off1 = t->off1; a.off2 = t->off2; a.off3 = t->off3;
     a.filter_words = t->filter_words;
     a.edges = t->d_edges;
     a.emask = t->emask;
