@@ -28,269 +28,10 @@
 #include <vector>
 
 #include "../../include/krep_gpu.h"
-#include "kg_common.h"
+#include "kg_ac_common.h"
 #include "kg_internal.h"
 
 namespace kg {
-
-using u32 = uint32_t;
-using u64 = unsigned long long;
-
-constexpr int kAcBlock = 1024;             // 16 waves share one copy of the filter tables in LDS
-constexpr int kAcWaves = kAcBlock / 64;
-constexpr u32 kT1Words = 256 / 32;         // 1-byte patterns: direct
-constexpr u32 kT2Words = 65536 / 32;       // 2-byte patterns: direct (8 KiB)
-constexpr u32 kT3Bits = 17, kT3Words = (1u << kT3Bits) / 32; // 3-byte patterns: hashed (16 KiB)
-constexpr u32 kT4Bits = 19, kT4Words = (1u << kT4Bits) / 32; // >= 4-byte patterns: hashed (64 KiB)
-constexpr u32 kHashMul = 0x9E3779B1u;
-
-struct AcArgs
-{
-    const uint8_t *text;
-    u64 text_len, own_lo, own_hi, anchor, num_tiles, global_base;
-    u64 end_lo, end_hi;          // range of END indices this launch examines
-    u32 flags;                   // F_CI | F_WW | F_POS | F_LINES
-    u32 lmax;
-    u32 has1, has2, has3, has4;  // which length classes exist
-    const u32 *filter;           // T4 | T1 | T2 | T3 (T4/T2/T3 only when present)
-    u32 off1, off2, off3, filter_words; // word offsets of T1/T2/T3 in LDS; T4 (>= 4-byte class) is at offset 0
-    const uint2 *edges;          // open addressing: {key = node << 8 | byte, val = child | has_out << 31}
-    u32 emask;
-    const u32 *copies;           // per node: number of patterns equal to the node's string
-    u64 unit_base;               // global index of this launch's first unit (chunked filter -> verify pipeline)
-    u32 *cand;                   // [units * cand_cap] candidate end offsets (relative to the unit), split pipeline
-    u32 *candcnt;                // [units] number of candidates, or kAcFlooded
-    u32 cand_cap;
-    const uint4 *sfx;            // whole-pattern table, 2 x uint4 per entry: {bytes right-aligned in 16}, {len, copies, 0, 0}
-    const unsigned long long *tags; // per slot: (suffix hash << 32) | (copies << 8) | len, 0 = empty
-    u32 sfxmask, lenmask;        // entries-1; bit L set <=> some pattern has length L (1..16)
-    const uint2 *gram4;          // exact last-4-bytes -> {key, depth-4 node | has_out << 31} (val 0 = empty)
-    u32 g4mask;
-    unsigned long long *unitinfo;
-    Counters *ctr;
-    u64 *stage;
-    u32 stage_cap;
-    u32 emit_mode;
-    const u64 *offsets;
-    u64 *positions;
-    u64 pos_cap;
-};
-
-__device__ __forceinline__ u32 ac_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
-__device__ __forceinline__ u64 ac_rfl64(u64 v)
-{
-    return ((u64)__builtin_amdgcn_readfirstlane((u32)(v >> 32)) << 32) | __builtin_amdgcn_readfirstlane((u32)v);
-}
-__device__ __forceinline__ u32 ac_fold4(u32 x)
-{
-    u32 t = x & 0x7f7f7f7fu;
-    return x | (((t + 0x3f3f3f3fu) & ~(t + 0x25252525u) & ~x & 0x80808080u) >> 2);
-}
-__device__ __forceinline__ u32 ac_eq_bytes(u32 x, u32 c4)
-{
-    u32 y = x ^ c4;
-    return ~(((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y | 0x7f7f7f7fu);
-}
-__device__ __forceinline__ u32 ac_movemask4(u32 t) { return (((t >> 7) * 0x00204081u) >> 21) & 0xfu; }
-__device__ __forceinline__ bool ac_wordc(u32 c) { return (c - '0' < 10u) || ((c | 0x20u) - 'a' < 26u) || c == '_'; }
-
-struct LS2 { u32 cnt; bool nl, head, tail; };
-__device__ __forceinline__ LS2 ls2_combine(const LS2 &a, const LS2 &b)
-{
-    return LS2{a.cnt + b.cnt - ((a.tail && b.head) ? 1u : 0u), a.nl || b.nl, a.nl ? a.head : (a.head || b.head),
-               b.nl ? b.tail : (a.tail || b.tail)};
-}
-
-// Walk the reversed trie from end index i.  EMIT == false: returns the number of matches ending at i
-// (after ownership and -w).  EMIT == true: additionally hands them to `put`, longest first.
-// Deliberately NOT inlined per call site: the scan loop keeps one copy of each instantiation.
-template <bool CI, bool EMIT, bool JUMP, typename Put>
-__device__ __forceinline__ u32 ac_walk(const AcArgs &a, u64 i, u32 total, Put put)
-{
-    u32 node = 0, seen = 0;
-    const bool ww = (a.flags & F_WW) != 0, lines = (a.flags & F_LINES) != 0;
-    const u64 maxd = (i + 1 < (u64)a.lmax) ? i + 1 : (u64)a.lmax;
-    u64 d = 1;
-    u32 child = 0xffffffffu;
-    if (JUMP && i >= 3)
-    {
-        // every pattern has >= 4 bytes: resolve trie levels 1..4 with ONE probe keyed by the exact last 4 bytes
-        struct __attribute__((packed)) U32p { u32 v; };
-        u32 E = reinterpret_cast<const U32p *>(a.text + (i - 3))->v; // one unaligned dword load
-        if (CI)
-            E = ac_fold4(E);
-        for (u32 h = (E * kHashMul) >> 9;; ++h)
-        {
-            const uint2 e = a.gram4[h & a.g4mask];
-            if (e.y == 0u)
-                return 0u; // not a suffix of any pattern
-            if (e.x == E)
-            {
-                child = e.y;
-                break;
-            }
-        }
-        d = 4;
-    }
-    else if (JUMP)
-        return 0u; // fewer than 4 bytes before i: no pattern of length >= 4 can end here
-    for (; d <= maxd; ++d)
-    {
-        if (!(JUMP && d == 4))
-        {
-            u32 c = a.text[i + 1 - d];
-            if (CI && (c - 'A' < 26u))
-                c += 32u;
-            const u32 key = (node << 8) | c;
-            u32 h = (key * kHashMul) >> 7;
-            child = 0xffffffffu;
-            for (;; ++h)
-            {
-                const uint2 e = a.edges[h & a.emask];
-                if (e.x == key)
-                {
-                    child = e.y;
-                    break;
-                }
-                if (e.x == 0xffffffffu)
-                    break;
-            }
-            if (child == 0xffffffffu)
-                break;
-        }
-        node = child & 0x7fffffffu;
-        if (child & 0x80000000u)
-        {
-            const u64 s = i + 1 - d;
-            bool ok = lines ? true : (s >= a.own_lo && s < a.own_hi); // -c owns by END index (see ac_scan)
-            if (ok && ww)
-            {
-                if (s > 0 && ac_wordc(a.text[s - 1]))
-                    ok = false;
-                else if (i + 1 < a.text_len && ac_wordc(a.text[i + 1]))
-                    ok = false;
-            }
-            if (ok)
-            {
-                const u32 k = a.copies[node];
-                if (EMIT)
-                    for (u32 q = 0; q < k; ++q)
-                        put(total - seen - k + q, s, (u32)d);
-                seen += k;
-            }
-        }
-    }
-    return seen;
-}
-
-// Fast verifier for pattern sets whose patterns all have >= 4 bytes (CLS == 8): ONE pass.
-//  * the 16 bytes ending at the candidate are loaded once (one unaligned 16-byte load) — the walk then needs one
-//    dependent access per level (the edge probe) instead of two (text byte + edge probe);
-//  * levels 1..4 are resolved by the exact 4-gram table;
-//  * the depths at which a pattern ends are remembered in a bit mask, so the longest-first emission needs no second
-//    walk (falls back to it when a pattern has duplicate copies or the set has patterns longer than 64 bytes).
-template <bool CI>
-__device__ __forceinline__ u32 ac_walk_fast(const AcArgs &a, u64 i, bool own_by_end, u64 &depthmask, bool &simple)
-{
-    depthmask = 0;
-    simple = true;
-    const bool ww = (a.flags & F_WW) != 0;
-    if (i < 15)
-    { // too close to the start of the text for the 16-byte window: generic walk
-        simple = false;
-        return ac_walk<CI, false, true>(a, i, 0u, [](u32, u64, u32) {});
-    }
-    struct __attribute__((packed)) U32p { u32 v; };
-    const U32p *q = reinterpret_cast<const U32p *>(a.text + (i - 15));
-    u32 T[4] = {q[0].v, q[1].v, q[2].v, q[3].v};
-    if (CI)
-    {
-#pragma unroll
-        for (int w = 0; w < 4; ++w)
-            T[w] = ac_fold4(T[w]);
-    }
-    u32 child = 0xffffffffu;
-    for (u32 h = (T[3] * kHashMul) >> 9;; ++h)
-    {
-        const uint2 e = a.gram4[h & a.g4mask];
-        if (e.y == 0u)
-            return 0u; // not a suffix of any pattern
-        if (e.x == T[3])
-        {
-            child = e.y;
-            break;
-        }
-    }
-    u32 node = 0, seen = 0;
-    const u64 maxd = (i + 1 < (u64)a.lmax) ? i + 1 : (u64)a.lmax;
-    for (u64 d = 4; d <= maxd; ++d)
-    {
-        if (d > 4)
-        {
-            u32 c;
-            if (d <= 16)
-            {
-                const u32 bi = 16u - (u32)d; // byte i-d+1 sits at index 16-d of the window
-                const u32 w = bi >> 2;
-                const u32 word = w == 0 ? T[0] : w == 1 ? T[1] : w == 2 ? T[2] : T[3];
-                c = (word >> (8 * (bi & 3u))) & 0xffu;
-            }
-            else
-            {
-                c = a.text[i + 1 - d];
-                if (CI && (c - 'A' < 26u))
-                    c += 32u;
-            }
-            const u32 key = (node << 8) | c;
-            child = 0xffffffffu;
-            for (u32 h = (key * kHashMul) >> 7;; ++h)
-            {
-                const uint2 e = a.edges[h & a.emask];
-                if (e.x == key)
-                {
-                    child = e.y;
-                    break;
-                }
-                if (e.x == 0xffffffffu)
-                    break;
-            }
-            if (child == 0xffffffffu)
-                break;
-        }
-        node = child & 0x7fffffffu;
-        if (child & 0x80000000u)
-        {
-            const u64 s = i + 1 - d;
-            bool ok = own_by_end ? true : (s >= a.own_lo && s < a.own_hi);
-            if (ok && ww)
-            {
-                if (s > 0 && ac_wordc(a.text[s - 1]))
-                    ok = false;
-                else if (i + 1 < a.text_len && ac_wordc(a.text[i + 1]))
-                    ok = false;
-            }
-            if (ok)
-            {
-                const u32 k = a.copies[node];
-                seen += k;
-                if (k != 1u || d > 63)
-                    simple = false;
-                else
-                    depthmask |= 1ull << d;
-            }
-        }
-    }
-    return seen;
-}
-
-constexpr u32 kAcUnitsPerTicket = 4;   // 64 KiB of haystack per wave ticket
-constexpr u32 kAcQueue = 512;          // candidate queue entries per wave (u32 each)
-constexpr int kAcRounds = 2;            // load rounds per unit: one candidate drain per 16 KiB (53 of 64 lanes busy)
-constexpr u32 kAcUnitBytes = kAcRounds * kSegBytes;
-constexpr u32 kAcBitmapWords = kAcUnitBytes / 32; // one bit per end position of a unit (LINES)
-
-// bit of table `base` at hash h
-__device__ __forceinline__ u32 ac_tbit(const u32 *tab, u32 base, u32 h) { return (tab[base + (h >> 5)] >> (h & 31u)) & 1u; }
 
 // CLS: bit 0/1/2/3 = 1-/2-/3-/>=4-byte patterns present.  CLS == 8 is the common case (all >= 4).
 template <bool CI, bool LINES, int CLS>
@@ -629,470 +370,6 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
         atomicAdd(&a.ctr->total, acc_total);
 }
 
-// ================================================================================================
-// Split pipeline (positions / counts): FILTER kernel -> candidate lists -> VERIFY kernel.
-// The trie walk is a chain of dependent L2 accesses (2-3 us each under a saturated HBM stream); inside
-// the streaming kernel (128 VGPRs, 16 waves/CU) it cost 17 us per 8 KiB unit and capped the scan at
-// ~1.2 TB/s.  Split, the filter keeps streaming and the verifier runs as a small-footprint kernel whose
-// latency is hidden by occupancy.
-// ================================================================================================
-constexpr u32 kAcFlooded = 0xffffffffu;
-
-template <bool CI, int CLS>
-__global__ __launch_bounds__(kAcBlock) void ac_filter_kernel(const AcArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) u32 s_mem[]; // filter tables
-    const u32 lane = ac_lane();
-    for (u32 w = threadIdx.x; w < a.filter_words; w += kAcBlock)
-        s_mem[w] = a.filter[w];
-    __syncthreads();
-    for (;;)
-    {
-        u64 tk = 0;
-        if (lane == 0)
-            tk = __hip_atomic_fetch_add(&a.ctr->ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        tk = ac_rfl64(tk);
-        const u64 u_begin = tk * (u64)kAcUnitsPerTicket;
-        if (u_begin >= a.num_tiles)
-            break;
-        const u64 u_end = (u_begin + kAcUnitsPerTicket < a.num_tiles) ? u_begin + kAcUnitsPerTicket : a.num_tiles;
-        for (u64 unit = u_begin; unit < u_end; ++unit)
-        {
-            const u64 seg = a.anchor + unit * (u64)kSegBytes;
-            const bool fast = seg + kSegBytes <= a.text_len;
-            const bool interior = seg >= a.end_lo && seg + kSegBytes <= a.end_hi;
-            uint4 d[kCells];
-            u32 before = 0;
-            if (fast)
-            {
-                const uint4 *src = reinterpret_cast<const uint4 *>(a.text + seg) + lane;
-#pragma unroll
-                for (int j = 0; j < kCells; ++j)
-                    d[j] = src[j * kWave];
-            }
-            if (seg >= 4 && seg <= a.text_len)
-                before = *reinterpret_cast<const u32 *>(a.text + seg - 4);
-            else
-                for (u32 b = 0; b < 4; ++b)
-                    if (seg + b >= 4 && seg + b - 4 < a.text_len)
-                        before |= (u32)a.text[seg + b - 4] << (8 * b);
-            u32 *out = a.cand + (a.unit_base + unit) * (u64)a.cand_cap;
-            u32 qn = 0;
-            bool flooded = false;
-#pragma unroll
-            for (int j = 0; j < kCells; ++j)
-            {
-                const u64 lbase = seg + (u64)j * kCellBytes + (u64)lane * 16u;
-                u32 W[5];
-                if (fast)
-                {
-                    W[1] = d[j].x; W[2] = d[j].y; W[3] = d[j].z; W[4] = d[j].w;
-                    const u32 up = __shfl_up(W[4], 1);
-                    const u32 edge = (j == 0) ? before : __builtin_amdgcn_readlane(d[j > 0 ? j - 1 : 0].w, 63);
-                    W[0] = (lane == 0u) ? edge : up;
-                }
-                else
-                {
-#pragma unroll 1
-                    for (int w = 0; w < 5; ++w)
-                    {
-                        u32 v = 0;
-                        for (int b = 0; b < 4; ++b)
-                        {
-                            const u64 o = lbase + (u64)(w * 4 + b);
-                            if (o >= 4 && o - 4 < a.text_len)
-                                v |= (u32)a.text[o - 4] << (8 * b);
-                        }
-                        W[w] = v;
-                    }
-                }
-                if (CI)
-                {
-#pragma unroll
-                    for (int w = 0; w < 5; ++w)
-                        W[w] = ac_fold4(W[w]);
-                }
-                u32 cand = 0;
-#pragma unroll
-                for (int k = 0; k < 16; ++k)
-                {
-                    const int o = k + 1;
-                    const u32 E = ((o & 3) == 0) ? W[o >> 2] : __builtin_amdgcn_alignbyte(W[(o >> 2) + 1], W[o >> 2], (u32)(o & 3));
-                    u32 hit = 0;
-                    if (CLS & 8)
-                        {
-                        // the >= 4-byte table sits at LDS byte 0: byte-addressed, no base add
-                        const u32 t = E * kHashMul;
-                        const u32 by = reinterpret_cast<const unsigned char *>(s_mem)[t >> (32 - kT4Bits + 3)];
-                        hit |= (by >> ((t >> (32 - kT4Bits)) & 7u)) & 1u;
-                    }
-                    if (CLS & 4)
-                        hit |= ac_tbit(s_mem, a.off3, ((E >> 8) * kHashMul) >> (32 - kT3Bits));
-                    if (CLS & 2)
-                        hit |= ac_tbit(s_mem, a.off2, E >> 16);
-                    if (CLS & 1)
-                        hit |= ac_tbit(s_mem, a.off1, E >> 24);
-                    cand |= hit << k;
-                }
-                if (!interior)
-                {
-                    const u64 lo = a.end_lo, hi = a.end_hi;
-                    const u32 klo = lo > lbase ? (u32)((lo - lbase) < 16 ? (lo - lbase) : 16) : 0u;
-                    const u32 khi = hi > lbase ? (u32)((hi - lbase) < 16 ? (hi - lbase) : 16) : 0u;
-                    cand &= khi > klo ? (((1u << khi) - 1u) & ~((1u << klo) - 1u)) : 0u;
-                }
-                if (a.flags & (1u << 31)) // ablation hook (KREP_GPU_AC_NOVERIFY)
-                    cand = 0;
-                if (!flooded && __ballot(cand != 0u))
-                {
-                    const u32 c = __popc(cand);
-                    u32 tot = 0, ex = 0;
-#pragma unroll
-                    for (int b = 0; b < 5; ++b)
-                    {
-                        const u64 m = __ballot((c >> b) & 1u);
-                        tot += (u32)__popcll(m) << b;
-                        ex += (u32)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)) << b;
-                    }
-                    if (qn + tot > a.cand_cap)
-                        flooded = true;
-                    else
-                    {
-                        u32 at = qn + ex, rest = cand;
-                        const u32 rel0 = (u32)j * kCellBytes + lane * 16u;
-                        while (rest)
-                        {
-                            const u32 k = __builtin_ctz(rest);
-                            rest &= rest - 1u;
-                            out[at++] = rel0 + k;
-                        }
-                        qn += tot;
-                    }
-                }
-            }
-            if (lane == 0)
-                a.candcnt[a.unit_base + unit] = flooded ? kAcFlooded : qn;
-        }
-    }
-}
-
-// one wave per unit: verify its candidates (or, for a flooded unit, every end position), rank, stage / emit
-template <bool CI, bool JUMP>
-__global__ __launch_bounds__(256) void ac_verify_kernel(const AcArgs a)
-{
-    const u32 lane = ac_lane();
-    const u64 n_waves = (u64)gridDim.x * 4, wid = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const bool want_pos = (a.flags & F_POS) != 0;
-    const bool emit_final = a.emit_mode != 0;
-    u64 acc_total = 0;
-    for (u64 lunit = wid; lunit < a.num_tiles; lunit += n_waves)
-    {
-        const u64 unit = a.unit_base + lunit; // global unit index (arrays); lunit addresses the chunk's text
-        if (emit_final && (u32)(a.unitinfo[unit] & kUiCountMask) <= a.stage_cap)
-            continue;
-        const u32 cc = a.candcnt[unit];
-        const bool flooded = cc == kAcFlooded;
-        const u32 n = flooded ? kSegBytes : cc;
-        const u64 seg = a.anchor + lunit * (u64)kSegBytes;
-        const u32 *cl = a.cand + unit * (u64)a.cand_cap;
-        u64 *slot = reinterpret_cast<u64 *>(a.stage) + unit * (u64)a.stage_cap;
-        const bool do_final = emit_final && want_pos, do_stage = !emit_final && want_pos;
-        const u64 fbase = do_final ? a.offsets[unit] : 0ull;
-        u32 wcnt = 0;
-        for (u32 b0 = 0; b0 < n; b0 += 64)
-        {
-            const u32 qi = b0 + lane;
-            bool live = qi < n;
-            const u32 rel = flooded ? qi : (live ? cl[qi] : 0u);
-            const u64 pos = seg + rel;
-            if (flooded)
-                live = pos >= a.end_lo && pos < a.end_hi;
-            u32 c = 0;
-            if (live)
-                c = ac_walk<CI, false, JUMP>(a, pos, 0u, [](u32, u64, u32) {});
-            if (!__ballot(c != 0u))
-                continue;
-            u32 incl = c;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1)
-            {
-                const u32 t = __shfl_up(incl, o);
-                if (lane >= (u32)o)
-                    incl += t;
-            }
-            const u32 rank0 = wcnt + incl - c;
-            wcnt += __shfl(incl, 63);
-            if (c && (do_stage || do_final))
-                ac_walk<CI, true, JUMP>(a, pos, c, [&](u32 r, u64 s, u32 len) {
-                    const u32 at = rank0 + r;
-                    if (do_stage)
-                    {
-                        if (at < a.stage_cap)
-                            slot[at] = ((s + a.global_base) << 11) | len;
-                    }
-                    else
-                    {
-                        const u64 g = fbase + at;
-                        if (g < a.pos_cap)
-                        {
-                            const u64 st = s + a.global_base, en = st + len;
-                            *reinterpret_cast<uint4 *>(a.positions + 2 * g) =
-                                make_uint4((u32)st, (u32)(st >> 32), (u32)en, (u32)(en >> 32));
-                        }
-                    }
-                });
-        }
-        acc_total += wcnt;
-        if (want_pos && !emit_final && lane == 0)
-        {
-            a.unitinfo[unit] = (u64)wcnt | (wcnt ? (kLnHead | kLnTail) : 0ull);
-            if (wcnt > a.stage_cap)
-            {
-                atomicAdd(&a.ctr->overflow_units, 1ull);
-                atomicMax(&a.ctr->max_unit_count, (u64)wcnt);
-            }
-        }
-    }
-    if (lane == 0 && acc_total && !emit_final)
-        atomicAdd(&a.ctr->total, acc_total);
-}
-
-// ---- verify, fast form: every pattern is <= 16 bytes -------------------------------------------------
-// A trie walk costs two dependent memory accesses per matched byte and the reference order needs the total
-// before the first record (two walks): ~40 dependent accesses for a 10-byte match.  Here the 16 bytes ending at
-// the candidate are loaded once and each PRESENT pattern length L is resolved by ONE probe of a hash table of
-// whole patterns keyed by (L, suffix hash) — all probes independent, exact byte compare, results kept in
-// registers per length, emitted longest first.  Latency per candidate ~ 2 memory round trips, any match length.
-__device__ __forceinline__ u32 sfx_hash_step(u32 h, u32 byte) { return (h ^ byte) * 0x01000193u; } // FNV-1a over bytes i, i-1, ...
-__device__ __forceinline__ u32 sfx_slot(u32 h, u32 L) { return ((h ^ (L * 0x9E3779B1u)) * 0x85EBCA6Bu) >> 8; }
-
-template <bool CI>
-__global__ __launch_bounds__(256) void ac_verify16_kernel(const AcArgs a)
-{
-    const u32 lane = ac_lane();
-    const u64 n_waves = (u64)gridDim.x * 4, wid = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const bool want_pos = (a.flags & F_POS) != 0, ww = (a.flags & F_WW) != 0;
-    const bool emit_final = a.emit_mode != 0;
-    u64 acc_total = 0;
-    for (u64 lunit = wid; lunit < a.num_tiles; lunit += n_waves)
-    {
-        const u64 unit = a.unit_base + lunit;
-        if (emit_final && (u32)(a.unitinfo[unit] & kUiCountMask) <= a.stage_cap)
-            continue;
-        const u32 cc = a.candcnt[unit];
-        const bool flooded = cc == kAcFlooded;
-        const u32 n = flooded ? kSegBytes : cc;
-        const u64 seg = a.anchor + lunit * (u64)kSegBytes;
-        const u32 *cl = a.cand + unit * (u64)a.cand_cap;
-        u64 *slot = reinterpret_cast<u64 *>(a.stage) + unit * (u64)a.stage_cap;
-        const bool do_final = emit_final && want_pos, do_stage = !emit_final && want_pos;
-        const u64 fbase = do_final ? a.offsets[unit] : 0ull;
-        u32 wcnt = 0;
-        for (u32 b0 = 0; b0 < n; b0 += 64)
-        {
-            const u32 qi = b0 + lane;
-            bool live = qi < n;
-            const u32 rel = flooded ? qi : (live ? cl[qi] : 0u);
-            const u64 i = seg + rel; // END index
-            if (flooded)
-                live = i >= a.end_lo && i < a.end_hi;
-            // the 16 bytes ending at i: T[w] = bytes [i-15+4w, i-12+4w]
-            u32 T[4] = {0u, 0u, 0u, 0u};
-            if (live)
-            {
-                if (i >= 15)
-                {
-                    struct __attribute__((packed)) U32p { u32 v; };
-                    const U32p *q = reinterpret_cast<const U32p *>(a.text + (i - 15));
-                    T[0] = q[0].v; T[1] = q[1].v; T[2] = q[2].v; T[3] = q[3].v;
-                }
-                else
-                    for (u32 b = 0; b < 16; ++b)
-                        if (i + b >= 15)
-                            T[b >> 2] |= (u32)a.text[i + b - 15] << (8 * (b & 3));
-                if (CI)
-                {
-#pragma unroll
-                    for (int w = 0; w < 4; ++w)
-                        T[w] = ac_fold4(T[w]);
-                }
-            }
-            // gate: when every pattern has >= 4 bytes, a candidate whose exact last 4 bytes are no pattern suffix
-            // is a hash false positive of the LDS filter — one probe, then done
-            if (live && a.gram4 && a.lenmask >= (1u << 4) && !(a.lenmask & 0xeu))
-            {
-                bool any4 = false;
-                if (i >= 3)
-                    for (u32 hh = (T[3] * kHashMul) >> 9;; ++hh)
-                    {
-                        const uint2 e = a.gram4[hh & a.g4mask];
-                        if (e.y == 0u)
-                            break;
-                        if (e.x == T[3])
-                        {
-                            any4 = true;
-                            break;
-                        }
-                    }
-                live = any4;
-            }
-            // pass 1: suffix hashes of every length; ONE 8-byte tag load per PRESENT length, all in flight together
-            u64 tg[17];
-            u32 hs[17];
-            {
-                u32 h = 0x811C9DC5u;
-#pragma unroll
-                for (int L = 1; L <= 16; ++L)
-                {
-                    const int bi = 16 - L; // index of byte i-L+1 inside T
-                    h = sfx_hash_step(h, (T[bi >> 2] >> (8 * (bi & 3))) & 0xffu);
-                    hs[L] = h;
-                    tg[L] = 0;
-                    if ((a.lenmask >> L) & 1u) // uniform
-                        if (live)
-                            tg[L] = a.tags[sfx_slot(h, (u32)L) & a.sfxmask];
-                }
-            }
-            // pass 2: which lengths need a look?  tag hit -> exact compare; occupied slot with another key -> probe on
-            u32 look = 0;
-#pragma unroll
-            for (int L = 1; L <= 16; ++L)
-                if ((a.lenmask >> L) & 1u)
-                    look |= (tg[L] != 0ull && (u64)L <= i + 1) ? (1u << L) : 0u;
-            // rare part, longest first: resolve the looked-at lengths exactly (linear probing + 16-byte compare)
-            u32 c = 0, okmask = 0;
-            u64 cps = 0; // 4 bits of copies per validated length would not fit: copies are re-read at emission
-            for (u32 rest = look; rest;)
-            {
-                const u32 L = 31u - (u32)__builtin_clz(rest);
-                rest &= ~(1u << L);
-                const u32 bi = 16u - L;
-                u32 V[4];
-#pragma unroll
-                for (int w = 0; w < 4; ++w)
-                {
-                    const int lo = (int)bi - 4 * w;
-                    V[w] = lo <= 0 ? T[w] : lo >= 4 ? 0u : (T[w] & (0xffffffffu << (8 * lo)));
-                }
-                // recompute the hash of this length (hs[] is indexed statically only)
-                u32 h = 0x811C9DC5u;
-                for (u32 k = 0; k < L; ++k)
-                    h = sfx_hash_step(h, (T[(15 - k) >> 2] >> (8 * ((15 - k) & 3))) & 0xffu);
-                u32 copies = 0;
-                for (u32 sl = sfx_slot(h, L);; ++sl)
-                {
-                    const u64 tv = a.tags[sl & a.sfxmask];
-                    if (tv == 0ull)
-                        break;
-                    if ((u32)(tv >> 32) == h && (u32)(tv & 0xffu) == L)
-                    {
-                        const uint4 by = a.sfx[2 * (sl & a.sfxmask)];
-                        if (by.x == V[0] && by.y == V[1] && by.z == V[2] && by.w == V[3])
-                        {
-                            copies = (u32)(tv >> 8) & 0xffffffu;
-                            break;
-                        }
-                    }
-                }
-                if (copies)
-                {
-                    const u64 st = i + 1 - (u64)L;
-                    bool ok = st >= a.own_lo && st < a.own_hi;
-                    if (ok && ww)
-                    {
-                        if (st > 0 && ac_wordc(a.text[st - 1]))
-                            ok = false;
-                        else if (i + 1 < a.text_len && ac_wordc(a.text[i + 1]))
-                            ok = false;
-                    }
-                    if (ok)
-                    {
-                        c += copies;
-                        okmask |= 1u << L;
-                    }
-                }
-            }
-            (void)cps;
-            (void)hs;
-            if (!__ballot(c != 0u))
-                continue;
-            u32 incl = c;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1)
-            {
-                const u32 t = __shfl_up(incl, o);
-                if (lane >= (u32)o)
-                    incl += t;
-            }
-            u32 at = wcnt + incl - c;
-            wcnt += __shfl(incl, 63);
-            if (c && (do_stage || do_final))
-            {
-                for (u32 rest = okmask; rest;) // longest first (aho_corasick.c:353-431)
-                {
-                    const u32 L = 31u - (u32)__builtin_clz(rest);
-                    rest &= ~(1u << L);
-                    // copies of this (validated) pattern: find its slot again
-                    u32 h = 0x811C9DC5u;
-                    for (u32 k = 0; k < L; ++k)
-                        h = sfx_hash_step(h, (T[(15 - k) >> 2] >> (8 * ((15 - k) & 3))) & 0xffu);
-                    const u32 bi = 16u - L;
-                    u32 V[4];
-#pragma unroll
-                    for (int w = 0; w < 4; ++w)
-                    {
-                        const int lo = (int)bi - 4 * w;
-                        V[w] = lo <= 0 ? T[w] : lo >= 4 ? 0u : (T[w] & (0xffffffffu << (8 * lo)));
-                    }
-                    u32 copies = 0;
-                    for (u32 sl = sfx_slot(h, L);; ++sl)
-                    {
-                        const u64 tv = a.tags[sl & a.sfxmask];
-                        if (tv == 0ull)
-                            break;
-                        if ((u32)(tv >> 32) == h && (u32)(tv & 0xffu) == L)
-                        {
-                            const uint4 by = a.sfx[2 * (sl & a.sfxmask)];
-                            if (by.x == V[0] && by.y == V[1] && by.z == V[2] && by.w == V[3])
-                            {
-                                copies = (u32)(tv >> 8) & 0xffffffu;
-                                break;
-                            }
-                        }
-                    }
-                    for (u32 q = 0; q < copies; ++q, ++at)
-                    {
-                        const u64 st = i + 1 - (u64)L + a.global_base;
-                        if (do_stage)
-                        {
-                            if (at < a.stage_cap)
-                                slot[at] = (st << 11) | L;
-                        }
-                        else if (fbase + at < a.pos_cap)
-                        {
-                            const u64 en = st + (u64)L;
-                            *reinterpret_cast<uint4 *>(a.positions + 2 * (fbase + at)) =
-                                make_uint4((u32)st, (u32)(st >> 32), (u32)en, (u32)(en >> 32));
-                        }
-                    }
-                }
-            }
-        }
-        acc_total += wcnt;
-        if (want_pos && !emit_final && lane == 0)
-        {
-            a.unitinfo[unit] = (u64)wcnt | (wcnt ? (kLnHead | kLnTail) : 0ull);
-            if (wcnt > a.stage_cap)
-            {
-                atomicAdd(&a.ctr->overflow_units, 1ull);
-                atomicMax(&a.ctr->max_unit_count, (u64)wcnt);
-            }
-        }
-    }
-    if (lane == 0 && acc_total && !emit_final)
-        atomicAdd(&a.ctr->total, acc_total);
-}
-
 // ---------------------------------------------------------------------------------------------- host
 struct AcTables
 {
@@ -1376,7 +653,6 @@ void ac_free(AcTables *t)
 
 int g_ac_force_stage_cap = 0; // test hook (krep_gpu_debug_force_stage_cap)
 static const int g_ac_split = getenv("KREP_GPU_AC_SPLIT") ? 1 : 0;
-static const int g_ac_force_walk = getenv("KREP_GPU_AC_FORCE_WALK") ? 1 : 0; // test hook: trie-walk verifier
 static const int g_ac_chunk_mib = getenv("KREP_GPU_AC_CHUNK_MIB") ? atoi(getenv("KREP_GPU_AC_CHUNK_MIB")) : 0;
 
 static u32 ac_lds_bytes(u32 filter_words, bool lines)
@@ -1407,45 +683,6 @@ static hipError_t ac_launch(const AcArgs &a, u32 grid, u32 lds, hipStream_t st)
     if (ci) return ac_launch2<true, false>(a, grid, lds, st);
     if (ln) return ac_launch2<false, true>(a, grid, lds, st);
     return ac_launch2<false, false>(a, grid, lds, st);
-}
-
-template <bool CI, int CLS>
-static hipError_t ac_filter_launch2(const AcArgs &a, u32 grid, u32 lds, hipStream_t st)
-{
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ac_filter_kernel<CI, CLS>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess)
-    {
-        fail("hipFuncSetAttribute(ac_filter_kernel, %u B LDS) failed: %s", lds, hipGetErrorString(e));
-        return e;
-    }
-    hipLaunchKernelGGL((ac_filter_kernel<CI, CLS>), dim3(grid), dim3(kAcBlock), lds, st, a);
-    e = hipGetLastError();
-    if (e != hipSuccess)
-        fail("ac_filter_kernel<%d,%d> launch failed: %s (grid %u, lds %u)", (int)CI, CLS, hipGetErrorString(e), grid, lds);
-    return e;
-}
-static hipError_t ac_filter_launch(const AcArgs &a, u32 grid, u32 lds, hipStream_t st)
-{
-    const bool only4 = a.has4 && !a.has1 && !a.has2 && !a.has3;
-    if (a.flags & F_CI)
-        return only4 ? ac_filter_launch2<true, 8>(a, grid, lds, st) : ac_filter_launch2<true, 15>(a, grid, lds, st);
-    return only4 ? ac_filter_launch2<false, 8>(a, grid, lds, st) : ac_filter_launch2<false, 15>(a, grid, lds, st);
-}
-static hipError_t ac_verify_launch(const AcArgs &a, u32 grid, hipStream_t st)
-{
-    const bool only4 = a.has4 && !a.has1 && !a.has2 && !a.has3, ci = a.flags & F_CI;
-    if (a.sfx && !g_ac_force_walk)
-    { // every pattern <= 16 bytes: independent per-length probes instead of the trie walk
-        if (ci) hipLaunchKernelGGL((ac_verify16_kernel<true>), dim3(grid), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((ac_verify16_kernel<false>), dim3(grid), dim3(256), 0, st, a);
-        return hipGetLastError();
-    }
-    if (ci && only4) hipLaunchKernelGGL((ac_verify_kernel<true, true>), dim3(grid), dim3(256), 0, st, a);
-    else if (ci) hipLaunchKernelGGL((ac_verify_kernel<true, false>), dim3(grid), dim3(256), 0, st, a);
-    else if (only4) hipLaunchKernelGGL((ac_verify_kernel<false, true>), dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((ac_verify_kernel<false, false>), dim3(grid), dim3(256), 0, st, a);
-    return hipGetLastError();
 }
 
 int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, int num_cu, const uint8_t *d_text, size_t text_len,

@@ -1,0 +1,276 @@
+// kg_ac_common.h — shared device code of the multi-pattern scan (kg_ac.hip: the shipped fused kernel + host side;
+// kg_ac_split.hip: the measured filter -> verify alternatives).  See kg_ac.hip for the design notes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "kg_common.h"
+
+namespace kg {
+
+
+using u32 = uint32_t;
+using u64 = unsigned long long;
+
+constexpr int kAcBlock = 1024;             // 16 waves share one copy of the filter tables in LDS
+constexpr int kAcWaves = kAcBlock / 64;
+constexpr u32 kT1Words = 256 / 32;         // 1-byte patterns: direct
+constexpr u32 kT2Words = 65536 / 32;       // 2-byte patterns: direct (8 KiB)
+constexpr u32 kT3Bits = 17, kT3Words = (1u << kT3Bits) / 32; // 3-byte patterns: hashed (16 KiB)
+constexpr u32 kT4Bits = 19, kT4Words = (1u << kT4Bits) / 32; // >= 4-byte patterns: hashed (64 KiB)
+constexpr u32 kHashMul = 0x9E3779B1u;
+
+struct AcArgs
+{
+    const uint8_t *text;
+    u64 text_len, own_lo, own_hi, anchor, num_tiles, global_base;
+    u64 end_lo, end_hi;          // range of END indices this launch examines
+    u32 flags;                   // F_CI | F_WW | F_POS | F_LINES
+    u32 lmax;
+    u32 has1, has2, has3, has4;  // which length classes exist
+    const u32 *filter;           // T4 | T1 | T2 | T3 (T4/T2/T3 only when present)
+    u32 off1, off2, off3, filter_words; // word offsets of T1/T2/T3 in LDS; T4 (>= 4-byte class) is at offset 0
+    const uint2 *edges;          // open addressing: {key = node << 8 | byte, val = child | has_out << 31}
+    u32 emask;
+    const u32 *copies;           // per node: number of patterns equal to the node's string
+    u64 unit_base;               // global index of this launch's first unit (chunked filter -> verify pipeline)
+    u32 *cand;                   // [units * cand_cap] candidate end offsets (relative to the unit), split pipeline
+    u32 *candcnt;                // [units] number of candidates, or kAcFlooded
+    u32 cand_cap;
+    const uint4 *sfx;            // whole-pattern table, 2 x uint4 per entry: {bytes right-aligned in 16}, {len, copies, 0, 0}
+    const unsigned long long *tags; // per slot: (suffix hash << 32) | (copies << 8) | len, 0 = empty
+    u32 sfxmask, lenmask;        // entries-1; bit L set <=> some pattern has length L (1..16)
+    const uint2 *gram4;          // exact last-4-bytes -> {key, depth-4 node | has_out << 31} (val 0 = empty)
+    u32 g4mask;
+    unsigned long long *unitinfo;
+    Counters *ctr;
+    u64 *stage;
+    u32 stage_cap;
+    u32 emit_mode;
+    const u64 *offsets;
+    u64 *positions;
+    u64 pos_cap;
+};
+
+__device__ __forceinline__ u32 ac_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ u64 ac_rfl64(u64 v)
+{
+    return ((u64)__builtin_amdgcn_readfirstlane((u32)(v >> 32)) << 32) | __builtin_amdgcn_readfirstlane((u32)v);
+}
+__device__ __forceinline__ u32 ac_fold4(u32 x)
+{
+    u32 t = x & 0x7f7f7f7fu;
+    return x | (((t + 0x3f3f3f3fu) & ~(t + 0x25252525u) & ~x & 0x80808080u) >> 2);
+}
+__device__ __forceinline__ u32 ac_eq_bytes(u32 x, u32 c4)
+{
+    u32 y = x ^ c4;
+    return ~(((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y | 0x7f7f7f7fu);
+}
+__device__ __forceinline__ u32 ac_movemask4(u32 t) { return (((t >> 7) * 0x00204081u) >> 21) & 0xfu; }
+__device__ __forceinline__ bool ac_wordc(u32 c) { return (c - '0' < 10u) || ((c | 0x20u) - 'a' < 26u) || c == '_'; }
+
+struct LS2 { u32 cnt; bool nl, head, tail; };
+__device__ __forceinline__ LS2 ls2_combine(const LS2 &a, const LS2 &b)
+{
+    return LS2{a.cnt + b.cnt - ((a.tail && b.head) ? 1u : 0u), a.nl || b.nl, a.nl ? a.head : (a.head || b.head),
+               b.nl ? b.tail : (a.tail || b.tail)};
+}
+
+// Walk the reversed trie from end index i.  EMIT == false: returns the number of matches ending at i
+// (after ownership and -w).  EMIT == true: additionally hands them to `put`, longest first.
+// Deliberately NOT inlined per call site: the scan loop keeps one copy of each instantiation.
+template <bool CI, bool EMIT, bool JUMP, typename Put>
+__device__ __forceinline__ u32 ac_walk(const AcArgs &a, u64 i, u32 total, Put put)
+{
+    u32 node = 0, seen = 0;
+    const bool ww = (a.flags & F_WW) != 0, lines = (a.flags & F_LINES) != 0;
+    const u64 maxd = (i + 1 < (u64)a.lmax) ? i + 1 : (u64)a.lmax;
+    u64 d = 1;
+    u32 child = 0xffffffffu;
+    if (JUMP && i >= 3)
+    {
+        // every pattern has >= 4 bytes: resolve trie levels 1..4 with ONE probe keyed by the exact last 4 bytes
+        struct __attribute__((packed)) U32p { u32 v; };
+        u32 E = reinterpret_cast<const U32p *>(a.text + (i - 3))->v; // one unaligned dword load
+        if (CI)
+            E = ac_fold4(E);
+        for (u32 h = (E * kHashMul) >> 9;; ++h)
+        {
+            const uint2 e = a.gram4[h & a.g4mask];
+            if (e.y == 0u)
+                return 0u; // not a suffix of any pattern
+            if (e.x == E)
+            {
+                child = e.y;
+                break;
+            }
+        }
+        d = 4;
+    }
+    else if (JUMP)
+        return 0u; // fewer than 4 bytes before i: no pattern of length >= 4 can end here
+    for (; d <= maxd; ++d)
+    {
+        if (!(JUMP && d == 4))
+        {
+            u32 c = a.text[i + 1 - d];
+            if (CI && (c - 'A' < 26u))
+                c += 32u;
+            const u32 key = (node << 8) | c;
+            u32 h = (key * kHashMul) >> 7;
+            child = 0xffffffffu;
+            for (;; ++h)
+            {
+                const uint2 e = a.edges[h & a.emask];
+                if (e.x == key)
+                {
+                    child = e.y;
+                    break;
+                }
+                if (e.x == 0xffffffffu)
+                    break;
+            }
+            if (child == 0xffffffffu)
+                break;
+        }
+        node = child & 0x7fffffffu;
+        if (child & 0x80000000u)
+        {
+            const u64 s = i + 1 - d;
+            bool ok = lines ? true : (s >= a.own_lo && s < a.own_hi); // -c owns by END index (see ac_scan)
+            if (ok && ww)
+            {
+                if (s > 0 && ac_wordc(a.text[s - 1]))
+                    ok = false;
+                else if (i + 1 < a.text_len && ac_wordc(a.text[i + 1]))
+                    ok = false;
+            }
+            if (ok)
+            {
+                const u32 k = a.copies[node];
+                if (EMIT)
+                    for (u32 q = 0; q < k; ++q)
+                        put(total - seen - k + q, s, (u32)d);
+                seen += k;
+            }
+        }
+    }
+    return seen;
+}
+
+// Fast verifier for pattern sets whose patterns all have >= 4 bytes (CLS == 8): ONE pass.
+//  * the 16 bytes ending at the candidate are loaded once (one unaligned 16-byte load) — the walk then needs one
+//    dependent access per level (the edge probe) instead of two (text byte + edge probe);
+//  * levels 1..4 are resolved by the exact 4-gram table;
+//  * the depths at which a pattern ends are remembered in a bit mask, so the longest-first emission needs no second
+//    walk (falls back to it when a pattern has duplicate copies or the set has patterns longer than 64 bytes).
+template <bool CI>
+__device__ __forceinline__ u32 ac_walk_fast(const AcArgs &a, u64 i, bool own_by_end, u64 &depthmask, bool &simple)
+{
+    depthmask = 0;
+    simple = true;
+    const bool ww = (a.flags & F_WW) != 0;
+    if (i < 15)
+    { // too close to the start of the text for the 16-byte window: generic walk
+        simple = false;
+        return ac_walk<CI, false, true>(a, i, 0u, [](u32, u64, u32) {});
+    }
+    struct __attribute__((packed)) U32p { u32 v; };
+    const U32p *q = reinterpret_cast<const U32p *>(a.text + (i - 15));
+    u32 T[4] = {q[0].v, q[1].v, q[2].v, q[3].v};
+    if (CI)
+    {
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+            T[w] = ac_fold4(T[w]);
+    }
+    u32 child = 0xffffffffu;
+    for (u32 h = (T[3] * kHashMul) >> 9;; ++h)
+    {
+        const uint2 e = a.gram4[h & a.g4mask];
+        if (e.y == 0u)
+            return 0u; // not a suffix of any pattern
+        if (e.x == T[3])
+        {
+            child = e.y;
+            break;
+        }
+    }
+    u32 node = 0, seen = 0;
+    const u64 maxd = (i + 1 < (u64)a.lmax) ? i + 1 : (u64)a.lmax;
+    for (u64 d = 4; d <= maxd; ++d)
+    {
+        if (d > 4)
+        {
+            u32 c;
+            if (d <= 16)
+            {
+                const u32 bi = 16u - (u32)d; // byte i-d+1 sits at index 16-d of the window
+                const u32 w = bi >> 2;
+                const u32 word = w == 0 ? T[0] : w == 1 ? T[1] : w == 2 ? T[2] : T[3];
+                c = (word >> (8 * (bi & 3u))) & 0xffu;
+            }
+            else
+            {
+                c = a.text[i + 1 - d];
+                if (CI && (c - 'A' < 26u))
+                    c += 32u;
+            }
+            const u32 key = (node << 8) | c;
+            child = 0xffffffffu;
+            for (u32 h = (key * kHashMul) >> 7;; ++h)
+            {
+                const uint2 e = a.edges[h & a.emask];
+                if (e.x == key)
+                {
+                    child = e.y;
+                    break;
+                }
+                if (e.x == 0xffffffffu)
+                    break;
+            }
+            if (child == 0xffffffffu)
+                break;
+        }
+        node = child & 0x7fffffffu;
+        if (child & 0x80000000u)
+        {
+            const u64 s = i + 1 - d;
+            bool ok = own_by_end ? true : (s >= a.own_lo && s < a.own_hi);
+            if (ok && ww)
+            {
+                if (s > 0 && ac_wordc(a.text[s - 1]))
+                    ok = false;
+                else if (i + 1 < a.text_len && ac_wordc(a.text[i + 1]))
+                    ok = false;
+            }
+            if (ok)
+            {
+                const u32 k = a.copies[node];
+                seen += k;
+                if (k != 1u || d > 63)
+                    simple = false;
+                else
+                    depthmask |= 1ull << d;
+            }
+        }
+    }
+    return seen;
+}
+
+constexpr u32 kAcUnitsPerTicket = 4;   // 64 KiB of haystack per wave ticket
+constexpr u32 kAcQueue = 512;          // candidate queue entries per wave (u32 each)
+constexpr int kAcRounds = 2;            // load rounds per unit: one candidate drain per 16 KiB (53 of 64 lanes busy)
+constexpr u32 kAcUnitBytes = kAcRounds * kSegBytes;
+constexpr u32 kAcBitmapWords = kAcUnitBytes / 32; // one bit per end position of a unit (LINES)
+
+// bit of table `base` at hash h
+__device__ __forceinline__ u32 ac_tbit(const u32 *tab, u32 base, u32 h) { return (tab[base + (h >> 5)] >> (h & 31u)) & 1u; }
+
+
+constexpr u32 kAcFlooded = 0xffffffffu; // candcnt value of a unit whose candidate list overflowed (split pipeline)
+
+// kg_ac_split.hip
+hipError_t ac_filter_launch(const AcArgs &a, u32 grid, u32 lds, hipStream_t st);
+hipError_t ac_verify_launch(const AcArgs &a, u32 grid, hipStream_t st);
+
+} // namespace kg

@@ -540,9 +540,9 @@ static int scan_literal(krep_gpu_plan *pl, int algo, const uint8_t *d_text, size
     const uint64_t n_units = a.num_tiles * kWavesPerBlk;
     // staging slot per unit: sized for ~4x BASELINE's densities (1e-4/B literal, 1e-2/B single byte);
     // denser units take the emit-mode re-scan
-    a.stage_cap = (a.flags & F_POS) ? (m == 1 ? 512u : 64u) * (a.rounds == kRoundsBig ? 1u : 1u) : 0u;
-    if (a.rounds == 1 && a.stage_cap)
-        a.stage_cap = m == 1 ? 256u : 32u;
+    a.stage_cap = 0;
+    if (a.flags & F_POS)
+        a.stage_cap = a.rounds == kRoundsBig ? (m == 1 ? 512u : 64u) : (m == 1 ? 256u : 32u);
     if (g_force_stage_cap && (a.flags & F_POS))
         a.stage_cap = (uint32_t)g_force_stage_cap;
     if (chain)

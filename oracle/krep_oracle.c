@@ -10,7 +10,6 @@
  */
 #include "krep_oracle.h"
 
-#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -1067,60 +1066,4 @@ uint64_t ko_run(int algo, const search_params_t *p, const char *text, size_t n, 
 uint64_t ko_search(const search_params_t *p, const char *text, size_t n, match_result_t *r, int simd)
 {
     return ko_run(ko_select(p, simd), p, text, n, r);
-}
-
-/* ================================================================ chunked multi-thread driver (baseline only)
- * search_file()'s decomposition: T chunks of ceil(n/T) bytes, every chunk but the last extended by
- * max_pattern_len-1 (krep.c:2816-2905); per-chunk counts are summed (krep.c:2953-2962). */
-typedef struct
-{
-    int algo;
-    const search_params_t *p;
-    const char *t;
-    size_t n;
-    uint64_t out;
-} ko_job_t;
-static void *ko_job(void *v)
-{
-    ko_job_t *j = v;
-    j->out = ko_run(j->algo, j->p, j->t, j->n, NULL);
-    return NULL;
-}
-uint64_t ko_chunked_search(int algo, const search_params_t *p, const char *text, size_t n, int threads)
-{
-    if (threads < 1)
-        threads = 1;
-    size_t maxlen = p->pattern_len;
-    for (size_t k = 0; k < p->num_patterns; k++)
-        if (p->pattern_lens && p->pattern_lens[k] > maxlen)
-            maxlen = p->pattern_lens[k];
-    size_t chunk = (n + (size_t)threads - 1) / (size_t)threads, ov = maxlen ? maxlen - 1 : 0;
-    ko_job_t *jobs = calloc((size_t)threads, sizeof *jobs);
-    pthread_t *th = calloc((size_t)threads, sizeof *th);
-    int used = 0;
-    for (int i = 0; i < threads; i++)
-    {
-        size_t b = (size_t)i * chunk;
-        if (b >= n)
-            break;
-        size_t l = chunk;
-        if (b + l > n)
-            l = n - b;
-        else if (b + l + ov <= n && i != threads - 1)
-            l += ov;
-        else
-            l = n - b < l + ov ? n - b : l + ov;
-        jobs[i] = (ko_job_t){algo, p, text + b, l, 0};
-        pthread_create(&th[i], NULL, ko_job, &jobs[i]);
-        used++;
-    }
-    uint64_t sum = 0;
-    for (int i = 0; i < used; i++)
-    {
-        pthread_join(th[i], NULL);
-        sum += jobs[i].out;
-    }
-    free(jobs);
-    free(th);
-    return sum;
 }

@@ -54,11 +54,6 @@ size_t ko_line_start(const char *text, size_t n, size_t pos);
 size_t ko_line_end(const char *text, size_t n, size_t pos);
 bool ko_whole_word(const char *text, size_t n, size_t s, size_t e);
 
-/* multi-threaded chunked driver used ONLY as the cpu_baseline throughput leg: T threads, chunk =
- * ceil(n/T) with pattern_len-1 overlap, as search_file() does (krep.c:2816-2905).  Returns the sum of
- * per-chunk counts (which double-counts at boundaries exactly like the reference; throughput only). */
-uint64_t ko_chunked_search(int algo, const search_params_t *p, const char *text, size_t n, int threads);
-
 #ifdef __cplusplus
 }
 #endif

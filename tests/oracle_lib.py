@@ -127,9 +127,6 @@ class OracleEngine(_Engine):
         self.lib.ko_set_only_matching.argtypes = [C.c_int]
         self.lib.ko_set_force_no_simd.argtypes = [C.c_int]
         self.lib.ko_set_algo_override.argtypes = [C.c_int]
-        self.lib.ko_chunked_search.restype = C.c_uint64
-        self.lib.ko_chunked_search.argtypes = [C.c_int, C.POINTER(abi.SearchParams), C.c_void_p,
-                                               C.c_size_t, C.c_int]
         self.lib.ko_ac_num_states.restype = C.c_uint64
         self.lib.ko_ac_num_states.argtypes = [C.c_void_p]
 
@@ -138,18 +135,6 @@ class OracleEngine(_Engine):
 
     def set_only_matching(self, on: bool):
         self.lib.ko_set_only_matching(int(on))
-
-    def chunked(self, algo, params, text: TextBuf, threads: int) -> int:
-        trie = None
-        if algo == abi.RA_AHO_CORASICK:
-            trie = self._acb(params.ref)
-            params.s.ac_trie = trie
-        try:
-            return int(self.lib.ko_chunked_search(algo, params.ref, text.ptr, text.n, threads))
-        finally:
-            if trie:
-                self._acf(trie)
-                params.s.ac_trie = None
 
 
 _REF_FILES = {abi.REF_SCALAR: "libkrep_ref_scalar.so", abi.REF_SSE42: "libkrep_ref_sse42.so",
