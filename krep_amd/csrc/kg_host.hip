@@ -738,10 +738,27 @@ struct Stager
     hipStream_t st = nullptr;
     hipEvent_t done[2] = {nullptr, nullptr};
     int dev = -1;
+    void release()
+    {
+        if (dev < 0)
+            return;
+        (void)hipSetDevice(dev);
+        for (int i = 0; i < 2; ++i)
+        {
+            if (pin[i]) (void)hipHostFree(pin[i]);
+            if (done[i]) (void)hipEventDestroy(done[i]);
+            pin[i] = nullptr;
+            done[i] = nullptr;
+        }
+        if (st) (void)hipStreamDestroy(st);
+        st = nullptr;
+        dev = -1;
+    }
     int init(int device)
     {
         if (dev == device && pin[0])
             return 0;
+        release();
         HIPCHK(hipSetDevice(device));
         for (int i = 0; i < 2; ++i)
         {
@@ -791,6 +808,17 @@ struct Stager
 };
 thread_local Stager tl_stager;
 } // namespace
+
+namespace kg {
+// pinned, double-buffered host -> device copy on the calling thread's staging buffers (also used per shard thread)
+int stage_to_device(uint8_t *d_dst, const char *src, size_t len, int device)
+{
+    if (tl_stager.init(device))
+        return 2;
+    return tl_stager.copy(d_dst, src, len);
+}
+void stage_release() { tl_stager.release(); } // short-lived shard threads give their pinned buffers back
+} // namespace kg
 
 // memchr_search's final flush (krep.c:3976-3991 + :4026-4038): when max_count is a multiple of the
 // 4096-entry batch and more matches exist, the (max_count+1)-th record is stored FIRST (in front of

@@ -50,7 +50,9 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
             match_position_t *d_pos, uint64_t cap, bool ww, bool lines, bool track, size_t max_count, hipStream_t st,
             int time_it, hipEvent_t ev0, hipEvent_t ev1, krep_gpu_scan_out_t *out);
 
-int current_only_matching(); // the mirrored file-static `only_matching` (krep.c:117)
+int current_only_matching();
+int stage_to_device(uint8_t *d_dst, const char *src, size_t len, int device); // kg_host.hip: pinned double-buffered H2D
+void stage_release(); // the mirrored file-static `only_matching` (krep.c:117)
 
 // kg_multi.hip — one process driving several devices (search_buffer(num_gpus > 1))
 uint64_t multi_gpu_search(const search_params_t *params, const char *buf, size_t len, int num_gpus, match_result_t *out,

@@ -48,7 +48,7 @@ void run_shard(Shard *sh, const search_params_t *params, const char *buf, size_t
     {
         const size_t nb = sh->b1 - sh->b0;
         if (hipSetDevice(sh->device) != hipSuccess || hipMalloc(&d_text, nb + 64) != hipSuccess ||
-            hipMemcpy(d_text, buf + sh->b0, nb, hipMemcpyHostToDevice) != hipSuccess)
+            stage_to_device(d_text, buf + sh->b0, nb, sh->device) != 0)
         {
             sh->err = "shard staging failed";
             break;
@@ -95,6 +95,7 @@ void run_shard(Shard *sh, const search_params_t *params, const char *buf, size_t
     if (d_text) (void)hipFree(d_text);
     if (d_pos) (void)hipFree(d_pos);
     krep_gpu_plan_destroy(pl);
+    stage_release();
 }
 } // namespace
 
