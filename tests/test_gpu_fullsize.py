@@ -2,6 +2,8 @@
 parity is established through size-independent properties — the closed-form match count of the synthetic
 generator, strict sortedness, every reported offset really holding the pattern — plus oracle comparisons on
 windows (incl. every GiB boundary plant)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -109,3 +111,50 @@ def test_single_byte_8gib_checksum(gpu):
     assert bool(torch.all(starts[1:] > starts[:-1]))
     assert int(starts.sum().item()) == csum  # checksum of all offsets
     assert bool(torch.all(buf[starts] == ord("#")))
+
+
+def test_thousand_patterns_2gib_against_threaded_reference(gpu):
+    """BASELINE config 4 at 2 GiB: the complete GPU match list (11-byte average patterns, ~0.7 M matches) against the
+    CPU checker run on all host cores — chunked with overlap, each chunk keeping the matches whose START it owns."""
+    import ctypes as C
+    import threading
+    import torch
+    import random as pyrandom
+    import struct
+    rng = pyrandom.Random(1234)
+    pats = [bytes(rng.randrange(97, 123) for _ in range(rng.randint(4, 16))) for _ in range(1000)]
+    head = struct.pack("<I", len(pats))
+    off, body = 4 + 8 * len(pats), b""
+    for p in pats:
+        head += struct.pack("<II", off + len(body), len(p))
+        body += p
+    n = 2 * GIB
+    buf = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+    gpu.generate(buf.data_ptr(), n, 0, 4, SEED, head + body, 4096)
+    cap = n // 1500
+    pos = torch.empty(2 * cap, dtype=torch.int64, device="cuda")
+    out = gpu.plan(abi.Params(pats)).scan(buf.data_ptr(), n, 0, n, 0, pos.data_ptr(), cap)
+    assert not out.overflow and out.stored == out.total_matches
+    got = pos[: 2 * out.stored].view(-1, 2).cpu().numpy().astype(np.uint64)
+    # the reference's emission order: end ascending, then start ascending
+    assert np.all((got[1:, 1] > got[:-1, 1]) | ((got[1:, 1] == got[:-1, 1]) & (got[1:, 0] >= got[:-1, 0])))
+    text = buf[:n].cpu().numpy()
+    eng = ol.ref(abi.REF_SCALAR) or ol.oracle()
+    threads = min(64, os.cpu_count() or 8)
+    chunk = (n + threads - 1) // threads
+    parts = [None] * threads
+
+    def work(i):
+        lo, hi = i * chunk, min(n, (i + 1) * chunk)
+        b1 = min(n, hi + 16)
+        _, p = eng.call(abi.RA_AHO_CORASICK, abi.Params(pats), text[lo:b1])
+        p = p + np.uint64(lo)
+        parts[i] = p[(p[:, 0] >= lo) & (p[:, 0] < hi)]
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    want = np.concatenate(parts)
+    want = want[np.lexsort((want[:, 0], want[:, 1]))]
+    assert len(want) == out.count
+    assert np.array_equal(got, want)
