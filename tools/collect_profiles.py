@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Summarise gpurun_out/<tag>_<workload>_* (written by tools/profile_round.sh) into profiles/:
+<tag>_<workload>_bench.json, _kernel_stats.csv, _pmc_fetch_write.csv and traffic.json (read by bench.py).
+
+HBM bytes per launch of the dominant kernel = 2 x FETCH_SIZE + WRITE_SIZE, counters in KiB: FETCH_SIZE counts
+32-byte-request units and under-reports 16 B/lane streams by 2x on gfx950 (MI355X_MICROARCH.md, HBM section); the
+generator's WRITE_SIZE (exactly the bytes it fills) calibrates the unit.
+"""
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT, PROF = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
+DOMINANT = {"literal8": "kg::lit_scan", "memchr1": "kg::lit_scan", "ac1000": "kg::ac_scan_kernel"}
+
+
+def short(name):
+    return re.sub(r"^void ", "", name).split("(")[0]
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    tpath = os.path.join(PROF, "traffic.json")
+    traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
+    for w, dom in DOMINANT.items():
+        b = os.path.join(OUT, f"{tag}_{w}_bench.json")
+        if not os.path.exists(b):
+            continue
+        line = [l for l in open(b) if l.startswith("{")][-1]
+        bench = json.loads(line)
+        open(os.path.join(PROF, f"{tag}_{w}_bench.json"), "w").write(line)
+        ks = glob.glob(os.path.join(OUT, f"{tag}_{w}_kt", "**", "*kernel_stats.csv"), recursive=True)
+        if ks:
+            shutil.copy(ks[0], os.path.join(PROF, f"{tag}_{w}_kernel_stats.csv"))
+        agg = {}
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            for f in glob.glob(os.path.join(OUT, f"{tag}_{w}_{c}", "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    k = (short(row["Kernel_Name"]), row["Counter_Name"])
+                    s = agg.setdefault(k, [0, 0.0])
+                    s[0] += 1
+                    s[1] += float(row["Counter_Value"])
+        if not agg:
+            continue
+        with open(os.path.join(PROF, f"{tag}_{w}_pmc_fetch_write.csv"), "w") as f:
+            f.write("kernel,counter,dispatches,avg_value_KiB\n")
+            for (k, c), (n, v) in sorted(agg.items()):
+                if k.startswith("kg::") or k.startswith("synth"):
+                    f.write(f'"{k}",{c},{n},{v / n:.3f}\n')
+        fk = [(k, v) for (k, c), v in agg.items() if k.startswith(dom) and c == "FETCH_SIZE"]
+        wk = [(k, v) for (k, c), v in agg.items() if k.startswith(dom) and c == "WRITE_SIZE"]
+        if fk and wk:
+            fetch = sum(v[1] for _, v in fk) / sum(v[0] for _, v in fk)
+            write = sum(v[1] for _, v in wk) / sum(v[0] for _, v in wk)
+            alg = bench["roofline"]["algorithmic_bytes_per_launch"]
+            hbm = int((2 * fetch + write) * 1024)
+            traffic[w] = {
+                "hbm_bytes_per_launch": hbm, "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write,
+                "algorithmic_bytes": alg, "ratio": round(hbm / alg, 4), "kernel": dom,
+                "method": f"tools/profile_round.sh {tag}: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate "
+                          f"passes of `python bench.py --workload {w} --steps 2 --warmup 1 --no-cpu-baseline`; "
+                          "FETCH_SIZE doubled (16 B/lane streams on gfx950, MI355X_MICROARCH.md HBM section); counters "
+                          "in KiB (the generator's WRITE_SIZE calibrates to exactly the bytes it fills)"}
+            bench["roofline"]["traffic"] = hbm          # the PMC passes of this very run
+            open(os.path.join(PROF, f"{tag}_{w}_bench.json"), "w").write(json.dumps(bench) + "\n")
+            print(w, "traffic ratio", traffic[w]["ratio"], "value", bench["value"], "frac", bench["roofline"]["frac"])
+    json.dump(traffic, open(tpath, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
