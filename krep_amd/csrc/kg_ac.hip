@@ -43,9 +43,10 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
     for (u32 w = threadIdx.x; w < a.filter_words; w += kAcBlock)
         s_mem[w] = a.filter[w];
     const u32 fw = (a.filter_words + 3u) & ~3u;
-    constexpr u32 kPerWave = kAcQueue + (LINES ? kAcBitmapWords : 0u);
-    u32 *queue = s_mem + fw + 4u + wave * kPerWave;
-    u32 *bitmap = queue + kAcQueue;
+    constexpr u32 kPerWave = kAcQueue / 2 + (LINES ? kAcBitmapWords : 0u);
+    constexpr u32 XB = LINES ? kXBitsLines : kXBitsBig; // exact-class table (CLS == 8 only)
+    unsigned short *queue = reinterpret_cast<unsigned short *>(s_mem + fw + wave * kPerWave);
+    u32 *bitmap = s_mem + fw + wave * kPerWave + kAcQueue / 2;
     if (LINES)
         for (u32 w = lane; w < kAcBitmapWords; w += 64)
             bitmap[w] = 0u;
@@ -140,6 +141,32 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 for (int w = 0; w < 4; ++w)
                     NL |= ac_movemask4(ac_eq_bytes(W[w + 1], 0x0a0a0a0au)) << (4 * w);
             }
+            u32 cand = 0;
+            if (CLS == 8)
+            {
+                // ---- filter, exact-class table: the lane's 20 bytes as a 100-bit stream of 5-bit classes; the
+                //      index of end position k is the 20-bit window at bit 5(k+1): one v_alignbit, no hash ----
+                u32 c[5];
+#pragma unroll
+                for (int w = 0; w < 5; ++w)
+                    c[w] = ac_cls4(W[w]);
+                u32 R[5];
+                R[0] = c[0] | (c[1] << 20);
+                R[1] = (c[1] >> 12) | (c[2] << 8) | (c[3] << 28);
+                R[2] = (c[3] >> 4) | (c[4] << 16);
+                R[3] = c[4] >> 16;
+                R[4] = 0;
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                {
+                    const int o = 5 * (k + 1);
+                    const u32 x = (o & 31) ? __builtin_amdgcn_alignbit(R[(o >> 5) + 1], R[o >> 5], (u32)(o & 31)) : R[o >> 5];
+                    const u32 by = reinterpret_cast<const unsigned char *>(s_mem)[(x >> 3) & ((1u << (XB - 3)) - 1u)];
+                    cand |= ((by >> (x & 7u)) & 1u) << k;
+                }
+            }
+            else
+            {
             if (CI)
             {
 #pragma unroll
@@ -148,7 +175,6 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
             }
 
             // ---- filter: which of my 16 end positions can end a pattern?  (branch-free) ----------------
-            u32 cand = 0;
 #pragma unroll
             for (int k = 0; k < 16; ++k)
             {
@@ -170,6 +196,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 if (CLS & 1)
                     hit |= ac_tbit(s_mem, a.off1, E >> 24);
                 cand |= hit << k;
+            }
             }
             u32 nlm = NL;
             if (!interior)
@@ -209,7 +236,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                     {
                         const u32 k = __builtin_ctz(rest);
                         rest &= rest - 1u;
-                        queue[at++] = rel0 + k;
+                        queue[at++] = (unsigned short)(rel0 + k);
                     }
                     qn += tot;
                 }
@@ -378,6 +405,7 @@ struct AcTables
     bool ci = false, has_nl = false, has_empty = false;
     u32 has1 = 0, has2 = 0, has3 = 0, has4 = 0, off1 = 0, off2 = 0, off3 = 0, filter_words = 0;
     u32 *d_filter = nullptr;
+    u32 *d_filterx20 = nullptr, *d_filterx19 = nullptr; // exact-class tables of the fused kernel (all patterns >= 4 bytes)
     uint2 *d_edges = nullptr;
     u32 emask = 0;
     u32 *d_copies = nullptr;
@@ -617,6 +645,22 @@ AcTables *ac_build(const search_params_t &sp, int device)
     ACHK(hipMemcpy(t->d_gram4, g4.data(), g4.size() * sizeof(uint2), hipMemcpyHostToDevice));
     ACHK(hipMalloc(&t->d_filter, filter.size() * sizeof(u32)));
     ACHK(hipMemcpy(t->d_filter, filter.data(), filter.size() * sizeof(u32), hipMemcpyHostToDevice));
+    if (t->has4 && !t->has1 && !t->has2 && !t->has3)
+    {
+        std::vector<u32> X20((1u << kXBitsBig) / 32, 0), X19((1u << kXBitsLines) / 32, 0);
+        for (auto &p : pats)
+        {
+            const size_t n = p.size();
+            const u32 x = ac_cls4((u32)p[n - 4] | ((u32)p[n - 3] << 8) | ((u32)p[n - 2] << 16) | ((u32)p[n - 1] << 24));
+            X20[x >> 5] |= 1u << (x & 31);
+            const u32 y = x & ((1u << kXBitsLines) - 1u);
+            X19[y >> 5] |= 1u << (y & 31);
+        }
+        ACHK(hipMalloc(&t->d_filterx20, X20.size() * sizeof(u32)));
+        ACHK(hipMemcpy(t->d_filterx20, X20.data(), X20.size() * sizeof(u32), hipMemcpyHostToDevice));
+        ACHK(hipMalloc(&t->d_filterx19, X19.size() * sizeof(u32)));
+        ACHK(hipMemcpy(t->d_filterx19, X19.data(), X19.size() * sizeof(u32), hipMemcpyHostToDevice));
+    }
     ACHK(hipMalloc(&t->d_edges, tab.size() * sizeof(uint2)));
     ACHK(hipMemcpy(t->d_edges, tab.data(), tab.size() * sizeof(uint2), hipMemcpyHostToDevice));
     ACHK(hipMalloc(&t->d_copies, copies.size() * sizeof(u32)));
@@ -633,6 +677,8 @@ void ac_free(AcTables *t)
         return;
     (void)hipSetDevice(t->device);
     if (t->d_filter) (void)hipFree(t->d_filter);
+    if (t->d_filterx20) (void)hipFree(t->d_filterx20);
+    if (t->d_filterx19) (void)hipFree(t->d_filterx19);
     if (t->d_edges) (void)hipFree(t->d_edges);
     if (t->d_copies) (void)hipFree(t->d_copies);
     if (t->d_gram4) (void)hipFree(t->d_gram4);
@@ -657,8 +703,8 @@ static const int g_ac_chunk_mib = getenv("KREP_GPU_AC_CHUNK_MIB") ? atoi(getenv(
 
 static u32 ac_lds_bytes(u32 filter_words, bool lines)
 {
-    const u32 per_wave = kAcQueue + (lines ? kAcBitmapWords : 0u);
-    return (((filter_words + 3u) & ~3u) + 4u + kAcWaves * per_wave) * (u32)sizeof(u32);
+    const u32 per_wave = kAcQueue / 2 + (lines ? kAcBitmapWords : 0u);
+    return (((filter_words + 3u) & ~3u) + kAcWaves * per_wave) * (u32)sizeof(u32);
 }
 
 template <bool CI, bool LN, int CLS>
@@ -740,6 +786,11 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
     a.filter = t->d_filter;
     a.off1 = t->off1; a.off2 = t->off2; a.off3 = t->off3;
     a.filter_words = t->filter_words;
+    if (t->d_filterx20 && !split)
+    { // fused kernel, every pattern >= 4 bytes: the exact-class table instead of the hashed one
+        a.filter = lines ? t->d_filterx19 : t->d_filterx20;
+        a.filter_words = (1u << (lines ? kXBitsLines : kXBitsBig)) / 32;
+    }
     a.edges = t->d_edges;
     a.emask = t->emask;
     a.copies = t->d_copies;
@@ -792,7 +843,7 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
         a.cand = t->d_cand;
         a.candcnt = t->d_candcnt;
     }
-    const u32 lds = split ? (((t->filter_words + 3u) & ~3u) + 4u) * (u32)sizeof(u32) : ac_lds_bytes(t->filter_words, lines);
+    const u32 lds = split ? (((t->filter_words + 3u) & ~3u) + 4u) * (u32)sizeof(u32) : ac_lds_bytes(a.filter_words, lines);
     const u32 per_cu = lds <= 80 * 1024 ? 2u : 1u;
     const u64 n_tickets = (a.num_tiles + kAcUnitsPerTicket - 1) / kAcUnitsPerTicket;
     const u32 grid = (u32)std::min<u64>((n_tickets + kAcWaves - 1) / kAcWaves, (u64)num_cu * per_cu);

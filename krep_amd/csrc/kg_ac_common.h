@@ -258,10 +258,22 @@ __device__ __forceinline__ u32 ac_walk_fast(const AcArgs &a, u64 i, bool own_by_
 }
 
 constexpr u32 kAcUnitsPerTicket = 4;   // 64 KiB of haystack per wave ticket
-constexpr u32 kAcQueue = 512;          // candidate queue entries per wave (u32 each)
+constexpr u32 kAcQueue = 512;          // candidate queue entries per wave (u16 each: unit-relative end index)
 constexpr int kAcRounds = 2;            // load rounds per unit: one candidate drain per 16 KiB (53 of 64 lanes busy)
 constexpr u32 kAcUnitBytes = kAcRounds * kSegBytes;
 constexpr u32 kAcBitmapWords = kAcUnitBytes / 32; // one bit per end position of a unit (LINES)
+
+// Exact-class filter index of the fused kernel when every pattern has >= 4 bytes: class(b) = b & 31 (letters keep
+// their identity, upper/lower case share a class, so the table needs no case fold), index = the four classes of the
+// suffix 4-gram, 5 bits each, first byte lowest.  2^20 bits (128 KiB) in LDS; -c keeps 2^19 (top bit dropped) to
+// leave room for the per-wave line bitmaps.  A superset test like the hashed tables, but for text over one
+// 5-bit-class alphabet a hit IS a suffix 4-gram match: no hash false positives, and no multiply per position.
+constexpr u32 kXBitsBig = 20, kXBitsLines = 19;
+__host__ __device__ __forceinline__ u32 ac_cls4(u32 w)
+{ // bytes b0..b3 of w -> c(b0) | c(b1) << 5 | c(b2) << 10 | c(b3) << 15
+    const u32 t = (w & 0x001f001fu) | ((w >> 3) & 0x03e003e0u);
+    return (t & 0x3ffu) | ((t >> 6) & 0xffc00u);
+}
 
 // bit of table `base` at hash h
 __device__ __forceinline__ u32 ac_tbit(const u32 *tab, u32 base, u32 h) { return (tab[base + (h >> 5)] >> (h & 31u)) & 1u; }
