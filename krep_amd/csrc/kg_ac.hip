@@ -40,6 +40,8 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
     extern __shared__ __attribute__((aligned(16))) u32 s_mem[]; // filter | tickets | per-wave queue (+ bitmap)
     const u32 lane = ac_lane();
     const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (CLS == 8 && (u32)(size_t)((__attribute__((address_space(3))) u32 *)s_mem) != 0u)
+        __builtin_trap(); // the exact-class lookups address LDS absolutely (no static __shared__ in this kernel)
     for (u32 w = threadIdx.x; w < a.filter_words; w += kAcBlock)
         s_mem[w] = a.filter[w];
     const u32 fw = (a.filter_words + 3u) & ~3u;
@@ -70,6 +72,12 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
         if (u_begin >= a.num_tiles)
             break;
         const u64 u_end = (u_begin + kAcUnitsPerTicket < a.num_tiles) ? u_begin + kAcUnitsPerTicket : a.num_tiles;
+      // Rolling prefetch: as soon as cell j of a round has been copied out of d[j], the same registers receive cell j
+      // of the NEXT round (the rounds of a ticket are contiguous), so a wave always has 8 KiB in flight while it
+      // filters and verifies — no second buffer (1024-thread blocks cap a wave at 128 VGPRs).
+      uint4 d[kCells];
+      bool have = false; // d[] holds (or is receiving) the round about to be processed (uniform)
+      u32 carry = 0;     // the 4 bytes in front of that round (valid when have)
       for (u64 unit = u_begin; unit < u_end; ++unit)
       {
         const u64 useg = a.anchor + unit * (u64)kAcUnitBytes; // the unit = kAcRounds load rounds of 8 KiB
@@ -92,48 +100,31 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
         const u64 seg = useg + (u64)r * kSegBytes;
         const bool fast_now = seg + kSegBytes <= a.text_len;
         const bool interior = seg >= a.end_lo && seg + kSegBytes <= a.end_hi;
-        uint4 d[kCells];
         u32 before = 0; // the 4 bytes in front of the round
-        if (fast_now)
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.text + seg) + lane;
+        if (fast_now && !have)
         {
-            const uint4 *src = reinterpret_cast<const uint4 *>(a.text + seg) + lane;
 #pragma unroll
             for (int j = 0; j < kCells; ++j)
                 d[j] = src[j * kWave];
         }
-        if (seg >= 4 && seg <= a.text_len)
+        // the next round of this ticket, if it is a full one, streams in behind this one
+        const bool pf_next = fast_now && !emit_final && seg + 2 * (u64)kSegBytes <= a.text_len &&
+                             (r + 1 < kAcRounds || unit + 1 < u_end);
+        // always issued in the fast path (a uniform address select, not a branch: the s_waitcnt counts stay static);
+        // without a next round it re-reads this one, an L2 hit whose result is dropped
+        const uint4 *nsrc = pf_next ? src + kSegBytes / 16 : src;
+        if (have)
+            before = carry;
+        else if (seg >= 4 && seg <= a.text_len)
             before = *reinterpret_cast<const u32 *>(a.text + seg - 4);
         else
             for (u32 b = 0; b < 4; ++b)
                 if (seg + b >= 4 && seg + b - 4 < a.text_len)
                     before |= (u32)a.text[seg + b - 4] << (8 * b);
-#pragma unroll
-        for (int j = 0; j < kCells; ++j)
-        {
+        // W[0] = the 4 bytes before the lane, W[1..4] = the lane's 16 bytes of cell j
+        auto cell_body = [&](const int j, u32 (&W)[5]) __attribute__((always_inline)) {
             const u64 lbase = seg + (u64)j * kCellBytes + (u64)lane * 16u;
-            u32 W[5]; // W[0] = the 4 bytes before the lane, W[1..4] = the lane's 16 bytes
-            if (fast_now)
-            {
-                W[1] = d[j].x; W[2] = d[j].y; W[3] = d[j].z; W[4] = d[j].w;
-                const u32 up = __shfl_up(W[4], 1);
-                const u32 edge = (j == 0) ? before : __builtin_amdgcn_readlane(d[j > 0 ? j - 1 : 0].w, 63);
-                W[0] = (lane == 0u) ? edge : up;
-            }
-            else
-            {
-#pragma unroll 1
-                for (int w = 0; w < 5; ++w)
-                {
-                    u32 v = 0;
-                    for (int b = 0; b < 4; ++b)
-                    {
-                        const u64 o = lbase + (u64)(w * 4 + b);
-                        if (o >= 4 && o - 4 < a.text_len)
-                            v |= (u32)a.text[o - 4] << (8 * b);
-                    }
-                    W[w] = v;
-                }
-            }
             u32 NL = 0;
             if (LINES)
             {
@@ -156,14 +147,21 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 R[2] = (c[3] >> 4) | (c[4] << 16);
                 R[3] = c[4] >> 16;
                 R[4] = 0;
+                // per position 5 VALU: window, dword address, ds_read_b32, shift by the low 5 index bits (the shifter
+                // masks them itself), and a funnel shift that pushes the hit bit into the accumulator from the top
+                u32 acc = 0;
 #pragma unroll
                 for (int k = 0; k < 16; ++k)
                 {
                     const int o = 5 * (k + 1);
                     const u32 x = (o & 31) ? __builtin_amdgcn_alignbit(R[(o >> 5) + 1], R[o >> 5], (u32)(o & 31)) : R[o >> 5];
-                    const u32 by = reinterpret_cast<const unsigned char *>(s_mem)[(x >> 3) & ((1u << (XB - 3)) - 1u)];
-                    cand |= ((by >> (x & 7u)) & 1u) << k;
+                    // the table sits at LDS address 0 (checked at kernel entry): an absolute LDS pointer saves the
+                    // v_add of the (link-time) base of s_mem on every lookup
+                    typedef __attribute__((address_space(3))) const u32 lds_u32;
+                    const u32 dw = *(lds_u32 *)(size_t)((x >> 3) & ((1u << (XB - 3)) - 4u));
+                    acc = __builtin_amdgcn_alignbit(dw >> (x & 31u), acc, 1u);
                 }
+                cand = acc >> 16;
             }
             else
             {
@@ -241,8 +239,46 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                     qn += tot;
                 }
             }
+        };
+        if (fast_now)
+        { // straight-line: no branch between a prefetch and the next cell's read of d[]
+#pragma unroll
+            for (int j = 0; j < kCells; ++j)
+            {
+                u32 W[5];
+                W[1] = d[j].x; W[2] = d[j].y; W[3] = d[j].z; W[4] = d[j].w;
+                d[j] = nsrc[j * kWave];
+                const u32 up = __shfl_up(W[4], 1);
+                W[0] = (lane == 0u) ? before : up;
+                before = __builtin_amdgcn_readlane(W[4], 63); // the next cell's (and round's) left neighbour
+                cell_body(j, W);
+            }
+        }
+        else
+        { // the ragged end of the text: bytewise, bounds-checked
+#pragma unroll
+            for (int j = 0; j < kCells; ++j)
+            {
+                const u64 lbase = seg + (u64)j * kCellBytes + (u64)lane * 16u;
+                u32 W[5];
+#pragma unroll
+                for (int w = 0; w < 5; ++w)
+                {
+                    u32 v = 0;
+                    for (int b = 0; b < 4; ++b)
+                    {
+                        const u64 o = lbase + (u64)(w * 4 + b);
+                        if (o >= 4 && o - 4 < a.text_len)
+                            v |= (u32)a.text[o - 4] << (8 * b);
+                    }
+                    W[w] = v;
+                }
+                cell_body(j, W);
+            }
         }
 
+        have = pf_next;
+        carry = before;
         } // rounds
 
         // ---- verify (and stage/emit) the candidates, 64 at a time, one per lane; a flooded unit walks
@@ -411,6 +447,7 @@ struct AcTables
     u32 *d_copies = nullptr;
     u32 nnodes = 0;
     uint2 *d_gram4 = nullptr;
+    uint4 *d_g4x = nullptr; // chain-compressed entries, same slots as d_gram4
     u32 g4mask = 0;
     uint4 *d_sfx = nullptr;      // whole-pattern table (lmax <= 16)
     unsigned long long *d_tags = nullptr;
@@ -556,6 +593,7 @@ AcTables *ac_build(const search_params_t &sp, int device)
     }
     // exact 4-gram -> depth-4 node (used when every pattern has >= 4 bytes)
     std::vector<uint2> g4;
+    std::vector<uint4> g4x;
     {
         struct Item { u32 node, depth, gram; };
         std::vector<std::vector<std::pair<u32, u32>>> kids(t->nnodes); // node -> (byte, child)
@@ -580,12 +618,35 @@ AcTables *ac_build(const search_params_t &sp, int device)
             gcap <<= 1;
         t->g4mask = gcap - 1;
         g4.assign(gcap, make_uint2(0u, 0u));
+        g4x.assign(2 * (size_t)gcap, make_uint4(0u, 0u, 0u, 0u));
         for (auto &it : d4)
         {
             u32 h = (it.gram * kHashMul) >> 9;
             while (g4[h & t->g4mask].y != 0u)
                 ++h;
-            g4[h & t->g4mask] = make_uint2(it.gram, it.node | (copies[it.node] ? 0x80000000u : 0u));
+            const u32 child = it.node | (copies[it.node] ? 0x80000000u : 0u);
+            g4[h & t->g4mask] = make_uint2(it.gram, child);
+            // the unary chain below the depth-4 node (ac_walk_fast): <= 12 bytes, depths 5..16
+            u32 node = it.node, clen = 0, endmask = 0;
+            bool simple = copies[node] <= 1;
+            uint8_t cb[12] = {0};
+            while (clen < 12 && kids[node].size() == 1)
+            {
+                const u32 byte = kids[node][0].first;
+                node = kids[node][0].second;
+                cb[11 - clen] = (uint8_t)byte; // depth 5 + clen <-> window byte 16 - depth
+                if (copies[node])
+                {
+                    endmask |= 1u << clen;
+                    if (copies[node] != 1)
+                        simple = false;
+                }
+                ++clen;
+            }
+            const u32 info = clen | (simple ? kG4Simple : 0u) | (!kids[node].empty() ? kG4Cont : 0u);
+            auto word = [&](int w) { return (u32)cb[4 * w] | ((u32)cb[4 * w + 1] << 8) | ((u32)cb[4 * w + 2] << 16) | ((u32)cb[4 * w + 3] << 24); };
+            g4x[2 * (size_t)(h & t->g4mask)] = make_uint4(it.gram, child, info, endmask);
+            g4x[2 * (size_t)(h & t->g4mask) + 1] = make_uint4(word(0), word(1), word(2), 0u);
         }
     }
     // whole-pattern table for the fast verifier (all patterns <= 16 bytes)
@@ -643,6 +704,8 @@ AcTables *ac_build(const search_params_t &sp, int device)
     }
     ACHK(hipMalloc(&t->d_gram4, g4.size() * sizeof(uint2)));
     ACHK(hipMemcpy(t->d_gram4, g4.data(), g4.size() * sizeof(uint2), hipMemcpyHostToDevice));
+    ACHK(hipMalloc(&t->d_g4x, g4x.size() * sizeof(uint4)));
+    ACHK(hipMemcpy(t->d_g4x, g4x.data(), g4x.size() * sizeof(uint4), hipMemcpyHostToDevice));
     ACHK(hipMalloc(&t->d_filter, filter.size() * sizeof(u32)));
     ACHK(hipMemcpy(t->d_filter, filter.data(), filter.size() * sizeof(u32), hipMemcpyHostToDevice));
     if (t->has4 && !t->has1 && !t->has2 && !t->has3)
@@ -682,6 +745,7 @@ void ac_free(AcTables *t)
     if (t->d_edges) (void)hipFree(t->d_edges);
     if (t->d_copies) (void)hipFree(t->d_copies);
     if (t->d_gram4) (void)hipFree(t->d_gram4);
+    if (t->d_g4x) (void)hipFree(t->d_g4x);
     if (t->d_sfx) (void)hipFree(t->d_sfx);
     if (t->d_tags) (void)hipFree(t->d_tags);
     if (t->d_cand) (void)hipFree(t->d_cand);
@@ -795,6 +859,7 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
     a.emask = t->emask;
     a.copies = t->d_copies;
     a.gram4 = t->d_gram4;
+    a.g4x = t->d_g4x;
     a.sfx = t->d_sfx;
     a.tags = t->d_tags;
     a.sfxmask = t->sfxmask;

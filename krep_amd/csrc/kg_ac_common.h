@@ -40,6 +40,7 @@ struct AcArgs
     u32 sfxmask, lenmask;        // entries-1; bit L set <=> some pattern has length L (1..16)
     const uint2 *gram4;          // exact last-4-bytes -> {key, depth-4 node | has_out << 31} (val 0 = empty)
     u32 g4mask;
+    const uint4 *g4x;            // same slots, 2 x uint4 each: {key, child, info, endmask} {chain bytes x3, -}
     unsigned long long *unitinfo;
     Counters *ctr;
     u64 *stage;
@@ -164,7 +165,7 @@ __device__ __forceinline__ u32 ac_walk(const AcArgs &a, u64 i, u32 total, Put pu
 //  * the depths at which a pattern ends are remembered in a bit mask, so the longest-first emission needs no second
 //    walk (falls back to it when a pattern has duplicate copies or the set has patterns longer than 64 bytes).
 template <bool CI>
-__device__ __forceinline__ u32 ac_walk_fast(const AcArgs &a, u64 i, bool own_by_end, u64 &depthmask, bool &simple)
+__device__ __forceinline__ u32 ac_walk_levels(const AcArgs &a, u64 i, bool own_by_end, u64 &depthmask, bool &simple)
 {
     depthmask = 0;
     simple = true;
@@ -257,6 +258,81 @@ __device__ __forceinline__ u32 ac_walk_fast(const AcArgs &a, u64 i, bool own_by_
     return seen;
 }
 
+// Chain-compressed verifier (CLS == 8, the shipped path).  Below depth 4 almost every node of the reversed trie of a
+// large dictionary lies on a unary chain, so the 4-gram entry carries the next <= 12 bytes of that chain (in text
+// order, the window text[i-15 .. i-4] compares against it dword by dword) and the depths at which patterns end:
+// a candidate costs TWO dependent accesses (text window, table entry) however long the match is, instead of one
+// probe per trie level (12 serial L2 round trips for a 16-byte match — the latency that bounded the verify stage).
+// Anything the entry cannot express (branching below depth 4, duplicate patterns, chains continuing past depth 16,
+// -w, a candidate within 15 bytes of the text start) takes the level-by-level walk.
+constexpr u32 kG4Simple = 1u << 4, kG4Cont = 1u << 5; // info bits above the chain length [3:0]
+template <bool CI>
+__device__ __forceinline__ u32 ac_walk_fast(const AcArgs &a, u64 i, bool own_by_end, u64 &depthmask, bool &simple)
+{
+    bool slow = i < 15 || (a.flags & F_WW); // one (inlined) call site for the level walk
+    u32 dm = 0;
+    if (!slow)
+    {
+        struct __attribute__((packed)) U32p { u32 v; };
+        const U32p *q = reinterpret_cast<const U32p *>(a.text + (i - 15));
+        u32 T[4] = {q[0].v, q[1].v, q[2].v, q[3].v};
+        if (CI)
+        {
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+                T[w] = ac_fold4(T[w]);
+        }
+        uint4 e0, e1;
+        bool found = true;
+        for (u32 h = (T[3] * kHashMul) >> 9;; ++h)
+        {
+            const uint4 *e = a.g4x + 2 * (size_t)(h & a.g4mask);
+            e0 = e[0];
+            e1 = e[1]; // issued with e[0]: one latency
+            if (e0.y == 0u)
+            {
+                found = false; // not a suffix of any pattern
+                break;
+            }
+            if (e0.x == T[3])
+                break;
+        }
+        if (found)
+        {
+            const u32 info = e0.z, clen = info & 15u;
+            auto same = [](u32 m) -> u32 { return m ? (u32)__builtin_clz(m) >> 3 : 4u; }; // equal bytes from the top
+            u32 L = same(T[2] ^ e1.z);
+            if (L == 4u)
+            {
+                L += same(T[1] ^ e1.y);
+                if (L == 8u)
+                    L += same(T[0] ^ e1.x);
+            }
+            L = L < clen ? L : clen;
+            slow = !(info & kG4Simple) || (L == clen && (info & kG4Cont));
+            dm = ((e0.y >> 31) << 4) | ((e0.w & ((1u << L) - 1u)) << 5); // bit d: a pattern of length d ends at i
+            if (!own_by_end)
+            { // the match start s = i + 1 - d has to lie in [own_lo, own_hi)
+                const u64 e = i + 1;
+                if (e <= a.own_lo)
+                    dm = 0;
+                else
+                {
+                    if (e - a.own_lo < 32)
+                        dm &= (2u << (u32)(e - a.own_lo)) - 1u; // d <= e - own_lo
+                    if (e > a.own_hi)
+                        dm = (e - a.own_hi < 32) ? (dm & ~((2u << (u32)(e - a.own_hi)) - 1u)) : 0u; // d > e - own_hi
+                }
+            }
+        }
+    }
+    if (slow)
+        return ac_walk_levels<CI>(a, i, own_by_end, depthmask, simple);
+    depthmask = dm;
+    simple = true;
+    return (u32)__popc(dm);
+}
+
 constexpr u32 kAcUnitsPerTicket = 4;   // 64 KiB of haystack per wave ticket
 constexpr u32 kAcQueue = 512;          // candidate queue entries per wave (u16 each: unit-relative end index)
 constexpr int kAcRounds = 2;            // load rounds per unit: one candidate drain per 16 KiB (53 of 64 lanes busy)
@@ -271,8 +347,8 @@ constexpr u32 kAcBitmapWords = kAcUnitBytes / 32; // one bit per end position of
 constexpr u32 kXBitsBig = 20, kXBitsLines = 19;
 __host__ __device__ __forceinline__ u32 ac_cls4(u32 w)
 { // bytes b0..b3 of w -> c(b0) | c(b1) << 5 | c(b2) << 10 | c(b3) << 15
-    const u32 t = (w & 0x001f001fu) | ((w >> 3) & 0x03e003e0u);
-    return (t & 0x3ffu) | ((t >> 6) & 0xffc00u);
+    const u32 t = (w & 0x001f001fu) | ((w >> 3) & ~0x001f001fu); // two v_bfi: junk above each 10-bit pair ...
+    return ((t & 0x3ffu) | ((t >> 6) & ~0x3ffu)) & 0xfffffu;       // ... shifted out or masked here
 }
 
 // bit of table `base` at hash h
