@@ -103,3 +103,38 @@ def test_binary_patterns_and_text(gpu, oracle_engine):
     _check(gpu, oracle_engine, text, pats, dict())
     _check(gpu, oracle_engine, text, pats, dict(case_sensitive=False, whole_word=True))
     _check(gpu, oracle_engine, text, [p for p in pats if len(p) >= 4 and len(p) <= 16], dict(max_count=9))
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_long_pattern_sets_chain_verifier(gpu, oracle_engine, seed):
+    """Every pattern >= 4 bytes (the exact-class filter + chain-compressed verifier): unary chains with nested
+    pattern ends, chains running past depth 16, branching below depth 4, duplicates, -w, -i, -c, tiny texts."""
+    rng = np.random.RandomState(900 + seed)
+    for it in range(40):
+        alpha = [b"ab", b"abcd", b"abAB_ ", bytes(range(97, 123)) + b" \n"][it % 4]
+        n = [10, 17, 40, 500, 16384, 16400, 70000, 200000][rng.randint(0, 8)]
+        text = cases.rand_text(rng, n, alpha)
+        base = cases.pick_pattern(rng, text, [8, 20, 40, 70][rng.randint(0, 4)], alpha)
+        pats = [base]
+        for _ in range([1, 3, 8, 30][rng.randint(0, 4)]):
+            r = rng.rand()
+            if r < 0.3 and len(base) > 5:      # a suffix of `base`: ends nested along one chain
+                pats.append(base[rng.randint(0, len(base) - 4):])
+            elif r < 0.5 and len(base) > 6:    # same tail, different head: the trie branches below depth 4
+                cut = rng.randint(1, len(base) - 4)
+                pats.append(cases.rand_text(rng, rng.randint(1, 6), alpha).tobytes() + base[cut:])
+            elif r < 0.6:
+                pats.append(pats[rng.randint(0, len(pats))])  # duplicate
+            else:
+                pats.append(cases.pick_pattern(rng, text, rng.randint(4, 24), alpha))
+        pats = [p for p in pats if len(p) >= 4]
+        kw = dict(case_sensitive=bool(rng.rand() < 0.6), whole_word=bool(rng.rand() < 0.25),
+                  max_count=[abi.SIZE_MAX, abi.SIZE_MAX, 0, 1, 5][rng.randint(0, 5)])
+        mode = ["pos", "pos", "lines", "count"][rng.randint(0, 4)]
+        if mode == "lines":
+            if any(b"\n" in p for p in pats):
+                continue
+            kw.update(count_lines=True)
+        elif mode == "count":
+            kw.update(count_lines=True, only_match=True)
+        _check(gpu, oracle_engine, text, pats, kw)
