@@ -59,19 +59,19 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
     u64 acc_total = 0;
     __syncthreads(); // filter tables are in LDS from here on; the waves never synchronise again
 
-    // Waves are autonomous: each draws its own ticket for kAcUnitsPerTicket consecutive 8-KiB units (64 KiB:
-    // <= ~50 fetch-adds/us on the single ticket word at 3 TB/s).  A per-tile workgroup barrier (one block
-    // per CU because of the 64 KiB table) made every wave wait for the slowest verifier of its tile.
+    // Waves are autonomous: each draws its own ticket for a.upt consecutive 16-KiB units (128 KiB on large texts:
+    // ~25 fetch-adds/us on the single ticket word at 3 TB/s).  A per-tile workgroup barrier (one block per CU
+    // because of the table) made every wave wait for the slowest verifier of its tile.
     for (;;)
     {
         u64 tk = 0;
         if (lane == 0)
             tk = __hip_atomic_fetch_add(&a.ctr->ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         tk = ac_rfl64(tk);
-        const u64 u_begin = tk * (u64)kAcUnitsPerTicket;
+        const u64 u_begin = tk * (u64)a.upt;
         if (u_begin >= a.num_tiles)
             break;
-        const u64 u_end = (u_begin + kAcUnitsPerTicket < a.num_tiles) ? u_begin + kAcUnitsPerTicket : a.num_tiles;
+        const u64 u_end = (u_begin + a.upt < a.num_tiles) ? u_begin + a.upt : a.num_tiles;
       // Rolling prefetch: as soon as cell j of a round has been copied out of d[j], the same registers receive cell j
       // of the NEXT round (the rounds of a ticket are contiguous), so a wave always has 8 KiB in flight while it
       // filters and verifies — no second buffer (1024-thread blocks cap a wave at 128 VGPRs).
@@ -112,8 +112,8 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
         const bool pf_next = fast_now && !emit_final && seg + 2 * (u64)kSegBytes <= a.text_len &&
                              (r + 1 < kAcRounds || unit + 1 < u_end);
         // always issued in the fast path (a uniform address select, not a branch: the s_waitcnt counts stay static);
-        // without a next round it re-reads this one, an L2 hit whose result is dropped
-        const uint4 *nsrc = pf_next ? src + kSegBytes / 16 : src;
+        // without a next round every lane re-reads the first bytes of this one (one cached line per load, dropped)
+        const uint4 *nsrc = pf_next ? src + kSegBytes / 16 : reinterpret_cast<const uint4 *>(a.text + seg);
         if (have)
             before = carry;
         else if (seg >= 4 && seg <= a.text_len)
@@ -910,7 +910,11 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
     }
     const u32 lds = split ? (((t->filter_words + 3u) & ~3u) + 4u) * (u32)sizeof(u32) : ac_lds_bytes(a.filter_words, lines);
     const u32 per_cu = lds <= 80 * 1024 ? 2u : 1u;
-    const u64 n_tickets = (a.num_tiles + kAcUnitsPerTicket - 1) / kAcUnitsPerTicket;
+    // ticket size by text size: >= ~4 tickets per resident wave before tickets grow (small host buffers keep every
+    // CU busy), 8 units (128 KiB) on large texts
+    a.upt = split ? kAcUnitsPerTicket
+                  : (u32)std::min<u64>(kAcUnitsPerTicketMax, std::max<u64>(1, a.num_tiles / ((u64)num_cu * kAcWaves * 4)));
+    const u64 n_tickets = (a.num_tiles + a.upt - 1) / a.upt;
     const u32 grid = (u32)std::min<u64>((n_tickets + kAcWaves - 1) / kAcWaves, (u64)num_cu * per_cu);
     const u32 vgrid = (u32)std::min<u64>((n_units + 3) / 4, (u64)num_cu * 8);
     if (time_it) SCHK(hipEventRecord(ev0, st));

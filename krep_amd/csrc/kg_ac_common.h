@@ -35,6 +35,7 @@ struct AcArgs
     u32 *cand;                   // [units * cand_cap] candidate end offsets (relative to the unit), split pipeline
     u32 *candcnt;                // [units] number of candidates, or kAcFlooded
     u32 cand_cap;
+    u32 upt;                     // units per wave ticket of the fused kernel (1..kAcUnitsPerTicketMax, by text size)
     const uint4 *sfx;            // whole-pattern table, 2 x uint4 per entry: {bytes right-aligned in 16}, {len, copies, 0, 0}
     const unsigned long long *tags; // per slot: (suffix hash << 32) | (copies << 8) | len, 0 = empty
     u32 sfxmask, lenmask;        // entries-1; bit L set <=> some pattern has length L (1..16)
@@ -333,7 +334,8 @@ __device__ __forceinline__ u32 ac_walk_fast(const AcArgs &a, u64 i, bool own_by_
     return (u32)__popc(dm);
 }
 
-constexpr u32 kAcUnitsPerTicket = 4;   // 64 KiB of haystack per wave ticket
+constexpr u32 kAcUnitsPerTicket = 4;   // split pipelines: 4 x 8 KiB per wave ticket
+constexpr u32 kAcUnitsPerTicketMax = 8; // fused kernel: up to 128 KiB per wave ticket (one cold round in 16), fewer on small texts
 constexpr u32 kAcQueue = 512;          // candidate queue entries per wave (u16 each: unit-relative end index)
 constexpr int kAcRounds = 2;            // load rounds per unit: one candidate drain per 16 KiB (53 of 64 lanes busy)
 constexpr u32 kAcUnitBytes = kAcRounds * kSegBytes;
