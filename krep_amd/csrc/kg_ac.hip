@@ -45,10 +45,12 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
     for (u32 w = threadIdx.x; w < a.filter_words; w += kAcBlock)
         s_mem[w] = a.filter[w];
     const u32 fw = (a.filter_words + 3u) & ~3u;
-    constexpr u32 kPerWave = kAcQueue / 2 + (LINES ? kAcBitmapWords : 0u);
+    constexpr u32 kQ = LINES ? kAcQueue / 2 : kAcQueue; // -c: half the queue, the two bitmaps need the LDS
+    constexpr u32 kPerWave = kQ / 2 + (LINES ? 2u * kAcBitmapWords : 0u); // queue | hit bitmap | newline bitmap
     constexpr u32 XB = LINES ? kXBitsLines : kXBitsBig; // exact-class table (CLS == 8 only)
     unsigned short *queue = reinterpret_cast<unsigned short *>(s_mem + fw + wave * kPerWave);
-    u32 *bitmap = s_mem + fw + wave * kPerWave + kAcQueue / 2;
+    u32 *bitmap = s_mem + fw + wave * kPerWave + kQ / 2;
+    unsigned short *nlmap = reinterpret_cast<unsigned short *>(bitmap + kAcBitmapWords); // 16 bits per lane and cell
     if (LINES)
         for (u32 w = lane; w < kAcBitmapWords; w += 64)
             bitmap[w] = 0u;
@@ -93,7 +95,6 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
 
         bool flooded = false; // the candidate queue overflowed (uniform)
 
-        u32 NLm[kAcRounds][kCells];
 #pragma unroll
         for (int r = 0; r < kAcRounds; ++r)
         {
@@ -208,7 +209,8 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 if (LINES)
                     nlm &= clip(a.own_lo, a.own_hi);
             }
-            NLm[r][j] = nlm;
+            if (LINES) // kept in LDS, not in 16 registers, across the verify stage
+                nlmap[(u32)r * (kSegBytes / 16) + (u32)j * kWave + lane] = (unsigned short)nlm;
             if (a.flags & (1u << 31)) // ablation hook (KREP_GPU_AC_NOVERIFY): filter cost only
                 cand = 0;
 
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                     tot += (u32)__popcll(m) << b;
                     ex += (u32)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)) << b;
                 }
-                if (qn + tot > kAcQueue)
+                if (qn + tot > kQ)
                     flooded = true; // > 6 % of the unit's positions are candidates: verify every position instead
                 else
                 {
@@ -356,13 +358,11 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
         LS2 wls{0, false, false, false};
         if (LINES)
         {
-#pragma unroll
-            for (int r = 0; r < kAcRounds; ++r)
-#pragma unroll
-            for (int j = 0; j < kCells; ++j)
+#pragma unroll 1
+            for (int rj = 0; rj < kAcRounds * kCells; ++rj)
             {
-                const u32 bitoff = (u32)r * kSegBytes + (u32)j * kCellBytes + lane * 16u;
-                const u32 H = (bitmap[bitoff >> 5] >> (bitoff & 31u)) & 0xffffu, N = NLm[r][j];
+                const u32 bitoff = (u32)rj * kCellBytes + lane * 16u;
+                const u32 H = (bitmap[bitoff >> 5] >> (bitoff & 31u)) & 0xffffu, N = nlmap[bitoff >> 4];
                 const u64 anyhit = __ballot(H != 0u);
                 const bool l_nl = N != 0u;
                 const u64 B_nl = __ballot(l_nl);
@@ -767,7 +767,7 @@ static const int g_ac_chunk_mib = getenv("KREP_GPU_AC_CHUNK_MIB") ? atoi(getenv(
 
 static u32 ac_lds_bytes(u32 filter_words, bool lines)
 {
-    const u32 per_wave = kAcQueue / 2 + (lines ? kAcBitmapWords : 0u);
+    const u32 per_wave = (lines ? kAcQueue / 2 : kAcQueue) / 2 + (lines ? 2u * kAcBitmapWords : 0u);
     return (((filter_words + 3u) & ~3u) + kAcWaves * per_wave) * (u32)sizeof(u32);
 }
 

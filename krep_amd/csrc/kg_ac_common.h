@@ -14,7 +14,7 @@ constexpr int kAcBlock = 1024;             // 16 waves share one copy of the fil
 constexpr int kAcWaves = kAcBlock / 64;
 constexpr u32 kT1Words = 256 / 32;         // 1-byte patterns: direct
 constexpr u32 kT2Words = 65536 / 32;       // 2-byte patterns: direct (8 KiB)
-constexpr u32 kT3Bits = 17, kT3Words = (1u << kT3Bits) / 32; // 3-byte patterns: hashed (16 KiB)
+constexpr u32 kT3Bits = 16, kT3Words = (1u << kT3Bits) / 32; // 3-byte patterns: hashed (8 KiB)
 constexpr u32 kT4Bits = 19, kT4Words = (1u << kT4Bits) / 32; // >= 4-byte patterns: hashed (64 KiB)
 constexpr u32 kHashMul = 0x9E3779B1u;
 
