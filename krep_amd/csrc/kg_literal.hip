@@ -125,7 +125,7 @@ __device__ __noinline__ W6 load_window_guarded(const uint8_t *text, u64 text_len
 // next tile is fetched while the current one is scanned.  One barrier per tile (ticket broadcast).
 template <int KIND, bool MASKED, bool CI, bool LINES, int R>
 // >= 4 waves per SIMD (<= 128 VGPRs) for the plain variants: the allocator otherwise drifts to 137 and loses a wave
-__global__ __launch_bounds__(kBlock, (KIND <= 8 && !LINES) ? 4 : 1) void lit_scan(const LitArgs a)
+__global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
 {
     __shared__ u64 s_ticket[2];
     const u32 lane = lane_id();
@@ -298,17 +298,26 @@ __global__ __launch_bounds__(kBlock, (KIND <= 8 && !LINES) ? 4 : 1) void lit_sca
                         bool ok = true;
                         if (KIND == 9)
                         {
-                            for (u32 q = 8; q < a.m; ++q)
-                            {
-                                u32 tc = a.text[p + q];
-                                if (CI && (tc - 'A' < 26u))
-                                    tc += 32u;
-                                if (tc != a.pat[q])
-                                {
-                                    ok = false;
-                                    break;
-                                }
-                            }
+                            // bytes 8..m-1 in independent 8-byte chunks (all loads in flight together, no early
+                            // exit: a byte loop paid one dependent global access per byte — 5.6 -> 3.3 TB/s at
+                            // m = 9, 1.3 at m = 64); the last partial chunk is re-anchored at m - 8, which is
+                            // inside [p, p + m) and therefore inside the text
+                            struct __attribute__((packed)) U64p { unsigned long long v; };
+                            const unsigned char *tp = a.text + p;
+                            auto chunk = [&](u32 q) -> unsigned long long {
+                                unsigned long long t = reinterpret_cast<const U64p *>(tp + q)->v;
+                                if (CI)
+                                    t = (unsigned long long)fold4((u32)t) | ((unsigned long long)fold4((u32)(t >> 32)) << 32);
+                                return t ^ reinterpret_cast<const U64p *>(a.pat + q)->v;
+                            };
+                            unsigned long long diff = 0;
+                            u32 q = 8;
+#pragma unroll 4
+                            for (; q + 8 <= a.m; q += 8)
+                                diff |= chunk(q);
+                            if (q < a.m)
+                                diff |= chunk(a.m - 8);
+                            ok = diff == 0;
                         }
                         if (ok && ww)
                         {
