@@ -34,7 +34,11 @@
 namespace kg {
 
 // CLS: bit 0/1/2/3 = 1-/2-/3-/>=4-byte patterns present.  CLS == 8 is the common case (all >= 4).
-template <bool CI, bool LINES, int CLS>
+// STRIDE == 2 (CLS == 8 only): the filter tests the EVEN text positions only.  The table then holds, besides every
+// pattern's final 4-gram (a match ends at the tested position t), the 4-gram one byte earlier (the match ends at t + 1;
+// for a 4-byte pattern that gram has an unknown first byte: all 32 classes are set).  Half the LDS lookups — the
+// bank-conflict wall of 4.2 — and half the lookup VALU; a candidate verifies both ends, with both probes in flight.
+template <bool CI, bool LINES, int CLS, int STRIDE>
 __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) u32 s_mem[]; // filter | tickets | per-wave queue (+ bitmap)
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 // masks them itself), and a funnel shift that pushes the hit bit into the accumulator from the top
                 u32 acc = 0;
 #pragma unroll
-                for (int k = 0; k < 16; ++k)
+                for (int k = 0; k < 16; k += STRIDE)
                 {
                     const int o = 5 * (k + 1);
                     const u32 x = (o & 31) ? __builtin_amdgcn_alignbit(R[(o >> 5) + 1], R[o >> 5], (u32)(o & 31)) : R[o >> 5];
@@ -160,9 +164,9 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                     // v_add of the (link-time) base of s_mem on every lookup
                     typedef __attribute__((address_space(3))) const u32 lds_u32;
                     const u32 dw = *(lds_u32 *)(size_t)((x >> 3) & ((1u << (XB - 3)) - 4u));
-                    acc = __builtin_amdgcn_alignbit(dw >> (x & 31u), acc, 1u);
+                    acc = __builtin_amdgcn_alignbit(dw >> (x & 31u), acc, (u32)STRIDE);
                 }
-                cand = acc >> 16;
+                cand = STRIDE == 2 ? (acc >> 16) & 0x5555u : acc >> 16;
             }
             else
             {
@@ -205,7 +209,8 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                     u32 khi = hi > lbase ? (u32)((hi - lbase) < 16 ? (hi - lbase) : 16) : 0u;
                     return khi > klo ? (((1u << khi) - 1u) & ~((1u << klo) - 1u)) : 0u;
                 };
-                cand &= clip(a.end_lo, a.end_hi);
+                const u32 endm = clip(a.end_lo, a.end_hi);
+                cand &= STRIDE == 2 ? (endm | (endm >> 1)) : endm; // stride 2: t or t + 1 is an end of this launch
                 if (LINES)
                     nlm &= clip(a.own_lo, a.own_hi);
             }
@@ -287,24 +292,51 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
         //      every end position of the unit instead (exact, slow, pathological inputs only) ------------
         {
             const u32 n = flooded ? kAcUnitBytes : qn;
+            const bool pair = STRIDE == 2 && !flooded; // a queue entry stands for the ends t and t + 1
             for (u32 b0 = 0; b0 < n; b0 += 64)
             {
                 const u32 qi = b0 + lane;
-                bool live = qi < n;
+                const bool live = qi < n;
                 const u32 rel = flooded ? qi : (live ? queue[qi] : 0u);
                 const u64 pos = useg + rel;
-                if (flooded)
-                    live = pos >= a.end_lo && pos < a.end_hi;
-                u32 c = 0;
-                u64 depthmask = 0;
-                bool simple = false;
-                if (live)
+                bool liveA = live, liveB = false;
+                if (flooded || STRIDE == 2)
+                    liveA = live && pos >= a.end_lo && pos < a.end_hi;
+                if (pair)
+                    liveB = live && pos + 1 >= a.end_lo && pos + 1 < a.end_hi;
+                u32 cA = 0, cB = 0;
+                u64 dmA = 0, dmB = 0;
+                bool simA = false, simB = false;
+                if (CLS == 8 && STRIDE == 2)
+                {
+                    bool slA = liveA, slB = false; // flooded: every end takes the level walk
+                    if (pair)
+                    {
+                        u32 mA, mB;
+                        ac_walk_probe2<CI>(a, pos, liveA, liveB, LINES, mA, slA, mB, slB);
+                        dmA = mA; dmB = mB;
+                        cA = (u32)__popc(mA); cB = (u32)__popc(mB);
+                        simA = simB = true;
+                    }
+#pragma unroll 1
+                    for (int e = 0; e < 2; ++e) // the one call site of the level walk
+                        if (e ? slB : slA)
+                        {
+                            u64 dm;
+                            bool sim;
+                            const u32 c = ac_walk_levels<CI>(a, pos + (u64)e, LINES, dm, sim);
+                            if (e) { cB = c; dmB = dm; simB = sim; }
+                            else { cA = c; dmA = dm; simA = sim; }
+                        }
+                }
+                else if (liveA)
                 {
                     if (CLS == 8)
-                        c = ac_walk_fast<CI>(a, pos, LINES, depthmask, simple);
+                        cA = ac_walk_fast<CI>(a, pos, LINES, dmA, simA);
                     else
-                        c = ac_walk<CI, false, false>(a, pos, 0u, [](u32, u64, u32) {});
+                        cA = ac_walk<CI, false, false>(a, pos, 0u, [](u32, u64, u32) {});
                 }
+                const u32 c = cA + cB;
                 u32 incl = c;
 #pragma unroll
                 for (int o = 1; o < 64; o <<= 1)
@@ -315,10 +347,17 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 }
                 const u32 rank0 = wcnt + incl - c;
                 wcnt += __shfl(incl, 63);
-                if (c)
+#pragma unroll 1
+                for (int e = 0; e < (pair ? 2 : 1); ++e)
                 {
+                    const u32 ce = e ? cB : cA;
+                    if (!ce)
+                        continue;
+                    const u64 pe = pos + (u64)e, dme = e ? dmB : dmA;
+                    const u32 re = rank0 + (e ? cA : 0u), rele = rel + (u32)e;
+                    const bool sime = e ? simB : simA;
                     if (LINES)
-                        atomicOr(&bitmap[rel >> 5], 1u << (rel & 31u));
+                        atomicOr(&bitmap[rele >> 5], 1u << (rele & 31u));
                     if (do_stage || do_final)
                     {
                         auto write = [&](u32 at, u64 s0, u32 len) {
@@ -338,18 +377,18 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                                 }
                             }
                         };
-                        if (CLS == 8 && simple)
+                        if (CLS == 8 && sime)
                         {
-                            u32 at = rank0;
-                            for (u64 rest = depthmask; rest;) // longest first
+                            u32 at = re;
+                            for (u64 rest = dme; rest;) // longest first
                             {
                                 const u32 d = 63u - (u32)__builtin_clzll(rest);
                                 rest &= ~(1ull << d);
-                                write(at++, pos + 1 - (u64)d, d);
+                                write(at++, pe + 1 - (u64)d, d);
                             }
                         }
                         else
-                            ac_walk<CI, true, CLS == 8>(a, pos, c, [&](u32 r, u64 s2, u32 len) { write(rank0 + r, s2, len); });
+                            ac_walk<CI, true, CLS == 8>(a, pe, ce, [&](u32 r, u64 s2, u32 len) { write(re + r, s2, len); });
                     }
                 }
             }
@@ -442,6 +481,7 @@ struct AcTables
     u32 has1 = 0, has2 = 0, has3 = 0, has4 = 0, off1 = 0, off2 = 0, off3 = 0, filter_words = 0;
     u32 *d_filter = nullptr;
     u32 *d_filterx20 = nullptr, *d_filterx19 = nullptr; // exact-class tables of the fused kernel (all patterns >= 4 bytes)
+    u32 *d_filters20 = nullptr; // the same for the stride-2 filter (nullptr: stride 2 not worth it for this dictionary)
     uint2 *d_edges = nullptr;
     u32 emask = 0;
     u32 *d_copies = nullptr;
@@ -723,6 +763,31 @@ AcTables *ac_build(const search_params_t &sp, int device)
         ACHK(hipMemcpy(t->d_filterx20, X20.data(), X20.size() * sizeof(u32), hipMemcpyHostToDevice));
         ACHK(hipMalloc(&t->d_filterx19, X19.size() * sizeof(u32)));
         ACHK(hipMemcpy(t->d_filterx19, X19.data(), X19.size() * sizeof(u32), hipMemcpyHostToDevice));
+        // stride-2 table: final gram (match ends at the tested position) + the gram one byte earlier (ends one later)
+        std::vector<u32> S20(X20);
+        auto set2 = [&](u32 x) { S20[x >> 5] |= 1u << (x & 31); };
+        for (auto &p : pats)
+        {
+            const size_t n = p.size();
+            if (n >= 5)
+                set2(ac_cls4((u32)p[n - 5] | ((u32)p[n - 4] << 8) | ((u32)p[n - 3] << 16) | ((u32)p[n - 2] << 24)));
+            else // 4 bytes: the byte in front of the pattern is unknown — every class
+                for (u32 c = 0; c < 32; ++c)
+                    set2(c | ((ac_cls4((u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16)) << 5) & 0xfffffu));
+        }
+        u64 e1 = 0, e2 = 0;
+        for (size_t w = 0; w < X20.size(); ++w)
+        {
+            e1 += (u64)__builtin_popcount(X20[w]);
+            e2 += (u64)__builtin_popcount(S20[w]);
+        }
+        // worth it while the denser table keeps the candidate volume in the same range: per byte e2 / 2^21 against
+        // e1 / 2^20, and two ends to verify per candidate.  KREP_GPU_AC_STRIDE2=1 opts in (measured slower so far).
+        if (e2 <= 6 * e1 + 64 && e2 < (1u << kXBitsBig) / 64 && getenv("KREP_GPU_AC_STRIDE2"))
+        {
+            ACHK(hipMalloc(&t->d_filters20, S20.size() * sizeof(u32)));
+            ACHK(hipMemcpy(t->d_filters20, S20.data(), S20.size() * sizeof(u32), hipMemcpyHostToDevice));
+        }
     }
     ACHK(hipMalloc(&t->d_edges, tab.size() * sizeof(uint2)));
     ACHK(hipMemcpy(t->d_edges, tab.data(), tab.size() * sizeof(uint2), hipMemcpyHostToDevice));
@@ -742,6 +807,7 @@ void ac_free(AcTables *t)
     if (t->d_filter) (void)hipFree(t->d_filter);
     if (t->d_filterx20) (void)hipFree(t->d_filterx20);
     if (t->d_filterx19) (void)hipFree(t->d_filterx19);
+    if (t->d_filters20) (void)hipFree(t->d_filters20);
     if (t->d_edges) (void)hipFree(t->d_edges);
     if (t->d_copies) (void)hipFree(t->d_copies);
     if (t->d_gram4) (void)hipFree(t->d_gram4);
@@ -771,20 +837,22 @@ static u32 ac_lds_bytes(u32 filter_words, bool lines)
     return (((filter_words + 3u) & ~3u) + kAcWaves * per_wave) * (u32)sizeof(u32);
 }
 
-template <bool CI, bool LN, int CLS>
+template <bool CI, bool LN, int CLS, int STRIDE>
 static hipError_t ac_launch3(const AcArgs &a, u32 grid, u32 lds, hipStream_t st)
 {
     // more than 64 KiB of dynamic LDS has to be requested explicitly
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ac_scan_kernel<CI, LN, CLS>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ac_scan_kernel<CI, LN, CLS, STRIDE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((ac_scan_kernel<CI, LN, CLS>), dim3(grid), dim3(kAcBlock), lds, st, a);
+    hipLaunchKernelGGL((ac_scan_kernel<CI, LN, CLS, STRIDE>), dim3(grid), dim3(kAcBlock), lds, st, a);
     return hipGetLastError();
 }
 template <bool CI, bool LN>
 static hipError_t ac_launch2(const AcArgs &a, u32 grid, u32 lds, hipStream_t st)
 {
     const bool only4 = a.has4 && !a.has1 && !a.has2 && !a.has3;
-    return only4 ? ac_launch3<CI, LN, 8>(a, grid, lds, st) : ac_launch3<CI, LN, 15>(a, grid, lds, st);
+    if (only4)
+        return a.stride == 2 ? ac_launch3<CI, LN, 8, 2>(a, grid, lds, st) : ac_launch3<CI, LN, 8, 1>(a, grid, lds, st);
+    return ac_launch3<CI, LN, 15, 1>(a, grid, lds, st);
 }
 static hipError_t ac_launch(const AcArgs &a, u32 grid, u32 lds, hipStream_t st)
 {
@@ -847,6 +915,7 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
         a.flags |= 1u << 30;
     a.lmax = t->lmax;
     a.has1 = t->has1; a.has2 = t->has2; a.has3 = t->has3; a.has4 = t->has4;
+    a.stride = 1;
     a.filter = t->d_filter;
     a.off1 = t->off1; a.off2 = t->off2; a.off3 = t->off3;
     a.filter_words = t->filter_words;
@@ -854,6 +923,11 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
     { // fused kernel, every pattern >= 4 bytes: the exact-class table instead of the hashed one
         a.filter = lines ? t->d_filterx19 : t->d_filterx20;
         a.filter_words = (1u << (lines ? kXBitsLines : kXBitsBig)) / 32;
+        if (t->d_filters20 && !lines) // the -c variant of the stride-2 kernel spills (128-VGPR cap): stride 1 there
+        {
+            a.filter = t->d_filters20;
+            a.stride = 2;
+        }
     }
     a.edges = t->d_edges;
     a.emask = t->emask;

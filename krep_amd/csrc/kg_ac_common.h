@@ -35,6 +35,7 @@ struct AcArgs
     u32 *cand;                   // [units * cand_cap] candidate end offsets (relative to the unit), split pipeline
     u32 *candcnt;                // [units] number of candidates, or kAcFlooded
     u32 cand_cap;
+    u32 stride;                  // 1 or 2: text positions per filter lookup (2 = even positions only, see ac_scan_kernel)
     u32 upt;                     // units per wave ticket of the fused kernel (1..kAcUnitsPerTicketMax, by text size)
     const uint4 *sfx;            // whole-pattern table, 2 x uint4 per entry: {bytes right-aligned in 16}, {len, copies, 0, 0}
     const unsigned long long *tags; // per slot: (suffix hash << 32) | (copies << 8) | len, 0 = empty
@@ -332,6 +333,93 @@ __device__ __forceinline__ u32 ac_walk_fast(const AcArgs &a, u64 i, bool own_by_
     depthmask = dm;
     simple = true;
     return (u32)__popc(dm);
+}
+
+// The same for the two end positions i and i + 1 of a stride-2 candidate: both text windows and both table probes
+// are in flight together (one latency for the pair).  No level walk in here: an end that needs it comes back with
+// slow = true and the caller runs ac_walk_levels from its single call site.
+template <bool CI>
+__device__ __forceinline__ void ac_walk_probe2(const AcArgs &a, u64 i, bool liveA, bool liveB, bool own_by_end,
+                                               u32 &dmA, bool &slowA, u32 &dmB, bool &slowB)
+{
+    dmA = dmB = 0;
+    slowA = slowB = false;
+    if (i < 15 || (a.flags & F_WW))
+    {
+        slowA = liveA;
+        slowB = liveB;
+        return;
+    }
+    struct __attribute__((packed)) U32p { u32 v; };
+    const U32p *qa = reinterpret_cast<const U32p *>(a.text + (i - 15));
+    const U32p *qb = reinterpret_cast<const U32p *>(a.text + (i - 15) + (liveB ? 1 : 0)); // i + 1 < text_len iff liveB
+    u32 TA[4] = {qa[0].v, qa[1].v, qa[2].v, qa[3].v};
+    u32 TB[4] = {qb[0].v, qb[1].v, qb[2].v, qb[3].v};
+    if (CI)
+    {
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+        {
+            TA[w] = ac_fold4(TA[w]);
+            TB[w] = ac_fold4(TB[w]);
+        }
+    }
+    u32 hA = (TA[3] * kHashMul) >> 9, hB = (TB[3] * kHashMul) >> 9;
+    uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0, b0 = a0, b1 = a0;
+    bool doneA = !liveA, doneB = !liveB, foundA = false, foundB = false;
+    for (;;)
+    {
+        const uint4 *ea = a.g4x + 2 * (size_t)(hA & a.g4mask), *eb = a.g4x + 2 * (size_t)(hB & a.g4mask);
+        const uint4 x0 = ea[0], x1 = ea[1], y0 = eb[0], y1 = eb[1];
+        if (!doneA)
+        {
+            a0 = x0; a1 = x1;
+            if (x0.y == 0u) doneA = true;
+            else if (x0.x == TA[3]) doneA = foundA = true;
+            else ++hA;
+        }
+        if (!doneB)
+        {
+            b0 = y0; b1 = y1;
+            if (y0.y == 0u) doneB = true;
+            else if (y0.x == TB[3]) doneB = foundB = true;
+            else ++hB;
+        }
+        if (doneA && doneB)
+            break;
+    }
+    auto eval = [&](bool found, const u32 (&T)[4], const uint4 &e0, const uint4 &e1, u64 end, u32 &dm, bool &slow) {
+        if (!found)
+            return;
+        const u32 info = e0.z, clen = info & 15u;
+        auto same = [](u32 m) -> u32 { return m ? (u32)__builtin_clz(m) >> 3 : 4u; };
+        u32 L = same(T[2] ^ e1.z);
+        if (L == 4u)
+        {
+            L += same(T[1] ^ e1.y);
+            if (L == 8u)
+                L += same(T[0] ^ e1.x);
+        }
+        L = L < clen ? L : clen;
+        slow = !(info & kG4Simple) || (L == clen && (info & kG4Cont));
+        u32 m = ((e0.y >> 31) << 4) | ((e0.w & ((1u << L) - 1u)) << 5);
+        if (!own_by_end)
+        {
+            const u64 e = end + 1;
+            if (e <= a.own_lo)
+                m = 0;
+            else
+            {
+                if (e - a.own_lo < 32)
+                    m &= (2u << (u32)(e - a.own_lo)) - 1u;
+                if (e > a.own_hi)
+                    m = (e - a.own_hi < 32) ? (m & ~((2u << (u32)(e - a.own_hi)) - 1u)) : 0u;
+            }
+        }
+        dm = m;
+    };
+    eval(foundA, TA, a0, a1, i, dmA, slowA);
+    eval(foundB, TB, b0, b1, i + 1, dmB, slowB);
 }
 
 constexpr u32 kAcUnitsPerTicket = 4;   // split pipelines: 4 x 8 KiB per wave ticket
