@@ -653,7 +653,12 @@ AcTables *ac_build(const search_params_t &sp, int device)
                 // depth-1 byte is text[i] (top byte of E), depth-4 byte is text[i-3] (low byte)
                 st.push_back({bc.second, it.depth + 1, it.gram | (bc.first << (8 * (3 - it.depth)))});
         }
+        // sparse on purpose (load <= 1/16 while the table stays <= 8 MiB): a probe sequence is a chain of DEPENDENT L2
+        // round trips that the whole 64-candidate batch waits for; at load 1/2 the longest of ~80 probes took 4-5
+        // steps and the verify stage 3x as long (2.30 -> 3.34 TB/s on config 4 with the stride-2 filter)
         u32 gcap = 1024;
+        while (gcap < d4.size() * 16 + 16 && (size_t)gcap * 2 * 32 <= (8u << 20))
+            gcap <<= 1;
         while (gcap < d4.size() * 2 + 16)
             gcap <<= 1;
         t->g4mask = gcap - 1;
@@ -782,8 +787,8 @@ AcTables *ac_build(const search_params_t &sp, int device)
             e2 += (u64)__builtin_popcount(S20[w]);
         }
         // worth it while the denser table keeps the candidate volume in the same range: per byte e2 / 2^21 against
-        // e1 / 2^20, and two ends to verify per candidate.  KREP_GPU_AC_STRIDE2=1 opts in (measured slower so far).
-        if (e2 <= 6 * e1 + 64 && e2 < (1u << kXBitsBig) / 64 && getenv("KREP_GPU_AC_STRIDE2"))
+        // e1 / 2^20, and two ends to verify per candidate.  KREP_GPU_AC_STRIDE1=1 forces the one-position filter.
+        if (e2 <= 6 * e1 + 64 && e2 < (1u << kXBitsBig) / 64 && !getenv("KREP_GPU_AC_STRIDE1"))
         {
             ACHK(hipMalloc(&t->d_filters20, S20.size() * sizeof(u32)));
             ACHK(hipMemcpy(t->d_filters20, S20.data(), S20.size() * sizeof(u32), hipMemcpyHostToDevice));
