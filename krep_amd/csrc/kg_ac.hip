@@ -222,14 +222,26 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
             // ---- queue the candidates in position order -------------------------------------------------
             if (!flooded && __ballot(cand != 0u))
             {
+                // lanes before me hold how many candidates?  Almost always at most one per lane: one ballot; the
+                // bit-plane sum only when some lane has two or more
                 const u32 c = __popc(cand);
-                u32 tot = 0, ex = 0;
-#pragma unroll
-                for (int b = 0; b < 5; ++b)
+                u32 tot, ex;
+                if (!__ballot(c > 1u))
                 {
-                    const u64 m = __ballot((c >> b) & 1u);
-                    tot += (u32)__popcll(m) << b;
-                    ex += (u32)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)) << b;
+                    const u64 m = __ballot(c != 0u);
+                    tot = (u32)__popcll(m);
+                    ex = (u32)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+                }
+                else
+                {
+                    tot = ex = 0;
+#pragma unroll
+                    for (int b = 0; b < 5; ++b)
+                    {
+                        const u64 m = __ballot((c >> b) & 1u);
+                        tot += (u32)__popcll(m) << b;
+                        ex += (u32)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)) << b;
+                    }
                 }
                 if (qn + tot > kQ)
                     flooded = true; // > 6 % of the unit's positions are candidates: verify every position instead
