@@ -128,7 +128,9 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 if (seg + b >= 4 && seg + b - 4 < a.text_len)
                     before |= (u32)a.text[seg + b - 4] << (8 * b);
         // W[0] = the 4 bytes before the lane, W[1..4] = the lane's 16 bytes of cell j
-        auto cell_body = [&](const int j, u32 (&W)[5]) __attribute__((always_inline)) {
+        // have_c: the caller already holds the classes of W[0] and W[4] (fast path: it shuffles the 20-bit class word
+        // of the neighbour lane instead of its raw bytes, which saves one compress per cell)
+        auto cell_body = [&](const int j, u32 (&W)[5], const bool have_c, const u32 pc0, const u32 pc4) __attribute__((always_inline)) {
             const u64 lbase = seg + (u64)j * kCellBytes + (u64)lane * 16u;
             u32 NL = 0;
             if (LINES)
@@ -144,8 +146,10 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 //      index of end position k is the 20-bit window at bit 5(k+1): one v_alignbit, no hash ----
                 u32 c[5];
 #pragma unroll
-                for (int w = 0; w < 5; ++w)
+                for (int w = 1; w < 4; ++w)
                     c[w] = ac_cls4(W[w]);
+                c[0] = have_c ? pc0 : ac_cls4(W[0]);
+                c[4] = have_c ? pc4 : ac_cls4(W[4]);
                 u32 R[5];
                 R[0] = c[0] | (c[1] << 20);
                 R[1] = (c[1] >> 12) | (c[2] << 8) | (c[3] << 28);
@@ -267,10 +271,22 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 u32 W[5];
                 W[1] = d[j].x; W[2] = d[j].y; W[3] = d[j].z; W[4] = d[j].w;
                 d[j] = nsrc[j * kWave];
-                const u32 up = __shfl_up(W[4], 1);
-                W[0] = (lane == 0u) ? before : up;
-                before = __builtin_amdgcn_readlane(W[4], 63); // the next cell's (and round's) left neighbour
-                cell_body(j, W);
+                if (CLS == 8)
+                {
+                    const u32 c4 = ac_cls4(W[4]);
+                    const u32 up = __shfl_up(c4, 1);
+                    const u32 c0 = (lane == 0u) ? ac_cls4(before) : up; // `before` is uniform: scalar ALU
+                    W[0] = 0;
+                    before = __builtin_amdgcn_readlane(W[4], 63); // the next cell's (and round's) left neighbour
+                    cell_body(j, W, true, c0, c4);
+                }
+                else
+                {
+                    const u32 up = __shfl_up(W[4], 1);
+                    W[0] = (lane == 0u) ? before : up;
+                    before = __builtin_amdgcn_readlane(W[4], 63);
+                    cell_body(j, W, false, 0u, 0u);
+                }
             }
         }
         else
@@ -292,7 +308,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                     }
                     W[w] = v;
                 }
-                cell_body(j, W);
+                cell_body(j, W, false, 0u, 0u);
             }
         }
 
