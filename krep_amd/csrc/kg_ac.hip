@@ -208,9 +208,13 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
             u32 nlm = NL;
             if (!interior)
             {
+                // window bounds relative to the round (uniform, clamped to [0, 8 KiB]) against the lane's 32-bit offset
+                const u32 lrel = (u32)j * kCellBytes + lane * 16u;
                 auto clip = [&](u64 lo, u64 hi) -> u32 {
-                    u32 klo = lo > lbase ? (u32)((lo - lbase) < 16 ? (lo - lbase) : 16) : 0u;
-                    u32 khi = hi > lbase ? (u32)((hi - lbase) < 16 ? (hi - lbase) : 16) : 0u;
+                    const u32 rlo = lo > seg ? (u32)((lo - seg) < kSegBytes ? (lo - seg) : kSegBytes) : 0u;
+                    const u32 rhi = hi > seg ? (u32)((hi - seg) < kSegBytes ? (hi - seg) : kSegBytes) : 0u;
+                    const u32 klo = rlo > lrel ? ((rlo - lrel) < 16u ? (rlo - lrel) : 16u) : 0u;
+                    const u32 khi = rhi > lrel ? ((rhi - lrel) < 16u ? (rhi - lrel) : 16u) : 0u;
                     return khi > klo ? (((1u << khi) - 1u) & ~((1u << klo) - 1u)) : 0u;
                 };
                 const u32 endm = clip(a.end_lo, a.end_hi);
