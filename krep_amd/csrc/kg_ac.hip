@@ -158,18 +158,25 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 R[4] = 0;
                 // per position 5 VALU: window, dword address, ds_read_b32, shift by the low 5 index bits (the shifter
                 // masks them itself), and a funnel shift that pushes the hit bit into the accumulator from the top
-                u32 acc = 0;
+                // all table reads of the cell are issued before the first one is consumed (the scheduler otherwise
+                // serialises read -> wait -> shift through the accumulator chain: 8-16 LDS latencies per cell)
+                constexpr int NK = 16 / STRIDE;
+                u32 xs[NK], dws[NK];
+                typedef __attribute__((address_space(3))) const u32 lds_u32;
 #pragma unroll
-                for (int k = 0; k < 16; k += STRIDE)
+                for (int q = 0; q < NK; ++q)
                 {
-                    const int o = 5 * (k + 1);
-                    const u32 x = (o & 31) ? __builtin_amdgcn_alignbit(R[(o >> 5) + 1], R[o >> 5], (u32)(o & 31)) : R[o >> 5];
+                    const int o = 5 * (q * STRIDE + 1);
+                    xs[q] = (o & 31) ? __builtin_amdgcn_alignbit(R[(o >> 5) + 1], R[o >> 5], (u32)(o & 31)) : R[o >> 5];
                     // the table sits at LDS address 0 (checked at kernel entry): an absolute LDS pointer saves the
                     // v_add of the (link-time) base of s_mem on every lookup
-                    typedef __attribute__((address_space(3))) const u32 lds_u32;
-                    const u32 dw = *(lds_u32 *)(size_t)((x >> 3) & ((1u << (XB - 3)) - 4u));
-                    acc = __builtin_amdgcn_alignbit(dw >> (x & 31u), acc, (u32)STRIDE);
+                    dws[q] = *(lds_u32 *)(size_t)((xs[q] >> 3) & ((1u << (XB - 3)) - 4u));
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                u32 acc = 0;
+#pragma unroll
+                for (int q = 0; q < NK; ++q)
+                    acc = __builtin_amdgcn_alignbit(dws[q] >> (xs[q] & 31u), acc, (u32)STRIDE);
                 cand = STRIDE == 2 ? (acc >> 16) & 0x5555u : acc >> 16;
             }
             else
