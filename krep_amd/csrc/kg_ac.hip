@@ -33,25 +33,25 @@
 
 namespace kg {
 
-// CLS: bit 0/1/2/3 = 1-/2-/3-/>=4-byte patterns present.  CLS == 8 is the common case (all >= 4).
-// STRIDE == 2 (CLS == 8 only): the filter tests the EVEN text positions only.  The table then holds, besides every
+// SHORT: the dictionary holds 1-3-byte patterns (wildcard-expanded in the filter table, exact bitmaps in the verifier).
+// STRIDE == 2: the filter tests the EVEN text positions only.  The table then holds, besides every
 // pattern's final 4-gram (a match ends at the tested position t), the 4-gram one byte earlier (the match ends at t + 1;
 // for a 4-byte pattern that gram has an unknown first byte: all 32 classes are set).  Half the LDS lookups — the
 // bank-conflict wall of 4.2 — and half the lookup VALU; a candidate verifies both ends, with both probes in flight.
-template <bool CI, bool LINES, int CLS, int STRIDE>
+template <bool CI, bool LINES, bool SHORT, int STRIDE>
 __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) u32 s_mem[]; // filter | tickets | per-wave queue (+ bitmap)
     const u32 lane = ac_lane();
     const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (CLS == 8 && (u32)(size_t)((__attribute__((address_space(3))) u32 *)s_mem) != 0u)
-        __builtin_trap(); // the exact-class lookups address LDS absolutely (no static __shared__ in this kernel)
+    if ((u32)(size_t)((__attribute__((address_space(3))) u32 *)s_mem) != 0u)
+        __builtin_trap(); // the table lookups address LDS absolutely (no static __shared__ in this kernel)
     for (u32 w = threadIdx.x; w < a.filter_words; w += kAcBlock)
         s_mem[w] = a.filter[w];
     const u32 fw = (a.filter_words + 3u) & ~3u;
     constexpr u32 kQ = LINES ? kAcQueue / 2 : kAcQueue; // -c: half the queue, the two bitmaps need the LDS
     constexpr u32 kPerWave = kQ / 2 + (LINES ? 2u * kAcBitmapWords : 0u); // queue | hit bitmap | newline bitmap
-    constexpr u32 XB = LINES ? kXBitsLines : kXBitsBig; // exact-class table (CLS == 8 only)
+    constexpr u32 XB = LINES ? kXBitsLines : kXBitsBig; // index bits of the exact-class table
     unsigned short *queue = reinterpret_cast<unsigned short *>(s_mem + fw + wave * kPerWave);
     u32 *bitmap = s_mem + fw + wave * kPerWave + kQ / 2;
     unsigned short *nlmap = reinterpret_cast<unsigned short *>(bitmap + kAcBitmapWords); // 16 bits per lane and cell
@@ -140,7 +140,6 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                     NL |= ac_movemask4(ac_eq_bytes(W[w + 1], 0x0a0a0a0au)) << (4 * w);
             }
             u32 cand = 0;
-            if (CLS == 8)
             {
                 // ---- filter, exact-class table: the lane's 20 bytes as a 100-bit stream of 5-bit classes; the
                 //      index of end position k is the 20-bit window at bit 5(k+1): one v_alignbit, no hash ----
@@ -178,39 +177,6 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 for (int q = 0; q < NK; ++q)
                     acc = __builtin_amdgcn_alignbit(dws[q] >> (xs[q] & 31u), acc, (u32)STRIDE);
                 cand = STRIDE == 2 ? (acc >> 16) & 0x5555u : acc >> 16;
-            }
-            else
-            {
-            if (CI)
-            {
-#pragma unroll
-                for (int w = 0; w < 5; ++w)
-                    W[w] = ac_fold4(W[w]);
-            }
-
-            // ---- filter: which of my 16 end positions can end a pattern?  (branch-free) ----------------
-#pragma unroll
-            for (int k = 0; k < 16; ++k)
-            {
-                // E = bytes [k-3, k] of the lane (little endian: the byte at k is the top byte)
-                const int o = k + 1;
-                const u32 E = ((o & 3) == 0) ? W[o >> 2] : __builtin_amdgcn_alignbyte(W[(o >> 2) + 1], W[o >> 2], (u32)(o & 3));
-                u32 hit = 0;
-                if (CLS & 8)
-                    {
-                        // the >= 4-byte table sits at LDS byte 0: byte-addressed, no base add
-                        const u32 t = E * kHashMul;
-                        const u32 by = reinterpret_cast<const unsigned char *>(s_mem)[t >> (32 - kT4Bits + 3)];
-                        hit |= (by >> ((t >> (32 - kT4Bits)) & 7u)) & 1u;
-                    }
-                if (CLS & 4)
-                    hit |= ac_tbit(s_mem, a.off3, ((E >> 8) * kHashMul) >> (32 - kT3Bits));
-                if (CLS & 2)
-                    hit |= ac_tbit(s_mem, a.off2, E >> 16);
-                if (CLS & 1)
-                    hit |= ac_tbit(s_mem, a.off1, E >> 24);
-                cand |= hit << k;
-            }
             }
             u32 nlm = NL;
             if (!interior)
@@ -282,7 +248,6 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 u32 W[5];
                 W[1] = d[j].x; W[2] = d[j].y; W[3] = d[j].z; W[4] = d[j].w;
                 d[j] = nsrc[j * kWave];
-                if (CLS == 8)
                 {
                     const u32 c4 = ac_cls4(W[4]);
                     const u32 up = __shfl_up(c4, 1);
@@ -290,13 +255,6 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                     W[0] = 0;
                     before = __builtin_amdgcn_readlane(W[4], 63); // the next cell's (and round's) left neighbour
                     cell_body(j, W, true, c0, c4);
-                }
-                else
-                {
-                    const u32 up = __shfl_up(W[4], 1);
-                    W[0] = (lane == 0u) ? before : up;
-                    before = __builtin_amdgcn_readlane(W[4], 63);
-                    cell_body(j, W, false, 0u, 0u);
                 }
             }
         }
@@ -346,13 +304,13 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 u32 cA = 0, cB = 0;
                 u64 dmA = 0, dmB = 0;
                 bool simA = false, simB = false;
-                if (CLS == 8 && STRIDE == 2)
+                if (STRIDE == 2)
                 {
                     bool slA = liveA, slB = false; // flooded: every end takes the level walk
                     if (pair)
                     {
                         u32 mA, mB;
-                        ac_walk_probe2<CI>(a, pos, liveA, liveB, LINES, mA, slA, mB, slB);
+                        ac_walk_probe2<CI, SHORT>(a, pos, liveA, liveB, LINES, mA, slA, mB, slB);
                         dmA = mA; dmB = mB;
                         cA = (u32)__popc(mA); cB = (u32)__popc(mB);
                         simA = simB = true;
@@ -363,18 +321,13 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                         {
                             u64 dm;
                             bool sim;
-                            const u32 c = ac_walk_levels<CI>(a, pos + (u64)e, LINES, dm, sim);
+                            const u32 c = ac_walk_slow<CI, SHORT>(a, pos + (u64)e, LINES, dm, sim);
                             if (e) { cB = c; dmB = dm; simB = sim; }
                             else { cA = c; dmA = dm; simA = sim; }
                         }
                 }
                 else if (liveA)
-                {
-                    if (CLS == 8)
-                        cA = ac_walk_fast<CI>(a, pos, LINES, dmA, simA);
-                    else
-                        cA = ac_walk<CI, false, false>(a, pos, 0u, [](u32, u64, u32) {});
-                }
+                    cA = ac_walk_fast<CI, SHORT>(a, pos, LINES, dmA, simA);
                 const u32 c = cA + cB;
                 u32 incl = c;
 #pragma unroll
@@ -416,7 +369,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                                 }
                             }
                         };
-                        if (CLS == 8 && sime)
+                        if (sime)
                         {
                             u32 at = re;
                             for (u64 rest = dme; rest;) // longest first
@@ -427,7 +380,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                             }
                         }
                         else
-                            ac_walk<CI, true, CLS == 8>(a, pe, ce, [&](u32 r, u64 s2, u32 len) { write(re + r, s2, len); });
+                            ac_walk<CI, true, !SHORT>(a, pe, ce, [&](u32 r, u64 s2, u32 len) { write(re + r, s2, len); });
                     }
                 }
             }
@@ -517,10 +470,11 @@ struct AcTables
     int device = 0;
     u32 npat = 0, lmin = 0, lmax = 0;
     bool ci = false, has_nl = false, has_empty = false;
-    u32 has1 = 0, has2 = 0, has3 = 0, has4 = 0, off1 = 0, off2 = 0, off3 = 0, filter_words = 0;
-    u32 *d_filter = nullptr;
-    u32 *d_filterx20 = nullptr, *d_filterx19 = nullptr; // exact-class tables of the fused kernel (all patterns >= 4 bytes)
+    u32 has1 = 0, has2 = 0, has3 = 0, has4 = 0;
+    bool short_dup = false;     // a 1-3-byte pattern occurs more than once (the bitmaps cannot count copies)
+    u32 *d_filterx20 = nullptr, *d_filterx19 = nullptr; // exact-class filter tables (2^20 bits; 2^19 for -c)
     u32 *d_filters20 = nullptr; // the same for the stride-2 filter (nullptr: stride 2 not worth it for this dictionary)
+    u32 *d_s1 = nullptr, *d_s2 = nullptr, *d_s3 = nullptr; // exact bitmaps of the 1-/2-/3-byte patterns
     uint2 *d_edges = nullptr;
     u32 emask = 0;
     u32 *d_copies = nullptr;
@@ -528,11 +482,6 @@ struct AcTables
     uint2 *d_gram4 = nullptr;
     uint4 *d_g4x = nullptr; // chain-compressed entries, same slots as d_gram4
     u32 g4mask = 0;
-    uint4 *d_sfx = nullptr;      // whole-pattern table (lmax <= 16)
-    unsigned long long *d_tags = nullptr;
-    u32 sfxmask = 0, lenmask = 0;
-    u32 *d_cand = nullptr, *d_candcnt = nullptr; // split pipeline scratch
-    u64 cand_words = 0, candcnt_words = 0;
 };
 
 #define ACHK(x)                                                                                \
@@ -584,51 +533,23 @@ AcTables *ac_build(const search_params_t &sp, int device)
         t->lmin = t->lmin ? std::min<u32>(t->lmin, (u32)p.size()) : (u32)p.size();
         pats.push_back(std::move(p));
     }
-    // ---- filter tables ----
-    std::vector<u32> T1(kT1Words, 0), T2, T3, T4;
+    // ---- exact bitmaps of the short patterns (verifier) ----
+    std::vector<u32> S1, S2, S3;
     for (auto &p : pats)
     {
         const size_t n = p.size();
-        if (n == 1)
-        {
-            t->has1 = 1;
-            T1[p[0] >> 5] |= 1u << (p[0] & 31);
-        }
-        else if (n == 2)
-        {
-            if (!t->has2) T2.assign(kT2Words, 0);
-            t->has2 = 1;
-            const u32 h = (u32)p[0] | ((u32)p[1] << 8);
-            T2[h >> 5] |= 1u << (h & 31);
-        }
-        else if (n == 3)
-        {
-            if (!t->has3) T3.assign(kT3Words, 0);
-            t->has3 = 1;
-            const u32 x = (u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16);
-            const u32 h = (x * kHashMul) >> (32 - kT3Bits);
-            T3[h >> 5] |= 1u << (h & 31);
-        }
-        else
-        {
-            if (!t->has4) T4.assign(kT4Words, 0);
-            t->has4 = 1;
-            const u32 x = (u32)p[n - 4] | ((u32)p[n - 3] << 8) | ((u32)p[n - 2] << 16) | ((u32)p[n - 1] << 24);
-            const u32 h = (x * kHashMul) >> (32 - kT4Bits);
-            T4[h >> 5] |= 1u << (h & 31);
-        }
+        auto setbit = [&](std::vector<u32> &v, u32 words, u32 key) {
+            if (v.empty())
+                v.assign(words, 0);
+            if ((v[key >> 5] >> (key & 31)) & 1u)
+                t->short_dup = true;
+            v[key >> 5] |= 1u << (key & 31);
+        };
+        if (n == 1) { t->has1 = 1; setbit(S1, kS1Words, p[0]); }
+        else if (n == 2) { t->has2 = 1; setbit(S2, kS2Words, (u32)p[0] | ((u32)p[1] << 8)); }
+        else if (n == 3) { t->has3 = 1; setbit(S3, kS3Words, (u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16)); }
+        else t->has4 = 1;
     }
-    if (!(t->has4 && !t->has1 && !t->has2 && !t->has3))
-    { // the generic kernel variant tests all four tables: give the absent classes empty (all-zero) tables
-        if (T2.empty()) T2.assign(kT2Words, 0);
-        if (T3.empty()) T3.assign(kT3Words, 0);
-        if (T4.empty()) T4.assign(kT4Words, 0);
-    }
-    std::vector<u32> filter(T4); // the >= 4-byte table first: the kernels address it from LDS byte 0
-    t->off1 = (u32)filter.size(); filter.insert(filter.end(), T1.begin(), T1.end());
-    t->off2 = (u32)filter.size(); filter.insert(filter.end(), T2.begin(), T2.end());
-    t->off3 = (u32)filter.size(); filter.insert(filter.end(), T3.begin(), T3.end());
-    t->filter_words = (u32)filter.size();
     // ---- reversed trie ----
     std::unordered_map<u32, u32> edge; // key = node << 8 | byte
     std::vector<u32> copies(1, 0);
@@ -733,104 +654,78 @@ AcTables *ac_build(const search_params_t &sp, int device)
             g4x[2 * (size_t)(h & t->g4mask) + 1] = make_uint4(word(0), word(1), word(2), 0u);
         }
     }
-    // whole-pattern table for the fast verifier (all patterns <= 16 bytes)
-    std::vector<uint4> sfx;
-    std::vector<unsigned long long> tags;
-    if (t->lmax && t->lmax <= 16)
-    {
-        std::vector<std::pair<std::vector<uint8_t>, u32>> uniq; // distinct pattern -> copies
-        {
-            std::vector<std::vector<uint8_t>> sorted(pats);
-            std::sort(sorted.begin(), sorted.end());
-            for (size_t i = 0; i < sorted.size();)
-            {
-                size_t j = i;
-                while (j < sorted.size() && sorted[j] == sorted[i])
-                    ++j;
-                uniq.push_back({sorted[i], (u32)(j - i)});
-                i = j;
-            }
-        }
-        u32 scap = 1024;
-        while (scap < uniq.size() * 2 + 16)
-            scap <<= 1;
-        t->sfxmask = scap - 1;
-        sfx.assign(2 * (size_t)scap, make_uint4(0u, 0u, 0u, 0u));
-        tags.assign((size_t)scap, 0ull);
-        for (auto &pc : uniq)
-        {
-            const auto &p = pc.first;
-            const u32 L = (u32)p.size();
-            t->lenmask |= 1u << L;
-            uint8_t by[16] = {0};
-            memcpy(by + 16 - L, p.data(), L);
-            u32 h = 0x811C9DC5u;
-            for (u32 k = 0; k < L; ++k) // bytes i, i-1, ... = pattern bytes from the end
-                h = (h ^ p[L - 1 - k]) * 0x01000193u;
-            u32 sl = ((h ^ (L * 0x9E3779B1u)) * 0x85EBCA6Bu) >> 8;
-            while (sfx[2 * (size_t)(sl & t->sfxmask) + 1].x != 0u)
-                ++sl; // (tags[] is occupied exactly where sfx meta is)
-            uint4 b4;
-            memcpy(&b4, by, 16);
-            sfx[2 * (size_t)(sl & t->sfxmask)] = b4;
-            sfx[2 * (size_t)(sl & t->sfxmask) + 1] = make_uint4(L, pc.second, h, 0u);
-            tags[(size_t)(sl & t->sfxmask)] = ((unsigned long long)h << 32) | ((unsigned long long)(pc.second & 0xffffffu) << 8) | L;
-        }
-    }
-    if (hipSetDevice(device) != hipSuccess)
-        goto bad;
-    if (!sfx.empty())
-    {
-        ACHK(hipMalloc(&t->d_sfx, sfx.size() * sizeof(uint4)));
-        ACHK(hipMemcpy(t->d_sfx, sfx.data(), sfx.size() * sizeof(uint4), hipMemcpyHostToDevice));
-        ACHK(hipMalloc(&t->d_tags, tags.size() * sizeof(unsigned long long)));
-        ACHK(hipMemcpy(t->d_tags, tags.data(), tags.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
-    }
     ACHK(hipMalloc(&t->d_gram4, g4.size() * sizeof(uint2)));
     ACHK(hipMemcpy(t->d_gram4, g4.data(), g4.size() * sizeof(uint2), hipMemcpyHostToDevice));
     ACHK(hipMalloc(&t->d_g4x, g4x.size() * sizeof(uint4)));
     ACHK(hipMemcpy(t->d_g4x, g4x.data(), g4x.size() * sizeof(uint4), hipMemcpyHostToDevice));
-    ACHK(hipMalloc(&t->d_filter, filter.size() * sizeof(u32)));
-    ACHK(hipMemcpy(t->d_filter, filter.data(), filter.size() * sizeof(u32), hipMemcpyHostToDevice));
-    if (t->has4 && !t->has1 && !t->has2 && !t->has3)
     {
-        std::vector<u32> X20((1u << kXBitsBig) / 32, 0), X19((1u << kXBitsLines) / 32, 0);
+        // ---- filter: exact-class table over the last 4 bytes; a pattern shorter than 4 sets every class of the
+        //      bytes in front of it (32 / 1024 / 32768 entries) ----
+        std::vector<u32> X20((1u << kXBitsBig) / 32, 0), X19((1u << kXBitsLines) / 32, 0), S20;
+        auto expand = [&](std::vector<u32> &T20, std::vector<u32> *T19, const uint8_t *last, size_t known) {
+            // the `known` (<= 4) classes next to the tested position are fixed (last[0..known), text order), the rest free
+            u32 fixed = 0;
+            for (size_t q = 0; q < known; ++q)
+                fixed |= ((u32)last[q] & 31u) << (5 * (4 - known + q));
+            const u32 nfree = 1u << (5 * (4 - known));
+            for (u32 f = 0; f < nfree; ++f)
+            {
+                const u32 x = fixed | f;
+                T20[x >> 5] |= 1u << (x & 31);
+                if (T19)
+                {
+                    const u32 y = x & ((1u << kXBitsLines) - 1u);
+                    (*T19)[y >> 5] |= 1u << (y & 31);
+                }
+            }
+        };
         for (auto &p : pats)
         {
-            const size_t n = p.size();
-            const u32 x = ac_cls4((u32)p[n - 4] | ((u32)p[n - 3] << 8) | ((u32)p[n - 2] << 16) | ((u32)p[n - 1] << 24));
-            X20[x >> 5] |= 1u << (x & 31);
-            const u32 y = x & ((1u << kXBitsLines) - 1u);
-            X19[y >> 5] |= 1u << (y & 31);
+            const size_t n = p.size(), known = std::min<size_t>(n, 4);
+            expand(X20, &X19, p.data() + (n - known), known);
         }
         ACHK(hipMalloc(&t->d_filterx20, X20.size() * sizeof(u32)));
         ACHK(hipMemcpy(t->d_filterx20, X20.data(), X20.size() * sizeof(u32), hipMemcpyHostToDevice));
         ACHK(hipMalloc(&t->d_filterx19, X19.size() * sizeof(u32)));
         ACHK(hipMemcpy(t->d_filterx19, X19.data(), X19.size() * sizeof(u32), hipMemcpyHostToDevice));
-        // stride-2 table: final gram (match ends at the tested position) + the gram one byte earlier (ends one later)
-        std::vector<u32> S20(X20);
-        auto set2 = [&](u32 x) { S20[x >> 5] |= 1u << (x & 31); };
-        for (auto &p : pats)
+        // stride-2 table: final gram (match ends at the tested position) + the gram one byte earlier (the match ends
+        // one later: its last byte is not part of the tested gram, one class fewer is known)
+        if (!t->has1)
         {
-            const size_t n = p.size();
-            if (n >= 5)
-                set2(ac_cls4((u32)p[n - 5] | ((u32)p[n - 4] << 8) | ((u32)p[n - 3] << 16) | ((u32)p[n - 2] << 24)));
-            else // 4 bytes: the byte in front of the pattern is unknown — every class
-                for (u32 c = 0; c < 32; ++c)
-                    set2(c | ((ac_cls4((u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16)) << 5) & 0xfffffu));
+            S20 = X20;
+            for (auto &p : pats)
+            {
+                const size_t n = p.size(), known = std::min<size_t>(n - 1, 4);
+                expand(S20, nullptr, p.data() + (n - 1 - known), known);
+            }
+            u64 e1 = 0, e2 = 0;
+            for (size_t w = 0; w < X20.size(); ++w)
+            {
+                e1 += (u64)__builtin_popcount(X20[w]);
+                e2 += (u64)__builtin_popcount(S20[w]);
+            }
+            // worth it while the denser table keeps the candidate volume in the same range: per byte e2 / 2^21 against
+            // e1 / 2^20, and two ends to verify per candidate.  KREP_GPU_AC_STRIDE1=1 forces the one-position filter.
+            if (e2 <= 6 * e1 + 64 && e2 < (1u << kXBitsBig) / 64 && !getenv("KREP_GPU_AC_STRIDE1"))
+            {
+                ACHK(hipMalloc(&t->d_filters20, S20.size() * sizeof(u32)));
+                ACHK(hipMemcpy(t->d_filters20, S20.data(), S20.size() * sizeof(u32), hipMemcpyHostToDevice));
+            }
         }
-        u64 e1 = 0, e2 = 0;
-        for (size_t w = 0; w < X20.size(); ++w)
+        if (!S1.empty())
         {
-            e1 += (u64)__builtin_popcount(X20[w]);
-            e2 += (u64)__builtin_popcount(S20[w]);
+            ACHK(hipMalloc(&t->d_s1, S1.size() * sizeof(u32)));
+            ACHK(hipMemcpy(t->d_s1, S1.data(), S1.size() * sizeof(u32), hipMemcpyHostToDevice));
         }
-        // worth it while the denser table keeps the candidate volume in the same range: per byte e2 / 2^21 against
-        // e1 / 2^20, and two ends to verify per candidate.  KREP_GPU_AC_STRIDE1=1 forces the one-position filter.
-        if (e2 <= 6 * e1 + 64 && e2 < (1u << kXBitsBig) / 64 && !getenv("KREP_GPU_AC_STRIDE1"))
+        if (!S2.empty())
         {
-            ACHK(hipMalloc(&t->d_filters20, S20.size() * sizeof(u32)));
-            ACHK(hipMemcpy(t->d_filters20, S20.data(), S20.size() * sizeof(u32), hipMemcpyHostToDevice));
+            ACHK(hipMalloc(&t->d_s2, S2.size() * sizeof(u32)));
+            ACHK(hipMemcpy(t->d_s2, S2.data(), S2.size() * sizeof(u32), hipMemcpyHostToDevice));
+        }
+        if (!S3.empty())
+        {
+            ACHK(hipMalloc(&t->d_s3, S3.size() * sizeof(u32)));
+            ACHK(hipMemcpy(t->d_s3, S3.data(), S3.size() * sizeof(u32), hipMemcpyHostToDevice));
         }
     }
     ACHK(hipMalloc(&t->d_edges, tab.size() * sizeof(uint2)));
@@ -848,7 +743,9 @@ void ac_free(AcTables *t)
     if (!t)
         return;
     (void)hipSetDevice(t->device);
-    if (t->d_filter) (void)hipFree(t->d_filter);
+    if (t->d_s1) (void)hipFree(t->d_s1);
+    if (t->d_s2) (void)hipFree(t->d_s2);
+    if (t->d_s3) (void)hipFree(t->d_s3);
     if (t->d_filterx20) (void)hipFree(t->d_filterx20);
     if (t->d_filterx19) (void)hipFree(t->d_filterx19);
     if (t->d_filters20) (void)hipFree(t->d_filters20);
@@ -856,10 +753,6 @@ void ac_free(AcTables *t)
     if (t->d_copies) (void)hipFree(t->d_copies);
     if (t->d_gram4) (void)hipFree(t->d_gram4);
     if (t->d_g4x) (void)hipFree(t->d_g4x);
-    if (t->d_sfx) (void)hipFree(t->d_sfx);
-    if (t->d_tags) (void)hipFree(t->d_tags);
-    if (t->d_cand) (void)hipFree(t->d_cand);
-    if (t->d_candcnt) (void)hipFree(t->d_candcnt);
     delete t;
 }
 
@@ -872,8 +765,6 @@ void ac_free(AcTables *t)
     } while (0)
 
 int g_ac_force_stage_cap = 0; // test hook (krep_gpu_debug_force_stage_cap)
-static const int g_ac_split = getenv("KREP_GPU_AC_SPLIT") ? 1 : 0;
-static const int g_ac_chunk_mib = getenv("KREP_GPU_AC_CHUNK_MIB") ? atoi(getenv("KREP_GPU_AC_CHUNK_MIB")) : 0;
 
 static u32 ac_lds_bytes(u32 filter_words, bool lines)
 {
@@ -881,22 +772,22 @@ static u32 ac_lds_bytes(u32 filter_words, bool lines)
     return (((filter_words + 3u) & ~3u) + kAcWaves * per_wave) * (u32)sizeof(u32);
 }
 
-template <bool CI, bool LN, int CLS, int STRIDE>
+template <bool CI, bool LN, bool SHORT, int STRIDE>
 static hipError_t ac_launch3(const AcArgs &a, u32 grid, u32 lds, hipStream_t st)
 {
     // more than 64 KiB of dynamic LDS has to be requested explicitly
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ac_scan_kernel<CI, LN, CLS, STRIDE>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ac_scan_kernel<CI, LN, SHORT, STRIDE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((ac_scan_kernel<CI, LN, CLS, STRIDE>), dim3(grid), dim3(kAcBlock), lds, st, a);
+    hipLaunchKernelGGL((ac_scan_kernel<CI, LN, SHORT, STRIDE>), dim3(grid), dim3(kAcBlock), lds, st, a);
     return hipGetLastError();
 }
 template <bool CI, bool LN>
 static hipError_t ac_launch2(const AcArgs &a, u32 grid, u32 lds, hipStream_t st)
 {
-    const bool only4 = a.has4 && !a.has1 && !a.has2 && !a.has3;
-    if (only4)
-        return a.stride == 2 ? ac_launch3<CI, LN, 8, 2>(a, grid, lds, st) : ac_launch3<CI, LN, 8, 1>(a, grid, lds, st);
-    return ac_launch3<CI, LN, 15, 1>(a, grid, lds, st);
+    const bool shorts = a.has1 || a.has2 || a.has3;
+    if (a.stride == 2 && !LN) // the -c variant of the stride-2 kernel spills under the 128-VGPR cap: never launched
+        return shorts ? ac_launch3<CI, false, true, 2>(a, grid, lds, st) : ac_launch3<CI, false, false, 2>(a, grid, lds, st);
+    return shorts ? ac_launch3<CI, LN, true, 1>(a, grid, lds, st) : ac_launch3<CI, LN, false, 1>(a, grid, lds, st);
 }
 static hipError_t ac_launch(const AcArgs &a, u32 grid, u32 lds, hipStream_t st)
 {
@@ -949,8 +840,7 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
     a.end_lo = own_lo;
     a.end_hi = lines ? own_hi : std::min<u64>(text_len, (u64)own_hi + t->lmax - 1);
     a.anchor = own_lo & ~(u64)15;
-    const bool split = !lines && g_ac_split; // see below
-    const u64 unit_bytes = split ? (u64)kSegBytes : (u64)kAcUnitBytes;
+    const u64 unit_bytes = (u64)kAcUnitBytes;
     a.num_tiles = (a.end_hi - a.anchor + unit_bytes - 1) / unit_bytes;
     a.flags = (t->ci ? F_CI : 0) | (ww ? F_WW : 0) | (lines ? F_LINES : 0);
     if (getenv("KREP_GPU_AC_NOVERIFY"))
@@ -960,28 +850,21 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
     a.lmax = t->lmax;
     a.has1 = t->has1; a.has2 = t->has2; a.has3 = t->has3; a.has4 = t->has4;
     a.stride = 1;
-    a.filter = t->d_filter;
-    a.off1 = t->off1; a.off2 = t->off2; a.off3 = t->off3;
-    a.filter_words = t->filter_words;
-    if (t->d_filterx20 && !split)
-    { // fused kernel, every pattern >= 4 bytes: the exact-class table instead of the hashed one
-        a.filter = lines ? t->d_filterx19 : t->d_filterx20;
-        a.filter_words = (1u << (lines ? kXBitsLines : kXBitsBig)) / 32;
-        if (t->d_filters20 && !lines) // the -c variant of the stride-2 kernel spills (128-VGPR cap): stride 1 there
-        {
-            a.filter = t->d_filters20;
-            a.stride = 2;
-        }
+    a.filter = lines ? t->d_filterx19 : t->d_filterx20;
+    a.filter_words = (1u << (lines ? kXBitsLines : kXBitsBig)) / 32;
+    if (t->d_filters20 && !lines)
+    {
+        a.filter = t->d_filters20;
+        a.stride = 2;
     }
+    a.s1 = t->d_s1; a.s2 = t->d_s2; a.s3 = t->d_s3;
+    if (t->short_dup)
+        a.flags |= F_AC_SHORT_DUP;
     a.edges = t->d_edges;
     a.emask = t->emask;
     a.copies = t->d_copies;
     a.gram4 = t->d_gram4;
     a.g4x = t->d_g4x;
-    a.sfx = t->d_sfx;
-    a.tags = t->d_tags;
-    a.sfxmask = t->sfxmask;
-    a.lenmask = t->lenmask;
     a.g4mask = t->g4mask;
     a.ctr = d_ctr;
     const u64 want = (d_pos && cap && !lines) ? std::min<u64>(cap, (u64)max_count) : 0;
@@ -1001,105 +884,27 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
         a.offsets = (const u64 *)post.d_offsets;
     }
     SCHK(hipSetDevice(t->device));
-    // Default: the FUSED kernel (LDS filter + per-wave LDS candidate queue + dense in-kernel verify): 1.8 TB/s on
-    // BASELINE config 4.  The split pipelines (filter kernel -> candidate lists -> verify kernel) measured slower on
-    // MI355X and stay behind KREP_GPU_AC_SPLIT=1 as experiment switches (numbers in DESIGN.md §4.2); -c always
-    // uses the fused kernel (it needs the newline masks next to the hits).
-    if (split)
-    {
-        a.cand_cap = g_ac_force_stage_cap ? 8u : 128u;
-        const u64 cw = n_units * a.cand_cap;
-        if (cw > t->cand_words)
-        {
-            if (t->d_cand) (void)hipFree(t->d_cand);
-            t->d_cand = nullptr; t->cand_words = 0;
-            SCHK(hipMalloc(&t->d_cand, cw * sizeof(u32)));
-            t->cand_words = cw;
-        }
-        if (n_units > t->candcnt_words)
-        {
-            if (t->d_candcnt) (void)hipFree(t->d_candcnt);
-            t->d_candcnt = nullptr; t->candcnt_words = 0;
-            SCHK(hipMalloc(&t->d_candcnt, n_units * sizeof(u32)));
-            t->candcnt_words = n_units;
-        }
-        a.cand = t->d_cand;
-        a.candcnt = t->d_candcnt;
-    }
-    const u32 lds = split ? (((t->filter_words + 3u) & ~3u) + 4u) * (u32)sizeof(u32) : ac_lds_bytes(a.filter_words, lines);
+    const u32 lds = ac_lds_bytes(a.filter_words, lines);
     const u32 per_cu = lds <= 80 * 1024 ? 2u : 1u;
     // ticket size by text size: >= ~4 tickets per resident wave before tickets grow (small host buffers keep every
     // CU busy), 8 units (128 KiB) on large texts
-    a.upt = split ? kAcUnitsPerTicket
-                  : (u32)std::min<u64>(kAcUnitsPerTicketMax, std::max<u64>(1, a.num_tiles / ((u64)num_cu * kAcWaves * 4)));
+    a.upt = (u32)std::min<u64>(kAcUnitsPerTicketMax, std::max<u64>(1, a.num_tiles / ((u64)num_cu * kAcWaves * 4)));
     const u64 n_tickets = (a.num_tiles + a.upt - 1) / a.upt;
     const u32 grid = (u32)std::min<u64>((n_tickets + kAcWaves - 1) / kAcWaves, (u64)num_cu * per_cu);
-    const u32 vgrid = (u32)std::min<u64>((n_units + 3) / 4, (u64)num_cu * 8);
     if (time_it) SCHK(hipEventRecord(ev0, st));
     SCHK(hipMemsetAsync(d_ctr, 0, sizeof(Counters), st));
-    // optional chunking of filter -> verify (KREP_GPU_AC_CHUNK_MIB): measured slower than one pass at every chunk
-    // size (the verifier is bound by dependent-access depth, not by HBM), kept as an experiment switch
-    const u64 chunk_units = split ? (g_ac_chunk_mib ? (u64)g_ac_chunk_mib * 1024 * 1024 / kSegBytes : n_units) : n_units;
-    auto run_split = [&](const AcArgs &base, bool filter) -> int {
-        for (u64 u0 = 0; u0 < n_units; u0 += chunk_units)
-        {
-            AcArgs c = base;
-            c.unit_base = u0;
-            c.anchor = base.anchor + u0 * (u64)kSegBytes;
-            c.num_tiles = std::min<u64>(chunk_units, n_units - u0);
-            const u64 ct = (c.num_tiles + kAcUnitsPerTicket - 1) / kAcUnitsPerTicket;
-            const u32 cgrid = (u32)std::min<u64>((ct + kAcWaves - 1) / kAcWaves, (u64)num_cu * per_cu);
-            const u32 cvgrid = (u32)std::min<u64>((c.num_tiles + 3) / 4, (u64)num_cu * 8);
-            if (filter)
-            {
-                SCHK(hipMemsetAsync(&d_ctr->ticket, 0, sizeof(unsigned long long), st));
-                SCHK(ac_filter_launch(c, cgrid, lds, st));
-            }
-            SCHK(ac_verify_launch(c, cvgrid, st));
-        }
-        return 0;
-    };
-    if (split)
-    {
-        if (run_split(a, true))
-            return 2;
-    }
-    else
-        SCHK(ac_launch(a, grid, lds, st));
+    SCHK(ac_launch(a, grid, lds, st));
     if (chain && post_order(post, n_units, a.stage_cap, 0, 0, 0, lines, (uint64_t *)d_pos, want, d_ctr, num_cu, st))
         return 2;
     if (time_it) SCHK(hipEventRecord(ev1, st));
     SCHK(hipMemcpyAsync(h_ctr, d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, st));
     SCHK(hipStreamSynchronize(st));
-    if (split && getenv("KREP_GPU_DEBUG"))
-    {
-        std::vector<u32> cc(n_units);
-        (void)hipMemcpy(cc.data(), t->d_candcnt, n_units * sizeof(u32), hipMemcpyDeviceToHost);
-        u64 sum = 0, fl = 0;
-        u32 mx = 0;
-        for (u32 v : cc)
-        {
-            if (v == kAcFlooded) { ++fl; continue; }
-            sum += v;
-            mx = std::max(mx, v);
-        }
-        fprintf(stderr, "krep-gpu: (debug) candidates: units=%llu mean=%.1f max=%u flooded=%llu\n", (unsigned long long)n_units,
-                (double)sum / (double)std::max<u64>(1, n_units - fl), mx, (unsigned long long)fl);
-    }
     if (want && h_ctr->overflow_units)
     {
         AcArgs e = a;
         e.emit_mode = 1;
-        if (split)
-        {
-            if (run_split(e, false))
-                return 2;
-        }
-        else
-        {
-            SCHK(hipMemsetAsync(&d_ctr->ticket, 0, sizeof(unsigned long long), st));
-            SCHK(ac_launch(e, grid, lds, st));
-        }
+        SCHK(hipMemsetAsync(&d_ctr->ticket, 0, sizeof(unsigned long long), st));
+        SCHK(ac_launch(e, grid, lds, st));
         if (time_it) SCHK(hipEventRecord(ev1, st));
         SCHK(hipStreamSynchronize(st));
     }

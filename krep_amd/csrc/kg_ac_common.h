@@ -1,5 +1,5 @@
-// kg_ac_common.h — shared device code of the multi-pattern scan (kg_ac.hip: the shipped fused kernel + host side;
-// kg_ac_split.hip: the measured filter -> verify alternatives).  See kg_ac.hip for the design notes.
+// kg_ac_common.h — device code of the multi-pattern scan shared by the kernel variants of kg_ac.hip (verifiers, table
+// layouts, constants).  See kg_ac.hip for the design notes.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "kg_common.h"
@@ -12,10 +12,7 @@ using u64 = unsigned long long;
 
 constexpr int kAcBlock = 1024;             // 16 waves share one copy of the filter tables in LDS
 constexpr int kAcWaves = kAcBlock / 64;
-constexpr u32 kT1Words = 256 / 32;         // 1-byte patterns: direct
-constexpr u32 kT2Words = 65536 / 32;       // 2-byte patterns: direct (8 KiB)
-constexpr u32 kT3Bits = 16, kT3Words = (1u << kT3Bits) / 32; // 3-byte patterns: hashed (8 KiB)
-constexpr u32 kT4Bits = 19, kT4Words = (1u << kT4Bits) / 32; // >= 4-byte patterns: hashed (64 KiB)
+constexpr u32 kS1Words = 256 / 32, kS2Words = 65536 / 32, kS3Words = (1u << 24) / 32; // exact bitmaps of 1-/2-/3-byte patterns
 constexpr u32 kHashMul = 0x9E3779B1u;
 
 struct AcArgs
@@ -26,20 +23,14 @@ struct AcArgs
     u32 flags;                   // F_CI | F_WW | F_POS | F_LINES
     u32 lmax;
     u32 has1, has2, has3, has4;  // which length classes exist
-    const u32 *filter;           // T4 | T1 | T2 | T3 (T4/T2/T3 only when present)
-    u32 off1, off2, off3, filter_words; // word offsets of T1/T2/T3 in LDS; T4 (>= 4-byte class) is at offset 0
+    const u32 *filter;           // exact-class bit table (2^20 or 2^19 bits), copied to LDS address 0
+    u32 filter_words;
+    const u32 *s1, *s2, *s3;     // exact bitmaps of the 1-/2-/3-byte patterns (keys: last 1/2/3 text bytes, folded under -i)
     const uint2 *edges;          // open addressing: {key = node << 8 | byte, val = child | has_out << 31}
     u32 emask;
     const u32 *copies;           // per node: number of patterns equal to the node's string
-    u64 unit_base;               // global index of this launch's first unit (chunked filter -> verify pipeline)
-    u32 *cand;                   // [units * cand_cap] candidate end offsets (relative to the unit), split pipeline
-    u32 *candcnt;                // [units] number of candidates, or kAcFlooded
-    u32 cand_cap;
     u32 stride;                  // 1 or 2: text positions per filter lookup (2 = even positions only, see ac_scan_kernel)
     u32 upt;                     // units per wave ticket of the fused kernel (1..kAcUnitsPerTicketMax, by text size)
-    const uint4 *sfx;            // whole-pattern table, 2 x uint4 per entry: {bytes right-aligned in 16}, {len, copies, 0, 0}
-    const unsigned long long *tags; // per slot: (suffix hash << 32) | (copies << 8) | len, 0 = empty
-    u32 sfxmask, lenmask;        // entries-1; bit L set <=> some pattern has length L (1..16)
     const uint2 *gram4;          // exact last-4-bytes -> {key, depth-4 node | has_out << 31} (val 0 = empty)
     u32 g4mask;
     const uint4 *g4x;            // same slots, 2 x uint4 each: {key, child, info, endmask} {chain bytes x3, -}
@@ -260,18 +251,92 @@ __device__ __forceinline__ u32 ac_walk_levels(const AcArgs &a, u64 i, bool own_b
     return seen;
 }
 
-// Chain-compressed verifier (CLS == 8, the shipped path).  Below depth 4 almost every node of the reversed trie of a
-// large dictionary lies on a unary chain, so the 4-gram entry carries the next <= 12 bytes of that chain (in text
-// order, the window text[i-15 .. i-4] compares against it dword by dword) and the depths at which patterns end:
-// a candidate costs TWO dependent accesses (text window, table entry) however long the match is, instead of one
-// probe per trie level (12 serial L2 round trips for a 16-byte match — the latency that bounded the verify stage).
-// Anything the entry cannot express (branching below depth 4, duplicate patterns, chains continuing past depth 16,
-// -w, a candidate within 15 bytes of the text start) takes the level-by-level walk.
+// Chain-compressed verifier (the shipped path).  Below depth 4 almost every node of the reversed trie of a large
+// dictionary lies on a unary chain, so the 4-gram entry carries the next <= 12 bytes of that chain (in text order, the
+// window text[i-15 .. i-4] compares against it dword by dword) and the depths at which patterns end: a candidate costs
+// TWO dependent accesses (text window, table entry) however long the match is, instead of one probe per trie level
+// (12 serial L2 round trips for a 16-byte match — the latency that bounded the verify stage).  1-3-byte patterns
+// (SHORT dictionaries) are exact bitmap lookups keyed by the last bytes of the same window, in flight with the probe.
+// Anything this cannot express (branching below depth 4, duplicate patterns, chains continuing past depth 16, -w, a
+// candidate within 15 bytes of the text start) takes the level-by-level walk (ac_walk_slow, ONE call site per kernel).
 constexpr u32 kG4Simple = 1u << 4, kG4Cont = 1u << 5; // info bits above the chain length [3:0]
-template <bool CI>
+constexpr u32 F_AC_SHORT_DUP = 1u << 29;              // AcArgs.flags: a 1-3-byte pattern occurs twice: level walk only
+
+// bits 1..3 of the depth mask: which 1-/2-/3-byte patterns end with the 4 text bytes E (byte i on top)
+__device__ __forceinline__ u32 ac_short_bits(const AcArgs &a, u32 E)
+{
+    u32 sb = 0;
+    if (a.has1)
+    {
+        const u32 k = E >> 24;
+        sb |= ((a.s1[k >> 5] >> (k & 31u)) & 1u) << 1;
+    }
+    if (a.has2)
+    {
+        const u32 k = E >> 16;
+        sb |= ((a.s2[k >> 5] >> (k & 31u)) & 1u) << 2;
+    }
+    if (a.has3)
+    {
+        const u32 k = E >> 8;
+        sb |= ((a.s3[k >> 5] >> (k & 31u)) & 1u) << 3;
+    }
+    return sb;
+}
+
+// depth mask of the matches ending at `end` from a probed entry (found) and the short-pattern bits sb
+__device__ __forceinline__ void ac_eval_entry(const AcArgs &a, bool found, const u32 (&T)[4], const uint4 &e0, const uint4 &e1,
+                                              u32 sb, u64 end, bool own_by_end, u32 &dm, bool &slow)
+{
+    u32 m = sb;
+    if (found)
+    {
+        const u32 info = e0.z, clen = info & 15u;
+        auto same = [](u32 x) -> u32 { return x ? (u32)__builtin_clz(x) >> 3 : 4u; }; // equal bytes from the top
+        u32 L = same(T[2] ^ e1.z);
+        if (L == 4u)
+        {
+            L += same(T[1] ^ e1.y);
+            if (L == 8u)
+                L += same(T[0] ^ e1.x);
+        }
+        L = L < clen ? L : clen;
+        slow = !(info & kG4Simple) || (L == clen && (info & kG4Cont));
+        m |= ((e0.y >> 31) << 4) | ((e0.w & ((1u << L) - 1u)) << 5); // bit d: a pattern of length d ends here
+    }
+    if (!own_by_end)
+    { // the match start s = end + 1 - d has to lie in [own_lo, own_hi)
+        const u64 e = end + 1;
+        if (e <= a.own_lo)
+            m = 0;
+        else
+        {
+            if (e - a.own_lo < 32)
+                m &= (2u << (u32)(e - a.own_lo)) - 1u; // d <= e - own_lo
+            if (e > a.own_hi)
+                m = (e - a.own_hi < 32) ? (m & ~((2u << (u32)(e - a.own_hi)) - 1u)) : 0u; // d > e - own_hi
+        }
+    }
+    dm = m;
+}
+
+// the level-by-level walk behind the fast verifiers: count, and (dictionaries without short patterns) the depth mask
+template <bool CI, bool SHORT>
+__device__ __forceinline__ u32 ac_walk_slow(const AcArgs &a, u64 i, bool own_by_end, u64 &depthmask, bool &simple)
+{
+    if (SHORT)
+    {
+        depthmask = 0;
+        simple = false; // the emit pass walks again
+        return ac_walk<CI, false, false>(a, i, 0u, [](u32, u64, u32) {});
+    }
+    return ac_walk_levels<CI>(a, i, own_by_end, depthmask, simple);
+}
+
+template <bool CI, bool SHORT>
 __device__ __forceinline__ u32 ac_walk_fast(const AcArgs &a, u64 i, bool own_by_end, u64 &depthmask, bool &simple)
 {
-    bool slow = i < 15 || (a.flags & F_WW); // one (inlined) call site for the level walk
+    bool slow = i < 15 || (a.flags & (F_WW | (SHORT ? F_AC_SHORT_DUP : 0u))); // one (inlined) call site for the level walk
     u32 dm = 0;
     if (!slow)
     {
@@ -284,52 +349,27 @@ __device__ __forceinline__ u32 ac_walk_fast(const AcArgs &a, u64 i, bool own_by_
             for (int w = 0; w < 4; ++w)
                 T[w] = ac_fold4(T[w]);
         }
-        uint4 e0, e1;
-        bool found = true;
-        for (u32 h = (T[3] * kHashMul) >> 9;; ++h)
-        {
-            const uint4 *e = a.g4x + 2 * (size_t)(h & a.g4mask);
-            e0 = e[0];
-            e1 = e[1]; // issued with e[0]: one latency
-            if (e0.y == 0u)
-            {
-                found = false; // not a suffix of any pattern
-                break;
-            }
-            if (e0.x == T[3])
-                break;
-        }
+        const u32 sb = SHORT ? ac_short_bits(a, T[3]) : 0u;
+        uint4 e0 = make_uint4(0, 0, 0, 0), e1 = e0;
+        bool found = a.has4 != 0;
         if (found)
-        {
-            const u32 info = e0.z, clen = info & 15u;
-            auto same = [](u32 m) -> u32 { return m ? (u32)__builtin_clz(m) >> 3 : 4u; }; // equal bytes from the top
-            u32 L = same(T[2] ^ e1.z);
-            if (L == 4u)
+            for (u32 h = (T[3] * kHashMul) >> 9;; ++h)
             {
-                L += same(T[1] ^ e1.y);
-                if (L == 8u)
-                    L += same(T[0] ^ e1.x);
-            }
-            L = L < clen ? L : clen;
-            slow = !(info & kG4Simple) || (L == clen && (info & kG4Cont));
-            dm = ((e0.y >> 31) << 4) | ((e0.w & ((1u << L) - 1u)) << 5); // bit d: a pattern of length d ends at i
-            if (!own_by_end)
-            { // the match start s = i + 1 - d has to lie in [own_lo, own_hi)
-                const u64 e = i + 1;
-                if (e <= a.own_lo)
-                    dm = 0;
-                else
+                const uint4 *e = a.g4x + 2 * (size_t)(h & a.g4mask);
+                e0 = e[0];
+                e1 = e[1]; // issued with e[0]: one latency
+                if (e0.y == 0u)
                 {
-                    if (e - a.own_lo < 32)
-                        dm &= (2u << (u32)(e - a.own_lo)) - 1u; // d <= e - own_lo
-                    if (e > a.own_hi)
-                        dm = (e - a.own_hi < 32) ? (dm & ~((2u << (u32)(e - a.own_hi)) - 1u)) : 0u; // d > e - own_hi
+                    found = false; // not a suffix of any pattern
+                    break;
                 }
+                if (e0.x == T[3])
+                    break;
             }
-        }
+        ac_eval_entry(a, found, T, e0, e1, sb, i, own_by_end, dm, slow);
     }
     if (slow)
-        return ac_walk_levels<CI>(a, i, own_by_end, depthmask, simple);
+        return ac_walk_slow<CI, SHORT>(a, i, own_by_end, depthmask, simple);
     depthmask = dm;
     simple = true;
     return (u32)__popc(dm);
@@ -337,14 +377,14 @@ __device__ __forceinline__ u32 ac_walk_fast(const AcArgs &a, u64 i, bool own_by_
 
 // The same for the two end positions i and i + 1 of a stride-2 candidate: both text windows and both table probes
 // are in flight together (one latency for the pair).  No level walk in here: an end that needs it comes back with
-// slow = true and the caller runs ac_walk_levels from its single call site.
-template <bool CI>
+// slow = true and the caller runs ac_walk_slow from its single call site.
+template <bool CI, bool SHORT>
 __device__ __forceinline__ void ac_walk_probe2(const AcArgs &a, u64 i, bool liveA, bool liveB, bool own_by_end,
                                                u32 &dmA, bool &slowA, u32 &dmB, bool &slowB)
 {
     dmA = dmB = 0;
     slowA = slowB = false;
-    if (i < 15 || (a.flags & F_WW))
+    if (i < 15 || (a.flags & (F_WW | (SHORT ? F_AC_SHORT_DUP : 0u))))
     {
         slowA = liveA;
         slowB = liveB;
@@ -364,10 +404,11 @@ __device__ __forceinline__ void ac_walk_probe2(const AcArgs &a, u64 i, bool live
             TB[w] = ac_fold4(TB[w]);
         }
     }
+    const u32 sbA = SHORT ? ac_short_bits(a, TA[3]) : 0u, sbB = SHORT ? ac_short_bits(a, TB[3]) : 0u;
     u32 hA = (TA[3] * kHashMul) >> 9, hB = (TB[3] * kHashMul) >> 9;
     uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0, b0 = a0, b1 = a0;
-    bool doneA = !liveA, doneB = !liveB, foundA = false, foundB = false;
-    for (;;)
+    bool doneA = !liveA || !a.has4, doneB = !liveB || !a.has4, foundA = false, foundB = false;
+    while (!(doneA && doneB))
     {
         const uint4 *ea = a.g4x + 2 * (size_t)(hA & a.g4mask), *eb = a.g4x + 2 * (size_t)(hB & a.g4mask);
         const uint4 x0 = ea[0], x1 = ea[1], y0 = eb[0], y1 = eb[1];
@@ -385,44 +426,13 @@ __device__ __forceinline__ void ac_walk_probe2(const AcArgs &a, u64 i, bool live
             else if (y0.x == TB[3]) doneB = foundB = true;
             else ++hB;
         }
-        if (doneA && doneB)
-            break;
     }
-    auto eval = [&](bool found, const u32 (&T)[4], const uint4 &e0, const uint4 &e1, u64 end, u32 &dm, bool &slow) {
-        if (!found)
-            return;
-        const u32 info = e0.z, clen = info & 15u;
-        auto same = [](u32 m) -> u32 { return m ? (u32)__builtin_clz(m) >> 3 : 4u; };
-        u32 L = same(T[2] ^ e1.z);
-        if (L == 4u)
-        {
-            L += same(T[1] ^ e1.y);
-            if (L == 8u)
-                L += same(T[0] ^ e1.x);
-        }
-        L = L < clen ? L : clen;
-        slow = !(info & kG4Simple) || (L == clen && (info & kG4Cont));
-        u32 m = ((e0.y >> 31) << 4) | ((e0.w & ((1u << L) - 1u)) << 5);
-        if (!own_by_end)
-        {
-            const u64 e = end + 1;
-            if (e <= a.own_lo)
-                m = 0;
-            else
-            {
-                if (e - a.own_lo < 32)
-                    m &= (2u << (u32)(e - a.own_lo)) - 1u;
-                if (e > a.own_hi)
-                    m = (e - a.own_hi < 32) ? (m & ~((2u << (u32)(e - a.own_hi)) - 1u)) : 0u;
-            }
-        }
-        dm = m;
-    };
-    eval(foundA, TA, a0, a1, i, dmA, slowA);
-    eval(foundB, TB, b0, b1, i + 1, dmB, slowB);
+    if (liveA)
+        ac_eval_entry(a, foundA, TA, a0, a1, sbA, i, own_by_end, dmA, slowA);
+    if (liveB)
+        ac_eval_entry(a, foundB, TB, b0, b1, sbB, i + 1, own_by_end, dmB, slowB);
 }
 
-constexpr u32 kAcUnitsPerTicket = 4;   // split pipelines: 4 x 8 KiB per wave ticket
 constexpr u32 kAcUnitsPerTicketMax = 8; // fused kernel: up to 128 KiB per wave ticket (one cold round in 16), fewer on small texts
 constexpr u32 kAcQueue = 512;          // candidate queue entries per wave (u16 each: unit-relative end index)
 constexpr int kAcRounds = 2;            // load rounds per unit: one candidate drain per 16 KiB (53 of 64 lanes busy)
@@ -440,15 +450,5 @@ __host__ __device__ __forceinline__ u32 ac_cls4(u32 w)
     const u32 t = (w & 0x001f001fu) | ((w >> 3) & ~0x001f001fu); // two v_bfi: junk above each 10-bit pair ...
     return ((t & 0x3ffu) | ((t >> 6) & ~0x3ffu)) & 0xfffffu;       // ... shifted out or masked here
 }
-
-// bit of table `base` at hash h
-__device__ __forceinline__ u32 ac_tbit(const u32 *tab, u32 base, u32 h) { return (tab[base + (h >> 5)] >> (h & 31u)) & 1u; }
-
-
-constexpr u32 kAcFlooded = 0xffffffffu; // candcnt value of a unit whose candidate list overflowed (split pipeline)
-
-// kg_ac_split.hip
-hipError_t ac_filter_launch(const AcArgs &a, u32 grid, u32 lds, hipStream_t st);
-hipError_t ac_verify_launch(const AcArgs &a, u32 grid, hipStream_t st);
 
 } // namespace kg
