@@ -6,15 +6,18 @@
 // aho_corasick.c:353-431), duplicates of a pattern string once per copy.  That set is a pure
 // function of the bytes text[i-Lmax+1 .. i], so the sequential automaton walk is not needed to
 // reproduce it.  MI355X-first formulation:
-//   * FILTER (every byte, HBM-rate): the last min(len,4) bytes of every pattern are hashed into bit
-//     tables resident in LDS (<= 88 KiB: 256 b for 1-byte patterns, 64 Kib for 2-byte, 128 Kib hashed
-//     for 3-byte, 512 Kib hashed for >= 4-byte patterns).  A lane tests its 16 end positions with one
-//     v_alignbyte + multiply-shift + ds_read_b32 each; positions that miss every table cannot end a
-//     pattern.  The haystack is read once with the same coalesced 16 B/lane loads as the literal scan.
-//   * VERIFY (candidates only, ~0.4 % of positions for 1000 random patterns): walk the REVERSED-pattern
-//     trie backwards from i (edges in an open-addressing table in global memory, L2-resident); each
-//     node on the path that is a pattern end yields its copies.  Walking visits lengths ascending; the
-//     reference order (longest first) falls out of writing slot = base + (total_i - seen - copies).
+//   * FILTER (every byte): one bit table in LDS, indexed by the 5-bit classes (b & 31) of the last four bytes
+//     (2^20 bits = 128 KiB; a pattern shorter than 4 bytes sets every class of the bytes in front of it).  A lane
+//     turns its 20 bytes into a 100-bit class stream once; a position then costs a funnel shift, the dword address,
+//     one ds_read_b32 and two shifts.  With STRIDE == 2 only the even positions are looked up (see below).
+//     Positions whose bit is clear cannot end a pattern.  The haystack is read once with the same coalesced
+//     16 B/lane loads as the literal scan, the next round streaming into the registers the current one vacates.
+//   * VERIFY (candidates only, ~0.2 % of positions for 1000 random patterns): one candidate per lane, 64 at a time
+//     from a per-wave LDS queue.  The exact last 4 bytes select an entry of a sparse hash table that carries the
+//     next <= 12 bytes of the reversed-trie chain and the depths at which patterns end (kg_ac_common.h); 1-3-byte
+//     patterns are exact bitmap lookups.  Two dependent accesses per candidate; the level-by-level walk of the
+//     REVERSED-pattern trie (edges in an open-addressing table, L2-resident) remains for what that cannot express.
+//     The reference order (longest first at one end index) is the depth mask read from the top.
 //   * ORDER: same as the literal kernel — unit-local ranks, staging slot, info word, post-pass.
 // -w, -c (line counting), max_count and start-offset ownership are applied exactly as in the literal
 // kernel.  A dense DFA in LDS is impossible for the benchmark set (8605 states x 256 x 2 B = 4.4 MB
