@@ -219,12 +219,33 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
                 }
 
                 // newline mask before folding (folding never touches '\n')
+                // interior cells only need "does this lane hold a newline" (a zero-byte test on D ^ '\n'); the exact
+                // 16-bit mask (a multiply per dword) is computed where it is consumed: in cells that hold a hit, and in
+                // boundary cells, where it has to be clipped to the owned window
                 u32 NL = 0;
-                if (LINES)
-                {
+                bool nl_any = false;
+                auto exact_nl = [&]() -> u32 {
+                    u32 v = 0;
 #pragma unroll
                     for (int w = 0; w < 4; ++w)
-                        NL |= movemask4(eq_bytes(D[w], 0x0a0a0a0au)) << (4 * w);
+                        v |= movemask4(eq_bytes(D[w], 0x0a0a0a0au)) << (4 * w);
+                    return v;
+                };
+                if (LINES)
+                {
+                    if (interior)
+                    {
+                        u32 z = 0;
+#pragma unroll
+                        for (int w = 0; w < 4; ++w)
+                        {
+                            const u32 t = D[w] ^ 0x0a0a0a0au;
+                            z |= (t - 0x01010101u) & ~t;
+                        }
+                        nl_any = (z & 0x80808080u) != 0u;
+                    }
+                    else
+                        NL = exact_nl();
                 }
                 if (CI)
                 {
@@ -341,13 +362,14 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
                 if (LINES)
                 {
                     // per-lane summary of its 16 bytes
-                    const u32 H = m16, N = nlm;
-                    const bool l_nl = N != 0u;
+                    const u32 H = m16;
+                    const bool l_nl = interior ? nl_any : (nlm != 0u);
                     const u64 B_nl = __ballot(l_nl);
                     LS cell{0, B_nl != 0, false, false};
                     if (anyhit)
                     {
                         // first hit of every newline-delimited segment: see DESIGN.md (line bookkeeping)
+                        const u32 N = interior ? exact_nl() : nlm; // (folding never touches '\n')
                         const u32 S = ((N << 1) | 1u) & 0xffffu, Hs = H | N;
                         const u32 firsts = H & Hs & ~(Hs - S);
                         bool l_head, l_tail;
