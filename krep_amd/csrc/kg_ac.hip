@@ -117,7 +117,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 d[j] = src[j * kWave];
         }
         // the next round of this ticket, if it is a full one, streams in behind this one
-        const bool pf_next = fast_now && !emit_final && seg + 2 * (u64)kSegBytes <= a.text_len &&
+        const bool pf_next = !(LINES && STRIDE == 2) && fast_now && !emit_final && seg + 2 * (u64)kSegBytes <= a.text_len &&
                              (r + 1 < kAcRounds || unit + 1 < u_end);
         // always issued in the fast path (a uniform address select, not a branch: the s_waitcnt counts stay static);
         // without a next round every lane re-reads the first bytes of this one (one cached line per load, dropped)
@@ -476,7 +476,7 @@ struct AcTables
     u32 has1 = 0, has2 = 0, has3 = 0, has4 = 0;
     bool short_dup = false;     // a 1-3-byte pattern occurs more than once (the bitmaps cannot count copies)
     u32 *d_filterx20 = nullptr, *d_filterx19 = nullptr; // exact-class filter tables (2^20 bits; 2^19 for -c)
-    u32 *d_filters20 = nullptr; // the same for the stride-2 filter (nullptr: stride 2 not worth it for this dictionary)
+    u32 *d_filters20 = nullptr, *d_filters19 = nullptr; // the same for the stride-2 filter (nullptr: stride 2 not worth it)
     u32 *d_s1 = nullptr, *d_s2 = nullptr, *d_s3 = nullptr; // exact bitmaps of the 1-/2-/3-byte patterns
     uint2 *d_edges = nullptr;
     u32 emask = 0;
@@ -664,7 +664,7 @@ AcTables *ac_build(const search_params_t &sp, int device)
     {
         // ---- filter: exact-class table over the last 4 bytes; a pattern shorter than 4 sets every class of the
         //      bytes in front of it (32 / 1024 / 32768 entries) ----
-        std::vector<u32> X20((1u << kXBitsBig) / 32, 0), X19((1u << kXBitsLines) / 32, 0), S20;
+        std::vector<u32> X20((1u << kXBitsBig) / 32, 0), X19((1u << kXBitsLines) / 32, 0), S20, S19;
         auto expand = [&](std::vector<u32> &T20, std::vector<u32> *T19, const uint8_t *last, size_t known) {
             // the `known` (<= 4) classes next to the tested position are fixed (last[0..known), text order), the rest free
             u32 fixed = 0;
@@ -696,10 +696,11 @@ AcTables *ac_build(const search_params_t &sp, int device)
         if (!t->has1)
         {
             S20 = X20;
+            S19 = X19;
             for (auto &p : pats)
             {
                 const size_t n = p.size(), known = std::min<size_t>(n - 1, 4);
-                expand(S20, nullptr, p.data() + (n - 1 - known), known);
+                expand(S20, &S19, p.data() + (n - 1 - known), known);
             }
             u64 e1 = 0, e2 = 0;
             for (size_t w = 0; w < X20.size(); ++w)
@@ -714,6 +715,8 @@ AcTables *ac_build(const search_params_t &sp, int device)
             {
                 ACHK(hipMalloc(&t->d_filters20, S20.size() * sizeof(u32)));
                 ACHK(hipMemcpy(t->d_filters20, S20.data(), S20.size() * sizeof(u32), hipMemcpyHostToDevice));
+                ACHK(hipMalloc(&t->d_filters19, S19.size() * sizeof(u32)));
+                ACHK(hipMemcpy(t->d_filters19, S19.data(), S19.size() * sizeof(u32), hipMemcpyHostToDevice));
             }
         }
         if (!S1.empty())
@@ -753,6 +756,7 @@ void ac_free(AcTables *t)
     if (t->d_filterx20) (void)hipFree(t->d_filterx20);
     if (t->d_filterx19) (void)hipFree(t->d_filterx19);
     if (t->d_filters20) (void)hipFree(t->d_filters20);
+    if (t->d_filters19) (void)hipFree(t->d_filters19);
     if (t->d_edges) (void)hipFree(t->d_edges);
     if (t->d_copies) (void)hipFree(t->d_copies);
     if (t->d_gram4) (void)hipFree(t->d_gram4);
@@ -789,8 +793,8 @@ template <bool CI, bool LN>
 static hipError_t ac_launch2(const AcArgs &a, u32 grid, u32 lds, hipStream_t st)
 {
     const bool shorts = a.has1 || a.has2 || a.has3;
-    if (a.stride == 2 && !LN) // the -c variant of the stride-2 kernel spills under the 128-VGPR cap: never launched
-        return shorts ? ac_launch3<CI, false, true, 2>(a, grid, lds, st) : ac_launch3<CI, false, false, 2>(a, grid, lds, st);
+    if (a.stride == 2)
+        return shorts ? ac_launch3<CI, LN, true, 2>(a, grid, lds, st) : ac_launch3<CI, LN, false, 2>(a, grid, lds, st);
     return shorts ? ac_launch3<CI, LN, true, 1>(a, grid, lds, st) : ac_launch3<CI, LN, false, 1>(a, grid, lds, st);
 }
 static hipError_t ac_launch(const AcArgs &a, u32 grid, u32 lds, hipStream_t st)
@@ -856,9 +860,9 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
     a.stride = 1;
     a.filter = lines ? t->d_filterx19 : t->d_filterx20;
     a.filter_words = (1u << (lines ? kXBitsLines : kXBitsBig)) / 32;
-    if (t->d_filters20 && !lines)
+    if (t->d_filters20)
     {
-        a.filter = t->d_filters20;
+        a.filter = lines ? t->d_filters19 : t->d_filters20;
         a.stride = 2;
     }
     a.s1 = t->d_s1; a.s2 = t->d_s2; a.s3 = t->d_s3;
