@@ -117,6 +117,8 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 d[j] = src[j * kWave];
         }
         // the next round of this ticket, if it is a full one, streams in behind this one
+        // (not in the -c variant of the stride-2 kernel: with the prefetch registers live across the verify stage it
+        //  spilled 50-69 VGPRs under the 128 cap)
         const bool pf_next = !(LINES && STRIDE == 2) && fast_now && !emit_final && seg + 2 * (u64)kSegBytes <= a.text_len &&
                              (r + 1 < kAcRounds || unit + 1 < u_end);
         // always issued in the fast path (a uniform address select, not a branch: the s_waitcnt counts stay static);
