@@ -79,12 +79,16 @@ __device__ __forceinline__ LS ls_combine(const LS &a, const LS &b)
 __device__ __forceinline__ u64 ls_bits(const LS &s) { return (s.nl ? kLnNl : 0) | (s.head ? kLnHead : 0) | (s.tail ? kLnTail : 0); }
 
 // wave sum of a small per-lane value (< 32) through ballot bit-planes: SALU only
+// (two planes when no lane exceeds 3 — even the 1 % single-byte workload almost never has 4 hits in 16 bytes)
 __device__ __forceinline__ u32 wave_sum5(u32 v)
 {
-    u32 s = 0;
+    u32 s = (u32)__popcll(__ballot(v & 1u)) + ((u32)__popcll(__ballot((v >> 1) & 1u)) << 1);
+    if (__ballot(v > 3u))
+    {
 #pragma unroll
-    for (int b = 0; b < 5; ++b)
-        s += (u32)__popcll(__ballot((v >> b) & 1u)) << b;
+        for (int b = 2; b < 5; ++b)
+            s += (u32)__popcll(__ballot((v >> b) & 1u)) << b;
+    }
     return s;
 }
 // exclusive prefix over lanes of a small per-lane value (< 32)
@@ -459,12 +463,18 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
                             continue;
                         const u32 c = __popc(m16);
                         u32 idx = out, tot = 0;
-#pragma unroll
-                        for (int b = 0; b < 5; ++b) // exclusive lane prefix and wave total from the same ballots
-                        {
+                        auto plane = [&](int b) { // exclusive lane prefix and wave total from the same ballot
                             const u64 bm = __ballot((c >> b) & 1u);
                             idx += mbcnt64(bm) << b;
                             tot += (u32)__popcll(bm) << b;
+                        };
+                        plane(0);
+                        plane(1);
+                        if (__ballot(c > 3u)) // rare: some lane holds 4+ hits in its 16 bytes
+                        {
+                            plane(2);
+                            plane(3);
+                            plane(4);
                         }
                         out += tot;
                         const u32 rel0 = (u32)(r * kCells + j) * kCellBytes + lane * 16u;
