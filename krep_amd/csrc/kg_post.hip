@@ -272,25 +272,9 @@ __global__ __launch_bounds__(kPostBlock) void post_gather(const u64 *__restrict_
             const u32 c = __shfl(cnt, l);
             const u64 o = __shfl(off, l);
             const u64 sbase = (g + (u64)l) * (u64)stage_cap, org = origin + (g + (u64)l) * unit_bytes;
-            // four independent loads in flight per lane before the first store (a dense unit holds hundreds of
-            // records: the one-load-one-store loop ran at 4 TB/s of record writes, the fill rate is 6.4)
-            for (u32 i0 = lane; i0 < c; i0 += 256)
-            {
-                u64 w[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                {
-                    const u32 i = i0 + 64u * (u32)q;
-                    w[q] = (i < c) ? (fixed_len ? org + stage16[sbase + i] : stage[sbase + i]) : 0ull;
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                {
-                    const u32 i = i0 + 64u * (u32)q;
-                    if (i < c && o + i < pos_cap)
-                        put(o + i, w[q]);
-                }
-            }
+            for (u32 i = lane; i < c; i += 64)
+                if (o + i < pos_cap)
+                    put(o + i, fixed_len ? org + stage16[sbase + i] : stage[sbase + i]);
         }
     }
 }
