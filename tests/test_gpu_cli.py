@@ -48,3 +48,34 @@ def test_cli_gpu_equals_cpu(tmp_path):
     multi = run(["-t", "8", "-c", "Sherlock", str(f_big)], gpu=True)
     single = run(["-t", "1", "-c", "Sherlock", str(f_big)], gpu=False)
     assert multi[1] == single[1]
+
+
+@pytest.mark.skipif(not os.path.exists(CLI), reason="oracle/_ref/krep_gpu_cli not built (needs /root/reference)")
+def test_config1_one_gib_count(tmp_path):
+    """BASELINE.json configs[0] at full size: `krep -c -F Sherlock` over a 1 GiB file made of a 1 MiB block of
+    <= 80-byte ASCII lines repeated 1024 times, `Sherlock` on one line in 100 — the reference CLI's own CPU path
+    (one thread: its multi-chunk path double-counts) against the same CLI with the MI355X backend."""
+    import random
+    rng = random.Random(7)
+    words = [b"the", b"quick", b"brown", b"fox", b"jumps", b"over", b"lazy", b"dog", b"Holmes", b"Watson", b"Baker", b"street"]
+    block = bytearray()
+    lines = 0
+    while len(block) < (1 << 20) - 100:
+        line = b" ".join(rng.choice(words) for _ in range(rng.randint(3, 12)))[:70]
+        if lines % 100 == 17:
+            line = line[:30] + b" Sherlock " + line[30:60]
+        block += line + b"\n"
+        lines += 1
+    block += b"x" * ((1 << 20) - 1 - len(block)) + b"\n"
+    assert len(block) == 1 << 20
+    path = tmp_path / "cfg1.txt"
+    with open(path, "wb") as f:
+        for _ in range(1024):
+            f.write(block)
+    want_lines = sum(1 for ln in bytes(block).split(b"\n") if b"Sherlock" in ln) * 1024
+    cpu = run(["-t", "1", "-c", "-F", "Sherlock", str(path)], gpu=False)
+    gpu = run(["-t", "1", "-c", "-F", "Sherlock", str(path)], gpu=True)
+    assert b"krep-gpu:" not in gpu[2], gpu[2]
+    assert cpu[0] == 0 and gpu[0] == 0
+    assert gpu[1] == cpu[1], (cpu[1][:100], gpu[1][:100])
+    assert str(want_lines).encode() in gpu[1]
