@@ -853,10 +853,8 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
     const u64 unit_bytes = (u64)kAcUnitBytes;
     a.num_tiles = (a.end_hi - a.anchor + unit_bytes - 1) / unit_bytes;
     a.flags = (t->ci ? F_CI : 0) | (ww ? F_WW : 0) | (lines ? F_LINES : 0);
-    if (getenv("KREP_GPU_AC_NOVERIFY"))
+    if (getenv("KREP_GPU_AC_NOVERIFY")) // measurement hook: filter cost only (wrong results by design)
         a.flags |= 1u << 31;
-    if (getenv("KREP_GPU_AC_NOGATE"))
-        a.flags |= 1u << 30;
     a.lmax = t->lmax;
     a.has1 = t->has1; a.has2 = t->has2; a.has3 = t->has3; a.has4 = t->has4;
     a.stride = 1;
