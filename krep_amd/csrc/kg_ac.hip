@@ -34,9 +34,6 @@
 #include "kg_ac_common.h"
 #include "kg_internal.h"
 
-#ifndef KREP_AC_TOUCH
-#define KREP_AC_TOUCH 1
-#endif
 namespace kg {
 
 // SHORT: the dictionary holds 1-3-byte patterns (wildcard-expanded in the filter table, exact bitmaps in the verifier).
@@ -243,11 +240,6 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                         const u32 k = __builtin_ctz(rest);
                         rest &= rest - 1u;
                         queue[at++] = (unsigned short)(rel0 + k);
-#if KREP_AC_TOUCH
-                        // warm the L2 line the verifier will read for this candidate (the streamed text has left the
-                        // 4 MiB L2 by the time the unit drains): a discarded byte load
-                        (void)*reinterpret_cast<const volatile unsigned char *>(a.text + (useg + rel0 + k));
-#endif
                     }
                     qn += tot;
                 }
