@@ -93,3 +93,38 @@ def test_device_windows_concatenate(gpu, oracle_engine):
                 got = got[np.lexsort((got[:, 0], got[:, 1]))]
             assert sum(o.total_matches for o in outs) == want_ret
             assert np.array_equal(got, want_pos), (pats, kw)
+
+
+@pytest.mark.parametrize("workload", ["literal8", "memchr1", "ac1000"])
+def test_bench_rank_scheme_reproduces_the_single_buffer(gpu, workload):
+    """bench.py's one-process-per-GPU layout: every rank generates its own shard (+ a halo of the next one) from the
+    position-based generator, owns the matches STARTING in its shard, and the counts are summed by one all-reduce.
+    Three ranks' worth of shards scanned one after the other must give the count and the concatenated offsets of
+    the same text scanned as one buffer."""
+    import torch
+    import bench
+    wl = dict(bench.WORKLOADS[workload])
+    if wl["patterns"] is None:
+        wl["patterns"] = bench.ac_patterns()
+        wl["plant"] = bench.pack_dict(wl["patterns"])
+    n, world, halo = (24 << 20) + 4096 * 3 + 5, 3, 64   # ragged shard size: boundaries fall inside planted patterns
+    plan = gpu.plan(abi.Params(wl["patterns"], **wl["kw"]))
+    cap = n // 20
+    pos = torch.empty(2 * cap, dtype=torch.int64, device="cuda")
+    whole = torch.empty(world * n + halo, dtype=torch.uint8, device="cuda")
+    gpu.generate(whole.data_ptr(), world * n, 0, wl["kind"], bench.SEED, wl["plant"], wl["period"])
+    out = plan.scan(whole.data_ptr(), world * n, 0, world * n, 0, pos.data_ptr(), cap)
+    assert not out.overflow
+    want = pos[: 2 * out.stored].clone()
+    want_count = out.count
+    got, total = [], 0
+    for rank in range(world):
+        buf = torch.empty(n + halo, dtype=torch.uint8, device="cuda")
+        gpu.generate(buf.data_ptr(), n + halo, rank * n, wl["kind"], bench.SEED, wl["plant"], wl["period"])
+        text_len = n if rank == world - 1 else n + halo
+        o = plan.scan(buf.data_ptr(), text_len, 0, n, rank * n, pos.data_ptr(), cap)
+        assert not o.overflow
+        total += o.count
+        got.append(pos[: 2 * o.stored].clone())
+    assert total == want_count
+    assert torch.equal(torch.cat(got), want)
