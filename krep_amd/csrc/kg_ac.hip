@@ -52,11 +52,13 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
     for (u32 w = threadIdx.x; w < a.filter_words; w += kAcBlock)
         s_mem[w] = a.filter[w];
     const u32 fw = (a.filter_words + 3u) & ~3u;
-    constexpr u32 kQ = LINES ? kAcQueue / 2 : kAcQueue; // -c: half the queue, the two bitmaps need the LDS
-    constexpr u32 kPerWave = kQ / 2 + (LINES ? 2u * kAcBitmapWords : 0u); // queue | hit bitmap | newline bitmap
+    constexpr u32 kPerWave = kAcBitmapWords + (LINES ? 2u * kAcBitmapWords : 0u); // candidate | hit | newline bitmaps
     constexpr u32 XB = LINES ? kXBitsLines : kXBitsBig; // index bits of the exact-class table
-    unsigned short *queue = reinterpret_cast<unsigned short *>(s_mem + fw + wave * kPerWave);
-    u32 *bitmap = s_mem + fw + wave * kPerWave + kQ / 2;
+    // candidate bitmap of the unit: one bit per end position, written as the lane's 16-bit filter result per cell —
+    // entry (r * 8 + j) * 64 + lane, so that index order is position order
+    u32 *cbits = s_mem + fw + wave * kPerWave;
+    unsigned short *cbits16 = reinterpret_cast<unsigned short *>(cbits);
+    u32 *bitmap = cbits + kAcBitmapWords;
     unsigned short *nlmap = reinterpret_cast<unsigned short *>(bitmap + kAcBitmapWords); // 16 bits per lane and cell
     if (LINES)
         for (u32 w = lane; w < kAcBitmapWords; w += 64)
@@ -98,9 +100,6 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
         const bool do_stage = !emit_final && want_pos;
         const u64 fbase = do_final ? a.offsets[unit] : 0ull;
         u32 wcnt = 0; // matches of the unit so far == rank of the next one (uniform)
-        u32 qn = 0;   // queued candidates (uniform)
-
-        bool flooded = false; // the candidate queue overflowed (uniform)
 
 #pragma unroll
         for (int r = 0; r < kAcRounds; ++r)
@@ -205,45 +204,9 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
             if (a.flags & (1u << 31)) // ablation hook (KREP_GPU_AC_NOVERIFY): filter cost only
                 cand = 0;
 
-            // ---- queue the candidates in position order -------------------------------------------------
-            if (!flooded && __ballot(cand != 0u))
-            {
-                // lanes before me hold how many candidates?  Almost always at most one per lane: one ballot; the
-                // bit-plane sum only when some lane has two or more
-                const u32 c = __popc(cand);
-                u32 tot, ex;
-                if (!__ballot(c > 1u))
-                {
-                    const u64 m = __ballot(c != 0u);
-                    tot = (u32)__popcll(m);
-                    ex = (u32)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
-                }
-                else
-                {
-                    tot = ex = 0;
-#pragma unroll
-                    for (int b = 0; b < 5; ++b)
-                    {
-                        const u64 m = __ballot((c >> b) & 1u);
-                        tot += (u32)__popcll(m) << b;
-                        ex += (u32)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)) << b;
-                    }
-                }
-                if (qn + tot > kQ)
-                    flooded = true; // > 6 % of the unit's positions are candidates: verify every position instead
-                else
-                {
-                    u32 at = qn + ex, rest = cand;
-                    const u32 rel0 = (u32)r * kSegBytes + (u32)j * kCellBytes + lane * 16u;
-                    while (rest)
-                    {
-                        const u32 k = __builtin_ctz(rest);
-                        rest &= rest - 1u;
-                        queue[at++] = (unsigned short)(rel0 + k);
-                    }
-                    qn += tot;
-                }
-            }
+            // ---- the lane's candidates go into the unit's bitmap; they are enumerated once per unit (below) instead
+            //      of ranked per cell (ballots + a divergent store loop: ~15 VALU per cell), and nothing overflows ----
+            cbits16[(u32)r * (kSegBytes / 16) + (u32)j * kWave + lane] = (unsigned short)cand;
         };
         if (fast_now)
         { // straight-line: no branch between a prefetch and the next cell's read of d[]
@@ -290,19 +253,69 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
         carry = before;
         } // rounds
 
-        // ---- verify (and stage/emit) the candidates, 64 at a time, one per lane; a flooded unit walks
-        //      every end position of the unit instead (exact, slow, pathological inputs only) ------------
+        // ---- verify (and stage/emit) the candidates, 64 at a time, one per lane.  Lane L owns the 256 positions
+        //      [256 L, 256 L + 256) of the bitmap (8 dwords); a wave scan of the popcounts gives every lane its rank
+        //      range, and the lane verifying rank q finds its candidate by a binary search over those sums and a
+        //      select of the t-th set bit in the owner's block ------------------------------------------------
         {
-            const u32 n = flooded ? kAcUnitBytes : qn;
-            const bool pair = STRIDE == 2 && !flooded; // a queue entry stands for the ends t and t + 1
+            u32 myw[8];
+            u32 mycnt = 0;
+            {
+                const uint4 lo = *reinterpret_cast<const uint4 *>(cbits + lane * 8u), hi = *reinterpret_cast<const uint4 *>(cbits + lane * 8u + 4u);
+                myw[0] = lo.x; myw[1] = lo.y; myw[2] = lo.z; myw[3] = lo.w;
+                myw[4] = hi.x; myw[5] = hi.y; myw[6] = hi.z; myw[7] = hi.w;
+#pragma unroll
+                for (int w = 0; w < 8; ++w)
+                    mycnt += (u32)__popc(myw[w]);
+            }
+            u32 incl = mycnt; // inclusive prefix of the candidate counts over lanes
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1)
+            {
+                const u32 t = __shfl_up(incl, o);
+                if (lane >= (u32)o)
+                    incl += t;
+            }
+            const u32 n = __shfl(incl, 63);
+            constexpr bool pair = STRIDE == 2; // a candidate stands for the ends t and t + 1
             for (u32 b0 = 0; b0 < n; b0 += 64)
             {
                 const u32 qi = b0 + lane;
                 const bool live = qi < n;
-                const u32 rel = flooded ? qi : (live ? queue[qi] : 0u);
+                u32 rel = 0;
+                {
+                    // owner = first lane whose inclusive sum exceeds my rank
+                    u32 own = 0;
+#pragma unroll
+                    for (u32 step = 32; step; step >>= 1)
+                    {
+                        const u32 t = __shfl(incl, (own + step - 1u) & 63u);
+                        if (t <= qi)
+                            own += step;
+                    }
+                    own &= 63u;
+                    const u32 oincl = __shfl(incl, own), ocnt = __shfl(mycnt, own);
+                    if (live)
+                    {
+                        u32 t = qi - (oincl - ocnt); // my candidate is the t-th set bit of the owner's block
+                        const u32 *blk = cbits + own * 8u;
+                        u32 w = 0, word = blk[0];
+                        for (;;)
+                        {
+                            const u32 c = (u32)__popc(word);
+                            if (t < c)
+                                break;
+                            t -= c;
+                            word = blk[++w];
+                        }
+                        for (; t; --t)
+                            word &= word - 1u;
+                        rel = own * 256u + w * 32u + (u32)__builtin_ctz(word);
+                    }
+                }
                 const u64 pos = useg + rel;
                 bool liveA = live, liveB = false;
-                if (flooded || STRIDE == 2)
+                if (STRIDE == 2)
                     liveA = live && pos >= a.end_lo && pos < a.end_hi;
                 if (pair)
                     liveB = live && pos + 1 >= a.end_lo && pos + 1 < a.end_hi;
@@ -311,15 +324,12 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 bool simA = false, simB = false;
                 if (STRIDE == 2)
                 {
-                    bool slA = liveA, slB = false; // flooded: every end takes the level walk
-                    if (pair)
-                    {
-                        u32 mA, mB;
-                        ac_walk_probe2<CI, SHORT>(a, pos, liveA, liveB, LINES, mA, slA, mB, slB);
-                        dmA = mA; dmB = mB;
-                        cA = (u32)__popc(mA); cB = (u32)__popc(mB);
-                        simA = simB = true;
-                    }
+                    bool slA, slB;
+                    u32 mA, mB;
+                    ac_walk_probe2<CI, SHORT>(a, pos, liveA, liveB, LINES, mA, slA, mB, slB);
+                    dmA = mA; dmB = mB;
+                    cA = (u32)__popc(mA); cB = (u32)__popc(mB);
+                    simA = simB = true;
 #pragma unroll 1
                     for (int e = 0; e < 2; ++e) // the one call site of the level walk
                         if (e ? slB : slA)
@@ -778,7 +788,7 @@ int g_ac_force_stage_cap = 0; // test hook (krep_gpu_debug_force_stage_cap)
 
 static u32 ac_lds_bytes(u32 filter_words, bool lines)
 {
-    const u32 per_wave = (lines ? kAcQueue / 2 : kAcQueue) / 2 + (lines ? 2u * kAcBitmapWords : 0u);
+    const u32 per_wave = kAcBitmapWords + (lines ? 2u * kAcBitmapWords : 0u);
     return (((filter_words + 3u) & ~3u) + kAcWaves * per_wave) * (u32)sizeof(u32);
 }
 

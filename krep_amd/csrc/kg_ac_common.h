@@ -434,7 +434,6 @@ __device__ __forceinline__ void ac_walk_probe2(const AcArgs &a, u64 i, bool live
 }
 
 constexpr u32 kAcUnitsPerTicketMax = 8; // fused kernel: up to 128 KiB per wave ticket (one cold round in 16), fewer on small texts
-constexpr u32 kAcQueue = 1024;         // candidate queue entries per wave (u16 each: unit-relative end index)
 constexpr int kAcRounds = 2;            // load rounds per unit: one candidate drain per 16 KiB (53 of 64 lanes busy)
 constexpr u32 kAcUnitBytes = kAcRounds * kSegBytes;
 constexpr u32 kAcBitmapWords = kAcUnitBytes / 32; // one bit per end position of a unit (LINES)
