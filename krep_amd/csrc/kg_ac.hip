@@ -13,7 +13,7 @@
 //     Positions whose bit is clear cannot end a pattern.  The haystack is read once with the same coalesced
 //     16 B/lane loads as the literal scan, the next round streaming into the registers the current one vacates.
 //   * VERIFY (candidates only, ~0.2 % of positions for 1000 random patterns): one candidate per lane, 64 at a time
-//     from a per-wave LDS queue.  The exact last 4 bytes select an entry of a sparse hash table that carries the
+//     from the unit's candidate bitmap in LDS.  The exact last 4 bytes select an entry of a sparse hash table that carries the
 //     next <= 12 bytes of the reversed-trie chain and the depths at which patterns end (kg_ac_common.h); 1-3-byte
 //     patterns are exact bitmap lookups.  Two dependent accesses per candidate; the level-by-level walk of the
 //     REVERSED-pattern trie (edges in an open-addressing table, L2-resident) remains for what that cannot express.
@@ -44,7 +44,7 @@ namespace kg {
 template <bool CI, bool LINES, bool SHORT, int STRIDE>
 __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) u32 s_mem[]; // filter | tickets | per-wave queue (+ bitmap)
+    extern __shared__ __attribute__((aligned(16))) u32 s_mem[]; // filter table | per wave: candidate bitmap (+ hit and newline bitmaps for -c)
     const u32 lane = ac_lane();
     const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if ((u32)(size_t)((__attribute__((address_space(3))) u32 *)s_mem) != 0u)
