@@ -132,10 +132,6 @@ template <int KIND, bool MASKED, bool CI, bool LINES, int R>
 __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
 {
     __shared__ u64 s_ticket[2];
-    // dense units: the per-lane hit masks transposed through LDS (see the staging code); R * 4 dwords per owner lane,
-    // padded by one dword so that neither the cell-major writes nor the lane-major reads conflict
-    constexpr u32 kOwnWords = (u32)R * 4u, kOwnPitch = kOwnWords + 1u;
-    __shared__ u32 s_masks[kWavesPerBlk][64 * kOwnPitch];
     const u32 lane = lane_id();
     const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool want_pos = (a.flags & F_POS) != 0;
@@ -455,52 +451,6 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
                 // unit-relative 16-bit offsets (a unit spans <= 32 KiB): 2 B staged per hit instead of 8
                 unsigned short *slot = reinterpret_cast<unsigned short *>(a.stage) + unit * (u64)a.stage_cap;
                 u32 out = 0;
-                if (wcnt >= 48u)
-                {
-                    // Dense unit (the 1 % single-byte workload: ~330 hits): ranking every cell's hits with ballots
-                    // costs ~30 instructions per cell.  Instead the 16-bit masks go to LDS in cell-major order
-                    // (= position order), every lane takes over R * 128 consecutive positions, counts them, one wave
-                    // scan yields its first rank, and it writes its run of offsets.
-                    u32 *sm = s_masks[wave];
-                    unsigned short *sm16 = reinterpret_cast<unsigned short *>(sm);
-#pragma unroll
-                    for (int r = 0; r < R; ++r)
-#pragma unroll
-                        for (int j = 0; j < kCells; ++j)
-                        {
-                            const u32 e = (u32)(r * kCells + j) * 64u + lane; // u16 entry index, dword d = e / 2
-                            const u32 d = e >> 1;
-                            sm16[2u * (d + d / kOwnWords) + (e & 1u)] = (unsigned short)M[r][j];
-                        }
-                    u32 cnt = 0;
-#pragma unroll 1
-                    for (u32 w = 0; w < kOwnWords; ++w)
-                        cnt += (u32)__popc(sm[lane * kOwnPitch + w]);
-                    u32 incl = cnt;
-#pragma unroll
-                    for (int o = 1; o < 64; o <<= 1)
-                    {
-                        const u32 t = __shfl_up(incl, o);
-                        if (lane >= (u32)o)
-                            incl += t;
-                    }
-                    u32 idx = incl - cnt;
-#pragma unroll 1
-                    for (u32 w = 0; w < kOwnWords; ++w)
-                    {
-                        u32 word = sm[lane * kOwnPitch + w];
-                        const u32 rel0 = lane * (kOwnWords * 32u) + w * 32u;
-                        while (word)
-                        {
-                            const u32 k = __builtin_ctz(word);
-                            word &= word - 1u;
-                            if (idx < a.stage_cap)
-                                slot[idx] = (unsigned short)(rel0 + k);
-                            ++idx;
-                        }
-                    }
-                }
-                else
 #pragma unroll
                 for (int r = 0; r < R; ++r)
                 {
