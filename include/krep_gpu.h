@@ -200,6 +200,21 @@ void krep_gpu_generate_host(void *dst, size_t len, size_t global_off, int kind, 
  * returns the global distinct-line count given shard outputs in shard order. */
 uint64_t krep_gpu_combine_line_counts(const krep_gpu_scan_out_t *shards, int n);
 
+/* ---- formatter-side post-processing in HBM (what search_file() does on one host thread after the scan) --------------
+ * krep_gpu_order_by_start: the (start, end) order of compare_match_positions (krep.c:420-434) that search_file()
+ *   establishes with qsort() before printing (krep.c:3018-3023).  Input: n records ascending in `end` (the order of
+ *   every operator of this library); one stable device radix sort keyed on `start`, in place.
+ * krep_gpu_line_numbers: the 1-based line number of every record's start, as print_matching_items() derives them by
+ *   counting newlines (krep.c:589-668); d_lines[n] on the device.
+ * krep_gpu_set_result_order(1): krep_gpu_aho_corasick_search() hands back its records already in (start, end) order
+ *   (sorted on the device before the copy to the host), so the caller may skip its qsort().  Default 0: the
+ *   reference's emission order (end ascending, longest first).
+ * All return 0, or 2 with krep_gpu_last_error() set. */
+int krep_gpu_order_by_start(match_position_t *d_positions, uint64_t n, size_t text_len, void *stream);
+int krep_gpu_line_numbers(const void *d_text, size_t text_len, const match_position_t *d_positions, uint64_t n,
+                          uint64_t *d_lines, void *stream);
+void krep_gpu_set_result_order(int by_start);
+
 int krep_gpu_device_count(void);
 const char *krep_gpu_last_error(void); /* "" when the last call on this thread succeeded */
 void krep_gpu_clear_error(void);

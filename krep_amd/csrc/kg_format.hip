@@ -1,0 +1,171 @@
+// kg_format.hip — device-side post-processing of a match list for the reference's output formatter
+// (SURVEY.md §8f-4).  After the scan the reference's host code
+//   * qsort()s all records by (start, end) on one thread before printing (krep.c:3018-3023, comparator :420-434) —
+//     the multi-pattern scan emits them in (end, longest-first) order (aho_corasick.c:353-431);
+//   * derives the line number of every printed match by re-counting newlines (krep.c:589-668).
+// Both are data-parallel; these entry points do them in HBM so that the host tail is a plain copy.
+//
+// Ordering: the list is already ascending in `end`, so ONE stable sort keyed on `start` yields the lexicographic
+// (start, end) order.  The sort itself is the vendor's device radix sort (hipCUB, header-only in ROCm) — a
+// bandwidth-bound primitive off the hot path; the split/merge and the line-number kernels are ours.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include "../../include/krep_gpu.h"
+#include "kg_internal.h"
+
+namespace kg {
+
+using u32 = uint32_t;
+using u64 = unsigned long long;
+
+#define FCHK(x)                                                                                \
+    do                                                                                         \
+    {                                                                                          \
+        hipError_t e_ = (x);                                                                   \
+        if (e_ != hipSuccess)                                                                  \
+        {                                                                                      \
+            rc = fail("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+            goto done;                                                                         \
+        }                                                                                      \
+    } while (0)
+
+__global__ void fmt_split(const u64 *__restrict__ rec, u64 n, u64 *__restrict__ starts, u64 *__restrict__ ends)
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+    {
+        const uint4 r = *reinterpret_cast<const uint4 *>(rec + 2 * i);
+        starts[i] = ((u64)r.y << 32) | r.x;
+        ends[i] = ((u64)r.w << 32) | r.z;
+    }
+}
+
+__global__ void fmt_merge(const u64 *__restrict__ starts, const u64 *__restrict__ ends, u64 n, u64 *__restrict__ rec)
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+    {
+        const u64 s = starts[i], e = ends[i];
+        *reinterpret_cast<uint4 *>(rec + 2 * i) = make_uint4((u32)s, (u32)(s >> 32), (u32)e, (u32)(e >> 32));
+    }
+}
+
+constexpr u32 kLineBlock = 4096; // newline counts are kept per 4 KiB of text
+
+// one wave per 4 KiB block: 4 x (64 lanes x 16 B), SWAR byte-equality + popcount
+__global__ __launch_bounds__(256) void fmt_count_newlines(const uint8_t *__restrict__ text, u64 text_len, u64 nblocks,
+                                                          u64 *__restrict__ counts)
+{
+    const u32 lane = threadIdx.x & 63u;
+    const u64 wid = (u64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nw = (u64)gridDim.x * (blockDim.x >> 6);
+    for (u64 b = wid; b < nblocks; b += nw)
+    {
+        u32 c = 0;
+        const u64 base = b * kLineBlock;
+        for (u32 it = 0; it < kLineBlock / 1024; ++it)
+        {
+            const u64 off = base + (u64)it * 1024 + (u64)lane * 16;
+            if (off + 16 <= text_len && ((reinterpret_cast<size_t>(text) + off) & 15u) == 0)
+            {
+                const uint4 v = *reinterpret_cast<const uint4 *>(text + off);
+                const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                {
+                    const u32 y = w[q] ^ 0x0a0a0a0au;
+                    c += (u32)__popc(~(((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y | 0x7f7f7f7fu));
+                }
+            }
+            else
+                for (u32 q = 0; q < 16; ++q)
+                    if (off + q < text_len && text[off + q] == '\n')
+                        ++c;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1)
+            c += __shfl_xor(c, o);
+        if (lane == 0)
+            counts[b] = c;
+    }
+}
+
+// line number (1-based) of text[start]: newlines in the blocks before + newlines of the own block before `start`
+__global__ void fmt_line_numbers(const uint8_t *__restrict__ text, const u64 *__restrict__ rec, u64 n,
+                                 const u64 *__restrict__ block_prefix, u64 *__restrict__ lines)
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const u64 s = rec[2 * i], b = s / kLineBlock;
+    u64 ln = 1 + block_prefix[b];
+    for (u64 p = b * kLineBlock; p < s; ++p)
+        ln += text[p] == '\n';
+    lines[i] = ln;
+}
+
+} // namespace kg
+
+using namespace kg;
+
+extern "C" int krep_gpu_order_by_start(match_position_t *d_positions, uint64_t n, size_t text_len, void *stream)
+{
+    if (n < 2)
+        return 0;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = 0;
+    u64 *buf = nullptr;
+    void *tmp = nullptr;
+    size_t tmp_bytes = 0;
+    int bits = 1;
+    while (bits < 64 && ((u64)text_len >> bits))
+        ++bits;
+    {
+        FCHK(hipMalloc(&buf, 4 * n * sizeof(u64)));
+        u64 *k0 = buf, *k1 = buf + n, *v0 = buf + 2 * n, *v1 = buf + 3 * n;
+        const u32 grid = (u32)((n + 255) / 256);
+        hipLaunchKernelGGL(fmt_split, dim3(grid), dim3(256), 0, st, (const u64 *)d_positions, (u64)n, k0, v0);
+        FCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k0, k1, v0, v1, (int)n, 0, bits, st));
+        FCHK(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+        FCHK(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, k0, k1, v0, v1, (int)n, 0, bits, st));
+        hipLaunchKernelGGL(fmt_merge, dim3(grid), dim3(256), 0, st, (const u64 *)k1, (const u64 *)v1, (u64)n, (u64 *)d_positions);
+        FCHK(hipGetLastError());
+        FCHK(hipStreamSynchronize(st));
+    }
+done:
+    if (tmp) (void)hipFree(tmp);
+    if (buf) (void)hipFree(buf);
+    return rc;
+}
+
+extern "C" int krep_gpu_line_numbers(const void *d_text, size_t text_len, const match_position_t *d_positions, uint64_t n,
+                                     uint64_t *d_lines, void *stream)
+{
+    if (!n)
+        return 0;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = 0;
+    const u64 nblocks = ((u64)text_len + kLineBlock - 1) / kLineBlock + 1; // + 1: a match may start at text_len
+    u64 *cnt = nullptr;
+    void *tmp = nullptr;
+    size_t tmp_bytes = 0;
+    {
+        FCHK(hipMalloc(&cnt, 2 * nblocks * sizeof(u64)));
+        u64 *pre = cnt + nblocks;
+        FCHK(hipMemsetAsync(cnt, 0, nblocks * sizeof(u64), st));
+        const u32 grid = (u32)std::min<u64>((nblocks + 3) / 4, 256u * 32u);
+        hipLaunchKernelGGL(fmt_count_newlines, dim3(grid), dim3(256), 0, st, (const uint8_t *)d_text, (u64)text_len,
+                           (u64)(nblocks - 1), cnt);
+        FCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, cnt, pre, (int)nblocks, st));
+        FCHK(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+        FCHK(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, cnt, pre, (int)nblocks, st));
+        hipLaunchKernelGGL(fmt_line_numbers, dim3((u32)((n + 255) / 256)), dim3(256), 0, st, (const uint8_t *)d_text,
+                           (const u64 *)d_positions, (u64)n, (const u64 *)pre, (u64 *)d_lines);
+        FCHK(hipGetLastError());
+        FCHK(hipStreamSynchronize(st));
+    }
+done:
+    if (tmp) (void)hipFree(tmp);
+    if (cnt) (void)hipFree(cnt);
+    return rc;
+}

@@ -59,6 +59,8 @@ static int g_simd = KREP_REF_AVX2, g_only_matching = 0, g_no_simd = 0, g_algo_ov
 extern "C" void krep_gpu_set_reference_simd(int l) { g_simd = l; }
 extern "C" int krep_gpu_get_reference_simd(void) { return g_simd; }
 extern "C" void krep_gpu_set_only_matching(int on) { g_only_matching = on != 0; }
+static int g_result_order = 0;
+extern "C" void krep_gpu_set_result_order(int by_start) { g_result_order = by_start != 0; }
 namespace kg { int current_only_matching() { return g_only_matching; } }
 extern "C" void krep_gpu_set_force_no_simd(int on) { g_no_simd = on != 0; }
 extern "C" void krep_gpu_set_algo_override(int a) { g_algo_override = a; }
@@ -942,6 +944,12 @@ static uint64_t run_host_operator(const search_params_t *params, const char *tex
         ret = so.count;
         if (want_pos && so.stored)
         {
+            if (g_result_order && pl->ref_algo == KREP_RA_AHO_CORASICK &&
+                krep_gpu_order_by_start((match_position_t *)tl_pos.p, so.stored, text_len, nullptr))
+            {
+                ret = 0;
+                break;
+            }
             std::vector<match_position_t> tmp(so.stored);
             if (hipMemcpy(tmp.data(), tl_pos.p, so.stored * sizeof(match_position_t), hipMemcpyDeviceToHost) != hipSuccess)
             {

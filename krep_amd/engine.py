@@ -66,8 +66,13 @@ class Engine:
         L.krep_gpu_mirror_select.argtypes = [C.POINTER(abi.SearchParams), C.c_size_t]
         L.krep_gpu_algorithm_name.restype = C.c_char_p
         L.krep_gpu_algorithm_name.argtypes = [C.c_int]
+        L.krep_gpu_order_by_start.restype = C.c_int
+        L.krep_gpu_order_by_start.argtypes = [C.c_void_p, C.c_uint64, C.c_size_t, C.c_void_p]
+        L.krep_gpu_line_numbers.restype = C.c_int
+        L.krep_gpu_line_numbers.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
         for n in ("krep_gpu_set_reference_simd", "krep_gpu_set_only_matching", "krep_gpu_set_force_no_simd",
-                  "krep_gpu_set_algo_override", "krep_gpu_debug_force_rounds", "krep_gpu_debug_force_stage_cap"):
+                  "krep_gpu_set_algo_override", "krep_gpu_debug_force_rounds", "krep_gpu_debug_force_stage_cap",
+                  "krep_gpu_set_result_order"):
             getattr(L, n).restype = None
             getattr(L, n).argtypes = [C.c_int]
         L.krep_gpu_get_reference_simd.restype = C.c_int
@@ -103,6 +108,19 @@ class Engine:
 
     def device_count(self) -> int:
         return int(self.lib.krep_gpu_device_count())
+
+    # ---- formatter-side post-processing on the device (krep.c:3018-3023, :589-668) ----
+    def set_result_order(self, by_start: bool):
+        self.lib.krep_gpu_set_result_order(int(by_start))
+
+    def order_by_start(self, d_positions: int, n: int, text_len: int, stream: int = 0):
+        if self.lib.krep_gpu_order_by_start(C.c_void_p(d_positions), n, text_len, C.c_void_p(stream)):
+            raise KrepGpuError("krep_gpu_order_by_start failed: " + self.last_error())
+
+    def line_numbers(self, d_text: int, text_len: int, d_positions: int, n: int, d_lines: int, stream: int = 0):
+        if self.lib.krep_gpu_line_numbers(C.c_void_p(d_text), text_len, C.c_void_p(d_positions), n, C.c_void_p(d_lines),
+                                          C.c_void_p(stream)):
+            raise KrepGpuError("krep_gpu_line_numbers failed: " + self.last_error())
 
     # ---- search_func_t-shaped operators on host buffers ----
     def _ptr(self, text):
