@@ -2,7 +2,7 @@
 """Builds the reference krep CLI with the MI355X backend wired in — the "drops into the existing CLI" proof.
 
 Nothing of the reference is stored in this repository: the script reads /root/reference/krep.c, applies the
-five small insertions described in INTEGRATION.md to a TEMPORARY copy (regex anchors, no context lines kept
+six small edits described in INTEGRATION.md to a TEMPORARY copy (regex anchors, no context lines kept
 here), compiles it together with the untouched aho_corasick.c and links libkrep_gpu.so.  Output:
 oracle/_ref/krep_gpu_cli (git-ignored; travels to the GPU box with the other prebuilt checker binaries).
 
@@ -44,6 +44,7 @@ def main():
         krep_gpu_set_reference_simd(KREP_USE_AVX512 ? KREP_REF_AVX512 : KREP_USE_AVX2 ? KREP_REF_AVX2
                                     : KREP_USE_SSE42 ? KREP_REF_SSE42 : KREP_USE_NEON ? KREP_REF_NEON : KREP_REF_SCALAR);
         krep_gpu_set_only_matching(only_matching);
+        krep_gpu_set_result_order(1); /* records come back in (start, end) order: step 6 skips the qsort */
         krep_gpu_set_force_no_simd(force_no_simd);
         krep_gpu_set_algo_override(!algo_override || !strcmp(algo_override, "auto") ? KREP_ALGO_AUTO
                                    : !strcmp(algo_override, "bm") ? KREP_ALGO_BM
@@ -60,6 +61,12 @@ def main():
     src = insert_after(src, r'^\s*if \(actual_thread_count <= 0\)\s*\n\s*actual_thread_count = 1;', one_chunk)
     # 5. the CLI switch: environment variable, read at the top of main() (krep.c:3451)
     src = insert_after(src, r'^int main\(int argc, char \*argv\[\]\)\s*\{', '\n#ifdef KREP_WITH_GPU\n    use_gpu = getenv("KREP_GPU") != NULL;\n#endif\n')
+    # 6. the records of the GPU operators arrive in compare_match_positions order (sorted in HBM): no host qsort
+    #    (krep.c:3020-3023)
+    pat = r'if \(global_matches->count > 1\)(\s*\{\s*qsort\(global_matches->positions)'
+    if not re.search(pat, src):
+        raise SystemExit("anchor not found: qsort of the global match list")
+    src = re.sub(pat, r'if (global_matches->count > 1\n#ifdef KREP_WITH_GPU\n            && !(use_gpu && !current_params.use_regex)\n#endif\n            )\1', src, count=1)
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     with tempfile.TemporaryDirectory() as td:
         patched = os.path.join(td, "krep_gpu_patched.c")

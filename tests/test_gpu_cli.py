@@ -38,6 +38,10 @@ def test_cli_gpu_equals_cpu(tmp_path):
         (["-c", "-m", "7", "Sherlock"], f_big), (["Sherlock"], f_small), (["-o", "fox"], f_small),
         (["-i", "SHERLOCK"], f_small), (["-w", "fox"], f_small), (["-e", "fox", "-e", "Holmes"], f_small),
         (["-c", "absent-pattern"], f_big),
+        # overlapping matches of several patterns, printed one per line: the GPU records arrive already in the
+        # formatter's (start, end) order (sorted in HBM, the patched CLI skips its qsort)
+        (["-o", "-e", "Sherlock", "-e", "the", "-e", "he", "-e", "her"], f_big),
+        (["-e", "Sherlock", "-e", "lock"], f_big),
     ]
     for args, path in cases:
         cpu = run(["-t", "1", "--color=never"] + args + [str(path)], gpu=False)
