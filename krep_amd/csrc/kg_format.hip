@@ -123,6 +123,8 @@ extern "C" int krep_gpu_order_by_start(match_position_t *d_positions, uint64_t n
 {
     if (n < 2)
         return 0;
+    if (n > 0x7fffffffull)
+        return fail("krep_gpu_order_by_start: %llu records exceed the device sort's 2^31-1 item limit", (unsigned long long)n);
     hipStream_t st = (hipStream_t)stream;
     int rc = 0;
     u64 *buf = nullptr;
@@ -154,6 +156,8 @@ extern "C" int krep_gpu_line_numbers(const void *d_text, size_t text_len, const 
 {
     if (!n)
         return 0;
+    if ((u64)text_len / kLineBlock + 2 > 0x7fffffffull)
+        return fail("krep_gpu_line_numbers: text too long for the device scan");
     hipStream_t st = (hipStream_t)stream;
     int rc = 0;
     const u64 nblocks = ((u64)text_len + kLineBlock - 1) / kLineBlock + 1; // + 1: a match may start at text_len

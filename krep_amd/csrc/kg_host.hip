@@ -62,6 +62,7 @@ extern "C" void krep_gpu_set_only_matching(int on) { g_only_matching = on != 0; 
 static int g_result_order = 0;
 extern "C" void krep_gpu_set_result_order(int by_start) { g_result_order = by_start != 0; }
 namespace kg { int current_only_matching() { return g_only_matching; } }
+namespace kg { int current_result_order() { return g_result_order; } }
 extern "C" void krep_gpu_set_force_no_simd(int on) { g_no_simd = on != 0; }
 extern "C" void krep_gpu_set_algo_override(int a) { g_algo_override = a; }
 static int g_force_rounds = 0; // test hook: 0 = auto, 1 / 4 = force the tile shape

@@ -51,6 +51,7 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
             int time_it, hipEvent_t ev0, hipEvent_t ev1, krep_gpu_scan_out_t *out);
 
 int current_only_matching();
+int current_result_order(); // krep_gpu_set_result_order(): 1 = hand records back in (start, end) order
 int stage_to_device(uint8_t *d_dst, const char *src, size_t len, int device); // kg_host.hip: pinned double-buffered H2D
 void stage_release(); // the mirrored file-static `only_matching` (krep.c:117)
 

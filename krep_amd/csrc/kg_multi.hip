@@ -206,6 +206,10 @@ uint64_t multi_gpu_search(const search_params_t *params, const char *buf, size_t
             memmove(&all[f + 1], &all[f], 4095 * sizeof(match_position_t));
             all[f] = extra;
         }
+        if (params->num_patterns > 1 && current_result_order()) // the formatter's order (krep.c:420-434)
+            std::sort(all.begin(), all.begin() + n, [](const match_position_t &a, const match_position_t &b) {
+                return a.start_offset != b.start_offset ? a.start_offset < b.start_offset : a.end_offset < b.end_offset;
+            });
         const uint64_t need = out->count + n;
         if (need > out->capacity || !out->positions)
         {

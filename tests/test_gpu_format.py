@@ -68,3 +68,19 @@ def test_host_operator_hands_back_sorted_records(gpu, oracle_engine):
     finally:
         gpu.set_result_order(False)
     assert ret == len(want) and np.array_equal(got, want)
+
+
+def test_search_buffer_shards_hand_back_sorted_records(gpu, oracle_engine):
+    rng = np.random.RandomState(78)
+    alpha = b"abc \n"
+    text = cases.rand_text(rng, 200_000, alpha)
+    pats = [cases.pick_pattern(rng, text, m, alpha) for m in (2, 4, 6, 11)]
+    want = oracle_engine.call(abi.RA_AHO_CORASICK, abi.Params(pats), text)[1]
+    want = want[np.lexsort((want[:, 1], want[:, 0]))]
+    try:
+        gpu.set_result_order(True)
+        for shards in (1, 3):
+            rc, cnt, got = gpu.search_buffer(abi.Params(pats), text, num_gpus=shards)
+            assert rc == 0 and np.array_equal(got, want), shards
+    finally:
+        gpu.set_result_order(False)
