@@ -248,7 +248,7 @@ struct krep_gpu_plan
     size_t max_count = SIZE_MAX;
     std::vector<std::vector<uint8_t>> pats; // as given
     // single literal
-    uint32_t m = 0, p0 = 0, p1 = 0, k0 = 0, k1 = 0;
+    uint32_t m = 0, p0 = 0, p1 = 0, k0 = 0, k1 = 0, l0 = 0, l1 = 0;
     std::vector<uint8_t> pat_folded; // folded when !cs
     bool has_border = false;         // a proper prefix is also a suffix => all-occurrences != greedy
     bool has_newline = false;
@@ -355,6 +355,16 @@ extern "C" krep_gpu_plan_t *krep_gpu_plan_create(const search_params_t *p, int o
         memcpy(&pl->k1, k + 4, 4);
         if (pl->m == 1)
             pl->p0 = 0x01010101u * w[0];
+        if (!pl->cs)
+        { // letter lanes of the first 8 (folded) pattern bytes
+            uint8_t l[8] = {0};
+            for (uint32_t i = 0; i < 8 && i < pl->m; ++i)
+                l[i] = (w[i] >= 'a' && w[i] <= 'z') ? 0x20 : 0;
+            memcpy(&pl->l0, l, 4);
+            memcpy(&pl->l1, l + 4, 4);
+            if (pl->m == 1)
+                pl->l0 = 0x01010101u * l[0];
+        }
         ok = hipMalloc(&pl->d_pat, pl->m) == hipSuccess &&
              hipMemcpy(pl->d_pat, pl->pat_folded.data(), pl->m, hipMemcpyHostToDevice) == hipSuccess;
     }
@@ -507,6 +517,7 @@ static int scan_literal(krep_gpu_plan *pl, int algo, const uint8_t *d_text, size
     }
     a.m = m;
     a.p0 = pl->p0; a.p1 = pl->p1; a.k0 = pl->k0; a.k1 = pl->k1;
+    a.l0 = pl->l0; a.l1 = pl->l1;
     a.pat = pl->d_pat;
     a.ctr = pl->d_ctr;
 

@@ -252,19 +252,16 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
                     else
                         NL = exact_nl();
                 }
-                if (CI)
-                {
-#pragma unroll
-                    for (int w = 0; w < (KIND == 1 ? 4 : 6); ++w)
-                        D[w] = fold4(D[w]);
-                }
+                // -i: the text is NOT folded; a letter of the (folded) pattern is compared as (x | 0x20) == p, which
+                // holds exactly for its two cases (C locale) — one OR per compared dword instead of a SWAR fold of
+                // the whole window
 
                 u32 m16 = 0;
                 if (KIND == 1)
                 {
 #pragma unroll
                     for (int w = 0; w < 4; ++w)
-                        m16 |= movemask4(eq_bytes(D[w], a.p0)) << (4 * w);
+                        m16 |= movemask4(eq_bytes(CI ? (D[w] | a.l0) : D[w], a.p0)) << (4 * w);
                 }
                 else
                 {
@@ -279,7 +276,8 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
                     for (int k = 0; k < 16; ++k)
                     {
                         A0[k] = A(k);
-                        c[k] = (KIND == 4 && MASKED) ? (((A0[k] ^ a.p0) & a.k0) == 0u) : (A0[k] == a.p0);
+                        const u32 x0 = CI ? (A0[k] | a.l0) : A0[k];
+                        c[k] = (KIND == 4 && MASKED) ? (((x0 ^ a.p0) & a.k0) == 0u) : (x0 == a.p0);
                         any |= __ballot(c[k]);
                     }
                     if (any) // wave-uniform: almost never taken for a selective 4-byte prefix
@@ -290,7 +288,7 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
                             bool h = c[k];
                             if (KIND >= 8)
                             {
-                                const u32 a4 = (k < 12) ? A0[k + 4] : A(k + 4);
+                                const u32 a4 = ((k < 12) ? A0[k + 4] : A(k + 4)) | (CI ? a.l1 : 0u);
                                 h = h && ((KIND == 8 && MASKED) ? (((a4 ^ a.p1) & a.k1) == 0u) : (a4 == a.p1));
                             }
                             m16 |= h ? (1u << k) : 0u;
