@@ -66,6 +66,7 @@ struct LitArgs {
     uint32_t m;                   // pattern length (1..1024)
     uint32_t flags;
     uint32_t p0, p1, k0, k1;      // first <=8 pattern bytes (folded when F_CI) and their byte masks
+    uint32_t p2, p3, k2, k3, l2, l3; // pattern bytes 8..15 (m = 9..16 verify in registers), their byte and letter masks
     uint32_t l0, l1;              // F_CI: 0x20 in the byte lanes where the (folded) pattern holds a letter — (x | l) == p
                                   // is the C-locale case-insensitive compare of that byte (one OR instead of folding the text)
     const uint8_t *pat;           // device copy of the (folded) pattern, for m > 8

@@ -249,6 +249,7 @@ struct krep_gpu_plan
     std::vector<std::vector<uint8_t>> pats; // as given
     // single literal
     uint32_t m = 0, p0 = 0, p1 = 0, k0 = 0, k1 = 0, l0 = 0, l1 = 0;
+    uint32_t p2 = 0, p3 = 0, k2 = 0, k3 = 0, l2 = 0, l3 = 0; // bytes 8..15
     std::vector<uint8_t> pat_folded; // folded when !cs
     bool has_border = false;         // a proper prefix is also a suffix => all-occurrences != greedy
     bool has_newline = false;
@@ -355,6 +356,18 @@ extern "C" krep_gpu_plan_t *krep_gpu_plan_create(const search_params_t *p, int o
         memcpy(&pl->k1, k + 4, 4);
         if (pl->m == 1)
             pl->p0 = 0x01010101u * w[0];
+        {
+            uint8_t w2[8] = {0}, kk[8] = {0}, ll[8] = {0};
+            for (uint32_t i = 8; i < 16 && i < pl->m; ++i)
+            {
+                w2[i - 8] = pl->pat_folded[i];
+                kk[i - 8] = 0xff;
+                ll[i - 8] = (!pl->cs && w2[i - 8] >= 'a' && w2[i - 8] <= 'z') ? 0x20 : 0;
+            }
+            memcpy(&pl->p2, w2, 4); memcpy(&pl->p3, w2 + 4, 4);
+            memcpy(&pl->k2, kk, 4); memcpy(&pl->k3, kk + 4, 4);
+            memcpy(&pl->l2, ll, 4); memcpy(&pl->l3, ll + 4, 4);
+        }
         if (!pl->cs)
         { // letter lanes of the first 8 (folded) pattern bytes
             uint8_t l[8] = {0};
@@ -518,6 +531,7 @@ static int scan_literal(krep_gpu_plan *pl, int algo, const uint8_t *d_text, size
     a.m = m;
     a.p0 = pl->p0; a.p1 = pl->p1; a.k0 = pl->k0; a.k1 = pl->k1;
     a.l0 = pl->l0; a.l1 = pl->l1;
+    a.p2 = pl->p2; a.p3 = pl->p3; a.k2 = pl->k2; a.k3 = pl->k3; a.l2 = pl->l2; a.l3 = pl->l3;
     a.pat = pl->d_pat;
     a.ctr = pl->d_ctr;
 

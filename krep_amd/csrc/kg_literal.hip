@@ -170,12 +170,12 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
         for (int r = 0; r < R; ++r)
         {
             const u64 seg = ubase + (u64)r * kSegBytes;
-            const bool fast = seg + kSegBytes + 8 <= a.text_len;
+            const bool fast = seg + kSegBytes + (KIND == 9 ? 16 : 8) <= a.text_len;
             const bool interior = seg >= a.own_lo && seg + kSegBytes <= hi_match &&
                                   (seg + kSegBytes <= a.excl_lo || seg >= a.excl_hi);
 
             uint4 d[kCells];
-            uint2 after = make_uint2(0u, 0u);
+            uint4 after = make_uint4(0u, 0u, 0u, 0u); // the bytes behind the round (16 of them for the m = 9..16 verify)
             if (fast)
             {
                 const uint4 *src = reinterpret_cast<const uint4 *>(a.text + seg) + lane;
@@ -186,7 +186,13 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
                     const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src + j * kWave));
                     d[j] = make_uint4(v.x, v.y, v.z, v.w);
                 }
-                after = *reinterpret_cast<const uint2 *>(a.text + seg + kSegBytes);
+                if (KIND == 9)
+                    after = *reinterpret_cast<const uint4 *>(a.text + seg + kSegBytes);
+                else
+                {
+                    const uint2 t = *reinterpret_cast<const uint2 *>(a.text + seg + kSegBytes);
+                    after.x = t.x; after.y = t.y;
+                }
             }
 
 #pragma unroll
@@ -313,6 +319,26 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
                 // rare refinement on candidate lanes: verify the pattern tail (m > 8) and -w
                 if ((KIND == 9 || ww) && __ballot(m16 != 0u))
                 {
+                    // (wave-uniform branch) the next lane's bytes 8..15 for the in-register verify of m = 9..16
+                    const bool inreg = KIND == 9 && fast && a.m <= 16u;
+                    u32 D6 = 0, D7 = 0;
+                    if (inreg)
+                    {
+                        const u32 n2 = __shfl_down(D[2], 1), n3 = __shfl_down(D[3], 1);
+                        u32 e2, e3;
+                        if (j + 1 < kCells)
+                        {
+                            e2 = __builtin_amdgcn_readfirstlane(d[(j + 1 < kCells) ? j + 1 : j].z);
+                            e3 = __builtin_amdgcn_readfirstlane(d[(j + 1 < kCells) ? j + 1 : j].w);
+                        }
+                        else
+                        {
+                            e2 = after.z;
+                            e3 = after.w;
+                        }
+                        D6 = (lane == 63u) ? e2 : n2;
+                        D7 = (lane == 63u) ? e3 : n3;
+                    }
                     u32 rest = m16;
                     while (rest)
                     {
@@ -320,7 +346,19 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
                         rest &= rest - 1u;
                         const u64 p = lbase + k;
                         bool ok = true;
-                        if (KIND == 9)
+                        if (KIND == 9 && inreg)
+                        {
+                            // m = 9..16 on a full round: bytes 8..15 of the candidate lie in the lane's own 16 bytes
+                            // and the 16 of the next lane — compared in registers, no memory access at all
+                            const u32 q = (k + 8u) >> 2, sh = k & 3u; // dword index 2..5 of the 32-byte window
+                            auto sel = [&](u32 i) -> u32 {
+                                return i == 2u ? D[2] : i == 3u ? D[3] : i == 4u ? D[4] : i == 5u ? D[5] : i == 6u ? D6 : D7;
+                            };
+                            const u32 w0 = sel(q), w1 = sel(q + 1u), w2 = q + 2u <= 7u ? sel(q + 2u) : 0u;
+                            const u32 a8 = __builtin_amdgcn_alignbyte(w1, w0, sh), a12 = __builtin_amdgcn_alignbyte(w2, w1, sh);
+                            ok = ((((CI ? (a8 | a.l2) : a8) ^ a.p2) & a.k2) | (((CI ? (a12 | a.l3) : a12) ^ a.p3) & a.k3)) == 0u;
+                        }
+                        else if (KIND == 9)
                         {
                             // bytes 8..m-1 in independent 8-byte chunks (all loads in flight together, no early
                             // exit: a byte loop paid one dependent global access per byte — 5.6 -> 3.3 TB/s at
