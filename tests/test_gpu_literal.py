@@ -154,3 +154,36 @@ def test_binary_haystack_all_byte_values(gpu, oracle_engine):
     hi = np.frombuffer(bytes([0xC1, 0xE1, ord("A"), ord("a"), 0x41 + 0x80]) * 2000, dtype=np.uint8)
     _check(gpu, oracle_engine, hi, bytes([0xE1, ord("a")]), dict(case_sensitive=False), abi.REF_SCALAR)
     _check(gpu, oracle_engine, hi, b"A", dict(case_sensitive=False), abi.REF_SCALAR)
+
+
+@pytest.mark.parametrize("m", [9, 11, 12, 15, 16])
+def test_nine_to_sixteen_byte_verify_in_registers(gpu, oracle_engine, m):
+    """m = 9..16: bytes 8..15 are compared in registers against the lane's and the next lane's data (next cell /
+    the 16 bytes behind the round for lane 63).  Occurrences and near misses (same first 8 bytes, one of the later
+    bytes changed) straddling every lane, cell, round and unit boundary, with and without -i."""
+    rng = np.random.RandomState(1000 + m)
+    pat = (b"Sherlock" + b"HolmesXY")[:m]
+    n = 3 * 32768 + 777
+    text = cases.rand_text(rng, n, b"abcdefgh \n")
+    spots = []
+    for edge in (16, 1024, 8192, 32768, 65536, 98304, n):
+        for d in range(-m - 3, 3):
+            s = edge + d
+            if 0 <= s and s + m <= n:
+                spots.append(s)
+    spots = sorted(set(spots))
+    keep, last = [], -10**9
+    for s in spots:                      # non-overlapping plants, alternating hit / near miss
+        if s >= last + m:
+            keep.append(s)
+            last = s
+    for i, s in enumerate(keep):
+        p = bytearray(pat)
+        if i % 3 == 1:
+            p[8 + (i // 3) % (m - 8)] ^= 0x01        # near miss in the verified tail
+        if i % 3 == 2:
+            p = bytearray(bytes(p).swapcase())        # case variant: a hit only with -i
+        text[s:s + m] = np.frombuffer(bytes(p), dtype=np.uint8)
+    for cs in (True, False):
+        for kw in (dict(), dict(count_lines=True), dict(whole_word=True)):
+            _check(gpu, oracle_engine, text, pat, dict(case_sensitive=cs, **kw), abi.REF_SCALAR)
