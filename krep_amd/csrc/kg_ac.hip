@@ -497,6 +497,7 @@ struct AcTables
     uint2 *d_gram4 = nullptr;
     uint4 *d_g4x = nullptr; // chain-compressed entries, same slots as d_gram4
     u32 g4mask = 0;
+    u32 g4x_mode = 0, g4x_mask = 0, g4x_mul = 0;
 };
 
 #define ACHK(x)                                                                                \
@@ -667,6 +668,46 @@ AcTables *ac_build(const search_params_t &sp, int device)
             auto word = [&](int w) { return (u32)cb[4 * w] | ((u32)cb[4 * w + 1] << 8) | ((u32)cb[4 * w + 2] << 16) | ((u32)cb[4 * w + 3] << 24); };
             g4x[2 * (size_t)(h & t->g4mask)] = make_uint4(it.gram, child, info, endmask);
             g4x[2 * (size_t)(h & t->g4mask) + 1] = make_uint4(word(0), word(1), word(2), 0u);
+        }
+        // Preferred layout: buckets of two entries (one 64-byte line) with NO overfull bucket, so that a probe is one
+        // round trip without a loop; searched over a few multipliers and sizes up to 8 MiB.  Linear probing (above)
+        // stays as the fallback for dictionaries too large for that (the chance that three of n keys share one of nb
+        // buckets is ~ n^3 / (6 nb^2)).
+        static const u32 muls[] = {0x9E3779B1u, 0x85EBCA6Bu, 0xC2B2AE35u, 0x27D4EB2Fu, 0x165667B1u, 0xD3A2646Cu};
+        for (u32 nb = 1024; nb <= (8u << 20) / 64 && !t->g4x_mode && !d4.empty(); nb <<= 1)
+        {
+            if ((u64)nb * 2 < d4.size())
+                continue;
+            for (u32 mul : muls)
+            {
+                std::vector<uint8_t> fill(nb, 0);
+                bool ok = true;
+                for (auto &it : d4)
+                    if (++fill[((it.gram * mul) >> 9) & (nb - 1)] > 2)
+                    {
+                        ok = false;
+                        break;
+                    }
+                if (!ok)
+                    continue;
+                std::vector<uint4> bk(4 * (size_t)nb, make_uint4(0u, 0u, 0u, 0u));
+                std::fill(fill.begin(), fill.end(), 0);
+                for (u32 slot = 0; slot <= t->g4mask; ++slot)
+                {
+                    const uint4 e0 = g4x[2 * (size_t)slot], e1 = g4x[2 * (size_t)slot + 1];
+                    if (e0.y == 0u)
+                        continue;
+                    const u32 b = ((e0.x * mul) >> 9) & (nb - 1);
+                    const u32 way = fill[b]++;
+                    bk[4 * (size_t)b + 2 * way] = e0;
+                    bk[4 * (size_t)b + 2 * way + 1] = e1;
+                }
+                g4x.swap(bk);
+                t->g4x_mode = 1;
+                t->g4x_mask = nb - 1;
+                t->g4x_mul = mul;
+                break;
+            }
         }
     }
     ACHK(hipMalloc(&t->d_gram4, g4.size() * sizeof(uint2)));
@@ -884,6 +925,7 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
     a.gram4 = t->d_gram4;
     a.g4x = t->d_g4x;
     a.g4mask = t->g4mask;
+    a.g4x_mode = t->g4x_mode; a.g4x_mask = t->g4x_mask; a.g4x_mul = t->g4x_mul;
     a.ctr = d_ctr;
     const u64 want = (d_pos && cap && !lines) ? std::min<u64>(cap, (u64)max_count) : 0;
     if (want)

@@ -33,7 +33,9 @@ struct AcArgs
     u32 upt;                     // units per wave ticket of the fused kernel (1..kAcUnitsPerTicketMax, by text size)
     const uint2 *gram4;          // exact last-4-bytes -> {key, depth-4 node | has_out << 31} (val 0 = empty)
     u32 g4mask;
-    const uint4 *g4x;            // same slots, 2 x uint4 each: {key, child, info, endmask} {chain bytes x3, -}
+    const uint4 *g4x;            // entries of 2 x uint4: {key, child, info, endmask} {chain bytes x3, -}; layout by g4x_mode:
+    u32 g4x_mode, g4x_mask, g4x_mul; // 0: the slots of gram4 (linear probing); 1: buckets of TWO entries (64 B), no bucket
+                                 //    overfull, bucket = ((key * g4x_mul) >> 9) & g4x_mask: exactly one round trip per probe
     unsigned long long *unitinfo;
     Counters *ctr;
     u64 *stage;
@@ -352,7 +354,16 @@ __device__ __forceinline__ u32 ac_walk_fast(const AcArgs &a, u64 i, bool own_by_
         const u32 sb = SHORT ? ac_short_bits(a, T[3]) : 0u;
         uint4 e0 = make_uint4(0, 0, 0, 0), e1 = e0;
         bool found = a.has4 != 0;
-        if (found)
+        if (found && a.g4x_mode)
+        {
+            const uint4 *b = a.g4x + 4 * (size_t)(((T[3] * a.g4x_mul) >> 9) & a.g4x_mask);
+            const uint4 q0 = b[0], q1 = b[1], q2 = b[2], q3 = b[3];
+            const bool hit0 = q0.y != 0u && q0.x == T[3], hit1 = q2.y != 0u && q2.x == T[3];
+            e0 = hit0 ? q0 : q2;
+            e1 = hit0 ? q1 : q3;
+            found = hit0 || hit1;
+        }
+        else if (found)
             for (u32 h = (T[3] * kHashMul) >> 9;; ++h)
             {
                 const uint4 *e = a.g4x + 2 * (size_t)(h & a.g4mask);
@@ -408,6 +419,19 @@ __device__ __forceinline__ void ac_walk_probe2(const AcArgs &a, u64 i, bool live
     u32 hA = (TA[3] * kHashMul) >> 9, hB = (TB[3] * kHashMul) >> 9;
     uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0, b0 = a0, b1 = a0;
     bool doneA = !liveA || !a.has4, doneB = !liveB || !a.has4, foundA = false, foundB = false;
+    if (a.g4x_mode)
+    {
+        const uint4 *ba = a.g4x + 4 * (size_t)(((TA[3] * a.g4x_mul) >> 9) & a.g4x_mask);
+        const uint4 *bb = a.g4x + 4 * (size_t)(((TB[3] * a.g4x_mul) >> 9) & a.g4x_mask);
+        const uint4 x0 = ba[0], x1 = ba[1], x2 = ba[2], x3 = ba[3], y0 = bb[0], y1 = bb[1], y2 = bb[2], y3 = bb[3];
+        const bool ha0 = x0.y != 0u && x0.x == TA[3], ha1 = x2.y != 0u && x2.x == TA[3];
+        const bool hb0 = y0.y != 0u && y0.x == TB[3], hb1 = y2.y != 0u && y2.x == TB[3];
+        a0 = ha0 ? x0 : x2; a1 = ha0 ? x1 : x3;
+        b0 = hb0 ? y0 : y2; b1 = hb0 ? y1 : y3;
+        foundA = !doneA && (ha0 || ha1);
+        foundB = !doneB && (hb0 || hb1);
+        doneA = doneB = true;
+    }
     while (!(doneA && doneB))
     {
         const uint4 *ea = a.g4x + 2 * (size_t)(hA & a.g4mask), *eb = a.g4x + 2 * (size_t)(hB & a.g4mask);
