@@ -674,7 +674,8 @@ AcTables *ac_build(const search_params_t &sp, int device)
         // stays as the fallback for dictionaries too large for that (the chance that three of n keys share one of nb
         // buckets is ~ n^3 / (6 nb^2)).
         static const u32 muls[] = {0x9E3779B1u, 0x85EBCA6Bu, 0xC2B2AE35u, 0x27D4EB2Fu, 0x165667B1u, 0xD3A2646Cu};
-        for (u32 nb = 1024; nb <= (8u << 20) / 64 && !t->g4x_mode && !d4.empty(); nb <<= 1)
+        // (KREP_GPU_AC_LINEAR=1: test hook, keeps the linear-probing layout)
+        for (u32 nb = 1024; nb <= (8u << 20) / 64 && !t->g4x_mode && !d4.empty() && !getenv("KREP_GPU_AC_LINEAR"); nb <<= 1)
         {
             if ((u64)nb * 2 < d4.size())
                 continue;

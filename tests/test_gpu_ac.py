@@ -138,3 +138,18 @@ def test_long_pattern_sets_chain_verifier(gpu, oracle_engine, seed):
         elif mode == "count":
             kw.update(count_lines=True, only_match=True)
         _check(gpu, oracle_engine, text, pats, kw)
+
+
+def test_linear_probing_fallback_layout(gpu, oracle_engine, monkeypatch):
+    """Dictionaries too large for the two-entry-bucket layout of the 4-gram table keep linear probing; the test hook
+    forces that layout for ordinary dictionaries (fresh pattern sets: plans are cached per parameter set)."""
+    monkeypatch.setenv("KREP_GPU_AC_LINEAR", "1")
+    rng = np.random.RandomState(4242)
+    az = bytes(range(97, 123))
+    for it in range(6):
+        text = cases.rand_text(rng, [40000, 140000, 300000][it % 3], az + b" \n")
+        pats = [cases.pick_pattern(rng, text, int(rng.randint(4, 20)), az) for _ in range([30, 300, 900][it % 3])]
+        for kw in (dict(), dict(case_sensitive=False), dict(count_lines=True)):
+            if kw.get("count_lines") and any(b"\n" in p for p in pats):
+                continue
+            _check(gpu, oracle_engine, text, pats, kw)
