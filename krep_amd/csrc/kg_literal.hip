@@ -121,25 +121,6 @@ __device__ __noinline__ W6 load_window_guarded(const uint8_t *text, u64 text_len
     return r;
 }
 
-// bytes 8..m-1 of a candidate out of the LDS window (the cell's 1 KiB + 64 bytes): dword by dword with a funnel shift
-// for the candidate's byte offset b0, the last dword re-anchored at m - 4.  Deliberately not inlined: the rare path
-// must not cost the scan loop registers (inlined it spilled 32 VGPRs under the 128 cap).
-__device__ __noinline__ bool verify_from_window(const u32 *sw, u32 b0, u32 m, const uint8_t *pat, bool ci)
-{
-    struct __attribute__((packed)) U32p { u32 v; };
-    auto at = [&](u32 q) -> u32 {
-        const u32 b = b0 + q;
-        const u32 v = __builtin_amdgcn_alignbyte(sw[(b >> 2) + 1u], sw[b >> 2], b & 3u);
-        return ci ? fold4(v) : v;
-    };
-    u32 diff = 0, q = 8;
-    for (; q + 4 <= m; q += 4)
-        diff |= at(q) ^ reinterpret_cast<const U32p *>(pat + q)->v;
-    if (q < m)
-        diff |= at(m - 4u) ^ reinterpret_cast<const U32p *>(pat + (m - 4u))->v;
-    return diff == 0u;
-}
-
 // KIND: 1 -> m == 1 (SWAR), 4 -> 2..4 bytes (one word), 8 -> 5..8 bytes (two words), 9 -> m > 8 (filter+verify)
 // MASKED: the last compared word is partial (m = 2,3 or 5,6,7), so its compare needs the byte mask.
 // R: load rounds per chain unit.  A workgroup draws ONE ticket per tile (4 waves x R x 8 KiB); each
@@ -196,7 +177,7 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
                                   (seg + kSegBytes <= a.excl_lo || seg >= a.excl_hi);
 
             uint4 d[kCells];
-            uint4 after = make_uint4(0u, 0u, 0u, 0u); // the 8 (m > 8: 16) bytes behind the round, uniform
+            uint4 after = make_uint4(0u, 0u, 0u, 0u); // the bytes behind the round (m > 8: lane l & 3 holds bytes 16 (l & 3) ...)
             if (fast)
             {
                 const uint4 *src = reinterpret_cast<const uint4 *>(a.text + seg) + lane;
@@ -208,7 +189,9 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
                     d[j] = make_uint4(v.x, v.y, v.z, v.w);
                 }
                 if (KIND == 9)
-                    after = *reinterpret_cast<const uint4 *>(a.text + seg + kSegBytes);
+                {
+                    after = *reinterpret_cast<const uint4 *>(a.text + seg + kSegBytes + (lane & 3u) * 16u);
+                }
                 else
                 {
                     const uint2 t = *reinterpret_cast<const uint2 *>(a.text + seg + kSegBytes);
@@ -347,10 +330,8 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
                     { // the cell and the 64 bytes behind it, in text order
                         u32 *sw = s_win[KIND == 9 ? wave : 0];
                         *reinterpret_cast<uint4 *>(sw + lane * 4u) = make_uint4(D[0], D[1], D[2], D[3]);
-                        if (lane < 4u) // the 64 bytes behind the cell: the next cell's first lanes, or (last cell) a load
-                            *reinterpret_cast<uint4 *>(sw + 256u + lane * 4u) =
-                                (j + 1 < kCells) ? d[(j + 1 < kCells) ? j + 1 : j]
-                                                 : *reinterpret_cast<const uint4 *>(a.text + seg + kSegBytes + lane * 16u);
+                        if (lane < 4u)
+                            *reinterpret_cast<uint4 *>(sw + 256u + lane * 4u) = (j + 1 < kCells) ? d[(j + 1 < kCells) ? j + 1 : j] : after;
                     }
                     u32 D6 = 0, D7 = 0;
                     if (inreg)
@@ -394,7 +375,21 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
                             // m = 17..64 on a full round: the bytes come out of LDS (latency ~0.1 us instead of the
                             // ~2 us of a global access that the whole wave waits for), dword by dword with a funnel
                             // shift for the candidate's byte offset; the last dword is re-anchored at m - 4
-                            ok = verify_from_window(s_win[KIND == 9 ? wave : 0], lane * 16u + k, a.m, a.pat, CI);
+                            const u32 *sw = s_win[KIND == 9 ? wave : 0];
+                            const u32 b0 = lane * 16u + k; // byte offset of the candidate in the window
+                            auto at = [&](u32 q) -> u32 { // pattern-relative offset q -> the 4 text bytes there
+                                const u32 b = b0 + q;
+                                const u32 v = __builtin_amdgcn_alignbyte(sw[(b >> 2) + 1u], sw[b >> 2], b & 3u);
+                                return CI ? fold4(v) : v;
+                            };
+                            struct __attribute__((packed)) U32p { u32 v; };
+                            u32 diff = 0;
+                            u32 q = 8;
+                            for (; q + 4 <= a.m; q += 4)
+                                diff |= at(q) ^ reinterpret_cast<const U32p *>(a.pat + q)->v;
+                            if (q < a.m)
+                                diff |= at(a.m - 4u) ^ reinterpret_cast<const U32p *>(a.pat + (a.m - 4u))->v;
+                            ok = diff == 0u;
                         }
                         else if (KIND == 9)
                         {
