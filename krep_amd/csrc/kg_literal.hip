@@ -132,8 +132,6 @@ template <int KIND, bool MASKED, bool CI, bool LINES, int R>
 __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
 {
     __shared__ u64 s_ticket[2];
-    // m = 17..64: a candidate's bytes 8..m-1 are verified out of LDS (the cell's 1 KiB + the 64 bytes behind it)
-    __shared__ u32 s_win[KIND == 9 ? kWavesPerBlk : 1][KIND == 9 ? 272 : 1];
     const u32 lane = lane_id();
     const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool want_pos = (a.flags & F_POS) != 0;
@@ -172,12 +170,12 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
         for (int r = 0; r < R; ++r)
         {
             const u64 seg = ubase + (u64)r * kSegBytes;
-            const bool fast = seg + kSegBytes + (KIND == 9 ? 64 : 8) <= a.text_len;
+            const bool fast = seg + kSegBytes + (KIND == 9 ? 16 : 8) <= a.text_len;
             const bool interior = seg >= a.own_lo && seg + kSegBytes <= hi_match &&
                                   (seg + kSegBytes <= a.excl_lo || seg >= a.excl_hi);
 
             uint4 d[kCells];
-            uint4 after = make_uint4(0u, 0u, 0u, 0u); // the bytes behind the round (m > 8: lane l & 3 holds bytes 16 (l & 3) ...)
+            uint4 after = make_uint4(0u, 0u, 0u, 0u); // the bytes behind the round (16 of them for the m = 9..16 verify)
             if (fast)
             {
                 const uint4 *src = reinterpret_cast<const uint4 *>(a.text + seg) + lane;
@@ -189,9 +187,7 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
                     d[j] = make_uint4(v.x, v.y, v.z, v.w);
                 }
                 if (KIND == 9)
-                {
-                    after = *reinterpret_cast<const uint4 *>(a.text + seg + kSegBytes + (lane & 3u) * 16u);
-                }
+                    after = *reinterpret_cast<const uint4 *>(a.text + seg + kSegBytes);
                 else
                 {
                     const uint2 t = *reinterpret_cast<const uint2 *>(a.text + seg + kSegBytes);
@@ -218,8 +214,8 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
                         }
                         else
                         {
-                            e0 = __builtin_amdgcn_readfirstlane(after.x); // lane 0 holds the first 16 bytes behind the round
-                            e1 = __builtin_amdgcn_readfirstlane(after.y);
+                            e0 = after.x;
+                            e1 = after.y;
                         }
                         D[4] = (lane == 63u) ? e0 : n0;
                         D[5] = (lane == 63u) ? e1 : n1;
@@ -325,14 +321,6 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
                 {
                     // (wave-uniform branch) the next lane's bytes 8..15 for the in-register verify of m = 9..16
                     const bool inreg = KIND == 9 && fast && a.m <= 16u;
-                    const bool inlds = KIND == 9 && fast && a.m > 16u && a.m <= 64u;
-                    if (inlds)
-                    { // the cell and the 64 bytes behind it, in text order
-                        u32 *sw = s_win[KIND == 9 ? wave : 0];
-                        *reinterpret_cast<uint4 *>(sw + lane * 4u) = make_uint4(D[0], D[1], D[2], D[3]);
-                        if (lane < 4u)
-                            *reinterpret_cast<uint4 *>(sw + 256u + lane * 4u) = (j + 1 < kCells) ? d[(j + 1 < kCells) ? j + 1 : j] : after;
-                    }
                     u32 D6 = 0, D7 = 0;
                     if (inreg)
                     {
@@ -345,8 +333,8 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
                         }
                         else
                         {
-                            e2 = __builtin_amdgcn_readfirstlane(after.z);
-                            e3 = __builtin_amdgcn_readfirstlane(after.w);
+                            e2 = after.z;
+                            e3 = after.w;
                         }
                         D6 = (lane == 63u) ? e2 : n2;
                         D7 = (lane == 63u) ? e3 : n3;
@@ -369,27 +357,6 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
                             const u32 w0 = sel(q), w1 = sel(q + 1u), w2 = q + 2u <= 7u ? sel(q + 2u) : 0u;
                             const u32 a8 = __builtin_amdgcn_alignbyte(w1, w0, sh), a12 = __builtin_amdgcn_alignbyte(w2, w1, sh);
                             ok = ((((CI ? (a8 | a.l2) : a8) ^ a.p2) & a.k2) | (((CI ? (a12 | a.l3) : a12) ^ a.p3) & a.k3)) == 0u;
-                        }
-                        else if (KIND == 9 && inlds)
-                        {
-                            // m = 17..64 on a full round: the bytes come out of LDS (latency ~0.1 us instead of the
-                            // ~2 us of a global access that the whole wave waits for), dword by dword with a funnel
-                            // shift for the candidate's byte offset; the last dword is re-anchored at m - 4
-                            const u32 *sw = s_win[KIND == 9 ? wave : 0];
-                            const u32 b0 = lane * 16u + k; // byte offset of the candidate in the window
-                            auto at = [&](u32 q) -> u32 { // pattern-relative offset q -> the 4 text bytes there
-                                const u32 b = b0 + q;
-                                const u32 v = __builtin_amdgcn_alignbyte(sw[(b >> 2) + 1u], sw[b >> 2], b & 3u);
-                                return CI ? fold4(v) : v;
-                            };
-                            struct __attribute__((packed)) U32p { u32 v; };
-                            u32 diff = 0;
-                            u32 q = 8;
-                            for (; q + 4 <= a.m; q += 4)
-                                diff |= at(q) ^ reinterpret_cast<const U32p *>(a.pat + q)->v;
-                            if (q < a.m)
-                                diff |= at(a.m - 4u) ^ reinterpret_cast<const U32p *>(a.pat + (a.m - 4u))->v;
-                            ok = diff == 0u;
                         }
                         else if (KIND == 9)
                         {
