@@ -156,13 +156,13 @@ def test_binary_haystack_all_byte_values(gpu, oracle_engine):
     _check(gpu, oracle_engine, hi, b"A", dict(case_sensitive=False), abi.REF_SCALAR)
 
 
-@pytest.mark.parametrize("m", [9, 11, 12, 15, 16])
+@pytest.mark.parametrize("m", [9, 11, 12, 15, 16, 17, 23, 32, 33, 47, 63, 64, 65])
 def test_nine_to_sixteen_byte_verify_in_registers(gpu, oracle_engine, m):
     """m = 9..16: bytes 8..15 are compared in registers against the lane's and the next lane's data (next cell /
     the 16 bytes behind the round for lane 63).  Occurrences and near misses (same first 8 bytes, one of the later
     bytes changed) straddling every lane, cell, round and unit boundary, with and without -i."""
     rng = np.random.RandomState(1000 + m)
-    pat = (b"Sherlock" + b"HolmesXY")[:m]
+    pat = (b"Sherlock" + b"HolmesXY" + b"and-the-Hound_of_the-Baskervilles+0123456789abcdef")[:m]  # > 16: chunked loads
     n = 3 * 32768 + 777
     text = cases.rand_text(rng, n, b"abcdefgh \n")
     spots = []
