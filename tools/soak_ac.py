@@ -7,7 +7,7 @@ from krep_amd import abi
 import test_gpu_ac as T
 gpu = krep_amd.load(); o = ol.oracle()
 bad = 0
-for seed in range(2000, 2040):
+for seed in range(2000, 2000 + (int(sys.argv[1]) if len(sys.argv) > 1 else 40)):
     rng = np.random.RandomState(seed)
     for it in range(40):
         alpha = [b"ab", b"abc\n", b"abAB -\n", bytes(range(97, 105)) + b" \n", bytes(range(256))][it % 5]

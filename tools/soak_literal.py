@@ -11,7 +11,7 @@ gpu = krep_amd.load(); o = ol.oracle()
 bad = n = 0
 for rounds in (1, 4):
     gpu.force_rounds(rounds)
-    for seed in range(3000, 3012):
+    for seed in range(3000, 3000 + (int(sys.argv[1]) if len(sys.argv) > 1 else 12)):
         level = [abi.REF_SCALAR, abi.REF_SSE42, abi.REF_AVX2, abi.REF_AVX512][seed % 4]
         for text, pat, kw in cases.literal_cases(seed, 150):
             if level != abi.REF_SCALAR and kw.get("count_lines") and not kw.get("only_match") and len(pat) > 16 and kw["case_sensitive"]:
