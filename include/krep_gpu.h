@@ -104,11 +104,36 @@ enum krep_ref_algo
     KREP_RA_REGEX = 10        /* regex_search — out of scope, never executed here */
 };
 
+/* All of it in one explicit object.  Plans and search_buffer_ex() carry their configuration; the setters below write the
+ * PROCESS-WIDE defaults (like the reference's globals, set once by main() before the pool threads start; relaxed atomics),
+ * krep_gpu_set_thread_config() overrides them for the calling thread (NULL: back to the defaults).  No scan path writes
+ * any of this, so concurrent calls with different configurations do not interfere. */
+typedef struct krep_gpu_config
+{
+    int reference_simd;        /* enum krep_ref_simd: which reference BUILD is reproduced (krep.c:47-74)              */
+    int only_matching;         /* static only_matching (-o), krep.c:117                                                 */
+    int force_no_simd;         /* static force_no_simd, krep.c:118                                                      */
+    int algo_override;         /* enum krep_ref_algo_override (--algo), krep.c:120                                      */
+    int result_order;          /* 1: multi-pattern records come back in (start, end) order (see below)                  */
+    int device;                /* HIP device the host-buffer operators use (default: $KREP_GPU_DEVICE, else 0)          */
+    size_t stream_chunk_bytes; /* piece size of the streamed host path (0 = default 128 MiB); texts > 2 pieces stream   */
+} krep_gpu_config_t;
+void krep_gpu_config_default(krep_gpu_config_t *out);           /* the current process-wide defaults */
+void krep_gpu_set_thread_config(const krep_gpu_config_t *cfg);  /* calling thread only; NULL clears   */
+void krep_gpu_set_device(int device);                           /* process-wide default device         */
+void krep_gpu_set_stream_chunk(size_t bytes);                   /* process-wide default piece size     */
+/* frees every per-device context of the host path (device buffers, pinned staging ring, cached plans) */
+void krep_gpu_release_device_resources(void);
+
 void krep_gpu_set_reference_simd(int krep_ref_simd_level);   /* compile-time SIMD macros, krep.c:47-74 */
 void krep_gpu_set_only_matching(int on);                     /* static only_matching,   krep.c:117   */
 void krep_gpu_set_force_no_simd(int on);                     /* static force_no_simd,   krep.c:118   */
 void krep_gpu_set_algo_override(int krep_ref_algo_override); /* static algo_override,   krep.c:120   */
 int krep_gpu_get_reference_simd(void);
+/* test hook (host only, no GPU needed): the end-of-text replay of the block-structured -c paths
+ * (krep_amd/csrc/kg_replay.h) run on host memory, so that the CPU test-suite can pin it against the oracle */
+uint64_t krep_gpu_debug_replay_host(int krep_ref_algo, const void *text, size_t n, const void *pattern, uint32_t m,
+                                    int whole_word, size_t cur, int open_line);
 /* test hook: force the kernel tile shape (0 = auto, 1 = 32 KiB tiles, 4 = 128 KiB tiles) */
 void krep_gpu_debug_force_rounds(int rounds);
 /* test hook: staging records per scan unit (0 = auto); small values exercise the emit-mode re-scan */
@@ -130,9 +155,18 @@ uint64_t krep_gpu_literal_search(const search_params_t *params, const char *text
                                  size_t text_len, match_result_t *result);
 uint64_t krep_gpu_aho_corasick_search(const search_params_t *params, const char *text_start,
                                       size_t text_len, match_result_t *result);
-/* Drop-in for select_search_algorithm(): returns one of the two functions above, or NULL when the
- * reference would pick regex_search (not accelerated; the caller keeps the CPU function). */
+/* Drop-in for select_search_algorithm(): returns one of the two functions above, or NULL when the backend does not
+ * take the search — regex_search, and the two input classes krep_gpu_can_accelerate() names — so that the caller keeps
+ * the CPU function pointer the reference's own select_search_algorithm() gives it. */
 search_func_t krep_gpu_select_search_algorithm(const search_params_t *params);
+/* 1 when the backend reproduces the reference for `params` under the current configuration, 0 when not:
+ *   - use_regex;
+ *   - count_lines_mode with a '\n' inside a single pattern that the reference would run through simd_sse42_search or
+ *     kmp_search (the -c line skip of simd_sse42_search depends on the phase of its 16-byte window grid, krep.c:4787-4793);
+ *   - count_lines_mode together with only_matching through memchr_short_search (unreachable from the reference CLI,
+ *     krep.c:3811-3814).
+ * The operators refuse these loudly ("krep-gpu: ..." on stderr, return 0); nothing is silently approximated. */
+int krep_gpu_can_accelerate(const search_params_t *params);
 
 /* The in-memory twin of search_file()/search_string() that BASELINE.json calls search_buffer():
  * validation as krep.c:2013-2049 (no patterns -> 2; empty pattern among several -> 2; pattern
@@ -142,6 +176,10 @@ search_func_t krep_gpu_select_search_algorithm(const search_params_t *params);
  * Returns 0 = match found, 1 = none, 2 = error. */
 int search_buffer(const search_params_t *params, const char *buf, size_t len, int only_matching,
                   int num_gpus, match_result_t *out /* nullable */, uint64_t *count_out /* nullable */);
+/* The same with the whole configuration explicit (cfg == NULL: the calling thread's current configuration).
+ * Re-entrant: any number of threads may call it concurrently with different configurations. */
+int search_buffer_ex(const search_params_t *params, const char *buf, size_t len, const krep_gpu_config_t *cfg,
+                     int num_gpus, match_result_t *out /* nullable */, uint64_t *count_out /* nullable */);
 
 /* match_result_t helpers with the reference's allocation contract (krep.c:139-251), exported so a
  * caller without krep.c can own the results. */
@@ -170,6 +208,7 @@ typedef struct krep_gpu_scan_out
 } krep_gpu_scan_out_t;
 
 krep_gpu_plan_t *krep_gpu_plan_create(const search_params_t *params, int only_matching, int device);
+krep_gpu_plan_t *krep_gpu_plan_create_ex(const search_params_t *params, const krep_gpu_config_t *cfg /* NULL = current */);
 void krep_gpu_plan_destroy(krep_gpu_plan_t *plan);
 int krep_gpu_plan_ref_algo(const krep_gpu_plan_t *plan); /* enum krep_ref_algo this plan reproduces */
 
@@ -184,6 +223,17 @@ int krep_gpu_scan_device(krep_gpu_plan_t *plan, const void *d_text, size_t text_
                          size_t own_hi, size_t global_base, match_position_t *d_positions,
                          uint64_t position_capacity, void *stream, int time_it,
                          krep_gpu_scan_out_t *out);
+
+/* The same for a device buffer that is a SLICE [global_base, global_base + text_len) of a text of global_len bytes
+ * (global_len == 0: the buffer ends the text).  The reference functions place some of their behaviour by the length of
+ * the WHOLE text (the block simd_avx512_search leaves unexamined, krep.c:5171; the first byte of the scalar tail calls,
+ * which has no left neighbour for -w, krep.c:5059-5097): with global_len those land where the reference puts them, in
+ * whichever shard holds them.  The sequential match-set families (greedy SSE4.2/KMP selection of a bordered pattern,
+ * -o through BMH / memchr_short, -c through the AVX-512 / NEON / AVX2 -w block loops) need the whole text in ONE window
+ * and refuse anything else. */
+int krep_gpu_scan_device_ex(krep_gpu_plan_t *plan, const void *d_text, size_t text_len, size_t own_lo,
+                            size_t own_hi, size_t global_base, size_t global_len, match_position_t *d_positions,
+                            uint64_t position_capacity, void *stream, int time_it, krep_gpu_scan_out_t *out);
 
 /* Deterministic synthetic haystacks, generated directly in HBM by a counter-based
  * PRNG so that any [global_off, global_off+len) slice is reproducible on any rank.

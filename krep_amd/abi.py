@@ -22,7 +22,7 @@ ALGO_AUTO, ALGO_BM, ALGO_KMP = 0, 1, 2
 
 RA_NAMES = {RA_BMH: "boyer_moore_search", RA_KMP: "kmp_search", RA_MEMCHR: "memchr_search",
             RA_MEMCHR_SHORT: "memchr_short_search", RA_SSE42: "simd_sse42_search",
-            RA_AVX2: "simd_avx2_search", RA_AVX512: "simd_avx512_search",
+            RA_AVX2: "simd_avx2_search", RA_AVX512: "simd_avx512_search", RA_NEON: "neon_search",
             RA_AHO_CORASICK: "aho_corasick_search"}
 
 
@@ -53,6 +53,13 @@ class ScanOut(C.Structure):
     _fields_ = [("count", C.c_uint64), ("stored", C.c_uint64), ("total_matches", C.c_uint64),
                 ("line_count", C.c_uint64), ("head_line_hit", C.c_uint8), ("tail_line_hit", C.c_uint8),
                 ("has_newline", C.c_uint8), ("overflow", C.c_uint8), ("kernel_ms", C.c_float)]
+
+
+class Config(C.Structure):
+    """krep_gpu_config_t: the reference's build level and file-static option globals, explicit."""
+    _fields_ = [("reference_simd", C.c_int), ("only_matching", C.c_int), ("force_no_simd", C.c_int),
+                ("algo_override", C.c_int), ("result_order", C.c_int), ("device", C.c_int),
+                ("stream_chunk_bytes", C.c_size_t)]
 
 
 SEARCH_FUNC = C.CFUNCTYPE(C.c_uint64, C.POINTER(SearchParams), C.c_char_p, C.c_size_t,

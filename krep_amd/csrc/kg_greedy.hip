@@ -1,15 +1,26 @@
-// kg_greedy.hip — greedy leftmost non-overlapping selection on the ordered occurrence list.
+// kg_greedy.hip — the reference's SEQUENTIAL match-set families, resolved on the ordered list the scan produced.
 //
+// (1) Greedy leftmost non-overlapping selection:
 // simd_sse42_search (krep.c:4839-4848: advance = index + pattern_len after a hit) and kmp_search
 // (krep.c:1741: i = match_start + pattern_len) report the GREEDY subset of the occurrences: scan left
 // to right, after taking a hit at s the next candidate must start at >= s + m.  For a pattern without
 // a border (no proper prefix that is also a suffix) two occurrences can never overlap and the subset
 // is everything — the scan kernel's output is used as is.  For bordered patterns ("aa", "abab") this
 // pass runs on the occurrence list the scan produced (O(matches), the haystack is not re-read):
-//   g_mark    : occurrences split into clusters at gaps >= m; the first thread of a cluster walks it
+//   g_walk    : occurrences split into clusters at gaps >= m; the first thread of a cluster walks it
 //   g_ww      : -w applied AFTER the selection, as the reference does (a rejected hit still consumes)
 //   g_count/g_scan/g_scatter : order-preserving compaction into the caller's match_position_t buffer
 //   g_lines   : distinct lines among the survivors ('\n' between consecutive survivors)
+// boyer_moore_search under -o (krep.c:1371: i += pattern_len after a hit) is the same selection, with -w applied BEFORE it
+// (a rejected hit shifts by the bad-character table and consumes nothing, krep.c:1323-1329): the scan filters, g_walk selects.
+//
+// (2) memchr_short_search under -o (krep.c:4396-4500): the walk is over the FIRST-BYTE candidates (memchr / the folded
+// scalar loop), and `advance = (candidate - current) + (only_matching ? pattern_len : 1)` (:4495) also runs after a
+// candidate whose remaining bytes did NOT match — the next pattern_len - 1 positions are never examined.  A full match that
+// fails -w resumes one byte further (:4441-4446).  The list is the candidate list of a one-byte scan; the cluster head walks
+// it, classifies every visited candidate against the text (bytes 1..m-1, -w) and keeps the accepted matches.  A candidate
+// at least m bytes behind its predecessor is always visited (the resume point never passes candidate + m), so clusters
+// split at gaps >= m exactly as in (1).
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include "kg_common.h"
@@ -26,30 +37,62 @@ constexpr int kGBlockElems = kGB * kGPer;
 
 __device__ __forceinline__ bool g_wordc(u32 c) { return (c - '0' < 10u) || ((c | 0x20u) - 'a' < 26u) || c == '_'; }
 
-__global__ __launch_bounds__(kGB) void g_mark(const u64 *__restrict__ occ, u64 n, u64 base, u32 m, uint8_t *__restrict__ keep)
+__device__ __forceinline__ uint8_t g_fold(uint8_t c) { return (c >= 'A' && c <= 'Z') ? (uint8_t)(c + 32) : c; }
+
+// mode kWalkGreedy: element = occurrence, a visited element is kept and consumes m.
+// mode kWalkShortO: element = first-byte candidate (record start), classified on the fly.
+__global__ __launch_bounds__(kGB) void g_walk(const u64 *__restrict__ occ, u64 n, u64 base, const uint8_t *__restrict__ text,
+                                              u64 text_len, WalkSpec ws, uint8_t *__restrict__ keep)
 {
     const u64 i = (u64)blockIdx.x * kGB + threadIdx.x;
     if (i >= n)
         return;
+    const u32 m = ws.m;
     const u64 s = occ[2 * i];
     if (i != 0 && s - occ[2 * (i - 1)] < m)
         return; // not the head of a cluster
-    (void)base;
-    keep[i] = 1;
-    u64 last = s, prev = s;
-    for (u64 j = i + 1; j < n; ++j)
+    u64 cur = s, prev = s; // cur: first start the walk will look at next
+    for (u64 j = i; j < n; ++j)
     {
         const u64 sj = occ[2 * j];
-        if (sj - prev >= m)
+        if (j != i && sj - prev >= m)
             break; // next cluster: its own head thread takes over
-        if (sj >= last + m)
+        prev = sj;
+        if (sj < cur)
+        {
+            keep[j] = 0;
+            continue;
+        }
+        if (ws.mode == kWalkGreedy)
         {
             keep[j] = 1;
-            last = sj;
+            cur = sj + m;
+            continue;
         }
-        else
+        const u64 p = sj - base; // offset inside the device buffer; p + m <= text_len by construction of the list
+        uint8_t c1 = text[p + 1], c2 = m > 2 ? text[p + 2] : 0;
+        if (ws.ci)
+        {
+            c1 = g_fold(c1);
+            c2 = g_fold(c2);
+        }
+        const bool full = c1 == ws.b1 && (m < 3 || c2 == ws.b2);
+        if (!full)
+        {
             keep[j] = 0;
-        prev = sj;
+            cur = sj + m; // krep.c:4495
+            continue;
+        }
+        bool ok = true;
+        if (ws.ww)
+        {
+            if (p > 0 && g_wordc(text[p - 1]))
+                ok = false;
+            else if (p + m < text_len && g_wordc(text[p + m]))
+                ok = false;
+        }
+        keep[j] = ok ? 1 : 0;
+        cur = ok ? sj + m : sj + 1; // krep.c:4441-4446: a -w rejected match resumes one byte further
     }
 }
 
@@ -112,8 +155,9 @@ __global__ __launch_bounds__(64) void g_scan(u64 nb, u64 *__restrict__ blk, Coun
         ctr->total = run;
 }
 
+// set_len != 0: records are rewritten as {start, start + set_len} (the candidate list of kWalkShortO holds one-byte records)
 __global__ __launch_bounds__(kGB) void g_scatter(const u64 *__restrict__ occ, const uint8_t *__restrict__ keep, u64 n,
-                                                 const u64 *__restrict__ blk, u64 *__restrict__ out, u64 cap)
+                                                 const u64 *__restrict__ blk, u64 *__restrict__ out, u64 cap, u32 set_len)
 {
     __shared__ u32 s[4];
     const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -146,8 +190,9 @@ __global__ __launch_bounds__(kGB) void g_scatter(const u64 *__restrict__ occ, co
         {
             if (idx < cap)
             {
-                out[2 * idx] = occ[2 * (i0 + q)];
-                out[2 * idx + 1] = occ[2 * (i0 + q) + 1];
+                const u64 st = occ[2 * (i0 + q)];
+                out[2 * idx] = st;
+                out[2 * idx + 1] = set_len ? st + set_len : occ[2 * (i0 + q) + 1];
             }
             ++idx;
         }
@@ -190,11 +235,11 @@ __global__ __launch_bounds__(kGB) void g_lines(const u64 *__restrict__ lst, u64 
             return fail("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
-// occ: n_occ records already in post.d_occ.  Results: *total survivors; records into d_pos (<= want);
-// with `lines` the distinct-line count (the survivors are compacted into scratch for that).
-int post_greedy(PostScratch &s, const uint8_t *d_text, uint64_t text_len, uint64_t global_base, uint32_t m, bool ww,
-                bool lines, uint64_t n_occ, uint64_t *d_pos, uint64_t want, Counters *d_ctr, Counters *h_ctr, hipStream_t st,
-                uint64_t *total, uint64_t *nlines)
+// occ: n_occ records already in s.d_occ.  Results: *total kept matches; records into d_pos (<= want);
+// with ws.lines the distinct-line count (the survivors are compacted into scratch for that).
+int post_walk(PostScratch &s, const uint8_t *d_text, uint64_t text_len, uint64_t global_base, const WalkSpec &ws,
+              uint64_t n_occ, uint64_t *d_pos, uint64_t want, Counters *d_ctr, Counters *h_ctr, hipStream_t st,
+              uint64_t *total, uint64_t *nlines)
 {
     *total = 0;
     *nlines = 0;
@@ -214,16 +259,17 @@ int post_greedy(PostScratch &s, const uint8_t *d_text, uint64_t text_len, uint64
     }
     const u64 *occ = (const u64 *)s.d_occ;
     const u32 g1 = (u32)((n_occ + kGB - 1) / kGB);
+    const u32 set_len = ws.mode == kWalkShortO ? ws.m : 0u;
     GCHK(hipMemsetAsync(s.d_keep, 0, n_occ, st));
-    hipLaunchKernelGGL(g_mark, dim3(g1), dim3(kGB), 0, st, occ, (u64)n_occ, (u64)global_base, m, s.d_keep);
-    if (ww)
-        hipLaunchKernelGGL(g_ww, dim3(g1), dim3(kGB), 0, st, occ, (u64)n_occ, (u64)global_base, d_text, (u64)text_len, m, s.d_keep);
+    hipLaunchKernelGGL(g_walk, dim3(g1), dim3(kGB), 0, st, occ, (u64)n_occ, (u64)global_base, d_text, (u64)text_len, ws, s.d_keep);
+    if (ws.ww && ws.mode == kWalkGreedy) // -w AFTER the selection: a rejected hit still consumed (krep.c:4767, :1684)
+        hipLaunchKernelGGL(g_ww, dim3(g1), dim3(kGB), 0, st, occ, (u64)n_occ, (u64)global_base, d_text, (u64)text_len, ws.m, s.d_keep);
     hipLaunchKernelGGL(g_count, dim3((u32)nb), dim3(kGB), 0, st, (const uint8_t *)s.d_keep, (u64)n_occ, (u64 *)s.d_gblk);
     hipLaunchKernelGGL(g_scan, dim3(1), dim3(64), 0, st, (u64)nb, (u64 *)s.d_gblk, d_ctr);
-    if (lines)
+    if (ws.lines)
     {
         hipLaunchKernelGGL(g_scatter, dim3((u32)nb), dim3(kGB), 0, st, occ, (const uint8_t *)s.d_keep, (u64)n_occ,
-                           (const u64 *)s.d_gblk, (u64 *)s.d_surv, (u64)n_occ);
+                           (const u64 *)s.d_gblk, (u64 *)s.d_surv, (u64)n_occ, set_len);
         GCHK(hipMemcpyAsync(h_ctr, d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, st));
         GCHK(hipStreamSynchronize(st));
         const u64 nsurv = h_ctr->total;
@@ -236,12 +282,12 @@ int post_greedy(PostScratch &s, const uint8_t *d_text, uint64_t text_len, uint64
     }
     else if (d_pos && want)
         hipLaunchKernelGGL(g_scatter, dim3((u32)nb), dim3(kGB), 0, st, occ, (const uint8_t *)s.d_keep, (u64)n_occ,
-                           (const u64 *)s.d_gblk, (u64 *)d_pos, (u64)want);
+                           (const u64 *)s.d_gblk, (u64 *)d_pos, (u64)want, set_len);
     GCHK(hipGetLastError());
     GCHK(hipMemcpyAsync(h_ctr, d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, st));
     GCHK(hipStreamSynchronize(st));
     *total = h_ctr->total;
-    *nlines = lines ? h_ctr->lines : 0;
+    *nlines = ws.lines ? h_ctr->lines : 0;
     return 0;
 }
 

@@ -1,22 +1,24 @@
-// kg_host.hip — C-ABI of the krep-gpu backend (include/krep_gpu.h): plans, device scans, the
-// search_func_t operators, search_buffer(), the reference-algorithm mirror and the generators.
-// Host logic only; the scan kernels live in kg_literal.hip / kg_ac.hip / kg_post.hip.
+// kg_host.hip — core of the C-ABI of the krep-gpu backend (include/krep_gpu.h): configuration (the mirrored
+// reference globals), the select_search_algorithm() mirror, the result container, plans, and the device-resident
+// scan krep_gpu_scan_device[_ex]() with every reference return-value convention.
+// Host logic only; kernels live in kg_literal.hip / kg_ac.hip / kg_post.hip / kg_greedy.hip / kg_tail.hip.
+// The host-buffer operators (search_func_t entry points, search_buffer, streaming ingest) are in kg_ops.hip.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <mutex>
 #include <string>
-#include <thread>
 #include <vector>
 
 #include "../../include/krep_gpu.h"
 #include "kg_common.h"
-#include "kg_synth.h"
 #include "kg_internal.h"
+#include "kg_plan.h"
+#include "kg_replay.h"
 
 using namespace kg;
 
@@ -34,6 +36,7 @@ int fail(const char *fmt, ...)
     fprintf(stderr, "krep-gpu: %s\n", buf);
     return 2;
 }
+bool have_error() { return !g_err.empty(); }
 } // namespace kg
 #define HIPCHK(x)                                                                             \
     do                                                                                        \
@@ -45,7 +48,7 @@ int fail(const char *fmt, ...)
 
 extern "C" const char *krep_gpu_last_error(void) { return g_err.c_str(); }
 extern "C" void krep_gpu_clear_error(void) { g_err.clear(); }
-extern "C" const char *krep_gpu_version(void) { return "krep-gpu 0.1 (gfx950)"; }
+extern "C" const char *krep_gpu_version(void) { return "krep-gpu 0.2 (gfx950)"; }
 extern "C" int krep_gpu_device_count(void)
 {
     int n = 0;
@@ -54,22 +57,66 @@ extern "C" int krep_gpu_device_count(void)
     return n;
 }
 
-// ------------------------------------------------------------------------------------ mirror of the reference's globals
-static int g_simd = KREP_REF_AVX2, g_only_matching = 0, g_no_simd = 0, g_algo_override = KREP_ALGO_AUTO;
-extern "C" void krep_gpu_set_reference_simd(int l) { g_simd = l; }
-extern "C" int krep_gpu_get_reference_simd(void) { return g_simd; }
-extern "C" void krep_gpu_set_only_matching(int on) { g_only_matching = on != 0; }
-static int g_result_order = 0;
-extern "C" void krep_gpu_set_result_order(int by_start) { g_result_order = by_start != 0; }
-namespace kg { int current_only_matching() { return g_only_matching; } }
-namespace kg { int current_result_order() { return g_result_order; } }
-extern "C" void krep_gpu_set_force_no_simd(int on) { g_no_simd = on != 0; }
-extern "C" void krep_gpu_set_algo_override(int a) { g_algo_override = a; }
-static int g_force_rounds = 0; // test hook: 0 = auto, 1 / 4 = force the tile shape
-static int g_force_stage_cap = 0; // test hook: staging records per unit (0 = auto)
+// ------------------------------------------------------------------------------------ configuration
+// The reference decides its algorithm — hence the match-set family — from compile-time SIMD macros and three
+// file-static globals (krep.c:47-74, :117-120).  Here they are one explicit krep_gpu_config_t.  The setters below write
+// PROCESS-WIDE defaults (relaxed atomics: the reference's globals are process-wide too, set once by main() before the
+// pool threads start); krep_gpu_set_thread_config() overrides them for the calling thread; plans and search_buffer_ex()
+// carry their configuration explicitly.  Nothing on a scan path writes any of this.
+static std::atomic<int> g_simd{KREP_REF_AVX2}, g_only_matching{0}, g_no_simd{0}, g_algo_override{KREP_ALGO_AUTO},
+    g_result_order{0}, g_device{-1};
+static std::atomic<size_t> g_stream_chunk{0};
+static thread_local bool tl_cfg_set = false;
+static thread_local krep_gpu_config_t tl_cfg;
+
+static int env_device()
+{
+    const char *e = getenv("KREP_GPU_DEVICE");
+    return e && *e ? atoi(e) : 0;
+}
+extern "C" void krep_gpu_config_default(krep_gpu_config_t *c)
+{
+    if (!c)
+        return;
+    c->reference_simd = g_simd.load(std::memory_order_relaxed);
+    c->only_matching = g_only_matching.load(std::memory_order_relaxed);
+    c->force_no_simd = g_no_simd.load(std::memory_order_relaxed);
+    c->algo_override = g_algo_override.load(std::memory_order_relaxed);
+    c->result_order = g_result_order.load(std::memory_order_relaxed);
+    const int d = g_device.load(std::memory_order_relaxed);
+    c->device = d >= 0 ? d : env_device();
+    c->stream_chunk_bytes = g_stream_chunk.load(std::memory_order_relaxed);
+}
+extern "C" void krep_gpu_set_thread_config(const krep_gpu_config_t *c)
+{
+    tl_cfg_set = c != nullptr;
+    if (c)
+        tl_cfg = *c;
+}
+namespace kg {
+krep_gpu_config_t current_config()
+{
+    if (tl_cfg_set)
+        return tl_cfg;
+    krep_gpu_config_t c;
+    krep_gpu_config_default(&c);
+    return c;
+}
+} // namespace kg
+extern "C" void krep_gpu_set_reference_simd(int l) { g_simd.store(l, std::memory_order_relaxed); }
+extern "C" int krep_gpu_get_reference_simd(void) { return kg::current_config().reference_simd; }
+extern "C" void krep_gpu_set_only_matching(int on) { g_only_matching.store(on != 0, std::memory_order_relaxed); }
+extern "C" void krep_gpu_set_result_order(int by_start) { g_result_order.store(by_start != 0, std::memory_order_relaxed); }
+extern "C" void krep_gpu_set_force_no_simd(int on) { g_no_simd.store(on != 0, std::memory_order_relaxed); }
+extern "C" void krep_gpu_set_algo_override(int a) { g_algo_override.store(a, std::memory_order_relaxed); }
+extern "C" void krep_gpu_set_device(int d) { g_device.store(d, std::memory_order_relaxed); }
+extern "C" void krep_gpu_set_stream_chunk(size_t bytes) { g_stream_chunk.store(bytes, std::memory_order_relaxed); }
+
+static std::atomic<int> g_force_rounds{0};    // test hook: 0 = auto, 1 / 4 = force the tile shape
+static std::atomic<int> g_force_stage_cap{0}; // test hook: staging records per unit (0 = auto)
 namespace kg { extern int g_ac_force_stage_cap; }
-extern "C" void krep_gpu_debug_force_stage_cap(int c) { g_force_stage_cap = c; kg::g_ac_force_stage_cap = c; }
-extern "C" void krep_gpu_debug_force_rounds(int r) { g_force_rounds = r; }
+extern "C" void krep_gpu_debug_force_stage_cap(int c) { g_force_stage_cap.store(c); kg::g_ac_force_stage_cap = c; }
+extern "C" void krep_gpu_debug_force_rounds(int r) { g_force_rounds.store(r); }
 
 static inline uint8_t lo8(uint8_t c) { return (c >= 'A' && c <= 'Z') ? (uint8_t)(c + 32) : c; }
 
@@ -104,36 +151,38 @@ static bool repetitive_pattern(const char *s, size_t m)
     return false;
 }
 
+namespace kg {
 // The function pointer select_search_algorithm() would return (krep.c:1771-1870) ...
-static int mirror_top(const search_params_t *p)
+int mirror_top(const search_params_t *p, const krep_gpu_config_t &c)
 {
     if (p->use_regex)
         return KREP_RA_REGEX;
     if (p->num_patterns > 1)
         return KREP_RA_AHO_CORASICK;
-    if (g_algo_override == KREP_ALGO_BM)
+    if (c.algo_override == KREP_ALGO_BM)
         return KREP_RA_BMH;
-    if (g_algo_override == KREP_ALGO_KMP)
+    if (c.algo_override == KREP_ALGO_KMP)
         return KREP_RA_KMP;
-    const size_t simd_max = g_simd == KREP_REF_AVX512 ? 64 : g_simd == KREP_REF_AVX2 ? 32
-                          : (g_simd == KREP_REF_SSE42 || g_simd == KREP_REF_NEON)    ? 16 : 0;
-    const int top = g_simd == KREP_REF_AVX512 ? KREP_RA_AVX512 : g_simd == KREP_REF_AVX2 ? KREP_RA_AVX2
-                  : g_simd == KREP_REF_SSE42 ? KREP_RA_SSE42 : g_simd == KREP_REF_NEON ? KREP_RA_NEON : KREP_RA_NONE;
+    const int simd = c.reference_simd;
+    const size_t simd_max = simd == KREP_REF_AVX512 ? 64 : simd == KREP_REF_AVX2 ? 32
+                          : (simd == KREP_REF_SSE42 || simd == KREP_REF_NEON)    ? 16 : 0; // krep.c:101-113
+    const int top = simd == KREP_REF_AVX512 ? KREP_RA_AVX512 : simd == KREP_REF_AVX2 ? KREP_RA_AVX2
+                  : simd == KREP_REF_SSE42 ? KREP_RA_SSE42 : simd == KREP_REF_NEON ? KREP_RA_NEON : KREP_RA_NONE;
     const size_t m = p->pattern_len;
-    const bool can = !g_no_simd && simd_max > 0 && m <= simd_max;
+    const bool can = !c.force_no_simd && simd_max > 0 && m <= simd_max;
     if (m == 1)
         return KREP_RA_MEMCHR;
     if (m < 4)
         return (can && p->case_sensitive && top != KREP_RA_NONE) ? top : KREP_RA_MEMCHR_SHORT;
     if (can)
     {
-        if (g_simd == KREP_REF_AVX512 && m <= 64 && p->case_sensitive)
+        if (simd == KREP_REF_AVX512 && m <= 64 && p->case_sensitive)
             return KREP_RA_AVX512;
-        if ((g_simd == KREP_REF_AVX512 || g_simd == KREP_REF_AVX2) && m <= 32)
+        if ((simd == KREP_REF_AVX512 || simd == KREP_REF_AVX2) && m <= 32)
             return KREP_RA_AVX2;
-        if (g_simd == KREP_REF_SSE42 && m <= 16 && p->case_sensitive)
+        if (simd == KREP_REF_SSE42 && m <= 16 && p->case_sensitive)
             return KREP_RA_SSE42;
-        if (g_simd == KREP_REF_NEON && p->case_sensitive)
+        if (simd == KREP_REF_NEON && p->case_sensitive)
             return KREP_RA_NEON;
     }
     if (m < 8 && repetitive_pattern(p->pattern, m))
@@ -141,8 +190,8 @@ static int mirror_top(const search_params_t *p)
     return KREP_RA_BMH;
 }
 // ... and the function that ends up doing the work after the internal delegation chain
-// (krep.c:4708-4712, :4883-4896, :5114-5126; neon_search falls back like SSE4.2).
-static int mirror_effective(int top, const search_params_t *p, size_t text_len)
+// (krep.c:4512-4515, :4708-4712, :4883-4896, :5114-5126).
+int mirror_effective(int top, const search_params_t *p, size_t text_len)
 {
     const size_t m = p->pattern_len;
     int a = top;
@@ -163,15 +212,16 @@ static int mirror_effective(int top, const search_params_t *p, size_t text_len)
         if (m == 0 || m > 16 || !p->case_sensitive || text_len < m)
             a = KREP_RA_BMH;
     }
-    if (a == KREP_RA_NEON && (!p->case_sensitive || m == 0))
+    if (a == KREP_RA_NEON && (!p->case_sensitive || m == 0 || text_len < m))
         a = KREP_RA_BMH;
     return a;
 }
+} // namespace kg
 extern "C" int krep_gpu_mirror_select(const search_params_t *p, size_t text_len)
 {
     if (!p)
         return KREP_RA_NONE;
-    return mirror_effective(mirror_top(p), p, text_len);
+    return mirror_effective(mirror_top(p, kg::current_config()), p, text_len);
 }
 extern "C" const char *krep_gpu_algorithm_name(int a)
 {
@@ -189,6 +239,49 @@ extern "C" const char *krep_gpu_algorithm_name(int a)
     case KREP_RA_NEON: return "NEON";
     default: return "Unknown";
     }
+}
+
+// ------------------------------------------------------------------------------------ what is accelerated
+// Two input classes are NOT reproduced; for them krep_gpu_can_accelerate() says 0, krep_gpu_select_search_algorithm()
+// returns NULL (the caller keeps its CPU function pointer, exactly like the regex case) and the operators refuse loudly:
+//  * simd_sse42_search in -c mode with a pattern that contains '\n': its line skip adds (line_end + 1 - match) to the
+//    16-byte WINDOW start instead of to the match (krep.c:4787-4793), so where the scan resumes depends on the phase of
+//    the 17-m-byte window grid, which every earlier match has shifted — a sequential chain over the whole text.
+//    kmp_search -c with such a pattern resumes exactly behind the first '\n' (krep.c:1703-1707); it is kept off the
+//    GPU with it (same rarity: `--algo=kmp -c $'a\nb'`).
+//  * memchr_short_search in -c mode while the file-static only_matching is set: main() never produces that
+//    combination (krep.c:3811-3814 clears count_lines_mode under -o), so it has no reference behaviour to pin.
+static bool pattern_has_border(const uint8_t *p, size_t m)
+{
+    for (size_t k = 1; k < m; ++k)
+        if (memcmp(p, p + k, m - k) == 0)
+            return true;
+    return false;
+}
+namespace kg {
+const char *unsupported_reason(const search_params_t *p, const krep_gpu_config_t &c)
+{
+    if (!p)
+        return "NULL params";
+    if (p->use_regex)
+        return "regex search is not part of the accelerated path (keep krep's regex_search)";
+    if (p->num_patterns != 1 || !p->pattern)
+        return nullptr;
+    const int top = mirror_top(p, c);
+    const int eff = mirror_effective(top, p, SIZE_MAX / 2);
+    const bool has_nl = p->pattern_len && memchr(p->pattern, '\n', p->pattern_len) != nullptr;
+    if (p->count_lines_mode && has_nl && (eff == KREP_RA_SSE42 || eff == KREP_RA_KMP))
+        return "-c through simd_sse42_search / kmp_search with a pattern containing a newline is not accelerated "
+               "(window-phase dependent line skip, krep.c:4787-4793)";
+    if (p->count_lines_mode && c.only_matching && eff == KREP_RA_MEMCHR_SHORT)
+        return "memchr_short_search with count_lines_mode AND only_matching is not accelerated (unreachable from the "
+               "reference CLI, krep.c:3811-3814)";
+    return nullptr;
+}
+} // namespace kg
+extern "C" int krep_gpu_can_accelerate(const search_params_t *p)
+{
+    return kg::unsupported_reason(p, kg::current_config()) == nullptr ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------ result container (krep.c:139-251 contract)
@@ -221,8 +314,9 @@ extern "C" void krep_gpu_match_result_free(match_result_t *r)
     free(r->positions);
     free(r);
 }
+namespace kg {
 // make room for `extra` more records (malloc family, so the reference's match_result_free works)
-static bool result_reserve(match_result_t *r, uint64_t extra)
+bool result_reserve(match_result_t *r, uint64_t extra)
 {
     const uint64_t need = r->count + extra;
     if (need <= r->capacity && r->positions)
@@ -237,52 +331,18 @@ static bool result_reserve(match_result_t *r, uint64_t extra)
     r->capacity = cap;
     return true;
 }
+} // namespace kg
 
 // ------------------------------------------------------------------------------------ plans
-struct krep_gpu_plan
-{
-    int device = 0;
-    int ref_algo = KREP_RA_NONE; // top-level selection (delegation resolved per text length)
-    bool only_matching = false;
-    bool cs = true, ww = false, lines = false, track = false;
-    size_t max_count = SIZE_MAX;
-    std::vector<std::vector<uint8_t>> pats; // as given
-    // single literal
-    uint32_t m = 0, p0 = 0, p1 = 0, k0 = 0, k1 = 0, l0 = 0, l1 = 0;
-    uint32_t p2 = 0, p3 = 0, k2 = 0, k3 = 0, l2 = 0, l3 = 0; // bytes 8..15
-    std::vector<uint8_t> pat_folded; // folded when !cs
-    bool has_border = false;         // a proper prefix is also a suffix => all-occurrences != greedy
-    bool has_newline = false;
-    uint8_t *d_pat = nullptr;
-    // workspace
-    Counters *d_ctr = nullptr, *h_ctr = nullptr;
-    int num_cu = 256;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    // multi-pattern
-    AcTables *ac = nullptr;
-    // scratch for the greedy (family N) post-pass
-    PostScratch post;
-    search_params_t sp{}; // shallow copy with patterns pointing into `pats`
-    std::vector<const char *> pat_ptrs;
-    std::vector<size_t> pat_lens;
-};
-
-static bool pattern_has_border(const std::vector<uint8_t> &p)
-{
-    const size_t m = p.size();
-    for (size_t k = 1; k < m; ++k)
-        if (memcmp(p.data(), p.data() + k, m - k) == 0)
-            return true;
-    return false;
-}
-
-extern "C" krep_gpu_plan_t *krep_gpu_plan_create(const search_params_t *p, int only_matching, int device)
+extern "C" krep_gpu_plan_t *krep_gpu_plan_create_ex(const search_params_t *p, const krep_gpu_config_t *cfg_in)
 {
     if (!p)
     {
         kg::fail("plan_create: NULL params");
         return nullptr;
     }
+    const krep_gpu_config_t cfg = cfg_in ? *cfg_in : kg::current_config();
+    const int device = cfg.device;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     {
@@ -300,8 +360,9 @@ extern "C" krep_gpu_plan_t *krep_gpu_plan_create(const search_params_t *p, int o
         return nullptr;
     }
     auto *pl = new krep_gpu_plan();
+    pl->cfg = cfg;
     pl->device = device;
-    pl->only_matching = only_matching != 0;
+    pl->only_matching = cfg.only_matching != 0;
     pl->cs = p->case_sensitive;
     pl->ww = p->whole_word;
     pl->lines = p->count_lines_mode;
@@ -326,7 +387,9 @@ extern "C" krep_gpu_plan_t *krep_gpu_plan_create(const search_params_t *p, int o
         pl->sp.pattern = pl->pat_ptrs[0];
         pl->sp.pattern_len = pl->pat_lens[0];
     }
-    pl->ref_algo = mirror_top(&pl->sp);
+    pl->ref_algo = mirror_top(&pl->sp, cfg);
+    if (const char *why = kg::unsupported_reason(&pl->sp, cfg))
+        pl->unsupported = why;
 
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess)
@@ -342,7 +405,7 @@ extern "C" krep_gpu_plan_t *krep_gpu_plan_create(const search_params_t *p, int o
         if (!pl->cs)
             for (auto &c : pl->pat_folded)
                 c = lo8(c);
-        pl->has_border = pattern_has_border(pl->pat_folded);
+        pl->has_border = pattern_has_border(pl->pat_folded.data(), pl->pat_folded.size());
         pl->has_newline = memchr(raw.data(), '\n', raw.size()) != nullptr;
         uint8_t w[8] = {0}, k[8] = {0};
         for (uint32_t i = 0; i < 8 && i < pl->m; ++i)
@@ -383,6 +446,9 @@ extern "C" krep_gpu_plan_t *krep_gpu_plan_create(const search_params_t *p, int o
     }
     if (ok && pl->ref_algo == KREP_RA_AHO_CORASICK)
     {
+        for (auto &v : pl->pats)
+            if (!v.empty() && memchr(v.data(), '\n', v.size()))
+                pl->ac_has_newline = true;
         pl->ac = ac_build(pl->sp, device);
         ok = pl->ac != nullptr;
     }
@@ -394,6 +460,13 @@ extern "C" krep_gpu_plan_t *krep_gpu_plan_create(const search_params_t *p, int o
         return nullptr;
     }
     return pl;
+}
+extern "C" krep_gpu_plan_t *krep_gpu_plan_create(const search_params_t *p, int only_matching, int device)
+{
+    krep_gpu_config_t c = kg::current_config();
+    c.only_matching = only_matching != 0;
+    c.device = device;
+    return krep_gpu_plan_create_ex(p, &c);
 }
 
 #define DBGFREE(x)                                                                      \
@@ -415,6 +488,7 @@ extern "C" void krep_gpu_plan_destroy(krep_gpu_plan_t *pl)
     if (pl->ev1) DBGFREE(hipEventDestroy(pl->ev1));
     if (pl->ac) ac_free(pl->ac);
     post_free(pl->post);
+    post_free(pl->aux);
     delete pl;
 }
 extern "C" int krep_gpu_plan_ref_algo(const krep_gpu_plan_t *pl) { return pl ? pl->ref_algo : KREP_RA_NONE; }
@@ -433,10 +507,12 @@ static Verdict verdict_for(int algo, const krep_gpu_plan *pl, uint64_t total, ui
     case KREP_RA_MEMCHR: // krep.c:3897, :3955, :3976
     case KREP_RA_KMP:    // krep.c:1634, :1696, :1717
     case KREP_RA_AHO_CORASICK: // aho_corasick.c:316
+    case KREP_RA_SSE42: // :4713 then the pre-increment checks :4778/:4804
         if (maxc == 0)
             return v;
         break;
-    case KREP_RA_SSE42: // :4713 then the pre-increment checks :4778/:4804
+    case KREP_RA_NEON: // :4516 then the pre-increment checks :4582/:4616; count-only with max_count == 0 is resolved by
+                       // the caller (the tail call's BMH convention, scan_literal)
         if (maxc == 0)
             return v;
         break;
@@ -464,137 +540,122 @@ static Verdict verdict_for(int algo, const krep_gpu_plan *pl, uint64_t total, ui
     return v;
 }
 
-// ------------------------------------------------------------------------------------ device scan
-static int scan_literal(krep_gpu_plan *pl, int algo, const uint8_t *d_text, size_t text_len, size_t own_lo, size_t own_hi,
-                        size_t global_base, match_position_t *d_pos, uint64_t cap, hipStream_t st, int time_it,
-                        krep_gpu_scan_out_t *out)
+// ------------------------------------------------------------------------------------ device scan: single literal
+namespace {
+// the device buffer being scanned: a slice [global_base, global_base + text_len) of a text of global_len bytes
+struct Window
 {
-    const uint32_t m = pl->m;
-    memset(out, 0, sizeof *out);
-    if (m == 0 || text_len < m || own_lo >= own_hi)
-        return 0;
-    if (own_hi > text_len)
-        own_hi = text_len;
-    const uint64_t hi_match = std::min<uint64_t>(own_hi, text_len - m + 1);
-    if (hi_match <= own_lo)
-        return 0;
+    const uint8_t *d_text;
+    size_t text_len;          // bytes readable in the buffer
+    size_t own_lo, own_hi;    // buffer-relative ownership window
+    size_t global_base;       // offset of buffer byte 0 in the whole text (added to reported offsets)
+    size_t global_len;        // length of the whole text (== global_base + text_len for the buffer that holds its end)
+};
+// one pass of the literal kernel family + its ordering post-pass
+struct LitPass
+{
+    bool ww = false, lines = false;
+    bool first_byte = false;  // candidate pass of memchr_short -o: scan for pattern[0] only (starts clipped to n - m)
+    size_t own_lo = 0, own_hi = 0;
+    uint64_t excl_lo = 0, excl_hi = 0; // buffer-relative exclusion window (simd_avx512_search's unexamined block)
+    uint64_t ww_exempt = ~0ull;        // buffer-relative start whose left-neighbour test is skipped
+    enum Sink { COUNT, RECORDS, OCC } sink = COUNT;
+    uint64_t *d_out = nullptr;         // RECORDS: final match_position_t buffer
+    uint64_t out_cap = 0;
+    PostScratch *post = nullptr;
+    hipEvent_t ev_end = nullptr;       // recorded right behind the last kernel of the pass (before the counter read-back)
+};
+struct LitResult
+{
+    uint64_t total = 0, lines = 0;
+    unsigned long long summary = 0;
+    uint64_t n_units = 0, unit_bytes = 0, anchor = 0;
+};
+} // namespace
 
-    // match-set family of the reference algorithm being reproduced
-    bool greedy = (algo == KREP_RA_SSE42 || algo == KREP_RA_KMP);
-    if (pl->only_matching && !pl->lines)
-    { // -o inverts BMH and SSE4.2 (krep.c:1371, :4842); memchr_short's -o quirk is not reproduced
-        if (algo == KREP_RA_BMH)
-            greedy = true;
-        else if (algo == KREP_RA_SSE42)
-            greedy = false;
-        else if (algo == KREP_RA_MEMCHR_SHORT)
-            return kg::fail("memchr_short_search with -o (krep.c:4495 skips after failed candidates) is not supported");
-    }
-    bool need_post = greedy && pl->has_border && m > 1;
-    if (need_post && pl->has_newline && pl->lines)
-        return kg::fail("greedy (SSE4.2/KMP) line counting with a pattern containing a newline is not supported");
-    // without -w a line holds a greedy hit iff it holds any occurrence (a line's first occurrence heads a
-    // cluster), so plain -c needs no selection pass
-    if (need_post && pl->lines && !pl->ww)
-        need_post = false;
+static int lit_pass(krep_gpu_plan *pl, const Window &w, const LitPass &ps, hipStream_t st, LitResult *res)
+{
+    *res = LitResult{};
+    const uint32_t m_scan = ps.first_byte ? 1u : pl->m;
+    size_t own_hi = std::min(ps.own_hi, w.text_len);
+    if (ps.first_byte)
+        own_hi = std::min<size_t>(own_hi, w.text_len - pl->m + 1);
+    const uint64_t hi_match = std::min<uint64_t>(own_hi, w.text_len - m_scan + 1);
+    if (hi_match <= ps.own_lo)
+        return 0;
+    PostScratch &post = *ps.post;
 
     LitArgs a{};
-    a.text = d_text;
-    a.text_len = text_len;
-    a.own_lo = own_lo;
+    a.text = w.d_text;
+    a.text_len = w.text_len;
+    a.own_lo = ps.own_lo;
     a.own_hi = own_hi;
-    a.anchor = own_lo & ~(uint64_t)15;
+    a.anchor = ps.own_lo & ~(uint64_t)15;
     {
         // big tiles (128 KiB) once there are enough of them to fill the chip several times over
         const uint64_t span = hi_match - a.anchor;
         a.rounds = span >= ((uint64_t)pl->num_cu * 16 * kRoundsBig * kSegBytes * kWavesPerBlk) ? kRoundsBig : 1;
-        if (g_force_rounds == 1 || g_force_rounds == kRoundsBig)
-            a.rounds = (uint32_t)g_force_rounds;
+        const int fr = g_force_rounds.load(std::memory_order_relaxed);
+        if (fr == 1 || fr == kRoundsBig)
+            a.rounds = (uint32_t)fr;
         const uint64_t tile_bytes = (uint64_t)a.rounds * kSegBytes * kWavesPerBlk;
         a.num_tiles = (span + tile_bytes - 1) / tile_bytes;
     }
-    a.global_base = global_base;
-    a.ww_exempt_left = ~0ull;
-    a.excl_lo = a.excl_hi = 0; // empty
-    if (algo == KREP_RA_AVX512 && !pl->lines && text_len >= 64 && (text_len % 64) < (uint64_t)m - 1)
-    { // krep.c:5171: the last full 64-byte block is stepped over unexamined when remaining < (m-1)+64
-        a.excl_hi = text_len - text_len % 64;
-        a.excl_lo = a.excl_hi - 64;
-    }
-    if (pl->ww && !pl->lines)
-    { // the BMH tail call of the AVX paths sees the tail as its own text: no left context at its first byte
-        if (algo == KREP_RA_AVX2 && (text_len % 32) >= m)
-            a.ww_exempt_left = text_len - text_len % 32;
-        if (algo == KREP_RA_AVX512 && (text_len % 64) >= m)
-            a.ww_exempt_left = text_len - text_len % 64;
-    }
-    a.m = m;
-    a.p0 = pl->p0; a.p1 = pl->p1; a.k0 = pl->k0; a.k1 = pl->k1;
-    a.l0 = pl->l0; a.l1 = pl->l1;
-    a.p2 = pl->p2; a.p3 = pl->p3; a.k2 = pl->k2; a.k3 = pl->k3; a.l2 = pl->l2; a.l3 = pl->l3;
-    a.pat = pl->d_pat;
-    a.ctr = pl->d_ctr;
-
-    const uint64_t maxc = pl->max_count;
-    uint64_t want = 0; // records the caller can use
-    if (d_pos && cap)
+    a.global_base = w.global_base;
+    a.ww_exempt_left = ps.ww_exempt;
+    a.excl_lo = ps.excl_lo;
+    a.excl_hi = ps.excl_hi;
+    a.m = m_scan;
+    if (ps.first_byte)
     {
-        want = maxc;
-        if (algo == KREP_RA_KMP && maxc != SIZE_MAX)
-            want = maxc + 1;
-        // memchr batch quirk needs the (max_count+1)-th match as well
-        if (algo == KREP_RA_MEMCHR && maxc != SIZE_MAX)
-            want = maxc + 1;
-        want = std::min<uint64_t>(want, cap);
-    }
-
-    a.flags = (pl->cs ? 0 : F_CI);
-    if (!need_post)
-    {
-        if (pl->ww) a.flags |= F_WW;
-        if (pl->lines) a.flags |= F_LINES;
-        if (want) a.flags |= F_POS;
-        a.positions = (uint64_t *)d_pos;
-        a.pos_cap = want;
+        const uint8_t b = pl->pat_folded[0];
+        a.p0 = 0x01010101u * b;
+        a.k0 = 0xffu;
+        a.l0 = (!pl->cs && b >= 'a' && b <= 'z') ? 0x20202020u : 0u;
     }
     else
     {
-        // all occurrences first (no -w, no lines); greedy selection, -w and lines in the post-pass
-        a.flags |= F_POS;
+        a.p0 = pl->p0; a.p1 = pl->p1; a.k0 = pl->k0; a.k1 = pl->k1;
+        a.l0 = pl->l0; a.l1 = pl->l1;
+        a.p2 = pl->p2; a.p3 = pl->p3; a.k2 = pl->k2; a.k3 = pl->k3; a.l2 = pl->l2; a.l3 = pl->l3;
     }
-
-    HIPCHK(hipSetDevice(pl->device));
+    a.pat = pl->d_pat;
+    a.ctr = pl->d_ctr;
+    a.flags = (pl->cs ? 0 : F_CI) | (ps.ww ? F_WW : 0) | (ps.lines ? F_LINES : 0) | (ps.sink != LitPass::COUNT ? F_POS : 0);
     const bool chain = (a.flags & (F_POS | F_LINES)) != 0;
     const uint64_t n_units = a.num_tiles * kWavesPerBlk;
     // staging slot per unit: sized for ~4x BASELINE's densities (1e-4/B literal, 1e-2/B single byte);
     // denser units take the emit-mode re-scan
     a.stage_cap = 0;
     if (a.flags & F_POS)
-        a.stage_cap = a.rounds == kRoundsBig ? (m == 1 ? 512u : 64u) : (m == 1 ? 256u : 32u);
-    if (g_force_stage_cap && (a.flags & F_POS))
-        a.stage_cap = (uint32_t)g_force_stage_cap;
+        a.stage_cap = a.rounds == kRoundsBig ? (m_scan == 1 ? 512u : 64u) : (m_scan == 1 ? 256u : 32u);
+    const int fsc = g_force_stage_cap.load(std::memory_order_relaxed);
+    if (fsc && (a.flags & F_POS))
+        a.stage_cap = (uint32_t)fsc;
     if (chain)
     {
-        if (post_reserve(pl->post, n_units, (n_units * a.stage_cap + 3) / 4)) // 16-bit staging entries
+        if (post_reserve(post, n_units, (n_units * a.stage_cap + 3) / 4)) // 16-bit staging entries
             return 2;
-        a.unitinfo = pl->post.d_unitinfo;
-        a.stage = (uint64_t *)pl->post.d_stage;
-        a.offsets = (const uint64_t *)pl->post.d_offsets;
+        a.unitinfo = post.d_unitinfo;
+        a.stage = (uint64_t *)post.d_stage;
+        a.offsets = (const uint64_t *)post.d_offsets;
     }
     const uint32_t grid = (uint32_t)std::min<uint64_t>(a.num_tiles, (uint64_t)pl->num_cu * 8);
+    const uint64_t unit_bytes = (uint64_t)a.rounds * kSegBytes, origin = a.anchor + w.global_base;
+    res->n_units = n_units;
+    res->unit_bytes = unit_bytes;
+    res->anchor = a.anchor;
 
-    if (time_it) HIPCHK(hipEventRecord(pl->ev0, st));
-    uint64_t total = 0, lines = 0;
-    unsigned long long summary = 0;
-    if (!need_post)
+    HIPCHK(hipMemsetAsync(pl->d_ctr, 0, sizeof(Counters), st));
+    if (ps.sink != LitPass::OCC)
     {
-        HIPCHK(hipMemsetAsync(pl->d_ctr, 0, sizeof(Counters), st));
+        a.positions = ps.d_out;
+        a.pos_cap = ps.sink == LitPass::RECORDS ? ps.out_cap : 0;
         HIPCHK(launch_literal(a, grid, st));
-        const uint64_t unit_bytes = (uint64_t)a.rounds * kSegBytes, origin = a.anchor + global_base;
-        if (chain && post_order(pl->post, n_units, a.stage_cap, m, origin, unit_bytes, pl->lines, (uint64_t *)d_pos, want, pl->d_ctr,
+        if (chain && post_order(post, n_units, a.stage_cap, m_scan, origin, unit_bytes, ps.lines, ps.d_out, a.pos_cap, pl->d_ctr,
                                 pl->num_cu, st))
             return 2;
-        if (time_it) HIPCHK(hipEventRecord(pl->ev1, st));
+        if (ps.ev_end) HIPCHK(hipEventRecord(ps.ev_end, st));
         HIPCHK(hipMemcpyAsync(pl->h_ctr, pl->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         if ((a.flags & F_POS) && pl->h_ctr->overflow_units)
@@ -604,65 +665,373 @@ static int scan_literal(krep_gpu_plan *pl, int algo, const uint8_t *d_text, size
             e.emit_mode = 1;
             HIPCHK(hipMemsetAsync(&pl->d_ctr->ticket, 0, sizeof(unsigned long long), st));
             HIPCHK(launch_literal(e, grid, st));
-            if (time_it) HIPCHK(hipEventRecord(pl->ev1, st));
-            HIPCHK(hipStreamSynchronize(st));
+            if (ps.ev_end) HIPCHK(hipEventRecord(ps.ev_end, st));
         }
-        total = pl->h_ctr->total;
-        lines = pl->h_ctr->lines;
-        summary = pl->h_ctr->summary;
-        if (!chain)
-            summary = total ? (kLnHead | kLnTail) : 0;
     }
     else
     {
-        // family N with a bordered pattern: all occurrences first, then the greedy selection (kg_greedy.hip)
-        const bool ww_first = pl->ww && algo == KREP_RA_BMH; // BMH -o: a -w rejected hit does not consume (krep.c:1323-1329)
-        if (ww_first) a.flags |= F_WW;
-        HIPCHK(hipMemsetAsync(pl->d_ctr, 0, sizeof(Counters), st));
+        // all owned hits into post.d_occ (sized after the count is known): input of the sequential-family walks
         HIPCHK(launch_literal(a, grid, st));
-        if (post_offsets_pass(pl->post, n_units, false, pl->d_ctr, st))
+        if (post_offsets_pass(post, n_units, false, pl->d_ctr, st))
             return 2;
         HIPCHK(hipMemcpyAsync(pl->h_ctr, pl->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         const uint64_t n_occ = pl->h_ctr->total;
-        if (n_occ > pl->post.occ_cap)
+        if (n_occ > post.occ_cap)
         {
-            if (pl->post.d_occ) (void)hipFree(pl->post.d_occ);
-            pl->post.d_occ = nullptr;
-            pl->post.occ_cap = 0;
-            HIPCHK(hipMalloc(&pl->post.d_occ, n_occ * 2 * sizeof(uint64_t)));
-            pl->post.occ_cap = n_occ;
+            if (post.d_occ) (void)hipFree(post.d_occ);
+            post.d_occ = nullptr;
+            post.occ_cap = 0;
+            HIPCHK(hipMalloc(&post.d_occ, n_occ * 2 * sizeof(uint64_t)));
+            post.occ_cap = n_occ;
         }
         if (n_occ)
         {
-            if (post_gather_pass(pl->post, n_units, a.stage_cap, m, a.anchor + global_base, (uint64_t)a.rounds * kSegBytes,
-                                 pl->post.d_occ, n_occ, pl->num_cu, st))
+            if (post_gather_pass(post, n_units, a.stage_cap, m_scan, origin, unit_bytes, post.d_occ, n_occ, pl->num_cu, st))
                 return 2;
             if (pl->h_ctr->overflow_units)
             {
                 LitArgs e = a;
                 e.emit_mode = 1;
-                e.positions = pl->post.d_occ;
+                e.positions = post.d_occ;
                 e.pos_cap = n_occ;
                 HIPCHK(hipMemsetAsync(&pl->d_ctr->ticket, 0, sizeof(unsigned long long), st));
                 HIPCHK(launch_literal(e, grid, st));
             }
+        }
+    }
+    res->total = pl->h_ctr->total;
+    res->lines = pl->h_ctr->lines;
+    res->summary = chain ? pl->h_ctr->summary : (res->total ? (kLnHead | kLnTail) : 0);
+    return 0;
+}
+
+// ---- match-set family of the reference algorithm being reproduced -----------------------------------------------
+namespace {
+struct Family
+{
+    bool greedy = false;    // greedy leftmost non-overlapping occurrences (SSE4.2 / KMP; BMH under -o)
+    bool mshort_o = false;  // memchr_short_search under -o: candidate walk
+    bool need_walk = false; // a sequential pass over the ordered list is required (kg_greedy.hip)
+    bool replay = false;    // -c through a block-structured function: end-of-text replay (kg_replay.h)
+    bool neon_zero = false; // neon_search, count-only, max_count == 0 (tail-call convention)
+    bool whole_text() const { return need_walk || replay || neon_zero; } // cannot be scanned in pieces
+};
+Family family_of(int algo, bool only_matching, bool lines, bool ww, bool track, size_t maxc, bool has_border, uint32_t m)
+{
+    Family f;
+    f.greedy = (algo == KREP_RA_SSE42 || algo == KREP_RA_KMP);
+    if (only_matching)
+    {
+        if (algo == KREP_RA_SSE42)
+            f.greedy = false; // -o: advance = index + 1 (krep.c:4842), in every mode
+        else if (algo == KREP_RA_BMH && !lines)
+            f.greedy = true; // -o without -c: i += pattern_len after a hit (krep.c:1371)
+        else if (algo == KREP_RA_MEMCHR_SHORT)
+            f.mshort_o = true; // -o: advance = candidate + pattern_len, also after a FAILED candidate (krep.c:4495)
+    }
+    f.need_walk = (f.greedy && has_border && m > 1) || f.mshort_o;
+    // without -w a line holds a greedy hit iff it holds any occurrence (a line's first occurrence heads a cluster),
+    // so plain -c needs no selection pass
+    if (f.need_walk && !f.mshort_o && lines && !ww)
+        f.need_walk = false;
+    f.replay = lines && (algo == KREP_RA_AVX512 || algo == KREP_RA_NEON || (algo == KREP_RA_AVX2 && ww));
+    f.neon_zero = algo == KREP_RA_NEON && maxc == 0 && !lines && !track;
+    return f;
+}
+} // namespace
+namespace kg {
+// May the text be scanned in pieces (start-offset ownership + halo) whose results are merged?  Not for the sequential
+// families above, and not for multi-pattern -c with a '\n' inside a pattern (emission-order line transitions).
+bool shardable(const search_params_t *p, const krep_gpu_config_t &c, size_t text_len)
+{
+    if (!p || p->use_regex || p->num_patterns == 0)
+        return false;
+    if (p->num_patterns > 1)
+    {
+        if (!p->count_lines_mode)
+            return true;
+        for (size_t i = 0; i < p->num_patterns; ++i)
+            if (p->pattern_lens[i] && memchr(p->patterns[i], '\n', p->pattern_lens[i]))
+                return false;
+        return true;
+    }
+    const char *pat = p->patterns && p->pattern_lens ? p->patterns[0] : p->pattern;
+    const size_t m = p->patterns && p->pattern_lens ? p->pattern_lens[0] : p->pattern_len;
+    if (!pat || m == 0)
+        return true;
+    search_params_t q = *p;
+    q.pattern = pat;
+    q.pattern_len = m;
+    const int algo = mirror_effective(mirror_top(&q, c), &q, text_len);
+    std::vector<uint8_t> f((const uint8_t *)pat, (const uint8_t *)pat + m);
+    if (!p->case_sensitive)
+        for (auto &b : f)
+            b = lo8(b);
+    const Family fam = family_of(algo, c.only_matching != 0, p->count_lines_mode, p->whole_word, p->track_positions, p->max_count,
+                                 pattern_has_border(f.data(), m), (uint32_t)m);
+    return !fam.whole_text();
+}
+} // namespace kg
+
+// Where the reference's block loop stands when it enters the last kReplayWindow bytes (kg_replay.h): `cur`, and for
+// neon_search whether the (unterminated) line holding `cur` is already counted.  Uses the per-unit info words the
+// canonical -c pass over [0, X) just left in pl->post.
+static int replay_entry(krep_gpu_plan *pl, int algo, const Window &w, const LitResult &lr, uint64_t X, hipStream_t st,
+                        uint64_t *cur_out, int *open_out)
+{
+    const uint64_t n = w.text_len, B = algo == KREP_RA_AVX512 ? 64 : algo == KREP_RA_AVX2 ? 32 : 16;
+    unsigned long long *d_slot = &pl->d_ctr->pad[0], *h_slot = &pl->h_ctr->pad[0];
+    // last accepted occurrence with start < limit (limit <= X): the last unit reporting hits, re-scanned with records
+    auto last_accepted_before = [&](uint64_t limit, bool *found, uint64_t *q) -> int {
+        *found = false;
+        if (limit == 0 || lr.n_units == 0)
+            return 0;
+        uint64_t lim_units = std::min<uint64_t>(lr.n_units, (limit - lr.anchor + lr.unit_bytes - 1) / lr.unit_bytes);
+        while (lim_units)
+        {
+            uint64_t up1 = 0;
+            if (tail_last_hit(pl->post.d_unitinfo, lim_units, d_slot, h_slot, st, &up1))
+                return 2;
+            if (!up1)
+                return 0;
+            const uint64_t u = up1 - 1, ulo = lr.anchor + u * lr.unit_bytes;
+            LitPass ps;
+            ps.ww = pl->ww;
+            ps.own_lo = ulo;
+            ps.own_hi = std::min<uint64_t>(ulo + lr.unit_bytes, limit);
+            ps.sink = LitPass::OCC;
+            ps.post = &pl->aux;
+            LitResult r2;
+            if (lit_pass(pl, w, ps, st, &r2))
+                return 2;
+            if (r2.total)
+            {
+                uint64_t rec[2];
+                HIPCHK(hipMemcpy(rec, pl->aux.d_occ + 2 * (r2.total - 1), sizeof rec, hipMemcpyDeviceToHost));
+                *found = true;
+                *q = rec[0] - w.global_base;
+                return 0;
+            }
+            lim_units = u; // every hit of that unit starts at or after `limit`: look further left
+        }
+        return 0;
+    };
+    bool have_q = false;
+    uint64_t q = 0;
+    if (last_accepted_before(X, &have_q, &q))
+        return 2;
+    *open_out = 0;
+    if (!have_q)
+    {
+        *cur_out = (X / B) * B; // the block grid never left offset 0
+        return 0;
+    }
+    uint64_t nl = n;
+    if (tail_find_next_newline(w.d_text, q, n, d_slot, h_slot, st, &nl))
+        return 2;
+    if (nl < n)
+    {
+        const uint64_t nls = nl + 1; // the loop restarted here after counting q's line
+        *cur_out = nls <= X ? nls + ((X - nls) / B) * B : nls;
+        return 0;
+    }
+    if (algo != KREP_RA_NEON)
+    {
+        *cur_out = n; // unterminated line counted: the clamped advance ends the scan (krep.c:5006-5008, :5211-5213)
+        return 0;
+    }
+    // neon_search does not restart on an unterminated line: the grid is still the one set by the previous counted line
+    uint64_t lsp1 = 0;
+    if (tail_find_prev_newline(w.d_text, q, d_slot, h_slot, st, &lsp1))
+        return 2;
+    const uint64_t ls = lsp1; // start of q's line (0 when no '\n' precedes it)
+    bool have_q2 = false;
+    uint64_t q2 = 0, grid0 = 0;
+    if (last_accepted_before(ls, &have_q2, &q2))
+        return 2;
+    if (have_q2)
+    {
+        uint64_t nl2 = n;
+        if (tail_find_next_newline(w.d_text, q2, n, d_slot, h_slot, st, &nl2))
+            return 2;
+        grid0 = nl2 + 1; // <= ls
+    }
+    *cur_out = grid0 + ((X - grid0) / B) * B;
+    *open_out = 1;
+    return 0;
+}
+
+static int scan_literal(krep_gpu_plan *pl, int algo, const Window &w, match_position_t *d_pos, uint64_t cap, hipStream_t st,
+                        int time_it, krep_gpu_scan_out_t *out)
+{
+    const uint32_t m = pl->m;
+    memset(out, 0, sizeof *out);
+    // the reference function sees the WHOLE text: its length decides the delegation and every early-out
+    if (m == 0 || w.global_len < m || w.text_len < m || w.own_lo >= w.own_hi)
+        return 0;
+    const size_t own_hi = std::min(w.own_hi, w.text_len);
+    const bool whole = w.global_base == 0 && w.own_lo == 0 && own_hi + m > w.text_len && w.global_len == w.text_len;
+
+    const Family fam = family_of(algo, pl->only_matching, pl->lines, pl->ww, pl->track, pl->max_count, pl->has_border, m);
+    const bool mshort_o = fam.mshort_o, need_walk = fam.need_walk, replay = fam.replay;
+    if (need_walk && !whole)
+        return kg::fail("the greedy / only-matching families couple neighbouring matches: scan the whole text in one window "
+                        "(%s, pattern length %u)", krep_gpu_algorithm_name(algo), m);
+
+    // ---- where the block-structured functions put their quirks: positions in the WHOLE text, translated to the buffer
+    uint64_t excl_lo = 0, excl_hi = 0, ww_exempt = ~0ull;
+    {
+        const uint64_t G = w.global_len, base = w.global_base;
+        auto to_local = [&](uint64_t g) -> uint64_t { return g >= base && g - base < w.text_len ? g - base : ~0ull; };
+        if (algo == KREP_RA_AVX512 && !pl->lines && G >= 64 && (G % 64) < (uint64_t)m - 1)
+        { // krep.c:5171: the last full 64-byte block is stepped over unexamined when remaining < (m-1)+64
+            const uint64_t ghi = G - G % 64, glo = ghi - 64;
+            if (ghi > base && glo < base + w.text_len)
+            {
+                excl_lo = glo > base ? glo - base : 0;
+                excl_hi = std::min<uint64_t>(ghi - base, w.text_len);
+            }
+        }
+        if (pl->ww && !pl->lines)
+        { // the scalar tail call of the block functions sees the tail as its own text: no left context at its first byte
+            const uint64_t B = algo == KREP_RA_AVX2 ? 32 : algo == KREP_RA_AVX512 ? 64 : algo == KREP_RA_NEON ? 16 : 0;
+            if (B && (G % B) >= m)
+                ww_exempt = to_local(G - G % B);
+        }
+    }
+
+    const uint64_t maxc = pl->max_count;
+    uint64_t want = 0; // records the caller can use
+    if (d_pos && cap && !pl->lines)
+    {
+        want = maxc;
+        if ((algo == KREP_RA_KMP || algo == KREP_RA_MEMCHR) && maxc != SIZE_MAX)
+            want = maxc + 1; // KMP stores one more (krep.c:1717); the memchr batch quirk needs the next record too
+        want = std::min<uint64_t>(want, cap);
+    }
+
+    HIPCHK(hipSetDevice(pl->device));
+    if (time_it) HIPCHK(hipEventRecord(pl->ev0, st));
+    uint64_t total = 0, lines = 0;
+    unsigned long long summary = 0;
+    LitResult lr;
+    bool ev1_recorded = false;
+    if (replay)
+    {
+        // canonical -c over the starts before the last kReplayWindow bytes, then the reference's own walk over the rest
+        const uint64_t G = w.global_len, X = G > kReplayWindow ? G - kReplayWindow : 0;
+        if (!whole)
+        {
+            if (w.global_base + own_hi > X)
+                return kg::fail("-c through %s restarts its block grid at every counted line: the window that reaches the "
+                                "end of the text must be the whole text", krep_gpu_algorithm_name(algo));
+            LitPass ps;
+            ps.ww = pl->ww; ps.lines = true; ps.own_lo = w.own_lo; ps.own_hi = own_hi; ps.post = &pl->post;
+            if (lit_pass(pl, w, ps, st, &lr))
+                return 2;
+            total = lr.total; lines = lr.lines; summary = lr.summary;
+        }
+        else
+        {
+            uint64_t cur = 0, extra = 0;
+            int open = 0;
+            if (X)
+            {
+                LitPass ps;
+                ps.ww = pl->ww; ps.lines = true; ps.own_lo = 0; ps.own_hi = X; ps.post = &pl->post;
+                if (lit_pass(pl, w, ps, st, &lr))
+                    return 2;
+                if (replay_entry(pl, algo, w, lr, X, st, &cur, &open))
+                    return 2;
+            }
+            ReplayIn r{};
+            r.algo = algo; r.m = m; r.ww = pl->ww; r.n = G; r.cur = cur; r.open = open;
+            r.text = w.d_text; r.pat = pl->d_pat;
+            if (cur < G && tail_run_replay(r, &pl->d_ctr->pad[0], &pl->h_ctr->pad[0], st, &extra))
+                return 2;
+            lines = lr.lines + extra;
+            total = lines; // occurrence totals are not defined by a -c scan
+            summary = lines ? (kLnHead | kLnTail) : 0;
+        }
+    }
+    else if (!need_walk)
+    {
+        if (fam.neon_zero)
+        {
+            // count-only with max_count == 0: the first body hit returns 0 (krep.c:4616); with no body hit the tail call's
+            // BMH returns 1 on its first hit (krep.c:1355-1367)
+            const uint64_t G = w.global_len, T = G - G % 16;
+            if (!whole)
+                return kg::fail("neon_search with max_count == 0 needs the whole text in one window");
+            LitPass ps;
+            ps.ww = pl->ww; ps.own_lo = 0; ps.own_hi = T; ps.ww_exempt = ww_exempt; ps.post = &pl->post;
+            if (lit_pass(pl, w, ps, st, &lr))
+                return 2;
+            uint64_t ret = 0;
+            if (lr.total == 0 && G - T >= m)
+            {
+                ps.own_lo = T; ps.own_hi = G;
+                if (lit_pass(pl, w, ps, st, &lr))
+                    return 2;
+                ret = lr.total ? 1 : 0;
+            }
+            if (time_it) HIPCHK(hipEventRecord(pl->ev1, st));
+            HIPCHK(hipStreamSynchronize(st));
+            out->count = ret;
+            out->total_matches = lr.total;
+            return 0;
+        }
+        LitPass ps;
+        ps.ww = pl->ww; ps.lines = pl->lines; ps.own_lo = w.own_lo; ps.own_hi = own_hi;
+        ps.excl_lo = excl_lo; ps.excl_hi = excl_hi; ps.ww_exempt = ww_exempt;
+        ps.sink = want ? LitPass::RECORDS : LitPass::COUNT;
+        ps.d_out = (uint64_t *)d_pos; ps.out_cap = want; ps.post = &pl->post;
+        ps.ev_end = time_it ? pl->ev1 : nullptr;
+        if (lit_pass(pl, w, ps, st, &lr))
+            return 2;
+        ev1_recorded = time_it != 0 && lr.n_units != 0;
+        total = lr.total; lines = lr.lines; summary = lr.summary;
+    }
+    else
+    {
+        // sequential families on the ordered list (kg_greedy.hip): greedy non-overlapping selection (SSE4.2 / KMP, and BMH
+        // under -o) over all occurrences, or memchr_short's -o walk over the first-byte candidates
+        const bool ww_first = pl->ww && algo == KREP_RA_BMH; // BMH -o: a -w rejected hit does not consume (krep.c:1323-1329)
+        LitPass ps;
+        ps.own_lo = w.own_lo; ps.own_hi = own_hi; ps.sink = LitPass::OCC; ps.post = &pl->post;
+        ps.first_byte = mshort_o;
+        ps.ww = ww_first;
+        if (lit_pass(pl, w, ps, st, &lr))
+            return 2;
+        if (lr.total)
+        {
+            WalkSpec ws{};
+            ws.mode = mshort_o ? kWalkShortO : kWalkGreedy;
+            ws.m = m;
+            ws.ww = pl->ww && !ww_first;
+            ws.lines = pl->lines;
+            ws.ci = !pl->cs;
+            ws.b1 = m > 1 ? pl->pat_folded[1] : 0;
+            ws.b2 = m > 2 ? pl->pat_folded[2] : 0;
             HIPCHK(hipMemsetAsync(pl->d_ctr, 0, sizeof(Counters), st));
-            int rc = post_greedy(pl->post, d_text, text_len, global_base, m, pl->ww && !ww_first, pl->lines, n_occ,
-                                 (uint64_t *)d_pos, want, pl->d_ctr, pl->h_ctr, st, &total, &lines);
+            int rc = post_walk(pl->post, w.d_text, w.text_len, w.global_base, ws, lr.total, (uint64_t *)d_pos, want, pl->d_ctr,
+                               pl->h_ctr, st, &total, &lines);
             if (rc)
                 return rc;
         }
-        if (time_it) HIPCHK(hipEventRecord(pl->ev1, st));
-        HIPCHK(hipStreamSynchronize(st));
         summary = total ? (kLnHead | kLnTail) : 0; // shard line bits are not produced on this path
     }
     if (time_it)
     {
+        if (!ev1_recorded) HIPCHK(hipEventRecord(pl->ev1, st));
+        HIPCHK(hipStreamSynchronize(st));
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, pl->ev0, pl->ev1));
         out->kernel_ms = ms;
     }
+    else
+        HIPCHK(hipStreamSynchronize(st));
     out->total_matches = total;
     out->line_count = lines;
     out->has_newline = (summary & kLnNl) != 0;
@@ -670,7 +1039,7 @@ static int scan_literal(krep_gpu_plan *pl, int algo, const uint8_t *d_text, size
     out->tail_line_hit = (summary & kLnTail) != 0;
     Verdict v = verdict_for(algo, pl, total, lines, d_pos != nullptr);
     out->count = v.ret;
-    if (d_pos && cap && pl->track)
+    if (d_pos && cap && pl->track && !pl->lines)
     {
         // records the reference semantics need (memchr: one more than max_count, the host fixes the order)
         const uint64_t needed = (algo == KREP_RA_MEMCHR && maxc != SIZE_MAX && maxc != 0) ? std::min<uint64_t>(total, maxc + 1)
@@ -681,9 +1050,65 @@ static int scan_literal(krep_gpu_plan *pl, int algo, const uint8_t *d_text, size
     return 0;
 }
 
-extern "C" int krep_gpu_scan_device(krep_gpu_plan_t *pl, const void *d_text, size_t text_len, size_t own_lo, size_t own_hi,
-                                    size_t global_base, match_position_t *d_positions, uint64_t position_capacity,
-                                    void *stream, int time_it, krep_gpu_scan_out_t *out)
+// aho_corasick_search -c when a pattern contains '\n': matches are visited in emission order (end ascending, longest
+// first) and the counter is bumped whenever the line of a match START differs from the line of the previously counted
+// one (aho_corasick.c:383-396) — with a newline inside a pattern a later match may start on an EARLIER line, so a line
+// can be counted more than once.  Reproduced literally: the ordered match list, the line number of every start
+// (kg_format.hip), the number of changes along the list.
+static int scan_ac_newline_lines(krep_gpu_plan *pl, const Window &w, hipStream_t st, int time_it, krep_gpu_scan_out_t *out)
+{
+    if (!(w.global_base == 0 && w.own_lo == 0 && w.own_hi >= w.text_len && w.global_len == w.text_len))
+        return kg::fail("multi-pattern -c with a newline inside a pattern counts emission-order line changes: scan the whole "
+                        "text in one window");
+    if (pl->max_count == 0) // aho_corasick.c:316
+        return 0;
+    if (time_it) HIPCHK(hipEventRecord(pl->ev0, st));
+    krep_gpu_scan_out_t o1;
+    int rc = ac_scan(pl->ac, pl->d_ctr, pl->h_ctr, pl->post, pl->num_cu, w.d_text, w.text_len, 0, w.text_len, 0, nullptr, 0, pl->ww,
+                     false, false, SIZE_MAX, st, 0, pl->ev0, pl->ev1, &o1);
+    if (rc)
+        return rc;
+    const uint64_t total = o1.total_matches;
+    uint64_t changes = 0;
+    if (total)
+    {
+        match_position_t *d_rec = nullptr;
+        uint64_t *d_ln = nullptr;
+        HIPCHK(hipMalloc(&d_rec, total * sizeof(match_position_t)));
+        if (hipMalloc(&d_ln, total * sizeof(uint64_t)) != hipSuccess)
+        {
+            (void)hipFree(d_rec);
+            return kg::fail("line-number buffer allocation failed");
+        }
+        rc = ac_scan(pl->ac, pl->d_ctr, pl->h_ctr, pl->post, pl->num_cu, w.d_text, w.text_len, 0, w.text_len, 0, d_rec, total, pl->ww,
+                     false, true, SIZE_MAX, st, 0, pl->ev0, pl->ev1, &o1);
+        if (!rc)
+            rc = krep_gpu_line_numbers(w.d_text, w.text_len, d_rec, total, d_ln, st);
+        if (!rc)
+            rc = tail_count_changes(d_ln, total, &pl->d_ctr->pad[0], &pl->h_ctr->pad[0], st, &changes);
+        (void)hipFree(d_rec);
+        (void)hipFree(d_ln);
+        if (rc)
+            return rc;
+    }
+    if (time_it)
+    {
+        HIPCHK(hipEventRecord(pl->ev1, st));
+        HIPCHK(hipStreamSynchronize(st));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, pl->ev0, pl->ev1));
+        out->kernel_ms = ms;
+    }
+    out->total_matches = total;
+    out->line_count = changes;
+    out->head_line_hit = out->tail_line_hit = changes != 0;
+    out->count = std::min<uint64_t>(changes, pl->max_count);
+    return 0;
+}
+
+extern "C" int krep_gpu_scan_device_ex(krep_gpu_plan_t *pl, const void *d_text, size_t text_len, size_t own_lo, size_t own_hi,
+                                       size_t global_base, size_t global_len, match_position_t *d_positions,
+                                       uint64_t position_capacity, void *stream, int time_it, krep_gpu_scan_out_t *out)
 {
     krep_gpu_scan_out_t tmp;
     if (!out)
@@ -691,6 +1116,10 @@ extern "C" int krep_gpu_scan_device(krep_gpu_plan_t *pl, const void *d_text, siz
     memset(out, 0, sizeof *out);
     if (!pl || (!d_text && text_len))
         return kg::fail("scan_device: bad arguments");
+    if (global_len == 0)
+        global_len = global_base + text_len;
+    if (global_len < global_base + text_len)
+        return kg::fail("scan_device: global_len %zu is shorter than global_base + text_len", global_len);
     {
         // hipGetLastError() is sticky per thread: an earlier, deliberately ignored failure (e.g. a hipFree in a
         // destructor) must not be mistaken for a failure of the launches below
@@ -699,17 +1128,29 @@ extern "C" int krep_gpu_scan_device(krep_gpu_plan_t *pl, const void *d_text, siz
             fprintf(stderr, "krep-gpu: (debug) cleared stale HIP error: %s\n", hipGetErrorString(stale));
     }
     hipStream_t st = (hipStream_t)stream;
-    if (pl->ref_algo == KREP_RA_REGEX)
-        return kg::fail("regex search is not part of the accelerated path");
+    if (pl->unsupported)
+        return kg::fail("%s", pl->unsupported);
+    if (pl->ref_algo == KREP_RA_AHO_CORASICK && pl->lines && pl->ac_has_newline)
+    {
+        Window w{(const uint8_t *)d_text, text_len, own_lo, own_hi, global_base, global_len};
+        return scan_ac_newline_lines(pl, w, st, time_it, out);
+    }
     if (pl->ref_algo == KREP_RA_AHO_CORASICK)
         return ac_scan(pl->ac, pl->d_ctr, pl->h_ctr, pl->post, pl->num_cu, (const uint8_t *)d_text,
                        text_len, own_lo, own_hi, global_base, d_positions, position_capacity, pl->ww, pl->lines, pl->track,
                        pl->max_count, st, time_it, pl->ev0, pl->ev1, out);
     if (pl->sp.num_patterns != 1)
         return kg::fail("scan_device: no pattern");
-    const int algo = mirror_effective(pl->ref_algo, &pl->sp, text_len);
-    return scan_literal(pl, algo, (const uint8_t *)d_text, text_len, own_lo, own_hi, global_base, d_positions,
-                        position_capacity, st, time_it, out);
+    const int algo = mirror_effective(pl->ref_algo, &pl->sp, global_len);
+    Window w{(const uint8_t *)d_text, text_len, own_lo, own_hi, global_base, global_len};
+    return scan_literal(pl, algo, w, d_positions, position_capacity, st, time_it, out);
+}
+extern "C" int krep_gpu_scan_device(krep_gpu_plan_t *pl, const void *d_text, size_t text_len, size_t own_lo, size_t own_hi,
+                                    size_t global_base, match_position_t *d_positions, uint64_t position_capacity,
+                                    void *stream, int time_it, krep_gpu_scan_out_t *out)
+{
+    return krep_gpu_scan_device_ex(pl, d_text, text_len, own_lo, own_hi, global_base, 0, d_positions, position_capacity, stream,
+                                   time_it, out);
 }
 
 extern "C" uint64_t krep_gpu_combine_line_counts(const krep_gpu_scan_out_t *s, int n)
@@ -724,412 +1165,4 @@ extern "C" uint64_t krep_gpu_combine_line_counts(const krep_gpu_scan_out_t *s, i
         open = s[i].has_newline ? (s[i].tail_line_hit != 0) : (open || s[i].head_line_hit != 0);
     }
     return total;
-}
-
-// ------------------------------------------------------------------------------------ host-buffer operators
-namespace {
-struct DevBuf
-{
-    uint8_t *p = nullptr;
-    size_t cap = 0;
-    int dev = -1;
-};
-thread_local DevBuf tl_text, tl_pos;
-int ensure(DevBuf &b, size_t n, int dev)
-{
-    if (b.dev == dev && b.cap >= n && b.p)
-        return 0;
-    if (b.p)
-    {
-        (void)hipSetDevice(b.dev);
-        (void)hipFree(b.p);
-        b.p = nullptr;
-        b.cap = 0;
-    }
-    HIPCHK(hipSetDevice(dev));
-    size_t want = std::max<size_t>(n, 1 << 20);
-    HIPCHK(hipMalloc(&b.p, want));
-    b.cap = want;
-    b.dev = dev;
-    return 0;
-}
-} // namespace
-
-// Host buffer -> HBM through two pinned staging buffers: the CPU copy of chunk k+1 overlaps the DMA of chunk k
-// (the reference mmaps with MAP_POPULATE, krep.c:2630-2726; a pageable hipMemcpy stages serially).
-// PCIe-bound by construction (<= ~55 GB/s); this rate is reported separately and is never the roofline number.
-namespace {
-struct Stager
-{
-    static constexpr size_t kChunk = 32u << 20;
-    uint8_t *pin[2] = {nullptr, nullptr};
-    hipStream_t st = nullptr;
-    hipEvent_t done[2] = {nullptr, nullptr};
-    int dev = -1;
-    void release()
-    {
-        if (dev < 0)
-            return;
-        (void)hipSetDevice(dev);
-        for (int i = 0; i < 2; ++i)
-        {
-            if (pin[i]) (void)hipHostFree(pin[i]);
-            if (done[i]) (void)hipEventDestroy(done[i]);
-            pin[i] = nullptr;
-            done[i] = nullptr;
-        }
-        if (st) (void)hipStreamDestroy(st);
-        st = nullptr;
-        dev = -1;
-    }
-    int init(int device)
-    {
-        if (dev == device && pin[0])
-            return 0;
-        release();
-        HIPCHK(hipSetDevice(device));
-        for (int i = 0; i < 2; ++i)
-        {
-            HIPCHK(hipHostMalloc(&pin[i], kChunk));
-            HIPCHK(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
-        }
-        HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-        dev = device;
-        return 0;
-    }
-    int copy(uint8_t *d_dst, const char *src, size_t len)
-    {
-        if (len < (4u << 20)) // small buffers: one synchronous copy is cheaper than the pipeline
-        {
-            HIPCHK(hipMemcpy(d_dst, src, len, hipMemcpyHostToDevice));
-            return 0;
-        }
-        size_t off = 0;
-        for (int k = 0; off < len; ++k, off += kChunk)
-        {
-            const int b = k & 1;
-            const size_t n = std::min(kChunk, len - off);
-            if (k >= 2)
-                HIPCHK(hipEventSynchronize(done[b])); // the DMA that last used this staging buffer
-            {
-                // the staging copy is the bottleneck of the host path (one core ~12 GB/s): split it over 4 threads
-                constexpr int kT = 4;
-                std::thread th[kT - 1];
-                const size_t part = (n + kT - 1) / kT;
-                for (int q = 1; q < kT; ++q)
-                {
-                    const size_t o = (size_t)q * part;
-                    if (o < n)
-                        th[q - 1] = std::thread([=] { memcpy(pin[b] + o, src + off + o, std::min(part, n - o)); });
-                }
-                memcpy(pin[b], src + off, std::min(part, n));
-                for (auto &t : th)
-                    if (t.joinable())
-                        t.join();
-            }
-            HIPCHK(hipMemcpyAsync(d_dst + off, pin[b], n, hipMemcpyHostToDevice, st));
-            HIPCHK(hipEventRecord(done[b], st));
-        }
-        HIPCHK(hipStreamSynchronize(st));
-        return 0;
-    }
-};
-thread_local Stager tl_stager;
-} // namespace
-
-namespace kg {
-// pinned, double-buffered host -> device copy on the calling thread's staging buffers (also used per shard thread)
-int stage_to_device(uint8_t *d_dst, const char *src, size_t len, int device)
-{
-    if (tl_stager.init(device))
-        return 2;
-    return tl_stager.copy(d_dst, src, len);
-}
-void stage_release() { tl_stager.release(); } // short-lived shard threads give their pinned buffers back
-} // namespace kg
-
-// memchr_search's final flush (krep.c:3976-3991 + :4026-4038): when max_count is a multiple of the
-// 4096-entry batch and more matches exist, the (max_count+1)-th record is stored FIRST (in front of
-// the last batch) and the max_count-th is dropped.
-static void memchr_batch_quirk(match_position_t *recs, uint64_t have, size_t maxc)
-{
-    if (maxc == SIZE_MAX || maxc == 0 || have <= maxc || (maxc % 4096) != 0)
-        return;
-    const uint64_t f = maxc - 4096;
-    match_position_t extra = recs[maxc];
-    memmove(recs + f + 1, recs + f, 4095 * sizeof(match_position_t));
-    recs[f] = extra;
-}
-
-// One cached plan per calling thread: the CLI calls the operator once per file (krep.c:1950) with the same params,
-// and building a plan costs device allocations + (multi-pattern) table construction.  Keyed by every field the scan
-// depends on, including the mirrored globals.
-namespace {
-struct PlanKey
-{
-    std::vector<std::vector<uint8_t>> pats;
-    bool cs, lines, track, ww;
-    size_t max_count;
-    int simd, only_matching, no_simd, algo;
-    bool operator==(const PlanKey &o) const
-    {
-        return pats == o.pats && cs == o.cs && lines == o.lines && track == o.track && ww == o.ww && max_count == o.max_count &&
-               simd == o.simd && only_matching == o.only_matching && no_simd == o.no_simd && algo == o.algo;
-    }
-};
-struct PlanCache
-{
-    PlanKey key;
-    krep_gpu_plan_t *plan = nullptr;
-    ~PlanCache()
-    {
-        // process teardown: the HIP runtime may already be gone, so the plan is deliberately not destroyed here
-    }
-};
-thread_local PlanCache tl_plan;
-} // namespace
-
-static krep_gpu_plan_t *cached_plan(const search_params_t *p)
-{
-    PlanKey k;
-    if (p->num_patterns >= 1 && p->patterns && p->pattern_lens)
-        for (size_t i = 0; i < p->num_patterns; ++i)
-            k.pats.emplace_back((const uint8_t *)p->patterns[i], (const uint8_t *)p->patterns[i] + p->pattern_lens[i]);
-    else if (p->pattern)
-        k.pats.emplace_back((const uint8_t *)p->pattern, (const uint8_t *)p->pattern + p->pattern_len);
-    k.cs = p->case_sensitive; k.lines = p->count_lines_mode; k.track = p->track_positions; k.ww = p->whole_word;
-    k.max_count = p->max_count;
-    k.simd = g_simd; k.only_matching = g_only_matching; k.no_simd = g_no_simd; k.algo = g_algo_override;
-    if (tl_plan.plan && tl_plan.key == k)
-        return tl_plan.plan;
-    if (tl_plan.plan)
-    {
-        krep_gpu_plan_destroy(tl_plan.plan);
-        tl_plan.plan = nullptr;
-    }
-    tl_plan.plan = krep_gpu_plan_create(p, g_only_matching, 0);
-    tl_plan.key = std::move(k);
-    return tl_plan.plan;
-}
-
-static uint64_t run_host_operator(const search_params_t *params, const char *text, size_t text_len, match_result_t *result,
-                                  int *status)
-{
-    if (status)
-        *status = 2;
-    if (!params || (!text && text_len))
-    {
-        kg::fail("NULL params/text");
-        return 0;
-    }
-    krep_gpu_plan_t *pl = cached_plan(params);
-    if (!pl)
-        return 0;
-    uint64_t ret = 0;
-    do
-    {
-        if (pl->ref_algo == KREP_RA_AHO_CORASICK && !params->ac_trie)
-        { // aho_corasick.c:306: no trie, no matches
-            if (status) *status = 0;
-            break;
-        }
-        if (ensure(tl_text, text_len + 64, 0))
-            break;
-        if (text_len && (tl_stager.init(0) || tl_stager.copy(tl_text.p, text, text_len)))
-        {
-            if (g_err.empty())
-                kg::fail("H2D copy failed");
-            break;
-        }
-        const bool want_pos = params->track_positions && result != nullptr && !params->count_lines_mode;
-        uint64_t cap = 0;
-        if (want_pos)
-        {
-            cap = std::max<uint64_t>(1u << 16, text_len / 64);
-            if (params->max_count != SIZE_MAX)
-                cap = std::min<uint64_t>(cap, (uint64_t)params->max_count + 1);
-            cap = std::max<uint64_t>(cap, 1);
-        }
-        krep_gpu_scan_out_t so;
-        int rc = 0;
-        for (int attempt = 0; attempt < 2; ++attempt)
-        {
-            if (cap && ensure(tl_pos, cap * sizeof(match_position_t), 0))
-            {
-                rc = 2;
-                break;
-            }
-            rc = krep_gpu_scan_device(pl, tl_text.p, text_len, 0, text_len, 0, cap ? (match_position_t *)tl_pos.p : nullptr, cap,
-                                      nullptr, 0, &so);
-            if (rc || !so.overflow)
-                break;
-            cap = so.total_matches + 1; // exact size, second and last pass
-        }
-        if (rc)
-            break;
-        ret = so.count;
-        if (want_pos && so.stored)
-        {
-            if (g_result_order && pl->ref_algo == KREP_RA_AHO_CORASICK &&
-                krep_gpu_order_by_start((match_position_t *)tl_pos.p, so.stored, text_len, nullptr))
-            {
-                ret = 0;
-                break;
-            }
-            std::vector<match_position_t> tmp(so.stored);
-            if (hipMemcpy(tmp.data(), tl_pos.p, so.stored * sizeof(match_position_t), hipMemcpyDeviceToHost) != hipSuccess)
-            {
-                kg::fail("D2H copy failed");
-                ret = 0;
-                break;
-            }
-            uint64_t n = so.stored;
-            const int algo = pl->ref_algo == KREP_RA_AHO_CORASICK ? KREP_RA_AHO_CORASICK
-                                                                   : mirror_effective(pl->ref_algo, &pl->sp, text_len);
-            if (algo == KREP_RA_MEMCHR && params->max_count != SIZE_MAX)
-            {
-                memchr_batch_quirk(tmp.data(), n, params->max_count);
-                n = std::min<uint64_t>(n, params->max_count);
-            }
-            if (!result_reserve(result, n))
-            {
-                kg::fail("out of memory growing match_result_t");
-                ret = 0;
-                break;
-            }
-            memcpy(result->positions + result->count, tmp.data(), n * sizeof(match_position_t));
-            result->count += n;
-        }
-        if (status)
-            *status = 0;
-    } while (0);
-    return ret; // the plan stays in this thread's one-entry cache
-}
-
-extern "C" uint64_t krep_gpu_literal_search(const search_params_t *params, const char *text, size_t len, match_result_t *result)
-{
-    return run_host_operator(params, text, len, result, nullptr);
-}
-extern "C" uint64_t krep_gpu_aho_corasick_search(const search_params_t *params, const char *text, size_t len,
-                                                 match_result_t *result)
-{
-    return run_host_operator(params, text, len, result, nullptr);
-}
-extern "C" search_func_t krep_gpu_select_search_algorithm(const search_params_t *params)
-{
-    if (!params || params->use_regex)
-        return nullptr;
-    return params->num_patterns > 1 ? krep_gpu_aho_corasick_search : krep_gpu_literal_search;
-}
-
-// search_string()'s validation and verdict (krep.c:2013-2049, :2166-2199), minus strlen and printing
-extern "C" int search_buffer(const search_params_t *params, const char *buf, size_t len, int only_matching, int num_gpus,
-                             match_result_t *out, uint64_t *count_out)
-{
-    if (count_out)
-        *count_out = 0;
-    if (!params || params->num_patterns == 0)
-        return kg::fail("Error: No pattern specified.");
-    if (!buf && len)
-        return kg::fail("Error: NULL text in search_buffer.");
-    if (params->use_regex)
-        return kg::fail("regex search is not accelerated; keep krep's regex_search for it");
-    for (size_t i = 0; i < params->num_patterns; ++i)
-    {
-        if (params->pattern_lens[i] == 0)
-        {
-            if (params->num_patterns > 1)
-                return kg::fail("Error: Empty pattern provided for literal search with multiple patterns.");
-        }
-        else if (params->pattern_lens[i] > 1024) // MAX_PATTERN_LENGTH, krep.c:77
-            return kg::fail("Error: Pattern too long (max 1024).");
-    }
-    const int saved = g_only_matching;
-    g_only_matching = only_matching != 0;
-    int st = 2;
-    uint64_t n = 0;
-    if (num_gpus > 1)
-        n = multi_gpu_search(params, buf, len, num_gpus, out, &st);
-    else
-    {
-        search_params_t local = *params;
-        static int dummy_trie;
-        if (local.num_patterns > 1 && !local.ac_trie)
-            local.ac_trie = (ac_trie_t *)&dummy_trie; // search_string builds the trie itself (krep.c:2067-2078)
-        n = run_host_operator(&local, buf, len, out, &st);
-    }
-    g_only_matching = saved;
-    if (st)
-        return 2;
-    const size_t maxc = params->max_count;
-    if (maxc != SIZE_MAX && n > maxc)
-        n = maxc;
-    if (out && maxc != SIZE_MAX && out->count > maxc)
-        out->count = maxc;
-    bool found;
-    if (params->count_lines_mode || params->count_matches_mode)
-        found = n > 0;
-    else
-    {
-        found = out && out->count > 0;
-        if (found)
-            n = out->count;
-        else if (!out)
-            found = n > 0;
-    }
-    if (count_out)
-        *count_out = n;
-    return found ? 0 : 1;
-}
-
-// ------------------------------------------------------------------------------------ generators
-__global__ void synth_kernel(uint8_t *dst, size_t len, size_t goff, int kind, uint64_t seed, const uint8_t *plant,
-                             uint64_t plen, uint64_t period)
-{
-    const size_t stride = (size_t)gridDim.x * blockDim.x * 16;
-    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 16; i < len; i += stride)
-    {
-        uint32_t w[4] = {0, 0, 0, 0};
-        const size_t n = len - i < 16 ? len - i : 16;
-        for (size_t b = 0; b < n; ++b)
-            w[b >> 2] |= (uint32_t)synth_byte(goff + i + b, kind, seed, plant, plen, period) << (8 * (b & 3));
-        if (n == 16 && (((uintptr_t)(dst + i)) & 15) == 0)
-            *reinterpret_cast<uint4 *>(dst + i) = make_uint4(w[0], w[1], w[2], w[3]);
-        else
-            for (size_t b = 0; b < n; ++b)
-                dst[i + b] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
-    }
-}
-
-extern "C" int krep_gpu_generate(void *d_dst, size_t len, size_t global_off, int kind, uint64_t seed, const void *plant,
-                                 size_t plant_len, uint64_t period, void *stream)
-{
-    if (!len)
-        return 0;
-    if ((kind == 2 || kind == 3 || kind == 4) && (!plant || !plant_len))
-        return kg::fail("generate: kind %d needs a plant", kind);
-    if ((kind == 2) && period < plant_len)
-        return kg::fail("generate: period < plant length");
-    hipStream_t st = (hipStream_t)stream;
-    uint8_t *d_plant = nullptr;
-    if (plant_len)
-    {
-        HIPCHK(hipMalloc(&d_plant, plant_len));
-        HIPCHK(hipMemcpyAsync(d_plant, plant, plant_len, hipMemcpyHostToDevice, st));
-    }
-    const uint64_t plen = (kind == 4) ? 0 : plant_len;
-    hipLaunchKernelGGL(synth_kernel, dim3(256 * 16), dim3(256), 0, st, (uint8_t *)d_dst, len, global_off, kind, seed, d_plant,
-                       plen, period ? period : 1);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(st));
-    if (d_plant) (void)hipFree(d_plant);
-    return 0;
-}
-extern "C" void krep_gpu_generate_host(void *dst, size_t len, size_t global_off, int kind, uint64_t seed, const void *plant,
-                                       size_t plant_len, uint64_t period)
-{
-    uint8_t *d = (uint8_t *)dst;
-    const uint64_t plen = (kind == 4) ? 0 : plant_len;
-    for (size_t i = 0; i < len; ++i)
-        d[i] = synth_byte(global_off + i, kind, seed, (const uint8_t *)plant, plen, period ? period : 1);
 }

@@ -36,10 +36,30 @@ int post_order(PostScratch &s, uint64_t n_units, uint32_t stage_cap, uint32_t fi
 int post_offsets_pass(PostScratch &s, uint64_t n_units, bool want_lines, Counters *d_ctr, hipStream_t st);
 int post_gather_pass(PostScratch &s, uint64_t n_units, uint32_t stage_cap, uint32_t fixed_len, uint64_t origin,
                      uint64_t unit_bytes, uint64_t *d_pos, uint64_t pos_cap, int num_cu, hipStream_t st);
-// greedy non-overlapping selection (simd_sse42_search / kmp_search family) on the ordered occurrence list
-int post_greedy(PostScratch &s, const uint8_t *d_text, uint64_t text_len, uint64_t global_base, uint32_t m, bool ww,
-                bool lines, uint64_t n_occ, uint64_t *d_pos, uint64_t want, Counters *d_ctr, Counters *h_ctr, hipStream_t st,
-                uint64_t *total, uint64_t *nlines);
+// kg_greedy.hip — the sequential match-set families, walked cluster by cluster on the ordered list in s.d_occ
+constexpr uint32_t kWalkGreedy = 0; // simd_sse42_search / kmp_search (and BMH under -o): greedy non-overlapping occurrences
+constexpr uint32_t kWalkShortO = 1; // memchr_short_search under -o: first-byte candidates, m skipped after a failed one too
+struct WalkSpec
+{
+    uint32_t mode, m;
+    bool ww, lines, ci;
+    uint8_t b1, b2; // kWalkShortO: (folded) pattern bytes 1 and 2
+};
+int post_walk(PostScratch &s, const uint8_t *d_text, uint64_t text_len, uint64_t global_base, const WalkSpec &ws,
+              uint64_t n_occ, uint64_t *d_pos, uint64_t want, Counters *d_ctr, Counters *h_ctr, hipStream_t st,
+              uint64_t *total, uint64_t *nlines);
+
+// kg_tail.hip — end-of-text replay of the block-structured -c paths (kg_replay.h)
+struct ReplayIn;
+int tail_last_hit(const unsigned long long *d_unitinfo, uint64_t limit_units, unsigned long long *d_slot,
+                  unsigned long long *h_slot, hipStream_t st, uint64_t *unit_plus1);
+int tail_find_next_newline(const uint8_t *d_text, uint64_t from, uint64_t n, unsigned long long *d_slot,
+                           unsigned long long *h_slot, hipStream_t st, uint64_t *pos);
+int tail_find_prev_newline(const uint8_t *d_text, uint64_t before, unsigned long long *d_slot, unsigned long long *h_slot,
+                           hipStream_t st, uint64_t *pos_plus1);
+int tail_count_changes(const uint64_t *d_v, uint64_t n, unsigned long long *d_slot, unsigned long long *h_slot, hipStream_t st,
+                       uint64_t *changes);
+int tail_run_replay(const ReplayIn &r, unsigned long long *d_slot, unsigned long long *h_slot, hipStream_t st, uint64_t *lines);
 
 // kg_ac.hip — multi-pattern scan
 struct AcTables;
@@ -50,13 +70,22 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
             match_position_t *d_pos, uint64_t cap, bool ww, bool lines, bool track, size_t max_count, hipStream_t st,
             int time_it, hipEvent_t ev0, hipEvent_t ev1, krep_gpu_scan_out_t *out);
 
-int current_only_matching();
-int current_result_order(); // krep_gpu_set_result_order(): 1 = hand records back in (start, end) order
-int stage_to_device(uint8_t *d_dst, const char *src, size_t len, int device); // kg_host.hip: pinned double-buffered H2D
-void stage_release(); // the mirrored file-static `only_matching` (krep.c:117)
+// kg_host.hip — configuration (explicit; see krep_gpu_config_t), selector mirror, result container
+krep_gpu_config_t current_config(); // the calling thread's override, else the process-wide defaults
+int mirror_top(const search_params_t *p, const krep_gpu_config_t &c);
+int mirror_effective(int top, const search_params_t *p, size_t text_len);
+const char *unsupported_reason(const search_params_t *p, const krep_gpu_config_t &c); // NULL = accelerated
+bool shardable(const search_params_t *p, const krep_gpu_config_t &c, size_t text_len); // pieces + merge reproduce the result
+bool result_reserve(match_result_t *r, uint64_t extra);
+bool have_error();
+
+// kg_ops.hip — host-buffer side
+int stage_to_device(uint8_t *d_dst, const char *src, size_t len, int device); // pinned double-buffered H2D
+void stage_release();
+void memchr_batch_quirk(match_position_t *recs, uint64_t have, size_t maxc);
 
 // kg_multi.hip — one process driving several devices (search_buffer(num_gpus > 1))
-uint64_t multi_gpu_search(const search_params_t *params, const char *buf, size_t len, int num_gpus, match_result_t *out,
-                          int *status);
+uint64_t multi_gpu_search(const search_params_t *params, const char *buf, size_t len, int num_gpus,
+                          const krep_gpu_config_t &cfg, match_result_t *out, int *status);
 
 } // namespace kg

@@ -1,0 +1,768 @@
+// kg_ops.hip — the host-buffer side of the C-ABI: the search_func_t operators, search_buffer[_ex](), the drop-in for
+// select_search_algorithm(), and the executor that brings a host buffer through HBM:
+//   * ONE PIECE (the whole text staged, then scanned) for small inputs and for the sequential match-set families;
+//   * PIECES otherwise — contiguous chunks with start-offset ownership and Lmax+1 bytes of halo, spread over the requested
+//     devices (search_buffer(num_gpus > 1): the reference's chunk loop, krep.c:2816-2905, without its double counting) and,
+//     per device, STREAMED: piece k+1 is copied through the pinned staging ring (mmap'd / pageable source -> pinned ->
+//     DMA) while piece k is scanned, two device buffers per device, so a haystack larger than HBM works and the scan time
+//     hides under the PCIe time (the reference's counterpart is mmap + MAP_POPULATE, krep.c:2630-2726).
+// Every device has ONE context (buffers, staging ring, a small plan cache) behind a mutex: the operators are re-entrant
+// from any number of threads (SURVEY §8b "Threading", krep.c:1950), calls on one device serialise.  The configuration
+// travels explicitly (krep_gpu_config_t); nothing here writes a global.
+#include <hip/hip_runtime.h>
+#include <pthread.h>
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/krep_gpu.h"
+#include "kg_common.h"
+#include "kg_internal.h"
+#include "kg_plan.h"
+
+using namespace kg;
+
+#define HIPCHK(x)                                                                             \
+    do                                                                                        \
+    {                                                                                         \
+        hipError_t e_ = (x);                                                                  \
+        if (e_ != hipSuccess)                                                                 \
+            return kg::fail("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+namespace {
+// ---------------------------------------------------------------------------------------------- device buffers
+struct DevBuf
+{
+    uint8_t *p = nullptr;
+    size_t cap = 0;
+    int dev = -1;
+    int ensure(size_t n, int device)
+    {
+        if (dev == device && cap >= n && p)
+            return 0;
+        release();
+        HIPCHK(hipSetDevice(device));
+        const size_t want = std::max<size_t>(n, 1 << 20);
+        if (hipMalloc(&p, want) != hipSuccess)
+        {
+            p = nullptr;
+            (void)hipGetLastError();
+            return kg::fail("hipMalloc of %zu bytes failed on device %d", want, device);
+        }
+        cap = want;
+        dev = device;
+        return 0;
+    }
+    void release()
+    {
+        if (p)
+        {
+            (void)hipSetDevice(dev);
+            (void)hipFree(p);
+        }
+        p = nullptr;
+        cap = 0;
+        dev = -1;
+    }
+};
+
+// Host buffer -> HBM through two pinned staging buffers: the CPU copy of chunk k+1 overlaps the DMA of chunk k
+// (a pageable hipMemcpy stages serially).  PCIe-bound by construction (<= ~55 GB/s); this rate is reported separately and
+// is never the roofline number.
+struct Stager
+{
+    static constexpr size_t kChunk = 32u << 20;
+    uint8_t *pin[2] = {nullptr, nullptr};
+    hipStream_t st = nullptr;
+    hipEvent_t done[2] = {nullptr, nullptr};
+    int dev = -1;
+    void release()
+    {
+        if (dev < 0)
+            return;
+        (void)hipSetDevice(dev);
+        for (int i = 0; i < 2; ++i)
+        {
+            if (pin[i]) (void)hipHostFree(pin[i]);
+            if (done[i]) (void)hipEventDestroy(done[i]);
+            pin[i] = nullptr;
+            done[i] = nullptr;
+        }
+        if (st) (void)hipStreamDestroy(st);
+        st = nullptr;
+        dev = -1;
+    }
+    int init(int device)
+    {
+        if (dev == device && pin[0])
+            return 0;
+        release();
+        HIPCHK(hipSetDevice(device));
+        dev = device;
+        for (int i = 0; i < 2; ++i)
+        {
+            HIPCHK(hipHostMalloc(&pin[i], kChunk));
+            HIPCHK(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+        }
+        HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        return 0;
+    }
+    int copy(uint8_t *d_dst, const char *src, size_t len)
+    {
+        HIPCHK(hipSetDevice(dev));
+        if (len < (4u << 20)) // small buffers: one synchronous copy is cheaper than the pipeline
+        {
+            HIPCHK(hipMemcpy(d_dst, src, len, hipMemcpyHostToDevice));
+            return 0;
+        }
+        size_t off = 0;
+        for (int k = 0; off < len; ++k, off += kChunk)
+        {
+            const int b = k & 1;
+            const size_t n = std::min(kChunk, len - off);
+            if (k >= 2)
+                HIPCHK(hipEventSynchronize(done[b])); // the DMA that last used this staging buffer
+            {
+                // the staging copy is the bottleneck of the host path (one core ~12 GB/s): split it over 4 threads
+                constexpr int kT = 4;
+                std::thread th[kT - 1];
+                const size_t part = (n + kT - 1) / kT;
+                for (int q = 1; q < kT; ++q)
+                {
+                    const size_t o = (size_t)q * part;
+                    if (o < n)
+                        th[q - 1] = std::thread([=] { memcpy(pin[b] + o, src + off + o, std::min(part, n - o)); });
+                }
+                memcpy(pin[b], src + off, std::min(part, n));
+                for (auto &t : th)
+                    if (t.joinable())
+                        t.join();
+            }
+            HIPCHK(hipMemcpyAsync(d_dst + off, pin[b], n, hipMemcpyHostToDevice, st));
+            HIPCHK(hipEventRecord(done[b], st));
+        }
+        HIPCHK(hipStreamSynchronize(st));
+        return 0;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------- plan cache
+// The CLI calls the operator once per file (krep.c:1950) with the same params, and building a plan costs device
+// allocations + (multi-pattern) table construction.  Keyed by every field the scan depends on, configuration included.
+struct PlanKey
+{
+    std::vector<std::vector<uint8_t>> pats;
+    bool cs = true, lines = false, track = false, ww = false, regex = false;
+    size_t max_count = SIZE_MAX;
+    int simd = 0, only_matching = 0, no_simd = 0, algo = 0, device = 0;
+    bool operator==(const PlanKey &o) const
+    {
+        return pats == o.pats && cs == o.cs && lines == o.lines && track == o.track && ww == o.ww && regex == o.regex &&
+               max_count == o.max_count && simd == o.simd && only_matching == o.only_matching && no_simd == o.no_simd &&
+               algo == o.algo && device == o.device;
+    }
+};
+PlanKey key_of(const search_params_t *p, const krep_gpu_config_t &c, int device)
+{
+    PlanKey k;
+    if (p->num_patterns >= 1 && p->patterns && p->pattern_lens)
+        for (size_t i = 0; i < p->num_patterns; ++i)
+            k.pats.emplace_back((const uint8_t *)p->patterns[i], (const uint8_t *)p->patterns[i] + p->pattern_lens[i]);
+    else if (p->pattern)
+        k.pats.emplace_back((const uint8_t *)p->pattern, (const uint8_t *)p->pattern + p->pattern_len);
+    k.cs = p->case_sensitive; k.lines = p->count_lines_mode; k.track = p->track_positions; k.ww = p->whole_word;
+    k.regex = p->use_regex;
+    k.max_count = p->max_count;
+    k.simd = c.reference_simd; k.only_matching = c.only_matching; k.no_simd = c.force_no_simd; k.algo = c.algo_override;
+    k.device = device;
+    return k;
+}
+
+// ---------------------------------------------------------------------------------------------- per-device context
+struct DeviceCtx
+{
+    std::mutex mu; // one host-buffer operation at a time per device
+    int device = 0;
+    struct Entry
+    {
+        PlanKey key;
+        krep_gpu_plan_t *plan = nullptr;
+        uint64_t tick = 0;
+    };
+    std::vector<Entry> plans; // small LRU
+    uint64_t tick = 0;
+    DevBuf text[2], pos;
+    Stager stager;
+
+    krep_gpu_plan_t *plan_for(const search_params_t *p, const krep_gpu_config_t &c)
+    {
+        PlanKey k = key_of(p, c, device);
+        for (auto &e : plans)
+            if (e.key == k)
+            {
+                e.tick = ++tick;
+                return e.plan;
+            }
+        krep_gpu_config_t cc = c;
+        cc.device = device;
+        krep_gpu_plan_t *pl = krep_gpu_plan_create_ex(p, &cc);
+        if (!pl)
+            return nullptr;
+        constexpr size_t kMaxPlans = 4;
+        if (plans.size() >= kMaxPlans)
+        {
+            size_t victim = 0;
+            for (size_t i = 1; i < plans.size(); ++i)
+                if (plans[i].tick < plans[victim].tick)
+                    victim = i;
+            krep_gpu_plan_destroy(plans[victim].plan);
+            plans.erase(plans.begin() + (long)victim);
+        }
+        plans.push_back(Entry{std::move(k), pl, ++tick});
+        return pl;
+    }
+    void release()
+    {
+        for (auto &e : plans)
+            krep_gpu_plan_destroy(e.plan);
+        plans.clear();
+        text[0].release();
+        text[1].release();
+        pos.release();
+        stager.release();
+    }
+};
+std::mutex g_ctx_mu;
+std::vector<std::unique_ptr<DeviceCtx>> *g_ctx = nullptr; // leaked at process exit on purpose: the HIP runtime may be gone by then
+DeviceCtx *ctx_for(int device)
+{
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    if (!g_ctx)
+        g_ctx = new std::vector<std::unique_ptr<DeviceCtx>>();
+    if ((size_t)device >= g_ctx->size())
+        g_ctx->resize((size_t)device + 1);
+    if (!(*g_ctx)[device])
+    {
+        (*g_ctx)[device].reset(new DeviceCtx());
+        (*g_ctx)[device]->device = device;
+    }
+    return (*g_ctx)[device].get();
+}
+} // namespace
+
+extern "C" void krep_gpu_release_device_resources(void)
+{
+    std::vector<DeviceCtx *> all;
+    {
+        std::lock_guard<std::mutex> lk(g_ctx_mu);
+        if (g_ctx)
+            for (auto &c : *g_ctx)
+                if (c)
+                    all.push_back(c.get());
+    }
+    for (DeviceCtx *c : all)
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        c->release();
+    }
+}
+
+namespace kg {
+// pinned, double-buffered host -> device copy through the device's staging ring (caller holds no context lock)
+int stage_to_device(uint8_t *d_dst, const char *src, size_t len, int device)
+{
+    DeviceCtx *cx = ctx_for(device);
+    std::lock_guard<std::mutex> lk(cx->mu);
+    if (cx->stager.init(device))
+        return 2;
+    return cx->stager.copy(d_dst, src, len);
+}
+void stage_release() {}
+
+// memchr_search's final flush (krep.c:3976-3991 + :4026-4038): when max_count is a multiple of the
+// 4096-entry batch and more matches exist, the (max_count+1)-th record is stored FIRST (in front of
+// the last batch) and the max_count-th is dropped.
+void memchr_batch_quirk(match_position_t *recs, uint64_t have, size_t maxc)
+{
+    if (maxc == SIZE_MAX || maxc == 0 || have <= maxc || (maxc % 4096) != 0)
+        return;
+    const uint64_t f = maxc - 4096;
+    match_position_t extra = recs[maxc];
+    memmove(recs + f + 1, recs + f, 4095 * sizeof(match_position_t));
+    recs[f] = extra;
+}
+} // namespace kg
+
+// ------------------------------------------------------------------------------------------------ one piece
+// The whole text in one device buffer: every reference convention (max_count corners, batch quirk, sequential families,
+// end-of-text replay) is applied by krep_gpu_scan_device_ex() itself.
+static int run_whole(DeviceCtx &cx, const search_params_t *params, const krep_gpu_config_t &cfg, const char *text, size_t text_len,
+                     match_result_t *result, uint64_t *ret_out)
+{
+    *ret_out = 0;
+    krep_gpu_plan_t *pl = cx.plan_for(params, cfg);
+    if (!pl)
+        return 2;
+    if (pl->ref_algo == KREP_RA_AHO_CORASICK && !params->ac_trie)
+        return 0; // aho_corasick.c:306: no trie, no matches
+    if (cx.text[0].ensure(text_len + 64, cx.device))
+        return 2;
+    if (text_len && (cx.stager.init(cx.device) || cx.stager.copy(cx.text[0].p, text, text_len)))
+    {
+        if (!kg::have_error())
+            kg::fail("H2D copy failed");
+        return 2;
+    }
+    const bool want_pos = params->track_positions && result != nullptr && !params->count_lines_mode;
+    uint64_t cap = 0;
+    if (want_pos)
+    {
+        cap = std::max<uint64_t>(1u << 16, text_len / 64);
+        if (params->max_count != SIZE_MAX)
+            cap = std::min<uint64_t>(cap, (uint64_t)params->max_count + 1);
+        cap = std::max<uint64_t>(cap, 1);
+    }
+    krep_gpu_scan_out_t so;
+    for (int attempt = 0;; ++attempt)
+    {
+        if (cap && cx.pos.ensure(cap * sizeof(match_position_t), cx.device))
+            return 2;
+        if (krep_gpu_scan_device_ex(pl, cx.text[0].p, text_len, 0, text_len, 0, text_len, cap ? (match_position_t *)cx.pos.p : nullptr,
+                                    cap, nullptr, 0, &so))
+            return 2;
+        if (!so.overflow || attempt == 1)
+            break;
+        cap = so.total_matches + 1; // exact size, second and last pass
+    }
+    *ret_out = so.count;
+    if (want_pos && so.stored)
+    {
+        if (cfg.result_order && pl->ref_algo == KREP_RA_AHO_CORASICK &&
+            krep_gpu_order_by_start((match_position_t *)cx.pos.p, so.stored, text_len, nullptr))
+            return 2;
+        std::vector<match_position_t> tmp(so.stored);
+        if (hipMemcpy(tmp.data(), cx.pos.p, so.stored * sizeof(match_position_t), hipMemcpyDeviceToHost) != hipSuccess)
+            return kg::fail("D2H copy failed");
+        uint64_t n = so.stored;
+        const int algo = pl->ref_algo == KREP_RA_AHO_CORASICK ? KREP_RA_AHO_CORASICK : mirror_effective(pl->ref_algo, &pl->sp, text_len);
+        if (algo == KREP_RA_MEMCHR && params->max_count != SIZE_MAX)
+        {
+            memchr_batch_quirk(tmp.data(), n, params->max_count);
+            n = std::min<uint64_t>(n, params->max_count);
+        }
+        if (!result_reserve(result, n))
+            return kg::fail("out of memory growing match_result_t");
+        memcpy(result->positions + result->count, tmp.data(), n * sizeof(match_position_t));
+        result->count += n;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ pieces
+namespace {
+struct Piece
+{
+    size_t lo = 0, hi = 0; // owned window in the text
+    size_t b0 = 0, b1 = 0; // bytes staged: [b0, b1) superset of [lo, hi)
+    int device = 0;
+    krep_gpu_scan_out_t out{};
+    std::vector<match_position_t> recs;
+};
+inline bool rec_less(const match_position_t &a, const match_position_t &b) // emission order of aho_corasick_search
+{
+    return a.end_offset != b.end_offset ? a.end_offset < b.end_offset : a.start_offset < b.start_offset;
+}
+
+// all pieces of one device, in text order; piece k+1 is staged by a helper thread while piece k is scanned
+struct DeviceRun
+{
+    DeviceCtx *cx = nullptr;
+    std::vector<Piece *> pieces;
+    const search_params_t *params = nullptr;
+    krep_gpu_config_t cfg{};
+    const char *buf = nullptr;
+    size_t len = 0;
+    bool want_pos = false;
+    int rc = 0;
+    std::string err;
+};
+
+void run_device(DeviceRun *dr)
+{
+    DeviceCtx &cx = *dr->cx;
+    std::lock_guard<std::mutex> lk(cx.mu);
+    dr->rc = 2;
+    search_params_t local = *dr->params;
+    local.max_count = SIZE_MAX; // prefix-ordered truncation happens after the pieces are merged
+    krep_gpu_plan_t *pl = cx.plan_for(&local, dr->cfg);
+    if (!pl || hipSetDevice(cx.device) != hipSuccess || cx.stager.init(cx.device))
+    {
+        dr->err = krep_gpu_last_error();
+        return;
+    }
+    const size_t np = dr->pieces.size();
+    size_t maxb = 0;
+    for (Piece *p : dr->pieces)
+        maxb = std::max(maxb, p->b1 - p->b0);
+    for (int i = 0; i < (np > 1 ? 2 : 1); ++i)
+        if (cx.text[i].ensure(maxb + 64, cx.device))
+        {
+            dr->err = krep_gpu_last_error();
+            return;
+        }
+    // producer: stages piece k into buffer k & 1 once piece k-2 has been consumed
+    std::mutex m;
+    std::condition_variable cv;
+    size_t staged = 0, consumed = 0;
+    bool stage_failed = false, stop = false;
+    std::string stage_err;
+    std::thread producer([&] {
+        for (size_t k = 0; k < np; ++k)
+        {
+            {
+                std::unique_lock<std::mutex> l(m);
+                cv.wait(l, [&] { return stop || k < consumed + 2; });
+                if (stop)
+                    return;
+            }
+            Piece *p = dr->pieces[k];
+            const int rc = cx.stager.copy(cx.text[k & 1].p, dr->buf + p->b0, p->b1 - p->b0);
+            std::lock_guard<std::mutex> l(m);
+            if (rc)
+            {
+                stage_failed = true;
+                stage_err = krep_gpu_last_error(); // thread-local of the producer: hand it over
+                cv.notify_all();
+                return;
+            }
+            staged = k + 1;
+            cv.notify_all();
+        }
+    });
+    auto finish = [&](bool ok) {
+        {
+            std::lock_guard<std::mutex> l(m);
+            stop = true;
+        }
+        cv.notify_all();
+        producer.join();
+        if (ok)
+            dr->rc = 0;
+    };
+    for (size_t k = 0; k < np; ++k)
+    {
+        {
+            std::unique_lock<std::mutex> l(m);
+            cv.wait(l, [&] { return stage_failed || staged > k; });
+            if (stage_failed)
+            {
+                dr->err = "staging failed: " + stage_err;
+                l.unlock();
+                finish(false);
+                return;
+            }
+        }
+        Piece *p = dr->pieces[k];
+        const size_t nb = p->b1 - p->b0;
+        uint64_t cap = dr->want_pos ? std::max<uint64_t>(1u << 16, nb / 64) : 0;
+        int rc = 0;
+        for (int attempt = 0;; ++attempt)
+        {
+            if (cap && cx.pos.ensure(cap * sizeof(match_position_t), cx.device))
+            {
+                rc = 2;
+                break;
+            }
+            rc = krep_gpu_scan_device_ex(pl, cx.text[k & 1].p, nb, p->lo - p->b0, p->hi - p->b0, p->b0, dr->len,
+                                         cap ? (match_position_t *)cx.pos.p : nullptr, cap, nullptr, 0, &p->out);
+            if (rc || !p->out.overflow || attempt == 1)
+                break;
+            cap = p->out.total_matches + 1;
+        }
+        if (!rc && dr->want_pos && p->out.stored)
+        {
+            p->recs.resize(p->out.stored);
+            if (hipMemcpy(p->recs.data(), cx.pos.p, p->out.stored * sizeof(match_position_t), hipMemcpyDeviceToHost) != hipSuccess)
+            {
+                kg::fail("D2H copy failed");
+                rc = 2;
+            }
+        }
+        if (rc)
+        {
+            dr->err = krep_gpu_last_error();
+            finish(false);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> l(m);
+            consumed = k + 1;
+        }
+        cv.notify_all();
+    }
+    finish(true);
+}
+} // namespace
+
+static int run_pieces(const search_params_t *params, const krep_gpu_config_t &cfg, const char *buf, size_t len, int num_gpus,
+                      size_t chunk, match_result_t *out, uint64_t *ret_out)
+{
+    *ret_out = 0;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return kg::fail("no HIP device available (this library has no CPU fallback)");
+    size_t lmax = 1;
+    for (size_t i = 0; i < params->num_patterns; ++i)
+        lmax = std::max(lmax, params->pattern_lens[i]);
+    const int algo = params->num_patterns > 1 ? KREP_RA_AHO_CORASICK : mirror_effective(mirror_top(params, cfg), params, len);
+    int G = std::max(1, num_gpus);
+    if ((size_t)G > len / 4096 + 1)
+        G = (int)(len / 4096 + 1);
+    const size_t ctx = lmax + 1; // pattern_len-1 to complete straddling matches, +1 for -w, +1 slack
+    const size_t share = (len + (size_t)G - 1) / (size_t)G;
+    std::vector<Piece> pcs;
+    for (int g = 0; g < G; ++g)
+    {
+        const size_t glo = std::min(len, (size_t)g * share), ghi = std::min(len, glo + share);
+        if (ghi <= glo && !(len == 0 && g == 0))
+            continue;
+        const size_t step = chunk ? std::max<size_t>(chunk, 4096) : std::max<size_t>(ghi - glo, 1);
+        size_t lo = glo;
+        do
+        {
+            Piece p;
+            p.lo = lo;
+            p.hi = std::min(ghi, lo + step);
+            p.b0 = p.lo > ctx ? p.lo - ctx : 0;
+            p.b1 = std::min(len, p.hi + ctx);
+            p.device = (cfg.device + g) % ndev;
+            pcs.push_back(std::move(p));
+            lo += step;
+        } while (lo < ghi);
+    }
+    const bool want_pos = params->track_positions && out != nullptr && !params->count_lines_mode;
+    // one worker per PHYSICAL device (several logical shards may share one on a small box)
+    std::vector<DeviceRun> runs;
+    for (Piece &p : pcs)
+    {
+        DeviceRun *dr = nullptr;
+        for (auto &r : runs)
+            if (r.cx->device == p.device)
+                dr = &r;
+        if (!dr)
+        {
+            runs.emplace_back();
+            dr = &runs.back();
+            dr->cx = ctx_for(p.device);
+            dr->params = params;
+            dr->cfg = cfg;
+            dr->buf = buf;
+            dr->len = len;
+            dr->want_pos = want_pos;
+        }
+        dr->pieces.push_back(&p);
+    }
+    if (runs.size() == 1)
+        run_device(&runs[0]);
+    else
+    {
+        std::vector<std::thread> th;
+        for (auto &r : runs)
+            th.emplace_back(run_device, &r);
+        for (auto &t : th)
+            t.join();
+    }
+    for (auto &r : runs)
+        if (r.rc)
+            return kg::fail("device %d failed: %s", r.cx->device, r.err.c_str());
+
+    uint64_t total = 0;
+    std::vector<krep_gpu_scan_out_t> outs;
+    for (auto &p : pcs)
+    {
+        total += p.out.total_matches;
+        outs.push_back(p.out);
+    }
+    const uint64_t lines = krep_gpu_combine_line_counts(outs.data(), (int)outs.size());
+    const size_t maxc = params->max_count;
+    uint64_t ret;
+    if (maxc == 0)
+        ret = (algo == KREP_RA_BMH || algo == KREP_RA_MEMCHR_SHORT || algo == KREP_RA_AVX2 || algo == KREP_RA_AVX512) &&
+                      !params->count_lines_mode && !params->track_positions
+                  ? (total > 0 ? 1 : 0) // count-only: the first hit makes 1 >= 0 true (krep.c:1355-1367)
+                  : 0;
+    else
+        ret = std::min<uint64_t>(params->count_lines_mode ? lines : total, maxc);
+    *ret_out = ret;
+    if (want_pos && ret)
+    {
+        std::vector<match_position_t> all;
+        all.reserve((size_t)total);
+        for (auto &p : pcs)
+        {
+            const size_t old = all.size();
+            all.insert(all.end(), p.recs.begin(), p.recs.end());
+            if (params->num_patterns > 1 && old && all.size() > old)
+            {
+                // every piece list is in the reference's (end, start) order and owns its matches by START: only a suffix
+                // of what is there and a prefix of the new list can interleave — merge exactly that zone
+                const auto first_new = all.begin() + (long)old;
+                const auto zone_lo = std::upper_bound(all.begin(), first_new, *first_new, rec_less);
+                const auto zone_hi = std::upper_bound(first_new, all.end(), *(first_new - 1), rec_less);
+                std::inplace_merge(zone_lo, first_new, zone_hi, rec_less);
+            }
+            std::vector<match_position_t>().swap(p.recs);
+        }
+        uint64_t n = std::min<uint64_t>(all.size(), ret);
+        if (algo == KREP_RA_KMP && maxc != SIZE_MAX && all.size() > maxc)
+            n = maxc + 1; // krep.c:1717-1724
+        if (algo == KREP_RA_MEMCHR)
+            memchr_batch_quirk(all.data(), all.size(), maxc);
+        if (params->num_patterns > 1 && cfg.result_order) // the formatter's order (krep.c:420-434)
+            std::sort(all.begin(), all.begin() + (long)n, [](const match_position_t &a, const match_position_t &b) {
+                return a.start_offset != b.start_offset ? a.start_offset < b.start_offset : a.end_offset < b.end_offset;
+            });
+        if (!result_reserve(out, n))
+            return kg::fail("out of memory growing match_result_t");
+        memcpy(out->positions + out->count, all.data(), n * sizeof(match_position_t));
+        out->count += n;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ dispatcher
+static uint64_t run_host_operator(const search_params_t *params, const char *text, size_t text_len, match_result_t *result,
+                                  const krep_gpu_config_t &cfg, int num_gpus, int *status)
+{
+    if (status)
+        *status = 2;
+    if (!params || (!text && text_len))
+    {
+        kg::fail("NULL params/text");
+        return 0;
+    }
+    if (const char *why = kg::unsupported_reason(params, cfg))
+    {
+        kg::fail("%s", why);
+        return 0;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    {
+        kg::fail("no HIP device available (this library has no CPU fallback)");
+        return 0;
+    }
+    if (cfg.device < 0 || cfg.device >= ndev)
+    {
+        kg::fail("device %d out of range (have %d)", cfg.device, ndev);
+        return 0;
+    }
+    if (params->num_patterns > 1 && !params->ac_trie)
+    { // aho_corasick.c:306: no trie, no matches
+        if (status) *status = 0;
+        return 0;
+    }
+    // streaming threshold: pieces of `chunk` bytes once the text is larger than two of them
+    const size_t chunk = cfg.stream_chunk_bytes ? cfg.stream_chunk_bytes : ((size_t)128 << 20);
+    const bool can_split = kg::shardable(params, cfg, text_len);
+    const bool split = can_split && (num_gpus > 1 || text_len > 2 * chunk);
+    uint64_t ret = 0;
+    int rc;
+    if (!split)
+    {
+        DeviceCtx *cx = ctx_for(cfg.device);
+        std::lock_guard<std::mutex> lk(cx->mu);
+        rc = run_whole(*cx, params, cfg, text, text_len, result, &ret);
+    }
+    else
+        rc = run_pieces(params, cfg, text, text_len, num_gpus, text_len > 2 * chunk ? chunk : 0, result, &ret);
+    if (rc)
+        return 0;
+    if (status)
+        *status = 0;
+    return ret;
+}
+
+extern "C" uint64_t krep_gpu_literal_search(const search_params_t *params, const char *text, size_t len, match_result_t *result)
+{
+    return run_host_operator(params, text, len, result, kg::current_config(), 1, nullptr);
+}
+extern "C" uint64_t krep_gpu_aho_corasick_search(const search_params_t *params, const char *text, size_t len,
+                                                 match_result_t *result)
+{
+    return run_host_operator(params, text, len, result, kg::current_config(), 1, nullptr);
+}
+extern "C" search_func_t krep_gpu_select_search_algorithm(const search_params_t *params)
+{
+    if (!params || kg::unsupported_reason(params, kg::current_config()))
+        return nullptr; // the caller keeps the CPU function pointer select_search_algorithm() gives it
+    return params->num_patterns > 1 ? krep_gpu_aho_corasick_search : krep_gpu_literal_search;
+}
+
+// search_string()'s validation and verdict (krep.c:2013-2049, :2166-2199), minus strlen and printing
+extern "C" int search_buffer_ex(const search_params_t *params, const char *buf, size_t len, const krep_gpu_config_t *cfg_in,
+                                int num_gpus, match_result_t *out, uint64_t *count_out)
+{
+    if (count_out)
+        *count_out = 0;
+    if (!params || params->num_patterns == 0)
+        return kg::fail("Error: No pattern specified.");
+    if (!buf && len)
+        return kg::fail("Error: NULL text in search_buffer.");
+    if (params->use_regex)
+        return kg::fail("regex search is not accelerated; keep krep's regex_search for it");
+    for (size_t i = 0; i < params->num_patterns; ++i)
+    {
+        if (params->pattern_lens[i] == 0)
+        {
+            if (params->num_patterns > 1)
+                return kg::fail("Error: Empty pattern provided for literal search with multiple patterns.");
+        }
+        else if (params->pattern_lens[i] > 1024) // MAX_PATTERN_LENGTH, krep.c:77
+            return kg::fail("Error: Pattern too long (max 1024).");
+    }
+    const krep_gpu_config_t cfg = cfg_in ? *cfg_in : kg::current_config();
+    int st = 2;
+    search_params_t local = *params;
+    static int dummy_trie;
+    if (local.num_patterns > 1 && !local.ac_trie)
+        local.ac_trie = (ac_trie_t *)&dummy_trie; // search_string builds the trie itself (krep.c:2067-2078)
+    uint64_t n = run_host_operator(&local, buf, len, out, cfg, num_gpus, &st);
+    if (st)
+        return 2;
+    const size_t maxc = params->max_count;
+    if (maxc != SIZE_MAX && n > maxc)
+        n = maxc;
+    if (out && maxc != SIZE_MAX && out->count > maxc)
+        out->count = maxc;
+    bool found;
+    if (params->count_lines_mode || params->count_matches_mode)
+        found = n > 0;
+    else
+    {
+        found = out && out->count > 0;
+        if (found)
+            n = out->count;
+        else if (!out)
+            found = n > 0;
+    }
+    if (count_out)
+        *count_out = n;
+    return found ? 0 : 1;
+}
+extern "C" int search_buffer(const search_params_t *params, const char *buf, size_t len, int only_matching, int num_gpus,
+                             match_result_t *out, uint64_t *count_out)
+{
+    krep_gpu_config_t cfg = kg::current_config();
+    cfg.only_matching = only_matching != 0;
+    return search_buffer_ex(params, buf, len, &cfg, num_gpus, out, count_out);
+}

@@ -1,0 +1,40 @@
+// kg_plan.h — the plan object behind krep_gpu_plan_t (shared by kg_host.hip, kg_ops.hip and kg_multi.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "../../include/krep_gpu.h"
+#include "kg_common.h"
+#include "kg_internal.h"
+
+struct krep_gpu_plan
+{
+    krep_gpu_config_t cfg{};     // the configuration this plan was compiled for (explicit; no global is read after creation)
+    int device = 0;
+    int ref_algo = KREP_RA_NONE; // top-level selection (delegation resolved per text length)
+    const char *unsupported = nullptr; // non-NULL: why scans with this plan are refused (kg::unsupported_reason)
+    bool only_matching = false;
+    bool cs = true, ww = false, lines = false, track = false;
+    size_t max_count = SIZE_MAX;
+    std::vector<std::vector<uint8_t>> pats; // as given
+    // single literal
+    uint32_t m = 0, p0 = 0, p1 = 0, k0 = 0, k1 = 0, l0 = 0, l1 = 0;
+    uint32_t p2 = 0, p3 = 0, k2 = 0, k3 = 0, l2 = 0, l3 = 0; // bytes 8..15
+    std::vector<uint8_t> pat_folded; // folded when !cs
+    bool has_border = false;         // a proper prefix is also a suffix => all-occurrences != greedy
+    bool has_newline = false;
+    uint8_t *d_pat = nullptr;
+    // workspace
+    kg::Counters *d_ctr = nullptr, *h_ctr = nullptr;
+    int num_cu = 256;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // multi-pattern
+    kg::AcTables *ac = nullptr;
+    bool ac_has_newline = false; // some pattern of the set contains '\n' (-c then counts emission-order line changes)
+    kg::PostScratch post; // ordering post-pass / sequential-family scratch of the main pass
+    kg::PostScratch aux;  // small auxiliary passes that must not disturb `post` (end-of-text replay)
+    search_params_t sp{}; // shallow copy with patterns pointing into `pats`
+    std::vector<const char *> pat_ptrs;
+    std::vector<size_t> pat_lens;
+};

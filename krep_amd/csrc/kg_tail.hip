@@ -1,0 +1,218 @@
+// kg_tail.hip — device helpers for the end-of-text replay of the block-structured -c paths (kg_replay.h):
+//   tail_last_hit_unit : the last scan unit (below a limit) that reported an accepted occurrence (per-unit info words)
+//   tail_next_newline / tail_prev_newline : first '\n' at or after / last '\n' before a position (early-exit sweeps)
+//   tail_replay        : replay_lines() as a one-thread kernel over the last <= 320 bytes of the text in HBM
+// None of this is on the bandwidth path: a -c scan through simd_avx512_search / neon_search (or simd_avx2_search
+// with -w) pays four tiny launches after the canonical scan.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include "kg_common.h"
+#include "kg_internal.h"
+#include "kg_replay.h"
+
+namespace kg {
+
+using u32 = uint32_t;
+using u64 = unsigned long long;
+
+#define TCHK(x)                                                                                \
+    do                                                                                         \
+    {                                                                                          \
+        hipError_t e_ = (x);                                                                   \
+        if (e_ != hipSuccess)                                                                  \
+            return fail("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// out[0] = 1 + index of the last unit u < limit whose info word reports a hit (0 = none)
+__global__ __launch_bounds__(256) void tail_last_hit_unit(const u64 *__restrict__ info, u64 limit, u64 *out)
+{
+    u64 best = 0;
+    for (u64 u = (u64)blockIdx.x * blockDim.x + threadIdx.x; u < limit; u += (u64)gridDim.x * blockDim.x)
+        if (info[u] & kUiCountMask)
+            best = u + 1;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1)
+    {
+        const u64 v = __shfl_xor(best, o);
+        best = v > best ? v : best;
+    }
+    if ((threadIdx.x & 63) == 0 && best)
+        atomicMax(out, best);
+}
+
+constexpr u32 kNlChunk = 64 * 1024; // bytes one workgroup inspects per step
+
+// out[0] = min index >= from holding '\n' (initialised to n by the host).  Chunks are visited in ascending order
+// by block index; a block stops as soon as an earlier chunk has produced a result.
+__global__ __launch_bounds__(256) void tail_next_newline(const uint8_t *__restrict__ text, u64 from, u64 n, u64 *out)
+{
+    for (u64 c = blockIdx.x;; c += gridDim.x)
+    {
+        const u64 lo = from + c * kNlChunk;
+        if (lo >= n || __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < lo)
+            return;
+        const u64 hi = lo + kNlChunk < n ? lo + kNlChunk : n;
+        u64 best = ~0ull;
+        for (u64 i = lo + threadIdx.x; i < hi; i += blockDim.x)
+            if (text[i] == '\n')
+            {
+                best = i;
+                break;
+            }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1)
+        {
+            const u64 v = __shfl_xor(best, o);
+            best = v < best ? v : best;
+        }
+        if ((threadIdx.x & 63) == 0 && best != ~0ull)
+            atomicMin(out, best);
+    }
+}
+
+// out[0] = 1 + max index < before holding '\n' (0 = none; initialised to 0 by the host); chunks descend from `before`
+__global__ __launch_bounds__(256) void tail_prev_newline(const uint8_t *__restrict__ text, u64 before, u64 *out)
+{
+    for (u64 c = blockIdx.x;; c += gridDim.x)
+    {
+        if (c * kNlChunk >= before)
+            return;
+        const u64 hi = before - c * kNlChunk; // exclusive
+        if (__hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > hi)
+            return;
+        const u64 lo = hi > kNlChunk ? hi - kNlChunk : 0;
+        u64 best = 0;
+        for (u64 k = threadIdx.x; lo + k < hi; k += blockDim.x)
+        {
+            const u64 i = hi - 1 - k; // descending per thread: the first hit is the thread's maximum
+            if (text[i] == '\n')
+            {
+                best = i + 1;
+                break;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1)
+        {
+            const u64 v = __shfl_xor(best, o);
+            best = v > best ? v : best;
+        }
+        if ((threadIdx.x & 63) == 0 && best)
+            atomicMax(out, best);
+    }
+}
+
+// out[0] += number of i with v[i] != v[i-1] (i == 0 counts): aho_corasick_search's -c counter is bumped whenever the
+// line of the current match differs from the line of the PREVIOUS counted match (aho_corasick.c:383-396)
+__global__ __launch_bounds__(256) void tail_changes(const u64 *__restrict__ v, u64 n, u64 *out)
+{
+    u32 c = 0;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x)
+        c += (i == 0 || v[i] != v[i - 1]) ? 1u : 0u;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1)
+        c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0 && c)
+        atomicAdd(out, (u64)c);
+}
+
+__global__ void tail_replay(ReplayIn r, u64 *out)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+        out[0] = replay_lines(r);
+}
+
+// ---- host drivers (results come back through the plan's pinned counter block) -------------------------------------
+int tail_last_hit(const unsigned long long *d_unitinfo, uint64_t limit_units, unsigned long long *d_slot,
+                  unsigned long long *h_slot, hipStream_t st, uint64_t *unit_plus1)
+{
+    TCHK(hipMemsetAsync(d_slot, 0, sizeof(u64), st));
+    if (limit_units)
+    {
+        const u32 grid = (u32)std::min<u64>((limit_units + 255) / 256, 1024);
+        hipLaunchKernelGGL(tail_last_hit_unit, dim3(grid), dim3(256), 0, st, (const u64 *)d_unitinfo, (u64)limit_units, (u64 *)d_slot);
+        TCHK(hipGetLastError());
+    }
+    TCHK(hipMemcpyAsync(h_slot, d_slot, sizeof(u64), hipMemcpyDeviceToHost, st));
+    TCHK(hipStreamSynchronize(st));
+    *unit_plus1 = *h_slot;
+    return 0;
+}
+
+int tail_find_next_newline(const uint8_t *d_text, uint64_t from, uint64_t n, unsigned long long *d_slot,
+                           unsigned long long *h_slot, hipStream_t st, uint64_t *pos)
+{
+    *pos = n;
+    if (from >= n)
+        return 0;
+    *h_slot = n; // pinned: the sentinel "no newline"
+    TCHK(hipMemcpyAsync(d_slot, h_slot, sizeof(u64), hipMemcpyHostToDevice, st));
+    const u32 grid = (u32)std::min<u64>((n - from + kNlChunk - 1) / kNlChunk, 1024);
+    hipLaunchKernelGGL(tail_next_newline, dim3(grid), dim3(256), 0, st, d_text, (u64)from, (u64)n, (u64 *)d_slot);
+    TCHK(hipGetLastError());
+    TCHK(hipMemcpyAsync(h_slot, d_slot, sizeof(u64), hipMemcpyDeviceToHost, st));
+    TCHK(hipStreamSynchronize(st));
+    *pos = *h_slot;
+    return 0;
+}
+
+int tail_find_prev_newline(const uint8_t *d_text, uint64_t before, unsigned long long *d_slot, unsigned long long *h_slot,
+                           hipStream_t st, uint64_t *pos_plus1)
+{
+    *pos_plus1 = 0;
+    if (before == 0)
+        return 0;
+    TCHK(hipMemsetAsync(d_slot, 0, sizeof(u64), st));
+    const u32 grid = (u32)std::min<u64>((before + kNlChunk - 1) / kNlChunk, 1024);
+    hipLaunchKernelGGL(tail_prev_newline, dim3(grid), dim3(256), 0, st, d_text, (u64)before, (u64 *)d_slot);
+    TCHK(hipGetLastError());
+    TCHK(hipMemcpyAsync(h_slot, d_slot, sizeof(u64), hipMemcpyDeviceToHost, st));
+    TCHK(hipStreamSynchronize(st));
+    *pos_plus1 = *h_slot;
+    return 0;
+}
+
+int tail_count_changes(const uint64_t *d_v, uint64_t n, unsigned long long *d_slot, unsigned long long *h_slot, hipStream_t st,
+                       uint64_t *changes)
+{
+    TCHK(hipMemsetAsync(d_slot, 0, sizeof(u64), st));
+    if (n)
+    {
+        const u32 grid = (u32)std::min<u64>((n + 255) / 256, 2048);
+        hipLaunchKernelGGL(tail_changes, dim3(grid), dim3(256), 0, st, (const u64 *)d_v, (u64)n, (u64 *)d_slot);
+        TCHK(hipGetLastError());
+    }
+    TCHK(hipMemcpyAsync(h_slot, d_slot, sizeof(u64), hipMemcpyDeviceToHost, st));
+    TCHK(hipStreamSynchronize(st));
+    *changes = *h_slot;
+    return 0;
+}
+
+int tail_run_replay(const ReplayIn &r, unsigned long long *d_slot, unsigned long long *h_slot, hipStream_t st, uint64_t *lines)
+{
+    hipLaunchKernelGGL(tail_replay, dim3(1), dim3(64), 0, st, r, (u64 *)d_slot);
+    TCHK(hipGetLastError());
+    TCHK(hipMemcpyAsync(h_slot, d_slot, sizeof(u64), hipMemcpyDeviceToHost, st));
+    TCHK(hipStreamSynchronize(st));
+    *lines = *h_slot;
+    return 0;
+}
+
+} // namespace kg
+
+// The same replay_lines() on host memory: lets the CPU test-suite pin the replay (and the window decomposition
+// around it) against the oracle without a GPU.  Not used by any product path.
+extern "C" uint64_t krep_gpu_debug_replay_host(int algo, const void *text, size_t n, const void *pat, uint32_t m, int ww,
+                                               size_t cur, int open)
+{
+    kg::ReplayIn r{};
+    r.algo = algo;
+    r.m = m;
+    r.ww = ww;
+    r.n = n;
+    r.cur = cur;
+    r.open = open;
+    r.text = (const uint8_t *)text;
+    r.pat = (const uint8_t *)pat;
+    return kg::replay_lines(r);
+}

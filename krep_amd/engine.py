@@ -41,6 +41,23 @@ class Engine:
         L.search_buffer.restype = C.c_int
         L.search_buffer.argtypes = [C.POINTER(abi.SearchParams), C.c_void_p, C.c_size_t, C.c_int, C.c_int,
                                     C.POINTER(abi.MatchResult), C.POINTER(C.c_uint64)]
+        L.search_buffer_ex.restype = C.c_int
+        L.search_buffer_ex.argtypes = [C.POINTER(abi.SearchParams), C.c_void_p, C.c_size_t, C.POINTER(abi.Config), C.c_int,
+                                       C.POINTER(abi.MatchResult), C.POINTER(C.c_uint64)]
+        L.krep_gpu_can_accelerate.restype = C.c_int
+        L.krep_gpu_can_accelerate.argtypes = [C.POINTER(abi.SearchParams)]
+        L.krep_gpu_config_default.restype = None
+        L.krep_gpu_config_default.argtypes = [C.POINTER(abi.Config)]
+        L.krep_gpu_set_thread_config.restype = None
+        L.krep_gpu_set_thread_config.argtypes = [C.POINTER(abi.Config)]
+        L.krep_gpu_set_stream_chunk.restype = None
+        L.krep_gpu_set_stream_chunk.argtypes = [C.c_size_t]
+        L.krep_gpu_release_device_resources.restype = None
+        L.krep_gpu_plan_create_ex.restype = C.c_void_p
+        L.krep_gpu_plan_create_ex.argtypes = [C.POINTER(abi.SearchParams), C.POINTER(abi.Config)]
+        L.krep_gpu_scan_device_ex.restype = C.c_int
+        L.krep_gpu_scan_device_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t,
+                                              C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.POINTER(abi.ScanOut)]
         L.krep_gpu_match_result_init.restype = C.POINTER(abi.MatchResult)
         L.krep_gpu_match_result_init.argtypes = [C.c_uint64]
         L.krep_gpu_match_result_free.restype = None
@@ -72,7 +89,7 @@ class Engine:
         L.krep_gpu_line_numbers.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
         for n in ("krep_gpu_set_reference_simd", "krep_gpu_set_only_matching", "krep_gpu_set_force_no_simd",
                   "krep_gpu_set_algo_override", "krep_gpu_debug_force_rounds", "krep_gpu_debug_force_stage_cap",
-                  "krep_gpu_set_result_order"):
+                  "krep_gpu_set_result_order", "krep_gpu_set_device"):
             getattr(L, n).restype = None
             getattr(L, n).argtypes = [C.c_int]
         L.krep_gpu_get_reference_simd.restype = C.c_int
@@ -99,6 +116,27 @@ class Engine:
 
     def force_stage_cap(self, c: int):
         self.lib.krep_gpu_debug_force_stage_cap(c)
+
+    def default_config(self) -> abi.Config:
+        c = abi.Config()
+        self.lib.krep_gpu_config_default(C.byref(c))
+        return c
+
+    def set_thread_config(self, cfg: "abi.Config | None"):
+        self.lib.krep_gpu_set_thread_config(C.byref(cfg) if cfg is not None else None)
+
+    def set_stream_chunk(self, nbytes: int):
+        self.lib.krep_gpu_set_stream_chunk(nbytes)
+
+    def can_accelerate(self, params: abi.Params) -> bool:
+        return bool(self.lib.krep_gpu_can_accelerate(params.ref))
+
+    def select(self, params: abi.Params):
+        """krep_gpu_select_search_algorithm(): the operator's address, or None (the caller keeps its CPU function)."""
+        return self.lib.krep_gpu_select_search_algorithm(params.ref)
+
+    def release_device_resources(self):
+        self.lib.krep_gpu_release_device_resources()
 
     def mirror_select(self, params: abi.Params, text_len: int) -> int:
         return int(self.lib.krep_gpu_mirror_select(params.ref, text_len))
@@ -152,12 +190,15 @@ class Engine:
         del keep
         return int(ret), pos
 
-    def search_buffer(self, params: abi.Params, text, only_matching=False, num_gpus=1, want_result=True):
+    def search_buffer(self, params: abi.Params, text, only_matching=False, num_gpus=1, want_result=True, cfg=None):
         ptr, n, keep = self._ptr(text)
         res = self.lib.krep_gpu_match_result_init(16) if want_result else None
         cnt = C.c_uint64(0)
         try:
-            rc = self.lib.search_buffer(params.ref, ptr, n, int(only_matching), num_gpus, res, C.byref(cnt))
+            if cfg is not None:
+                rc = self.lib.search_buffer_ex(params.ref, ptr, n, C.byref(cfg), num_gpus, res, C.byref(cnt))
+            else:
+                rc = self.lib.search_buffer(params.ref, ptr, n, int(only_matching), num_gpus, res, C.byref(cnt))
             pos = abi.result_positions(res) if res else None
         finally:
             if res:
@@ -196,12 +237,12 @@ class Plan:
         return int(self.eng.lib.krep_gpu_plan_ref_algo(self.h))
 
     def scan(self, d_text: int, text_len: int, own_lo=0, own_hi=None, global_base=0, d_positions: int = 0,
-             capacity: int = 0, stream: int = 0, time_it=False) -> abi.ScanOut:
+             capacity: int = 0, stream: int = 0, time_it=False, global_len=0) -> abi.ScanOut:
         out = abi.ScanOut()
-        rc = self.eng.lib.krep_gpu_scan_device(self.h, C.c_void_p(d_text), text_len, own_lo,
-                                               text_len if own_hi is None else own_hi, global_base,
-                                               C.c_void_p(d_positions) if d_positions else None, capacity,
-                                               C.c_void_p(stream) if stream else None, int(time_it), C.byref(out))
+        rc = self.eng.lib.krep_gpu_scan_device_ex(self.h, C.c_void_p(d_text), text_len, own_lo,
+                                                  text_len if own_hi is None else own_hi, global_base, global_len,
+                                                  C.c_void_p(d_positions) if d_positions else None, capacity,
+                                                  C.c_void_p(stream) if stream else None, int(time_it), C.byref(out))
         if rc:
             raise KrepGpuError("krep_gpu_scan_device failed: " + self.eng.last_error())
         return out

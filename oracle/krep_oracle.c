@@ -503,13 +503,28 @@ uint64_t ko_sse42_search(const search_params_t *p, const char *text, size_t n, m
         return 0;
     const unsigned char *t = (const unsigned char *)text, *pat = (const unsigned char *)p->pattern;
     const size_t m = p->pattern_len, maxc = p->max_count;
+    const size_t step = 17 - m; /* a full 16-byte window without a hit advances 16 - m + 1 (:4858) */
     uint64_t cnt = 0;
-    size_t cur = 0, seen_line = SIZE_MAX;
-    for (;;)
+    size_t cp = 0, seen_line = SIZE_MAX; /* cp = current_pos - text_start */
+    while (n - cp >= m)
     {
-        size_t at = first_occ(t, n, pat, m, cur);
+        size_t at = first_occ(t, n, pat, m, cp);
         if (at == SIZE_MAX)
             break;
+        /* The window in which the reference's loop reports `at`: windows start at cp + j*step while >= 16
+         * bytes remain; the first window with fewer than 16 bytes left covers the whole rest (:4739-4750).
+         * Only the -c skip below depends on it: it adds (line_end + 1 - match) to the WINDOW start instead
+         * of to the match (:4787-4793), so the scan resumes `index` bytes before the next line. */
+        size_t j = (at - cp) / step;
+        if (n - cp < 16)
+            j = 0;
+        else
+        {
+            size_t jt = (n - 16 - cp) / step + 1; /* first window with < 16 bytes remaining */
+            if (jt < j)
+                j = jt;
+        }
+        const size_t win = cp + j * step;
         if (!p->whole_word || ko_whole_word(text, n, at, at + m))
         {
             bool bumped = false;
@@ -524,9 +539,9 @@ uint64_t ko_sse42_search(const search_params_t *p, const char *text, size_t n, m
                     seen_line = ls;
                     bumped = true;
                     size_t le = ko_line_end(text, n, ls);
-                    if (le < n) /* advance = le+1-at is always > 0 */
+                    if (le < n) /* advance = le + 1 - at is always > 0 */
                     {
-                        cur = le + 1;
+                        cp = win + (le + 1 - at);
                         continue;
                     }
                 }
@@ -543,7 +558,9 @@ uint64_t ko_sse42_search(const search_params_t *p, const char *text, size_t n, m
             if (bumped && cnt >= maxc)
                 break;
         }
-        cur = at + (g_only_matching ? 1 : m);
+        cp = at + (g_only_matching ? 1 : m); /* window start + index + m, clamped to the end (:4839-4851) */
+        if (cp > n)
+            cp = n;
     }
     return cnt;
 }
@@ -724,6 +741,97 @@ uint64_t ko_avx512_search(const search_params_t *p, const char *text, size_t n, 
         {
             uint64_t from = res->count >= tc ? res->count - tc : 0;
             for (uint64_t k = 0; k < tc && from + k < res->count; k++)
+            {
+                res->positions[from + k].start_offset += cur;
+                res->positions[from + k].end_offset += cur;
+            }
+        }
+        cnt += tc;
+    }
+    return cnt;
+}
+
+/* ================================================================ neon_search, krep.c:4506-4694
+ * arm64 builds (krep.c:69-74); selected for case-sensitive patterns of 2..16 bytes (krep.c:1821, :1852).
+ * 16-byte blocks: every offset whose byte equals pattern[0] and that leaves >= m bytes (:4562) is
+ * verified with memcmp — ALL occurrences, any overlap.  max_count is tested BEFORE the increment
+ * (:4582, :4616).  -c: after a newly counted line the block loop restarts at the next line start, but
+ * only when the line is terminated (:4590-4611); on an unterminated last line the loop simply goes on
+ * (same line => nothing more is counted).  Tail (< 16 B) -> BMH on the slice as its own text (:4653-4690):
+ * no left neighbour for -w at its first byte, a fresh last-counted-line. */
+uint64_t ko_neon_search(const search_params_t *p, const char *text, size_t n, match_result_t *res)
+{
+    if (p->pattern_len == 0 || !p->case_sensitive || n < p->pattern_len)
+        return ko_boyer_moore_search(p, text, n, res);
+    if (p->max_count == 0 && (p->count_lines_mode || p->track_positions))
+        return 0;
+    const unsigned char *t = (const unsigned char *)text, *pat = (const unsigned char *)p->pattern;
+    const size_t m = p->pattern_len, maxc = p->max_count;
+    uint64_t cnt = 0;
+    size_t cur = 0, rem = n, seen_line = SIZE_MAX;
+    while (rem >= 16)
+    {
+        bool restarted = false;
+        for (size_t idx = 0; idx < 16 && !restarted; idx++)
+        {
+            if (t[cur + idx] != pat[0] || rem - idx < m)
+                continue;
+            if (memcmp(t + cur + idx, pat, m) != 0)
+                continue;
+            const size_t at = cur + idx;
+            if (p->whole_word && !ko_whole_word(text, n, at, at + m))
+                continue;
+            bool bumped = false;
+            if (p->count_lines_mode)
+            {
+                size_t ls = lstart(text, n, at);
+                if (ls != seen_line)
+                {
+                    if (cnt >= maxc)
+                        return cnt;
+                    cnt++;
+                    seen_line = ls;
+                    bumped = true;
+                    size_t le = ko_line_end(text, n, ls);
+                    if (le < n && le + 1 > cur)
+                    {
+                        size_t adv = le + 1 - cur;
+                        if (adv > rem)
+                            adv = rem;
+                        cur += adv;
+                        rem -= adv;
+                        restarted = true; /* goto next_chunk: the max_count test below is skipped, :4609 */
+                        continue;
+                    }
+                }
+            }
+            else
+            {
+                if (cnt >= maxc)
+                    return cnt;
+                cnt++;
+                bumped = true;
+                if (p->track_positions && res && cnt <= maxc)
+                    ko_result_add(res, at, at + m);
+            }
+            if (bumped && cnt >= maxc)
+                return cnt;
+        }
+        if (restarted)
+            continue;
+        cur += 16;
+        rem -= 16;
+    }
+    if (rem >= m)
+    {
+        search_params_t tp = *p;
+        if (maxc != SIZE_MAX)
+            tp.max_count = cnt >= maxc ? 0 : maxc - (size_t)cnt;
+        uint64_t tc = ko_boyer_moore_search(&tp, text + cur, rem, res);
+        if (res && p->track_positions && tc > 0 && res->count >= tc) /* :4676-4685 */
+        {
+            uint64_t from = res->count - tc;
+            for (uint64_t k = 0; k < tc; k++)
             {
                 res->positions[from + k].start_offset += cur;
                 res->positions[from + k].end_offset += cur;
@@ -1059,6 +1167,7 @@ uint64_t ko_run(int algo, const search_params_t *p, const char *text, size_t n, 
     case KREP_RA_SSE42: return ko_sse42_search(p, text, n, r);
     case KREP_RA_AVX2: return ko_avx2_search(p, text, n, r);
     case KREP_RA_AVX512: return ko_avx512_search(p, text, n, r);
+    case KREP_RA_NEON: return ko_neon_search(p, text, n, r);
     case KREP_RA_AHO_CORASICK: return ko_aho_corasick_search(p, text, n, r);
     default: return 0;
     }

@@ -37,6 +37,7 @@ uint64_t ko_memchr_short_search(const search_params_t *, const char *, size_t, m
 uint64_t ko_sse42_search(const search_params_t *, const char *, size_t, match_result_t *);
 uint64_t ko_avx2_search(const search_params_t *, const char *, size_t, match_result_t *);
 uint64_t ko_avx512_search(const search_params_t *, const char *, size_t, match_result_t *);
+uint64_t ko_neon_search(const search_params_t *, const char *, size_t, match_result_t *);
 uint64_t ko_aho_corasick_search(const search_params_t *, const char *, size_t, match_result_t *);
 
 /* Aho-Corasick automaton (aho_corasick.c:111-271); the handle goes into params->ac_trie */

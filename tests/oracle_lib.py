@@ -111,7 +111,8 @@ class OracleEngine(_Engine):
     fn = {abi.RA_BMH: "ko_boyer_moore_search", abi.RA_KMP: "ko_kmp_search",
           abi.RA_MEMCHR: "ko_memchr_search", abi.RA_MEMCHR_SHORT: "ko_memchr_short_search",
           abi.RA_SSE42: "ko_sse42_search", abi.RA_AVX2: "ko_avx2_search",
-          abi.RA_AVX512: "ko_avx512_search", abi.RA_AHO_CORASICK: "ko_aho_corasick_search"}
+          abi.RA_AVX512: "ko_avx512_search", abi.RA_NEON: "ko_neon_search",
+          abi.RA_AHO_CORASICK: "ko_aho_corasick_search"}
     init_name, free_name = "ko_result_init", "ko_result_free"
     ac_build, ac_free = "ko_ac_trie_build", "ko_ac_trie_free"
 
@@ -138,9 +139,10 @@ class OracleEngine(_Engine):
 
 
 _REF_FILES = {abi.REF_SCALAR: "libkrep_ref_scalar.so", abi.REF_SSE42: "libkrep_ref_sse42.so",
-              abi.REF_AVX2: "libkrep_ref_avx2.so", abi.REF_AVX512: "libkrep_ref_avx512.so"}
+              abi.REF_AVX2: "libkrep_ref_avx2.so", abi.REF_AVX512: "libkrep_ref_avx512.so",
+              abi.REF_NEON: "libkrep_ref_neon.so"}  # NEON: the arm64 path built against oracle/neon_shim (plain C)
 _REF_NEEDS = {abi.REF_SCALAR: set(), abi.REF_SSE42: {"sse4_2"}, abi.REF_AVX2: {"avx2", "sse4_2"},
-              abi.REF_AVX512: {"avx512f", "avx512bw", "avx2"}}
+              abi.REF_AVX512: {"avx512f", "avx512bw", "avx2"}, abi.REF_NEON: set()}
 
 
 class RefEngine(_Engine):
@@ -156,11 +158,13 @@ class RefEngine(_Engine):
         fn = {abi.RA_BMH: "boyer_moore_search", abi.RA_KMP: "kmp_search",
               abi.RA_MEMCHR: "memchr_search", abi.RA_MEMCHR_SHORT: "memchr_short_search",
               abi.RA_AHO_CORASICK: "aho_corasick_search"}
-        if level >= abi.REF_SSE42:
+        if level == abi.REF_NEON:
+            fn[abi.RA_NEON] = "neon_search"
+        if abi.REF_SSE42 <= level <= abi.REF_AVX512:
             fn[abi.RA_SSE42] = "simd_sse42_search"
-        if level >= abi.REF_AVX2:
+        if abi.REF_AVX2 <= level <= abi.REF_AVX512:
             fn[abi.RA_AVX2] = "simd_avx2_search"
-        if level >= abi.REF_AVX512:
+        if level == abi.REF_AVX512:
             fn[abi.RA_AVX512] = "simd_avx512_search"
         self.fn = fn
         self._setup()

@@ -22,12 +22,12 @@ def declared_functions():
     src = open(os.path.join(ROOT, "include", "krep_gpu.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     names = re.findall(r"\b([a-z_][a-z0-9_]*)\s*\([^;{]*\)\s*;", src)
-    return sorted({n for n in names if n.startswith("krep_gpu_") or n == "search_buffer"})
+    return sorted({n for n in names if n.startswith("krep_gpu_") or n.startswith("search_buffer")})
 
 
 def test_every_declared_symbol_is_exported(lib):
     fns = declared_functions()
-    assert len(fns) >= 20 and "search_buffer" in fns and "krep_gpu_literal_search" in fns
+    assert len(fns) >= 30 and "search_buffer" in fns and "search_buffer_ex" in fns and "krep_gpu_literal_search" in fns
     for n in fns:
         assert hasattr(lib, n), n
 

@@ -9,7 +9,7 @@ import pytest
 import oracle_lib as ol
 from krep_amd import abi
 
-LEVELS = [abi.REF_SCALAR, abi.REF_SSE42, abi.REF_AVX2, abi.REF_AVX512]
+LEVELS = [abi.REF_SCALAR, abi.REF_SSE42, abi.REF_AVX2, abi.REF_AVX512, abi.REF_NEON]
 ALPHAS = [b"ab", b"ab\n", b"abAB \n", b"abc_ \n-", bytes(range(97, 123)) + b" \n"]
 SIZES = [0, 1, 2, 3, 5, 8, 15, 16, 17, 31, 32, 33, 40, 63, 64, 65, 70, 100, 127, 128, 129, 200, 300, 1000]
 
@@ -26,9 +26,9 @@ def _case(rng):
     n = rng.choice(SIZES)
     text = bytes(rng.choice(alpha) for _ in range(n))
     algo = rng.choice([abi.RA_BMH, abi.RA_KMP, abi.RA_MEMCHR, abi.RA_MEMCHR_SHORT, abi.RA_SSE42,
-                       abi.RA_AVX2, abi.RA_AVX512, abi.RA_AHO_CORASICK])
+                       abi.RA_AVX2, abi.RA_AVX512, abi.RA_NEON, abi.RA_AHO_CORASICK])
     m = {abi.RA_MEMCHR: [1], abi.RA_MEMCHR_SHORT: [2, 3], abi.RA_AVX2: [2, 5, 16, 17, 18, 20, 32],
-         abi.RA_AVX512: [3, 17, 33, 34, 40, 64]}.get(algo, [1, 2, 3, 4, 5, 8, 9, 16])
+         abi.RA_AVX512: [3, 17, 33, 34, 40, 64], abi.RA_NEON: [1, 2, 3, 4, 5, 8, 9, 15, 16, 17, 20]}.get(algo, [1, 2, 3, 4, 5, 8, 9, 16])
     m = rng.choice(m)
 
     def mk(k):
