@@ -110,4 +110,27 @@ def golden_cases():
             kw.update(count_lines=True)
         out.append((cid, text, pats, kw, abi.RA_AHO_CORASICK, abi.REF_SCALAR))
         cid += 1
+    # round 2: neon_search (the reference's arm64 path, built against oracle/neon_shim) and the -c paths through the
+    # block-structured bodies; appended so that the vectors above keep their inputs
+    rng = np.random.RandomState(535353)
+    pyr = random.Random(535353)
+    for algo, level, lens in ((abi.RA_NEON, abi.REF_NEON, [2, 3, 4, 8, 13, 16]), (abi.RA_AVX2, abi.REF_AVX2, [17, 20, 32]),
+                              (abi.RA_AVX512, abi.REF_AVX512, [33, 40, 64])):
+        for rep in range(16):
+            alpha = [b"ab\n", b"ab \n", b"abc_ -\n", bytes(range(97, 123)) + b"  \n"][rep % 4]
+            m = pyr.choice(lens)
+            n = max(pyr.choice([90, 300, 777, 8200, 33000, 70001]), 2 * m)
+            text = rand_text(rng, n, alpha)
+            pat = rand_text(rng, m, alpha.replace(b"\n", b"")).tobytes()
+            for _k in range(pyr.choice([1, 3, 6])):
+                s = rng.randint(max(0, n - 150 - m), n - m + 1) if pyr.random() < 0.5 else rng.randint(0, n - m + 1)
+                text[s:s + m] = np.frombuffer(pat, dtype=np.uint8)
+            if rep % 5 == 4:
+                text[text == 10] = ord("a")  # no newline at all
+                text[n // 3] = 10
+            kw = dict(case_sensitive=True, whole_word=pyr.random() < 0.5, max_count=pyr.choice([abi.SIZE_MAX] * 3 + [1, 4]))
+            if rep % 4 != 3:
+                kw.update(count_lines=True)
+            out.append((cid, text, [pat], kw, algo, level))
+            cid += 1
     return out

@@ -45,9 +45,10 @@ def test_gpu_reproduces_reference_vectors():
             if eff != algo:
                 e.set_algo_override(abi.ALGO_AUTO)
                 continue  # the vector names a function the selector would not execute for this input
-            if algo in (abi.RA_AVX2, abi.RA_AVX512) and kw.get("count_lines") and not kw.get("only_match"):
+            if not e.can_accelerate(p):
+                assert e.select(p) is None
                 e.set_algo_override(abi.ALGO_AUTO)
-                continue  # block-structured -c of the AVX bodies: canonical semantics only
+                continue  # left to the CPU by contract (krep_gpu_can_accelerate): SSE4.2/KMP -c with '\n' in the pattern
         ret, pos = e.search(p, text)
         e.set_algo_override(abi.ALGO_AUTO)
         assert _same(v, ret, pos), (cid, v["algo"], pats, kw, ret, v["ret"])

@@ -158,3 +158,134 @@ def test_thousand_patterns_2gib_against_threaded_reference(gpu):
     want = want[np.lexsort((want[:, 0], want[:, 1]))]
     assert len(want) == out.count
     assert np.array_equal(got, want)
+
+
+def _wrap64(x):
+    return x & M64
+
+
+def test_single_byte_32gib_full_size(gpu):
+    """BASELINE config 3 AT FULL SIZE (32 GiB, 1 % hits, ~3.4e8 records = 5.5 GB of match_position_t): count, a
+    checksum of all offsets (mod 2^64), strict sortedness, every offset holds the byte, and EXACT record lists on windows
+    above 4, 8, 16 and 31 GiB — any 32-bit truncation of an offset on the staging/gather path fails here."""
+    import torch
+    n = 32 * GIB
+    free, _ = torch.cuda.mem_get_info()
+    if free < n + (12 << 30):
+        pytest.skip("not enough free HBM for the 32 GiB haystack + 5.5 GB of records")
+    buf = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+    gpu.generate(buf.data_ptr(), n, 0, 3, SEED, b"#", 0)
+    truth, csum = 0, 0
+    chunk = 1 << 30
+    for lo in range(0, n, chunk):
+        nz = torch.nonzero(buf[lo:lo + chunk] == ord("#")).flatten()
+        truth += int(nz.numel())
+        csum = _wrap64(csum + int(nz.sum().item()) + lo * int(nz.numel()))
+        del nz
+    cap = truth + 4096
+    pos = torch.empty(2 * cap, dtype=torch.int64, device="cuda")
+    out = gpu.plan(abi.Params([b"#"])).scan(buf.data_ptr(), n, 0, n, 0, pos.data_ptr(), cap)
+    assert out.count == truth == out.stored and not out.overflow
+    rec = pos[: 2 * truth].view(-1, 2)
+    starts = rec[:, 0].contiguous()
+    assert bool(torch.all(starts[1:] > starts[:-1]))
+    assert bool(torch.all(rec[:, 1] == starts + 1))
+    assert _wrap64(int(starts.sum().item())) == csum
+    assert int(starts[-1].item()) > 31 * GIB
+    for lo in range(0, truth, 1 << 26):  # every reported offset really holds the byte (chunked gather)
+        assert bool(torch.all(buf[starts[lo:lo + (1 << 26)]] == ord("#")))
+    for wlo in (4 * GIB - (1 << 19), 4 * GIB + 12345, 8 * GIB - 77, 16 * GIB + (1 << 20) + 5, 31 * GIB + 999, n - (1 << 20)):
+        whi = min(n, wlo + (1 << 20))
+        want = torch.nonzero(buf[wlo:whi] == ord("#")).flatten() + wlo
+        i0 = int(torch.searchsorted(starts, torch.tensor([wlo], device="cuda")).item())
+        i1 = int(torch.searchsorted(starts, torch.tensor([whi], device="cuda")).item())
+        assert torch.equal(starts[i0:i1], want), wlo
+    # the line count (-c) at full size against the same truth: distinct lines holding a '#'
+    is_nl = None
+    lines = 0
+    carry_open = False  # the line entering the chunk already holds a '#'
+    for lo in range(0, n, chunk):
+        seg = buf[lo:lo + chunk]
+        hit = seg == ord("#")
+        nl = seg == 10
+        line_id = torch.cumsum(nl.to(torch.int32), 0)  # line index of every byte relative to the chunk (0 = entering line)
+        ids = torch.unique(line_id[hit])
+        k = int(ids.numel())
+        first_is_entering = k > 0 and int(ids[0].item()) == 0
+        # a '#' that IS at a newline position cannot happen ('#' != '\n'); bytes after a '\n' have the incremented id
+        lines += k - (1 if (first_is_entering and carry_open) else 0)
+        last_id = int(line_id[-1].item())
+        if last_id == 0:
+            carry_open = carry_open or k > 0
+        else:
+            carry_open = k > 0 and int(ids[-1].item()) == last_id
+        del seg, hit, nl, line_id, ids
+    got = gpu.plan(abi.Params([b"#"], count_lines=True)).scan(buf.data_ptr(), n)
+    assert got.count == lines
+
+
+def _dictionary_1000():
+    import random as pyrandom
+    import struct
+    rng = pyrandom.Random(1234)
+    pats = [bytes(rng.randrange(97, 123) for _ in range(rng.randint(4, 16))) for _ in range(1000)]
+    head = struct.pack("<I", len(pats))
+    off, body = 4 + 8 * len(pats), b""
+    for p in pats:
+        head += struct.pack("<II", off + len(body), len(p))
+        body += p
+    return pats, head + body
+
+
+def test_thousand_patterns_32gib_full_size(gpu):
+    """BASELINE config 4 AT FULL SIZE (32 GiB, 1000 patterns of 4-16 bytes, ~1.1e7 matches):
+      * the whole list is in the reference's emission order (end ascending, then start ascending), in bounds, lengths 4..16;
+      * its length equals the SUM of the 1000 single-literal all-occurrence counts taken by the literal kernel at full size
+        (an independent code path; the reference's own check, test/test_multiple_patterns.c:350-466, at 1 MiB);
+      * exact (start, end) lists against the oracle's aho_corasick_search on 1 MiB windows above 4, 8, 16 and 31 GiB —
+        a 32-bit truncation of the staged word (start << 11 | len) or of the gather would fail here."""
+    import torch
+    n = 32 * GIB
+    free, _ = torch.cuda.mem_get_info()
+    if free < n + (4 << 30):
+        pytest.skip("not enough free HBM for the 32 GiB haystack")
+    pats, packed = _dictionary_1000()
+    buf = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+    gpu.generate(buf.data_ptr(), n, 0, 4, SEED, packed, 4096)
+    cap = n // 1500
+    pos = torch.empty(2 * cap, dtype=torch.int64, device="cuda")
+    out = gpu.plan(abi.Params(pats)).scan(buf.data_ptr(), n, 0, n, 0, pos.data_ptr(), cap)
+    assert not out.overflow and out.stored == out.total_matches == out.count
+    rec = pos[: 2 * out.stored].view(-1, 2)
+    st, en = rec[:, 0], rec[:, 1]
+    assert bool(torch.all((en[1:] > en[:-1]) | ((en[1:] == en[:-1]) & (st[1:] >= st[:-1]))))
+    ln = en - st
+    assert int(ln.min().item()) >= 4 and int(ln.max().item()) <= 16 and int(st.min().item()) >= 0 and int(en.max().item()) <= n
+    assert int(st.max().item()) > 31 * GIB
+    # sum of single-literal all-occurrence counts (boyer_moore_search family: --algo=bm) at full size
+    gpu.set_algo_override(abi.ALGO_BM)
+    try:
+        total = 0
+        for p in pats:
+            pl = gpu.plan(abi.Params([p], count_lines=True, only_match=True))
+            total += pl.scan(buf.data_ptr(), n).count
+            pl.close()
+    finally:
+        gpu.set_algo_override(abi.ALGO_AUTO)
+    assert total == out.count
+    o = ol.oracle()
+    order = torch.argsort(st, stable=True)  # by start, ties keep the (end) order
+    st_sorted = st[order]
+    for wlo in (4 * GIB - (1 << 19), 4 * GIB + 4321, 8 * GIB - 100, 16 * GIB + (1 << 20) + 7, 31 * GIB + 555, n - (1 << 20)):
+        whi = min(n, wlo + (1 << 20))
+        b0, b1 = max(0, wlo - 16), min(n, whi + 16)
+        win = buf[b0:b1].cpu().numpy()
+        _, wpos = o.call(abi.RA_AHO_CORASICK, abi.Params(pats), win)
+        wpos = wpos.astype(np.int64) + b0
+        keep = (wpos[:, 0] >= wlo) & (wpos[:, 0] < whi)
+        want = wpos[keep]  # already in (end, start) order
+        i0 = int(torch.searchsorted(st_sorted, torch.tensor([wlo], device="cuda")).item())
+        i1 = int(torch.searchsorted(st_sorted, torch.tensor([whi], device="cuda")).item())
+        idx = torch.sort(order[i0:i1]).values  # back to emission order
+        got = rec[idx].cpu().numpy()
+        assert np.array_equal(got, want), (wlo, len(got), len(want))

@@ -71,7 +71,7 @@ def test_device_windows_concatenate(gpu, oracle_engine):
     rng = np.random.RandomState(77)
     text = cases.rand_text(rng, 300_000, b"ab \n")
     d = torch.from_numpy(text).cuda()
-    for pats, kw in (([b"ab a"], dict()), ([b"b"], dict(count_lines=True)), ([b"ab", b"b a", b"a"], dict()),
+    for pats, kw in (([b"ab "], dict()), ([b"b"], dict(count_lines=True)), ([b"ab", b"b a", b"a"], dict()),
                      ([b"ba", b"ab"], dict(count_lines=True))):
         want_ret, want_pos = _oracle(oracle_engine, gpu, pats, kw, text)
         p = abi.Params(pats, **kw)
@@ -128,3 +128,19 @@ def test_bench_rank_scheme_reproduces_the_single_buffer(gpu, workload):
         got.append(pos[: 2 * o.stored].clone())
     assert total == want_count
     assert torch.equal(torch.cat(got), want)
+
+
+def test_partial_windows_refused_for_sequential_families(gpu):
+    """A bordered pattern through simd_sse42_search is a greedy chain over neighbouring occurrences: a partial ownership
+    window cannot reproduce it, and says so instead of returning an approximation."""
+    import torch
+    import krep_amd
+    gpu.set_reference_simd(abi.REF_AVX2)
+    text = np.frombuffer(b"ababababab " * 1000, dtype=np.uint8).copy()
+    d = torch.from_numpy(text).cuda()
+    plan = gpu.plan(abi.Params([b"abab"]))
+    whole = plan.scan(d.data_ptr(), text.size)
+    assert whole.count == 2000
+    with pytest.raises(krep_amd.KrepGpuError):
+        plan.scan(d.data_ptr(), text.size, 0, 5000)
+    plan.close()
