@@ -1,18 +1,24 @@
 #!/usr/bin/env python3
 """bench.py — the measurement contract.
 
-A step = one pass of krep's literal-scan hot path over one synthetic haystack already resident in
-HBM: the HIP scan of the 8-byte case-sensitive literal 'Sherlock' (BASELINE.json configs[1]: 32 GiB,
-~1e-4 matches/byte, match offsets produced) + for N > 1 the single RCCL all-reduce of the per-GPU
-counts.  One process per GPU (torch.distributed, backend nccl == RCCL); the buffer is sharded by
-contiguous 32 GiB chunk per rank (weak scaling), each rank generates its own shard in HBM with the
-counter-based generator at global offset rank*shard.
+A step = one pass of krep's literal-scan hot path over one synthetic haystack already resident in HBM: the HIP scan of
+the 8-byte case-sensitive literal 'Sherlock' (BASELINE.json configs[1]: 32 GiB, ~1e-4 matches/byte, match offsets
+produced) + for N > 1 the single RCCL all-reduce of the per-GPU counts.  One process per GPU (torch.distributed, backend
+nccl == RCCL); the buffer is sharded by contiguous 32 GiB chunk per rank (weak scaling), each rank generates its own shard
+in HBM with the counter-based generator at global offset rank*shard.
+
+    python bench.py                      # N = 1: literal8 + (extra) memchr1 and ac1000, roofline + cpu_baseline
+    python bench.py --gpus 8             # spawns the 8 ranks itself (torch.distributed.run on 127.0.0.1) ...
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 ... bench.py --gpus 8     # ... or is launched as ranks
+    python bench.py --gpus 2 --backend gloo   # CPU dry run of the launcher / collective plumbing (no scan, no number)
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -25,6 +31,7 @@ PERIOD = 10000
 SEED = 20260925
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 HBM_MEASURED_GBS = 6290.0  # the same guide: measured streaming ceiling
+
 
 def ac_patterns(n=1000, seed=1234):
     """BASELINE configs[3]: 1000 literal patterns, lengths uniform 4..16 over a-z (SURVEY.md §8d cfg 4)."""
@@ -58,11 +65,38 @@ WORKLOADS = {
 }
 
 
-def cpu_baseline(eng, wl, sample_bytes, d_buf):
+def workload(name):
+    wl = dict(WORKLOADS[name])
+    if wl["patterns"] is None:
+        wl["patterns"] = ac_patterns()
+        wl["plant"] = pack_dict(wl["patterns"])
+    return wl
+
+
+# ---------------------------------------------------------------------------------------------- CPU baseline
+def _best_reference_lib():
+    """The reference built with ITS OWN release flags (reference Makefile:9-11: -O3 -ffast-math -flto -funroll-loops ...) at
+    the SIMD level its Makefile would autodetect on this host (Makefile:23-42: avx512f in /proc/cpuinfo, else avx2);
+    prebuilt by oracle/Makefile (the GPU box has no reference sources)."""
+    import ctypes as C
+    import oracle_lib as ol
+    flags = ol._cpu_flags()
+    order = []
+    if {"avx512f", "avx512bw"} <= flags:
+        order.append(("libkrep_best_avx512.so", "-mavx512f -mavx512bw -msse4.2 -mavx2", "krep_best_avx512"))
+    if "avx2" in flags:
+        order.append(("libkrep_best_avx2.so", "-mavx2 -msse4.2", "krep_best"))
+    for fname, simd, cli in order:
+        path = os.path.join(ol.REF_DIR, fname)
+        if os.path.exists(path):
+            return C.CDLL(path), fname, simd, os.path.join(ol.REF_DIR, cli)
+    return None, None, None, None
+
+
+def cpu_baseline(wl, sample_bytes, d_buf):
     """krep's own CPU path on this host's cores, on a bounded sample of the same workload."""
     import ctypes as C
     import threading
-    import numpy as np
     import torch
     import oracle_lib as ol
     from krep_amd import abi
@@ -72,26 +106,27 @@ def cpu_baseline(eng, wl, sample_bytes, d_buf):
     host.copy_(d_buf[:n])
     torch.cuda.synchronize()
     text = host.numpy()
-    cores = os.cpu_count() or 1
-    threads = cores
-    flags = ol._cpu_flags()
-    level = abi.REF_AVX512 if {"avx512f", "avx512bw"} <= flags else abi.REF_AVX2 if "avx2" in flags else abi.REF_SSE42
-    ref = None
-    for lv in (level, abi.REF_AVX2, abi.REF_SSE42, abi.REF_SCALAR):
-        if lv <= level and ol.ref_available(lv):
-            ref = ol.ref(lv)
-            break
+    threads = os.cpu_count() or 1
     p = abi.Params(wl["patterns"], count_lines=True, only_match=True, **wl["kw"])  # -c -o: count matches
     m = max(len(x) for x in wl["patterns"])
     multi = len(wl["patterns"]) > 1
     chunk = (n + threads - 1) // threads
-    if ref is not None:
+    sf = [C.POINTER(abi.SearchParams), C.c_void_p, C.c_size_t, C.c_void_p]
+    lib, fname, simd, cli = _best_reference_lib()
+    if lib is not None:
         kind = "reference"
-        algo = ref.select(p)
-        fn = getattr(ref.lib, ref.fn[algo])
-        name = f"oracle/_ref/{ol._REF_FILES[ref.level]}:{ref.fn[algo]}"
+        lib.select_search_algorithm.restype = C.c_void_p
+        lib.select_search_algorithm.argtypes = [C.POINTER(abi.SearchParams)]
+        lib.get_algorithm_name.restype = C.c_char_p
+        lib.get_algorithm_name.argtypes = [C.c_void_p]
+        fptr = lib.select_search_algorithm(p.ref)  # the reference's own selector picks the function
+        fn = C.CFUNCTYPE(C.c_uint64, *sf)(fptr)
+        name = (f"oracle/_ref/{fname} (reference Makefile flags: -O3 -ffast-math -flto -funroll-loops -finline-functions "
+                f"{simd}), select_search_algorithm -> {lib.get_algorithm_name(fptr).decode()}")
         if multi:
-            p.s.ac_trie = ref._acb(p.ref)      # the caller builds the trie once (krep.c:2528-2535)
+            lib.ac_trie_build.restype = C.c_void_p
+            lib.ac_trie_build.argtypes = [C.POINTER(abi.SearchParams)]
+            p.s.ac_trie = lib.ac_trie_build(p.ref)  # the caller builds the trie once (krep.c:2528-2535)
     else:
         kind = "port"
         o = ol.oracle()
@@ -110,62 +145,78 @@ def cpu_baseline(eng, wl, sample_bytes, d_buf):
         ln = min(chunk + (m - 1 if i != threads - 1 else 0), n - b)
         counts[i] = fn(p.ref, C.c_void_p(base + b), ln, None)
 
-    best = None
+    times = []
     t_all = time.time()
-    reps = 0
-    while reps < 3 or (time.time() - t_all < 10 and reps < 20):
+    while len(times) < 3 or (time.time() - t_all < 8 and len(times) < 20):
         ths = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
         t0 = time.time()
         for t in ths:
             t.start()
         for t in ths:
             t.join()
-        dt = time.time() - t0
-        best = dt if best is None else min(best, dt)
-        reps += 1
-    return dict(value=round(n / best / 1e9, 3), unit="GB/s", cores=threads, kind=kind,
-                sample=f"{n / 2**30:.1f} GiB slice of the same haystack, {threads} threads x {name}, "
-                       f"chunk+overlap as krep.c:2851-2905, best of {reps}, count={sum(counts)}")
+        times.append(time.time() - t0)
+    best = min(times)
+    res = dict(value=round(n / best / 1e9, 3), unit="GB/s", cores=threads, kind=kind,
+               sample=f"{n / 2**30:.1f} GiB slice of the same haystack, {threads} threads x {name}, chunk+overlap as "
+                      f"krep.c:2851-2905, best of {len(times)} (median {n / statistics.median(times) / 1e9:.1f} GB/s), "
+                      f"count={sum(counts)}")
+    # the reference CLI itself (its own thread pool and mmap path) on a /dev/shm copy of the sample
+    if kind == "reference" and not multi and cli and os.path.exists(cli):
+        tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
+        path = f"{tmpdir}/krep_bench_{os.getpid()}.bin"
+        try:
+            nb = min(n, 2 << 30)
+            text[:nb].tofile(path)
+            pat = wl["patterns"][0].decode("latin-1")
+            tt = []
+            for _ in range(3):
+                t0 = time.time()
+                r = subprocess.run([cli, "-c", "-o", "--color=never", pat, path], capture_output=True, timeout=120)
+                tt.append(time.time() - t0)
+            res["cli"] = dict(value=round(nb / min(tt) / 1e9, 3), unit="GB/s",
+                              cmd=f"oracle/_ref/{os.path.basename(cli)} (reference Makefile flags, {simd}) -c -o {pat} {tmpdir}/<{nb / 2**30:.0f} GiB sample>, "
+                                  f"default threads, wall clock incl. mmap, best of 3, stdout={r.stdout.strip()[-40:].decode('latin-1')}")
+        except Exception as e:  # reported, never required
+            res["cli"] = dict(value=None, unit="GB/s", cmd=f"failed: {e}")
+        finally:
+            try:
+                os.remove(path)
+            except OSError:
+                pass
+    return res
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="literal8", choices=sorted(WORKLOADS))
-    ap.add_argument("--gib", type=float, default=32.0, help="haystack GiB per GPU")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-gib", type=float, default=4.0)
-    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and all-reduce even with one rank (self-test)")
-    args = ap.parse_args()
+# ---------------------------------------------------------------------------------------------- launcher
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) outside torchrun: start the N ranks ourselves, relay their output."""
+    port = int(os.environ.get("MASTER_PORT", "0")) or (29500 + os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
+
+def traffic_for(name):
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        return json.load(open(tpath)).get(name, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+# ---------------------------------------------------------------------------------------------- one workload on this rank
+def run_workload(name, args, eng, buf, dev, rank, world, local, use_dist):
+    """Generates the rank's shard, runs warmup + EXACTLY args.steps timed steps (barrier + synchronize on both sides, MAX over
+    ranks) and returns the measurement dict (rank 0) incl. the roofline object of the dominant kernel."""
     import torch
     import torch.distributed as dist
-    import krep_amd
     from krep_amd import abi
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    use_dist = args.gpus > 1 or world > 1 or args.force_dist
-    if use_dist:
-        assert world == args.gpus, f"launch with torchrun --nproc-per-node {args.gpus}"
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
-    wl = dict(WORKLOADS[args.workload])
-    if wl["patterns"] is None:
-        wl["patterns"] = ac_patterns()
-        wl["plant"] = pack_dict(wl["patterns"])
-    eng = krep_amd.load()
+    wl = workload(name)
     n = int(args.gib * (1 << 30))
     shard_off = rank * n                      # contiguous chunk per rank
     halo = 64                                 # >= pattern_len-1 bytes of the next shard (start-ownership)
-    buf = torch.empty(n + halo, dtype=torch.uint8, device=dev)
     eng.generate(buf.data_ptr(), n + halo, shard_off, wl["kind"], SEED, wl["plant"], wl["period"])
     last = rank == world - 1
     text_len = n if last else n + halo        # the global text ends with the last shard
@@ -179,7 +230,8 @@ def main():
     host_counts = torch.zeros(2, dtype=torch.int64).pin_memory()
 
     def step():
-        out = plan.scan(buf.data_ptr(), text_len, 0, n, shard_off, pos.data_ptr(), cap, stream, True)
+        out = plan.scan(buf.data_ptr(), text_len, 0, n, shard_off, pos.data_ptr(), cap, stream, True,
+                        global_len=world * n)
         if use_dist:
             host_counts[0] = out.count
             host_counts[1] = out.total_matches
@@ -193,10 +245,10 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    k_ms = 0.0
+    k_ms = []
     for _ in range(args.steps):
         out = step()
-        k_ms += out.kernel_ms
+        k_ms.append(out.kernel_ms)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -209,53 +261,158 @@ def main():
     else:
         total_matches = int(out.total_matches)
     assert not out.overflow, "position buffer too small"
+    stored = int(out.stored)
+    plan.close()
+    del pos
+    if rank != 0:
+        return None
+    ms_step = dt / args.steps * 1e3
+    value = n * world / (dt / args.steps) / 1e9
+    k_avg, k_med = sum(k_ms) / len(k_ms), statistics.median(k_ms)
+    achieved = n / (k_avg * 1e-3) / 1e9
+    return {
+        "wl": wl,
+        "value": round(value, 1), "ms_per_step": round(ms_step, 4), "matches": total_matches,
+        "matches_per_s": round(total_matches / (dt / args.steps), 1),
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic_for(name),
+                     "kernel": ("kg::ac_scan_kernel" if len(wl["patterns"]) > 1 else "kg::lit_scan")
+                     + " + post-pass, hipEvent-timed on the launch stream",
+                     # `achieved` uses the AVERAGE launch duration (comparable with rocprofv3's kernel-trace average in
+                     # profiles/); the median over the timed steps is next to it
+                     "kernel_ms": round(k_avg, 4), "kernel_ms_median": round(k_med, 4),
+                     "achieved_median": round(n / (k_med * 1e-3) / 1e9, 1),
+                     "frac_median": round(n / (k_med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "algorithmic_bytes_per_launch": n,
+                     # also against the measured streaming ceiling, and with the 16 B/match
+                     # result writes counted (the figure that matters for the 1 % single-byte config)
+                     "frac_of_measured_ceiling": round(achieved / HBM_MEASURED_GBS, 4),
+                     "achieved_incl_result_writes": round((n + 16 * stored) / (k_avg * 1e-3) / 1e9, 1)},
+    }
 
+
+def config_of(name, wl, args, world, n, res):
+    return {"workload": f"{name}: {wl['desc']}; {args.gib:g} GiB per GPU (BASELINE.json configs[{CONFIG_INDEX[name]}]"
+                        f"{' x' + str(world) + ' shards = configs[4] shape' if world > 1 else ''})",
+            "pattern": wl["patterns"][0].decode("latin-1") if len(wl["patterns"]) == 1 else f"{len(wl['patterns'])} patterns",
+            "bytes_per_gpu": n, "matches": res["matches"], "matches_per_s": res["matches_per_s"],
+            "parallelism": f"contiguous shards x{world}, start-offset ownership, 1 RCCL all-reduce of counts"}
+
+
+def dry_run(args, rank, world):
+    """CPU dry run (--backend gloo): no GPU, no scan, no number — the launcher, rendezvous, barrier, the one all-reduce of the
+    counts and the MAX-over-ranks timing run exactly as in the measured path (tests/test_shard_gloo.py)."""
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = int(args.gib * (1 << 30))
+    mine = torch.tensor([n // PERIOD, n // PERIOD], dtype=torch.int64)  # what a rank's scan would report (closed form)
+    for _ in range(args.warmup):
+        c = mine.clone()
+        dist.all_reduce(c)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        c = mine.clone()
+        dist.all_reduce(c)
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
     if rank == 0:
-        ms_step = dt / args.steps * 1e3
-        total_bytes = n * world
-        value = total_bytes / (dt / args.steps) / 1e9
-        k_avg_ms = k_ms / args.steps
-        achieved = n / (k_avg_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(args.workload, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        print(json.dumps({"metric": "dry run (gloo, CPU): launcher + collective plumbing only", "value": None, "unit": "GB/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True,
+                          "ms_per_step": round(float(t.item()) / args.steps * 1e3, 4), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "none",
+                          "config": {"workload": "none (dry run)", "matches": int(c[1].item())}}), flush=True)
+    dist.destroy_process_group()
+    return 0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="literal8", choices=sorted(WORKLOADS))
+    ap.add_argument("--gib", type=float, default=32.0, help="haystack GiB per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="N = 1: do not measure the other two BASELINE workloads")
+    ap.add_argument("--cpu-sample-gib", type=float, default=4.0)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo = CPU dry run of the plumbing")
+    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and all-reduce even with one rank (self-test)")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch `python bench.py --gpus N` (it spawns the ranks) "
+              f"or torch.distributed.run --nproc-per-node {args.gpus}", file=sys.stderr)
+        return 2
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    if args.backend == "gloo":
+        return dry_run(args, rank, world)
+
+    import torch
+    import torch.distributed as dist
+    import krep_amd
+
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    use_dist = args.gpus > 1 or world > 1 or args.force_dist
+    if use_dist:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    eng = krep_amd.load()
+    n = int(args.gib * (1 << 30))
+    buf = torch.empty(n + 64, dtype=torch.uint8, device=dev)
+
+    res = run_workload(args.workload, args, eng, buf, dev, rank, world, local, use_dist)
+    line = None
+    if rank == 0:
+        wl = res["wl"]
         line = {
             "metric": "GB/s scanned (literal scan, match offsets produced), haystack resident in HBM",
-            "value": round(value, 1), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": res["value"], "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {wl['desc']}; {args.gib:g} GiB per GPU "
-                                   f"(BASELINE.json configs[{CONFIG_INDEX[args.workload]}]"
-                                   f"{' x' + str(world) + ' shards = configs[4] shape' if world > 1 else ''})",
-                       "pattern": wl["patterns"][0].decode("latin-1") if len(wl["patterns"]) == 1
-                       else f"{len(wl['patterns'])} patterns", "bytes_per_gpu": n, "matches": total_matches,
-                       "matches_per_s": round(total_matches / (dt / args.steps), 1),
-                       "parallelism": f"contiguous shards x{world}, start-offset ownership, 1 RCCL all-reduce of counts"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": ("kg::ac_scan_kernel" if len(wl["patterns"]) > 1 else "kg::lit_scan")
-                         + " + post-pass, hipEvent-timed on the launch stream",
-                         "kernel_ms": round(k_avg_ms, 4), "algorithmic_bytes_per_launch": n,
-                         # also against the measured streaming ceiling, and with the 16 B/match
-                         # result writes counted (the figure that matters for the 1 % single-byte config)
-                         "frac_of_measured_ceiling": round(achieved / HBM_MEASURED_GBS, 4),
-                         "achieved_incl_result_writes": round(
-                             (n + 16 * int(out.stored)) / (k_avg_ms * 1e-3) / 1e9, 1)},
+            "config": config_of(args.workload, wl, args, world, n, res),
+            "roofline": res["roofline"],
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                line["cpu_baseline"] = cpu_baseline(eng, wl, min(n, int(args.cpu_sample_gib * (1 << 30))), buf)
+                line["cpu_baseline"] = cpu_baseline(wl, min(n, int(args.cpu_sample_gib * (1 << 30))), buf)
             except Exception as e:  # the baseline is reported, never required
                 line["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": os.cpu_count(), "kind": "port",
                                         "sample": f"failed: {e}"}
+    if world == 1 and not args.no_extra:
+        # the other two single-GPU BASELINE configurations, same protocol, same run (configs[2] and configs[3])
+        extra = {}
+        for name in ("literal8", "memchr1", "ac1000"):
+            if name == args.workload:
+                continue
+            try:
+                r = run_workload(name, args, eng, buf, dev, rank, world, local, use_dist)
+                e = {"value": r["value"], "unit": "GB/s", "ms_per_step": r["ms_per_step"],
+                     "config": config_of(name, r["wl"], args, world, n, r), "roofline": r["roofline"]}
+                if not args.no_cpu_baseline:
+                    try:
+                        e["cpu_baseline"] = cpu_baseline(r["wl"], min(n, int(min(args.cpu_sample_gib, 1.0) * (1 << 30))), buf)
+                    except Exception as ex:
+                        e["cpu_baseline"] = {"value": None, "sample": f"failed: {ex}"}
+                extra[name] = e
+            except Exception as ex:  # never lose the headline line to an extra
+                extra[name] = {"value": None, "error": repr(ex)}
+        if line is not None:
+            line["extra"] = extra
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -260,9 +260,15 @@ uint64_t krep_gpu_combine_line_counts(const krep_gpu_scan_out_t *shards, int n);
  *   (sorted on the device before the copy to the host), so the caller may skip its qsort().  Default 0: the
  *   reference's emission order (end ascending, longest first).
  * All return 0, or 2 with krep_gpu_last_error() set. */
-int krep_gpu_order_by_start(match_position_t *d_positions, uint64_t n, size_t text_len, void *stream);
+/* max_offset: upper bound of every start offset in the list (the WHOLE text's length when the records carry a
+ * global_base) — the radix key is sized from it. */
+int krep_gpu_order_by_start(match_position_t *d_positions, uint64_t n, size_t max_offset, void *stream);
+/* records must be relative to d_text[0]; use the _ex form (records minus global_base) for shard lists.  A record outside
+ * [global_base, global_base + text_len] gets line number 0. */
 int krep_gpu_line_numbers(const void *d_text, size_t text_len, const match_position_t *d_positions, uint64_t n,
                           uint64_t *d_lines, void *stream);
+int krep_gpu_line_numbers_ex(const void *d_text, size_t text_len, size_t global_base, const match_position_t *d_positions,
+                             uint64_t n, uint64_t *d_lines, void *stream);
 void krep_gpu_set_result_order(int by_start);
 
 int krep_gpu_device_count(void);

@@ -49,7 +49,7 @@ def main():
         krep_gpu_set_algo_override(!algo_override || !strcmp(algo_override, "auto") ? KREP_ALGO_AUTO
                                    : !strcmp(algo_override, "bm") ? KREP_ALGO_BM
                                    : !strcmp(algo_override, "kmp") ? KREP_ALGO_KMP : KREP_ALGO_AUTO);
-        search_func_t gpu_fn = krep_gpu_select_search_algorithm(params);
+        search_func_t gpu_fn = krep_gpu_select_search_algorithm(params); /* NULL: not accelerated -> CPU function below */
         if (gpu_fn)
             return gpu_fn;
     }
@@ -62,11 +62,12 @@ def main():
     # 5. the CLI switch: environment variable, read at the top of main() (krep.c:3451)
     src = insert_after(src, r'^int main\(int argc, char \*argv\[\]\)\s*\{', '\n#ifdef KREP_WITH_GPU\n    use_gpu = getenv("KREP_GPU") != NULL;\n#endif\n')
     # 6. the records of the GPU operators arrive in compare_match_positions order (sorted in HBM): no host qsort
-    #    (krep.c:3020-3023)
+    #    (krep.c:3020-3023).  Only when a GPU operator really was selected: for the input classes the backend leaves to the
+    #    CPU (krep_gpu_can_accelerate() == 0) the selector above falls through to the reference's own function.
     pat = r'if \(global_matches->count > 1\)(\s*\{\s*qsort\(global_matches->positions)'
     if not re.search(pat, src):
         raise SystemExit("anchor not found: qsort of the global match list")
-    src = re.sub(pat, r'if (global_matches->count > 1\n#ifdef KREP_WITH_GPU\n            && !(use_gpu && !current_params.use_regex)\n#endif\n            )\1', src, count=1)
+    src = re.sub(pat, r'if (global_matches->count > 1\n#ifdef KREP_WITH_GPU\n            && preselected_algo != krep_gpu_literal_search && preselected_algo != krep_gpu_aho_corasick_search\n#endif\n            )\1', src, count=1)
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     with tempfile.TemporaryDirectory() as td:
         patched = os.path.join(td, "krep_gpu_patched.c")

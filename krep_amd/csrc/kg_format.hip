@@ -91,13 +91,19 @@ __global__ __launch_bounds__(256) void fmt_count_newlines(const uint8_t *__restr
 }
 
 // line number (1-based) of text[start]: newlines in the blocks before + newlines of the own block before `start`
-__global__ void fmt_line_numbers(const uint8_t *__restrict__ text, const u64 *__restrict__ rec, u64 n,
+__global__ void fmt_line_numbers(const uint8_t *__restrict__ text, u64 text_len, u64 base, const u64 *__restrict__ rec, u64 n,
                                  const u64 *__restrict__ block_prefix, u64 *__restrict__ lines)
 {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n)
         return;
-    const u64 s = rec[2 * i], b = s / kLineBlock;
+    const u64 g = rec[2 * i];
+    if (g < base || g - base > text_len)
+    {
+        lines[i] = 0; // a record outside the buffer (wrong global_base): flagged, never read out of bounds
+        return;
+    }
+    const u64 s = g - base, b = s / kLineBlock;
     u64 ln = 1 + block_prefix[b];
     auto nl4 = [](u32 w) -> u32 { // newlines among the 4 bytes of w (exact SWAR byte equality)
         const u32 y = w ^ 0x0a0a0a0au;
@@ -119,8 +125,11 @@ __global__ void fmt_line_numbers(const uint8_t *__restrict__ text, const u64 *__
 
 using namespace kg;
 
-extern "C" int krep_gpu_order_by_start(match_position_t *d_positions, uint64_t n, size_t text_len, void *stream)
+// max_offset: an upper bound of every start offset in the list — the length of the WHOLE text when the records carry a
+// global_base (the radix key is sized from it)
+extern "C" int krep_gpu_order_by_start(match_position_t *d_positions, uint64_t n, size_t max_offset, void *stream)
 {
+    const size_t text_len = max_offset;
     if (n < 2)
         return 0;
     if (n > 0x7fffffffull)
@@ -154,6 +163,11 @@ done:
 extern "C" int krep_gpu_line_numbers(const void *d_text, size_t text_len, const match_position_t *d_positions, uint64_t n,
                                      uint64_t *d_lines, void *stream)
 {
+    return krep_gpu_line_numbers_ex(d_text, text_len, 0, d_positions, n, d_lines, stream);
+}
+extern "C" int krep_gpu_line_numbers_ex(const void *d_text, size_t text_len, size_t global_base, const match_position_t *d_positions,
+                                        uint64_t n, uint64_t *d_lines, void *stream)
+{
     if (!n)
         return 0;
     if ((u64)text_len / kLineBlock + 2 > 0x7fffffffull)
@@ -174,8 +188,8 @@ extern "C" int krep_gpu_line_numbers(const void *d_text, size_t text_len, const 
         FCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, cnt, pre, (int)nblocks, st));
         FCHK(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
         FCHK(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, cnt, pre, (int)nblocks, st));
-        hipLaunchKernelGGL(fmt_line_numbers, dim3((u32)((n + 255) / 256)), dim3(256), 0, st, (const uint8_t *)d_text,
-                           (const u64 *)d_positions, (u64)n, (const u64 *)pre, (u64 *)d_lines);
+        hipLaunchKernelGGL(fmt_line_numbers, dim3((u32)((n + 255) / 256)), dim3(256), 0, st, (const uint8_t *)d_text, (u64)text_len,
+                           (u64)global_base, (const u64 *)d_positions, (u64)n, (const u64 *)pre, (u64 *)d_lines);
         FCHK(hipGetLastError());
         FCHK(hipStreamSynchronize(st));
     }

@@ -358,6 +358,10 @@ static int run_whole(DeviceCtx &cx, const search_params_t *params, const krep_gp
         {
             memchr_batch_quirk(tmp.data(), n, params->max_count);
             n = std::min<uint64_t>(n, params->max_count);
+            if (cfg.result_order) // the caller skips its qsort: hand the (one displaced) record back in file order
+                std::sort(tmp.begin(), tmp.begin() + (long)n, [](const match_position_t &a, const match_position_t &b) {
+                    return a.start_offset < b.start_offset;
+                });
         }
         if (!result_reserve(result, n))
             return kg::fail("out of memory growing match_result_t");
@@ -627,7 +631,7 @@ static int run_pieces(const search_params_t *params, const krep_gpu_config_t &cf
             n = maxc + 1; // krep.c:1717-1724
         if (algo == KREP_RA_MEMCHR)
             memchr_batch_quirk(all.data(), all.size(), maxc);
-        if (params->num_patterns > 1 && cfg.result_order) // the formatter's order (krep.c:420-434)
+        if ((params->num_patterns > 1 || algo == KREP_RA_MEMCHR) && cfg.result_order) // the formatter's order (krep.c:420-434)
             std::sort(all.begin(), all.begin() + (long)n, [](const match_position_t &a, const match_position_t &b) {
                 return a.start_offset != b.start_offset ? a.start_offset < b.start_offset : a.end_offset < b.end_offset;
             });

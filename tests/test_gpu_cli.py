@@ -42,6 +42,14 @@ def test_cli_gpu_equals_cpu(tmp_path):
         # formatter's (start, end) order (sorted in HBM, the patched CLI skips its qsort)
         (["-o", "-e", "Sherlock", "-e", "the", "-e", "he", "-e", "her"], f_big),
         (["-e", "Sherlock", "-e", "lock"], f_big),
+        # round 2: memchr_short_search under -o (2-3 byte -i patterns) now runs on the GPU (candidate walk, krep.c:4495)
+        (["-o", "-i", "th"], f_big), (["-o", "-i", "-w", "he"], f_big), (["-c", "-o", "-i", "ock"], f_big),
+        # memchr_search with max_count a multiple of its 4096-entry batch: the displaced record (krep.c:3976-3991) must
+        # still come out in file order although the patched CLI skips its qsort for GPU results
+        (["-o", "-m", "4096", "e"], f_big),
+        # the input class left to the CPU (krep_gpu_can_accelerate() == 0): -c through simd_sse42_search with a newline in
+        # the pattern — the selector falls through to the reference's own function, output unchanged, nothing on stderr
+        (["-c", "fox\nSherlock"], f_small), (["-c", "e\nS"], f_big),
     ]
     for args, path in cases:
         cpu = run(["-t", "1", "--color=never"] + args + [str(path)], gpu=False)

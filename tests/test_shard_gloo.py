@@ -39,3 +39,27 @@ def test_gloo_ranks(world):
            "--master-addr", "127.0.0.1", "--master-port", str(29650 + world), os.path.join(HERE, "_dist_worker.py")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "DIST_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_bench_spawns_its_own_ranks_dry_run():
+    """`python bench.py --gpus N` outside torchrun starts the N ranks itself (the driver's plain invocation died
+    on an assert).  CPU dry run: gloo, no scan, no number — rendezvous on 127.0.0.1, barrier, the one all-reduce of the counts,
+    MAX-over-ranks timing and the single JSON line of rank 0."""
+    import json
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, MASTER_PORT="29711")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "3",
+                        "--warmup", "1", "--gib", "0.01"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["dry_run"] is True and j["steps"] == 3 and j["value"] is None
+    assert j["config"]["matches"] == 2 * (int(0.01 * (1 << 30)) // 10000)
+    # a mismatching launch is an error message, not an assert trace
+    env2 = dict(env, WORLD_SIZE="3", RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo"], env=env2,
+                        capture_output=True, text=True, timeout=60)
+    assert r2.returncode == 2 and "WORLD_SIZE=3" in r2.stderr

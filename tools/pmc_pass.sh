@@ -7,8 +7,8 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --pmc $CTRS --output-format csv -d $O -o pmc -- python $R/bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline > $O/run.log 2>&1
-python - "$O" <<'PY'
+timeout 600 rocprofv3 --pmc $CTRS --output-format csv -d $O -o pmc -- python $R/bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline --no-extra > $O/run.log 2>&1
+python - "$O" <<'PY' | tee $O/summary.txt
 import csv, glob, sys, collections
 agg = collections.defaultdict(lambda: [0, 0.0])
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
