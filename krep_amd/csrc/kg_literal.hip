@@ -346,6 +346,16 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
                         rest &= rest - 1u;
                         const u64 p = lbase + k;
                         bool ok = true;
+                        // -w neighbours: both byte loads are issued here, ahead of the pattern-tail loads, so that one
+                        // memory round trip serves the whole candidate
+                        u32 cL = 0, cR = 0;
+                        if (ww)
+                        {
+                            if (p > 0)
+                                cL = a.text[p - 1];
+                            if (p + a.m < a.text_len)
+                                cR = a.text[p + a.m];
+                        }
                         if (KIND == 9 && inreg)
                         {
                             // m = 9..16 on a full round: bytes 8..15 of the candidate lie in the lane's own 16 bytes
@@ -372,6 +382,10 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
                                     t = (unsigned long long)fold4((u32)t) | ((unsigned long long)fold4((u32)(t >> 32)) << 32);
                                 return t ^ reinterpret_cast<const U64p *>(a.pat + q)->v;
                             };
+                            // (measured round 2: under the 128-VGPR cap the compiler gives this rare branch two register pairs
+                            //  and waits after every chunk — one memory round trip PER CHUNK, ~0.3 us of wave time each; issuing
+                            //  eight clamped chunks per group did not change that and cost m = 17..40 six extra round trips:
+                            //  5.1 -> 4.5 TB/s.  Hence the counted loop; the real fix is DESIGN.md §8 "long patterns".)
                             unsigned long long diff = 0;
                             u32 q = 8;
 #pragma unroll 4
@@ -383,9 +397,9 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
                         }
                         if (ok && ww)
                         {
-                            if (p > 0 && p != a.ww_exempt_left && is_wordc(a.text[p - 1]))
+                            if (p > 0 && p != a.ww_exempt_left && is_wordc(cL))
                                 ok = false;
-                            else if (p + a.m < a.text_len && is_wordc(a.text[p + a.m]))
+                            else if (p + a.m < a.text_len && is_wordc(cR))
                                 ok = false;
                         }
                         if (!ok)

@@ -12,7 +12,8 @@ buf = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
 cap = n // 2000
 pos = torch.empty(2 * cap, dtype=torch.int64, device="cuda")
 base = b"Sherlock Holmes and the hound of the Baskervilles went out to sea"
-for m in (2, 3, 4, 5, 7, 8, 9, 12, 16, 17, 24, 32, 33, 48, 64, 65, 128):
+lens = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [2, 3, 4, 5, 7, 8, 9, 12, 16, 17, 24, 32, 33, 48, 64, 65, 128]
+for m in lens:
     pat = (base * 2)[:m]
     e.generate(buf.data_ptr(), n, 0, 2, 42, pat, 10000)
     torch.cuda.synchronize()
