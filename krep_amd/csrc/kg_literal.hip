@@ -24,7 +24,7 @@
 //    capped the ordered rate at ~3 TB/s (status round trips), see DESIGN.md;
 //  * a unit with more hits than its staging slot (very dense inputs) is re-scanned by the same
 //    kernel in emit mode, writing its records straight to their final offsets;
-//  * tiles are handed out by an atomic ticket (dynamic balance; one fetch-add per 128 KiB).
+//  * units are dealt out statically and interleaved (no ticket, no barrier: every wave runs on its own).
 #include <hip/hip_runtime.h>
 #include "kg_common.h"
 
@@ -123,15 +123,12 @@ __device__ __noinline__ W6 load_window_guarded(const uint8_t *text, u64 text_len
 
 // KIND: 1 -> m == 1 (SWAR), 4 -> 2..4 bytes (one word), 8 -> 5..8 bytes (two words), 9 -> m > 8 (filter+verify)
 // MASKED: the last compared word is partial (m = 2,3 or 5,6,7), so its compare needs the byte mask.
-// R: load rounds per chain unit.  A workgroup draws ONE ticket per tile (4 waves x R x 8 KiB); each
-// wave scans its own contiguous R x 8 KiB quarter (the chain UNIT), keeps the R x 8 per-lane hit
-// masks in registers, publishes the unit's aggregate, looks back, and emits.  The ticket for the
-// next tile is fetched while the current one is scanned.  One barrier per tile (ticket broadcast).
+// R: load rounds per UNIT.  A wave scans one contiguous R x 8 KiB unit at a time (statically dealt, see below), keeps the
+// R x 8 per-lane hit masks in registers and publishes the unit's aggregate + staged hits; no wave waits for another.
 template <int KIND, bool MASKED, bool CI, bool LINES, int R>
 // >= 4 waves per SIMD (<= 128 VGPRs) for the plain variants: the allocator otherwise drifts to 137 and loses a wave
 __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
 {
-    __shared__ u64 s_ticket[2];
     const u32 lane = lane_id();
     const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool want_pos = (a.flags & F_POS) != 0;
@@ -141,22 +138,15 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
     constexpr u64 kUnitBytes = (u64)R * kSegBytes;
 
     u64 acc_total = 0; // wave-uniform accumulator
-    u64 next_ticket = 0;
-    if (threadIdx.x == 0)
-        next_ticket = __hip_atomic_fetch_add(&a.ctr->ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-
-    for (u32 it = 0;; ++it)
+    // Units are dealt out STATICALLY: wave w of block b scans units (i * gridDim.x + b) * 4 + w — the four waves of a block
+    // read 4 x R x 8 KiB contiguous bytes per step, every wave runs on its own (no ticket, no barrier).  Round 1 drew one
+    // atomic ticket per 128 KiB tile and broadcast it through LDS behind a __syncthreads(): measured in isolation
+    // (tools/ubench/read_ceiling.hip, 32 GiB) that skeleton alone caps a pure reader at 6.5 TB/s against 7.07 TB/s for
+    // static striding — the barrier makes every wave wait for the slowest of its tile, 262 144 times per scan.  The
+    // interleaved static deal keeps the blocks balanced on skewed inputs as well.
+    const u64 n_units = a.num_tiles * kWavesPerBlk;
+    for (u64 unit = (u64)blockIdx.x * kWavesPerBlk + wave; unit < n_units; unit += (u64)gridDim.x * kWavesPerBlk)
     {
-        if (threadIdx.x == 0)
-            s_ticket[it & 1u] = next_ticket;
-        __syncthreads();
-        const u64 tile = rfl64(s_ticket[it & 1u]);
-        if (tile >= a.num_tiles)
-            break;
-        if (threadIdx.x == 0) // prefetch: consumed at the top of the next iteration
-            next_ticket = __hip_atomic_fetch_add(&a.ctr->ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-
-        const u64 unit = tile * kWavesPerBlk + wave;
         const u64 ubase = a.anchor + unit * kUnitBytes;
         if (a.emit_mode && (u32)(a.unitinfo[unit] & kUiCountMask) <= a.stage_cap)
             continue; // wave-uniform: only overflowed units are re-scanned

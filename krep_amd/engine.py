@@ -21,6 +21,7 @@ class Engine:
     takes raw device pointers (e.g. torch tensors' data_ptr())."""
 
     def __init__(self, path: str = LIB_PATH):
+        path = os.environ.get("KREP_GPU_LIB", path)  # development aid: A/B two builds of the library in one GPU session
         if not os.path.exists(path):
             raise KrepGpuError(f"{path} is missing: build it with `python -m krep_amd.build` "
                                "(hipcc --offload-arch=gfx950); there is no CPU fallback")

@@ -1,0 +1,232 @@
+// read_ceiling.hip — what read bandwidth can ANY kernel get out of this part?  (development probe; not product code)
+//   variants: register loads (dwordx4 per lane, LOADS in flight, nontemporal or plain), LDS-DMA (global_load_lds_dwordx4,
+//   nt or plain) + ds_read_b128 read-back; persistent grid, static tile striding, 256-thread blocks.
+// build & run on the GPU box:  hipcc --offload-arch=gfx950 -O3 -o /tmp/rc tools/ubench/read_ceiling.hip && /tmp/rc [GiB]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+#include <vector>
+#include <algorithm>
+
+#define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <int LOADS, bool NT>
+__global__ __launch_bounds__(256) void rd_regs(const uint8_t *__restrict__ p, size_t n, uint32_t *out)
+{
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t wave_bytes = (size_t)LOADS * 1024, tile = wave_bytes * 4;
+    uint32_t acc = 0;
+    for (size_t t = blockIdx.x; t * tile + tile <= n; t += gridDim.x)
+    {
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(p + t * tile + wave * wave_bytes) + lane;
+        u32x4 v[LOADS];
+#pragma unroll
+        for (int j = 0; j < LOADS; ++j)
+            v[j] = NT ? __builtin_nontemporal_load(src + j * 64) : src[j * 64];
+#pragma unroll
+        for (int j = 0; j < LOADS; ++j)
+            acc ^= v[j].x ^ v[j].y ^ v[j].z ^ v[j].w;
+    }
+    if (acc == 0x12345678u)
+        out[0] = acc;
+}
+
+// LDS-DMA: every wave owns LOADS KiB of LDS; 16 B per lane per instruction land at base + lane * 16
+template <int LOADS, int AUX>
+__global__ __launch_bounds__(256) void rd_ldsdma(const uint8_t *__restrict__ p, size_t n, uint32_t *out)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t wave_bytes = (size_t)LOADS * 1024, tile = wave_bytes * 4;
+    uint8_t *mine = smem + wave * wave_bytes;
+    uint32_t acc = 0;
+    for (size_t t = blockIdx.x; t * tile + tile <= n; t += gridDim.x)
+    {
+        const uint8_t *src = p + t * tile + wave * wave_bytes + lane * 16;
+#pragma unroll
+        for (int j = 0; j < LOADS; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + j * 1024),
+                                             (__attribute__((address_space(3))) void *)(mine + j * 1024), 16, 0, AUX);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < LOADS; ++j)
+        {
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(mine + j * 1024 + lane * 16);
+            acc ^= v.x ^ v.y ^ v.z ^ v.w;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if (acc == 0x12345678u)
+        out[0] = acc;
+}
+
+// the skeleton of kg::lit_scan without its compute: one atomic ticket per 128 KiB tile (prefetched), one __syncthreads per
+// tile, per wave R rounds of 8 x 1 KiB loads + the 8-byte look-ahead load behind each round.
+// WORK: 0 = xor only; 1 = the compare work of the 8-byte literal (12 v_alignbyte + 16 v_cmp + ballots per cell)
+template <int R, int WORK, int WAVES_PER_SIMD>
+__global__ __launch_bounds__(256, WAVES_PER_SIMD) void rd_skeleton(const uint8_t *__restrict__ p, size_t n, uint32_t *out,
+                                                                   unsigned long long *ticket, uint32_t p0, uint32_t p1)
+{
+    __shared__ unsigned long long s_ticket[2];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t unit = (size_t)R * 8192, tile = unit * 4, ntiles = n / tile;
+    uint32_t acc = 0;
+    unsigned long long hits = 0;
+    unsigned long long next = 0;
+    if (threadIdx.x == 0)
+        next = atomicAdd(ticket, 1ull);
+    for (uint32_t it = 0;; ++it)
+    {
+        if (threadIdx.x == 0)
+            s_ticket[it & 1] = next;
+        __syncthreads();
+        const unsigned long long t = s_ticket[it & 1];
+        if (t >= ntiles)
+            break;
+        if (threadIdx.x == 0)
+            next = atomicAdd(ticket, 1ull);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+        {
+            const uint8_t *seg = p + t * tile + wave * unit + (size_t)r * 8192;
+            const u32x4 *src = reinterpret_cast<const u32x4 *>(seg) + lane;
+            u32x4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                v[j] = __builtin_nontemporal_load(src + j * 64);
+            const uint2 after = (t * tile + wave * unit + (size_t)(r + 1) * 8192 + 8 <= n)
+                                    ? *reinterpret_cast<const uint2 *>(seg + 8192) : make_uint2(0, 0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+            {
+                if (WORK == 0)
+                    acc ^= v[j].x ^ v[j].y ^ v[j].z ^ v[j].w ^ after.x;
+                else
+                {
+                    uint32_t D[6] = {v[j].x, v[j].y, v[j].z, v[j].w, 0, 0};
+                    const uint32_t n0 = __shfl_down(D[0], 1), n1 = __shfl_down(D[1], 1);
+                    const uint32_t e0 = j + 1 < 8 ? __builtin_amdgcn_readfirstlane(v[j + 1 < 8 ? j + 1 : j].x) : after.x;
+                    const uint32_t e1 = j + 1 < 8 ? __builtin_amdgcn_readfirstlane(v[j + 1 < 8 ? j + 1 : j].y) : after.y;
+                    D[4] = lane == 63 ? e0 : n0;
+                    D[5] = lane == 63 ? e1 : n1;
+                    unsigned long long any = 0;
+                    uint32_t A0[16];
+                    bool c[16];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k)
+                    {
+                        A0[k] = (k & 3) == 0 ? D[k >> 2] : __builtin_amdgcn_alignbyte(D[(k >> 2) + 1], D[k >> 2], (uint32_t)(k & 3));
+                        c[k] = A0[k] == p0;
+                        any |= __ballot(c[k]);
+                    }
+                    if (any)
+                    {
+#pragma unroll
+                        for (int k = 0; k < 16; ++k)
+                        {
+                            const uint32_t a4 = k < 12 ? A0[k + 4] : __builtin_amdgcn_alignbyte(D[(k >> 2) + 2], D[(k >> 2) + 1], (uint32_t)(k & 3));
+                            if (c[k] && a4 == p1)
+                                hits += 1;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (acc == 0x12345678u)
+        out[0] = acc;
+    if (hits)
+        atomicAdd((unsigned long long *)(out + 2), hits);
+}
+
+__global__ void fill(uint32_t *p, size_t nwords)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (size_t)gridDim.x * blockDim.x)
+    {
+        uint64_t x = i * 0x9E3779B97F4A7C15ull;
+        x ^= x >> 29;
+        p[i] = (uint32_t)(x * 0xBF58476D1CE4E5B9ull >> 17);
+    }
+}
+
+template <typename F>
+static double time_it(F launch, int reps = 7)
+{
+    hipEvent_t a, b;
+    CHK(hipEventCreate(&a));
+    CHK(hipEventCreate(&b));
+    launch();
+    launch();
+    std::vector<float> ms;
+    for (int r = 0; r < reps; ++r)
+    {
+        CHK(hipEventRecord(a));
+        launch();
+        CHK(hipEventRecord(b));
+        CHK(hipEventSynchronize(b));
+        float t;
+        CHK(hipEventElapsedTime(&t, a, b));
+        ms.push_back(t);
+    }
+    std::sort(ms.begin(), ms.end());
+    return ms[ms.size() / 2];
+}
+
+int main(int argc, char **argv)
+{
+    const double gib = argc > 1 ? atof(argv[1]) : 32.0;
+    const size_t n = (size_t)(gib * (1ull << 30));
+    uint8_t *buf;
+    uint32_t *out;
+    CHK(hipMalloc(&buf, n));
+    CHK(hipMalloc(&out, 64));
+    hipLaunchKernelGGL(fill, dim3(4096), dim3(256), 0, 0, (uint32_t *)buf, n / 4);
+    CHK(hipDeviceSynchronize());
+    hipDeviceProp_t prop;
+    CHK(hipGetDeviceProperties(&prop, 0));
+    const int cu = prop.multiProcessorCount;
+#define RUN(name, kern, bpc, lds)                                                                                     \
+    {                                                                                                                 \
+        if (lds > 65536) CHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+        double ms = time_it([&] { hipLaunchKernelGGL(kern, dim3(cu * bpc), dim3(256), lds, 0, buf, n, out); });       \
+        CHK(hipGetLastError());                                                                                      \
+        printf("%-44s blocks/CU=%d  %7.3f ms  %7.1f GB/s  (%.3f of 8 TB/s)\n", name, bpc, ms, n / ms / 1e6, n / ms / 1e6 / 8000.0); \
+        fflush(stdout);                                                                                               \
+    }
+    unsigned long long *ticket;
+    CHK(hipMalloc(&ticket, 8));
+#define RUNS(name, kern, bpc)                                                                                        \
+    {                                                                                                                 \
+        double ms = time_it([&] {                                                                                     \
+            (void)hipMemsetAsync(ticket, 0, 8, 0);                                                                    \
+            hipLaunchKernelGGL(kern, dim3(cu * bpc), dim3(256), 0, 0, buf, n, out, ticket, 0x72656853u, 0x6b636f6cu); \
+        });                                                                                                           \
+        CHK(hipGetLastError());                                                                                      \
+        printf("%-44s blocks/CU=%d  %7.3f ms  %7.1f GB/s  (%.3f of 8 TB/s)\n", name, bpc, ms, n / ms / 1e6, n / ms / 1e6 / 8000.0); \
+        fflush(stdout);                                                                                               \
+    }
+    for (int bpc : {2, 4, 8})
+    {
+        RUNS("skeleton R=4, xor only, 4 waves/SIMD", (rd_skeleton<4, 0, 4>), bpc);
+        RUNS("skeleton R=4, literal8 compare, 4 w/SIMD", (rd_skeleton<4, 1, 4>), bpc);
+        RUNS("skeleton R=4, literal8 compare, 2 w/SIMD", (rd_skeleton<4, 1, 2>), bpc);
+        RUNS("skeleton R=1, literal8 compare, 4 w/SIMD", (rd_skeleton<1, 1, 4>), bpc);
+        RUNS("skeleton R=2, literal8 compare, 4 w/SIMD", (rd_skeleton<2, 1, 4>), bpc);
+    }
+    for (int bpc : {2, 4, 8})
+    {
+        RUN("regs  8 x dwordx4, nontemporal", (rd_regs<8, true>), bpc, 0);
+        RUN("regs  8 x dwordx4, plain", (rd_regs<8, false>), bpc, 0);
+        RUN("regs 16 x dwordx4, nontemporal", (rd_regs<16, true>), bpc, 0);
+        RUN("regs  4 x dwordx4, nontemporal", (rd_regs<4, true>), bpc, 0);
+    }
+    for (int bpc : {1, 2, 4})
+    {
+        RUN("lds-dma  8 KiB/wave, default policy", (rd_ldsdma<8, 0>), bpc, 4 * 8 * 1024);
+        RUN("lds-dma  8 KiB/wave, nt (aux=2)", (rd_ldsdma<8, 2>), bpc, 4 * 8 * 1024);
+        RUN("lds-dma 16 KiB/wave, nt (aux=2)", (rd_ldsdma<16, 2>), bpc > 2 ? 2 : bpc, 4 * 16 * 1024);
+    }
+    return 0;
+}
