@@ -640,9 +640,7 @@ static int lit_pass(krep_gpu_plan *pl, const Window &w, const LitPass &ps, hipSt
         a.stage = (uint64_t *)post.d_stage;
         a.offsets = (const uint64_t *)post.d_offsets;
     }
-    // static deal: exactly the resident set (4 blocks of 4 waves per CU under the kernels' 128-VGPR bound), one phase
-    static const int bpc = [] { const char *e = getenv("KREP_GPU_LIT_BLOCKS_PER_CU"); return e && atoi(e) > 0 ? atoi(e) : 4; }();
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(a.num_tiles, (uint64_t)pl->num_cu * bpc);
+    const uint32_t grid = (uint32_t)pl->num_cu; // launch_literal sizes the grid: resident blocks of the chosen variant x CUs
     const uint64_t unit_bytes = (uint64_t)a.rounds * kSegBytes, origin = a.anchor + w.global_base;
     res->n_units = n_units;
     res->unit_bytes = unit_bytes;

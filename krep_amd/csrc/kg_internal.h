@@ -9,7 +9,7 @@ namespace kg {
 int fail(const char *fmt, ...); // records krep_gpu_last_error(), prints "krep-gpu: ..." and returns 2
 
 // kg_literal.hip
-hipError_t launch_literal(const LitArgs &a, uint32_t grid, hipStream_t st);
+hipError_t launch_literal(const LitArgs &a, uint32_t num_cu, hipStream_t st); // grid = resident blocks of the variant x CUs
 
 // kg_post.hip — ordering post-pass shared by the literal and Aho-Corasick scans
 struct PostScratch

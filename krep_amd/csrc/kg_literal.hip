@@ -26,6 +26,8 @@
 //    kernel in emit mode, writing its records straight to their final offsets;
 //  * units are dealt out statically and interleaved (no ticket, no barrier: every wave runs on its own).
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdlib>
 #include "kg_common.h"
 
 namespace kg {
@@ -151,7 +153,10 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
         if (a.emit_mode && (u32)(a.unitinfo[unit] & kUiCountMask) <= a.stage_cap)
             continue; // wave-uniform: only overflowed units are re-scanned
 
-        u32 M[R][kCells]; // per-lane 16-bit hit masks of the whole unit
+        // KIND 1 (single byte, ~330 hits per unit at 1 %): every cell holds hits, so the masks are kept and written out in one go
+        // at the unit's end (inline stores between the loads cost it 7 %); the sparse kinds write their rare hits where they find them
+        constexpr bool kInline = KIND != 1;
+        u32 M[kInline ? 1 : R][kInline ? 1 : kCells];
         u32 wcnt = 0;     // unit total (uniform)
         LS wls{0, false, false, false};
         bool nl_pend = false; // -c: some lane saw a newline in the hit-free interior cells since the last flush (per lane)
@@ -397,12 +402,72 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
                     }
                 }
 
-                M[r][j] = m16;
                 const u64 anyhit = __ballot(m16 != 0u);
-                u32 ccnt = 0;
-                if (anyhit)
-                    ccnt = wave_sum5(__popc(m16));
-                wcnt += ccnt;
+                if (!kInline)
+                {
+                    M[kInline ? 0 : r][kInline ? 0 : j] = m16;
+                    if (anyhit)
+                        wcnt += wave_sum5(__popc(m16));
+                }
+                else if (anyhit)
+                {
+                    // the cell holds hits (10 % of the cells at 1e-4 hits per byte): rank them inside the unit — running unit
+                    // count + exclusive lane prefix, both from the same ballot bit-planes — and write them out HERE, in order:
+                    // 16-bit unit-relative offsets into the unit's staging slot, or (emit mode: a unit that overflowed its slot
+                    // is being re-scanned) final records at the unit's global offset.  Round 1 kept the R x 8 masks of the unit
+                    // in 32 registers and walked them again at the unit's end; without them the offsets-producing scan runs at
+                    // the count-only rate (the kernel is bound by how much load latency its registers let it cover, not by VALU).
+                    const u32 c = __popc(m16);
+                    u32 idx = wcnt, tot = 0;
+                    auto plane = [&](int b) { // exclusive lane prefix and wave total from the same ballot
+                        const u64 bm = __ballot((c >> b) & 1u);
+                        idx += mbcnt64(bm) << b;
+                        tot += (u32)__popcll(bm) << b;
+                    };
+                    plane(0);
+                    plane(1);
+                    if (__ballot(c > 3u)) // rare: some lane holds 4+ hits in its 16 bytes
+                    {
+                        plane(2);
+                        plane(3);
+                        plane(4);
+                    }
+                    wcnt += tot;
+                    if (want_pos)
+                    {
+                        u32 rest = m16;
+                        if (!a.emit_mode)
+                        {
+                            unsigned short *slot = reinterpret_cast<unsigned short *>(a.stage) + unit * (u64)a.stage_cap;
+                            const u32 rel0 = (u32)(r * kCells + j) * kCellBytes + lane * 16u;
+                            while (rest)
+                            {
+                                const u32 k = __builtin_ctz(rest);
+                                rest &= rest - 1u;
+                                if (idx < a.stage_cap)
+                                    slot[idx] = (unsigned short)(rel0 + k);
+                                ++idx;
+                            }
+                        }
+                        else
+                        {
+                            u64 o = a.offsets[unit] + idx;
+                            const u64 lb = lbase + a.global_base;
+                            while (rest)
+                            {
+                                const u32 k = __builtin_ctz(rest);
+                                rest &= rest - 1u;
+                                if (o < a.pos_cap)
+                                {
+                                    const u64 st = lb + k, en = st + a.m;
+                                    *reinterpret_cast<uint4 *>(a.positions + 2 * o) =
+                                        make_uint4((u32)st, (u32)(st >> 32), (u32)en, (u32)(en >> 32));
+                                }
+                                ++o;
+                            }
+                        }
+                    }
+                }
 
                 // A hit-free interior cell only matters through "was there a newline": remembered per lane and folded
                 // into the summary with ONE ballot when the next cell with a hit (or the unit's end) needs it —
@@ -486,7 +551,7 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
                     atomicMax(&a.ctr->max_unit_count, (u64)wcnt);
                 }
             }
-            if (want_pos && wcnt)
+            if (!kInline && want_pos && wcnt)
             {
                 // unit-relative 16-bit offsets (a unit spans <= 32 KiB): 2 B staged per hit instead of 8
                 unsigned short *slot = reinterpret_cast<unsigned short *>(a.stage) + unit * (u64)a.stage_cap;
@@ -497,7 +562,7 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
 #pragma unroll
                     for (int j = 0; j < kCells; ++j)
                     {
-                        u32 m16 = M[r][j];
+                        u32 m16 = M[kInline ? 0 : r][kInline ? 0 : j];
                         const u64 anyhit = __ballot(m16 != 0u);
                         if (!anyhit)
                             continue;
@@ -530,7 +595,7 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
                 }
             }
         }
-        else if (want_pos && wcnt > a.stage_cap)
+        else if (!kInline && want_pos && wcnt > a.stage_cap)
         {
             // ---- emit mode: this unit overflowed its staging slot; write its records in place -----------
             u64 out = a.offsets[unit];
@@ -542,7 +607,7 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
 #pragma unroll
                     for (int j = 0; j < kCells; ++j)
                     {
-                        u32 m16 = M[r][j];
+                        u32 m16 = M[kInline ? 0 : r][kInline ? 0 : j];
                         const u64 anyhit = __ballot(m16 != 0u);
                         if (!anyhit)
                             continue;
@@ -573,40 +638,61 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
 }
 
 // ---- launcher ----------------------------------------------------------------------------------
-template <int KIND, bool MASKED, bool CI, int R>
-static hipError_t launch3(const LitArgs &a, u32 grid, hipStream_t st)
+// The units are dealt out statically, so the grid is exactly the resident set: blocks per CU as the occupancy calculator
+// reports them for the chosen instantiation, at most 4 (16 waves per CU; more waves measured slower), one phase, no tail of
+// late blocks.  KREP_GPU_LIT_BLOCKS_PER_CU overrides (measurement aid).
+template <typename K>
+static u32 resident_blocks_per_cu(K kernel)
 {
-    if (a.flags & F_LINES)
-        hipLaunchKernelGGL((lit_scan<KIND, MASKED, CI, true, R>), dim3(grid), dim3(kBlock), 0, st, a);
-    else
-        hipLaunchKernelGGL((lit_scan<KIND, MASKED, CI, false, R>), dim3(grid), dim3(kBlock), 0, st, a);
+    static const u32 forced = [] { const char *e = getenv("KREP_GPU_LIT_BLOCKS_PER_CU"); return e && atoi(e) > 0 ? (u32)atoi(e) : 0u; }();
+    if (forced)
+        return forced;
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, kBlock, 0) != hipSuccess || n < 1)
+    {
+        (void)hipGetLastError();
+        n = 4;
+    }
+    return (u32)std::min(n, 4); // measured: a fifth wave per SIMD costs the 8-byte literal 4-8 % (5.40 -> 5.59 ms at 32 GiB)
+}
+template <int KIND, bool MASKED, bool CI, bool LINES, int R>
+static hipError_t launch4(const LitArgs &a, u32 num_cu, hipStream_t st)
+{
+    static const u32 bpc = resident_blocks_per_cu(lit_scan<KIND, MASKED, CI, LINES, R>);
+    const u32 grid = (u32)std::min<u64>(a.num_tiles, (u64)num_cu * bpc);
+    hipLaunchKernelGGL((lit_scan<KIND, MASKED, CI, LINES, R>), dim3(grid ? grid : 1), dim3(kBlock), 0, st, a);
     return hipGetLastError();
 }
-template <int KIND, bool MASKED, bool CI>
-static hipError_t launch2(const LitArgs &a, u32 grid, hipStream_t st)
+template <int KIND, bool MASKED, bool CI, int R>
+static hipError_t launch3(const LitArgs &a, u32 num_cu, hipStream_t st)
 {
-    return a.rounds == kRoundsBig ? launch3<KIND, MASKED, CI, kRoundsBig>(a, grid, st) : launch3<KIND, MASKED, CI, 1>(a, grid, st);
+    return (a.flags & F_LINES) ? launch4<KIND, MASKED, CI, true, R>(a, num_cu, st) : launch4<KIND, MASKED, CI, false, R>(a, num_cu, st);
+}
+template <int KIND, bool MASKED, bool CI>
+static hipError_t launch2(const LitArgs &a, u32 num_cu, hipStream_t st)
+{
+    return a.rounds == kRoundsBig ? launch3<KIND, MASKED, CI, kRoundsBig>(a, num_cu, st) : launch3<KIND, MASKED, CI, 1>(a, num_cu, st);
 }
 template <int KIND, bool MASKED>
-static hipError_t launch1(const LitArgs &a, u32 grid, hipStream_t st)
+static hipError_t launch1(const LitArgs &a, u32 num_cu, hipStream_t st)
 {
-    return (a.flags & F_CI) ? launch2<KIND, MASKED, true>(a, grid, st) : launch2<KIND, MASKED, false>(a, grid, st);
+    return (a.flags & F_CI) ? launch2<KIND, MASKED, true>(a, num_cu, st) : launch2<KIND, MASKED, false>(a, num_cu, st);
 }
 
 // a.num_tiles counts workgroup tiles of 4 x a.rounds x 8 KiB; a.rounds is 1 or kRoundsBig
-hipError_t launch_literal(const LitArgs &a, u32 grid, hipStream_t st)
+hipError_t launch_literal(const LitArgs &a, u32 num_cu, hipStream_t st)
 {
     if (a.m == 1)
-        return launch1<1, false>(a, grid, st);
+        return launch1<1, false>(a, num_cu, st);
     if (a.m < 4)
-        return launch1<4, true>(a, grid, st);
+        return launch1<4, true>(a, num_cu, st);
     if (a.m == 4)
-        return launch1<4, false>(a, grid, st);
+        return launch1<4, false>(a, num_cu, st);
     if (a.m < 8)
-        return launch1<8, true>(a, grid, st);
+        return launch1<8, true>(a, num_cu, st);
     if (a.m == 8)
-        return launch1<8, false>(a, grid, st);
-    return launch1<9, false>(a, grid, st);
+        return launch1<8, false>(a, num_cu, st);
+    return launch1<9, false>(a, num_cu, st);
 }
 
 } // namespace kg

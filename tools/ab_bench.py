@@ -1,0 +1,31 @@
+"""A/B of several builds of libkrep_gpu.so IN ONE PROCESS on the same HBM buffers (development aid).
+Process-to-process variance of a 32 GiB scan is +-4 % on this part (placement), far above most kernel-level differences.
+usage: python tools/ab_bench.py <gib> <kind: 2 literal8 | 3 memchr1 | 4 ac1000> <mode: pos|count|lines> <variant.so> [...]"""
+import os, sys, statistics
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from krep_amd import abi
+from krep_amd.engine import Engine
+import bench
+
+gib, kind, mode = float(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+libs = sys.argv[4:]
+n = int(gib * (1 << 30))
+engs = [(os.path.basename(p), Engine(p if os.path.isabs(p) else os.path.join(ROOT, "krep_amd", "lib", "variants", p))) for p in libs]
+wl = bench.workload({2: "literal8", 3: "memchr1", 4: "ac1000"}[kind])
+buf = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+engs[0][1].generate(buf.data_ptr(), n, 0, wl["kind"], 42, wl["plant"], wl["period"])
+kw = dict(count_lines=True, only_match=True) if mode == "count" else dict(count_lines=True) if mode == "lines" else {}
+cap = (n // 50 if kind == 3 else n // 1500) + 4096 if mode == "pos" else 0
+pos = torch.empty(2 * cap, dtype=torch.int64, device="cuda") if cap else None
+plans = [(name, e.plan(abi.Params(wl["patterns"], **kw))) for name, e in engs]
+times = {name: [] for name, _ in plans}
+for rep in range(int(os.environ.get("AB_REPS", "9"))):
+    for name, pl in plans:
+        out = pl.scan(buf.data_ptr(), n, 0, n, 0, pos.data_ptr() if cap else 0, cap, time_it=True)
+        if rep:
+            times[name].append(out.kernel_ms)
+for name, _ in plans:
+    t = times[name]
+    print(f"{name:16s} {mode:5s} kind={kind} median {statistics.median(t):7.3f} ms  min {min(t):7.3f}  {n / statistics.median(t) / 1e6:7.1f} GB/s   count={out.count}")

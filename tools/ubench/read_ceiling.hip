@@ -141,6 +141,92 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void rd_skeleton(const uint8_t
         atomicAdd((unsigned long long *)(out + 2), hits);
 }
 
+// static striding (what kg::lit_scan does since round 2) with the literal8 compare work; PF: rolling prefetch — as soon as cell j
+// has been copied out of its registers they receive cell j of the NEXT round (next unit at the end of a unit)
+template <int R, bool PF>
+__global__ __launch_bounds__(256, 4) void rd_static(const uint8_t *__restrict__ p, size_t n, uint32_t *out, unsigned long long *,
+                                                    uint32_t p0, uint32_t p1)
+{
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t unit_bytes = (size_t)R * 8192, n_units = n / unit_bytes;
+    unsigned long long hits = 0;
+    u32x4 v[8];
+    bool have = false;
+    const size_t stride = (size_t)gridDim.x * 4;
+    for (size_t unit = (size_t)blockIdx.x * 4 + wave; unit < n_units; unit += stride)
+    {
+        const uint8_t *ubase = p + unit * unit_bytes;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+        {
+            const uint8_t *seg = ubase + (size_t)r * 8192;
+            const u32x4 *src = reinterpret_cast<const u32x4 *>(seg) + lane;
+            if (!PF || !have)
+            {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    v[j] = __builtin_nontemporal_load(src + j * 64);
+            }
+            const bool last = r + 1 == R;
+            const bool more = !last || unit + stride < n_units;
+            const u32x4 *nsrc = !last ? src + 8192 / 16
+                                      : (more ? reinterpret_cast<const u32x4 *>(p + (unit + stride) * unit_bytes) + lane : src);
+            uint2 after = make_uint2(0, 0);
+            if ((!PF || last) && (size_t)(seg - p) + 8192 + 8 <= n)
+                after = *reinterpret_cast<const uint2 *>(seg + 8192);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+            {
+                uint32_t D[6] = {v[j].x, v[j].y, v[j].z, v[j].w, 0, 0};
+                if (PF)
+                    v[j] = __builtin_nontemporal_load(nsrc + j * 64);
+                const uint32_t n0 = __shfl_down(D[0], 1), n1 = __shfl_down(D[1], 1);
+                uint32_t e0, e1;
+                if (j + 1 < 8)
+                {
+                    e0 = __builtin_amdgcn_readfirstlane(v[j + 1 < 8 ? j + 1 : j].x);
+                    e1 = __builtin_amdgcn_readfirstlane(v[j + 1 < 8 ? j + 1 : j].y);
+                }
+                else if (PF && !last)
+                {
+                    e0 = __builtin_amdgcn_readfirstlane(v[0].x); // the next round's first bytes are already on their way in
+                    e1 = __builtin_amdgcn_readfirstlane(v[0].y);
+                }
+                else
+                {
+                    e0 = after.x;
+                    e1 = after.y;
+                }
+                D[4] = lane == 63 ? e0 : n0;
+                D[5] = lane == 63 ? e1 : n1;
+                unsigned long long any = 0;
+                uint32_t A0[16];
+                bool c[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                {
+                    A0[k] = (k & 3) == 0 ? D[k >> 2] : __builtin_amdgcn_alignbyte(D[(k >> 2) + 1], D[k >> 2], (uint32_t)(k & 3));
+                    c[k] = A0[k] == p0;
+                    any |= __ballot(c[k]);
+                }
+                if (any)
+                {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k)
+                    {
+                        const uint32_t a4 = k < 12 ? A0[k + 4] : __builtin_amdgcn_alignbyte(D[(k >> 2) + 2], D[(k >> 2) + 1], (uint32_t)(k & 3));
+                        if (c[k] && a4 == p1)
+                            hits += 1;
+                    }
+                }
+            }
+            have = PF && more;
+        }
+    }
+    if (hits)
+        atomicAdd((unsigned long long *)(out + 2), hits);
+}
+
 __global__ void fill(uint32_t *p, size_t nwords)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (size_t)gridDim.x * blockDim.x)
@@ -207,7 +293,17 @@ int main(int argc, char **argv)
         printf("%-44s blocks/CU=%d  %7.3f ms  %7.1f GB/s  (%.3f of 8 TB/s)\n", name, bpc, ms, n / ms / 1e6, n / ms / 1e6 / 8000.0); \
         fflush(stdout);                                                                                               \
     }
-    for (int bpc : {2, 4, 8})
+    for (int bpc : {4})
+    {
+        RUNS("static R=4, literal8 compare, no prefetch", (rd_static<4, false>), bpc);
+        RUNS("static R=4, literal8 compare, ROLLING PREFETCH", (rd_static<4, true>), bpc);
+        RUNS("static R=8, literal8 compare, no prefetch", (rd_static<8, false>), bpc);
+        RUNS("static R=8, literal8 compare, ROLLING PREFETCH", (rd_static<8, true>), bpc);
+        RUNS("static R=1, literal8 compare, ROLLING PREFETCH", (rd_static<1, true>), bpc);
+        RUNS("static R=4, literal8 compare, no prefetch", (rd_static<4, false>), bpc);
+        RUNS("static R=4, literal8 compare, ROLLING PREFETCH", (rd_static<4, true>), bpc);
+    }
+    for (int bpc : {4})
     {
         RUNS("skeleton R=4, xor only, 4 waves/SIMD", (rd_skeleton<4, 0, 4>), bpc);
         RUNS("skeleton R=4, literal8 compare, 4 w/SIMD", (rd_skeleton<4, 1, 4>), bpc);
@@ -215,7 +311,7 @@ int main(int argc, char **argv)
         RUNS("skeleton R=1, literal8 compare, 4 w/SIMD", (rd_skeleton<1, 1, 4>), bpc);
         RUNS("skeleton R=2, literal8 compare, 4 w/SIMD", (rd_skeleton<2, 1, 4>), bpc);
     }
-    for (int bpc : {2, 4, 8})
+    for (int bpc : {2, 4})
     {
         RUN("regs  8 x dwordx4, nontemporal", (rd_regs<8, true>), bpc, 0);
         RUN("regs  8 x dwordx4, plain", (rd_regs<8, false>), bpc, 0);
