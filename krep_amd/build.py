@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libkrep_gpu.so")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-cuda-compat"]
 
 
 def sources():

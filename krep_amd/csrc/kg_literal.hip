@@ -161,7 +161,8 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
         LS wls{0, false, false, false};
         bool nl_pend = false; // -c: some lane saw a newline in the hit-free interior cells since the last flush (per lane)
 
-#pragma unroll
+        // the rounds of a unit are a real loop for the sparse kinds (nothing is indexed by r any more): a quarter of the code
+#pragma unroll(KIND == 1 ? R : 1)
         for (int r = 0; r < R; ++r)
         {
             const u64 seg = ubase + (u64)r * kSegBytes;
