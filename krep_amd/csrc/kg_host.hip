@@ -443,6 +443,15 @@ extern "C" krep_gpu_plan_t *krep_gpu_plan_create_ex(const search_params_t *p, co
         }
         ok = hipMalloc(&pl->d_pat, pl->m) == hipSuccess &&
              hipMemcpy(pl->d_pat, pl->pat_folded.data(), pl->m, hipMemcpyHostToDevice) == hipSuccess;
+        if (ok && pl->m > 8)
+        {
+            pl->n_chunks = (pl->m - 8 + 7) / 8;
+            std::vector<unsigned long long> ch(pl->n_chunks);
+            for (uint32_t k = 0; k < pl->n_chunks; ++k)
+                memcpy(&ch[k], pl->pat_folded.data() + std::min<uint32_t>(8 + 8 * k, pl->m - 8), 8);
+            ok = hipMalloc(&pl->d_pat_chunks, ch.size() * 8) == hipSuccess &&
+                 hipMemcpy(pl->d_pat_chunks, ch.data(), ch.size() * 8, hipMemcpyHostToDevice) == hipSuccess;
+        }
     }
     if (ok && pl->ref_algo == KREP_RA_AHO_CORASICK)
     {
@@ -482,6 +491,7 @@ extern "C" void krep_gpu_plan_destroy(krep_gpu_plan_t *pl)
         return;
     (void)hipSetDevice(pl->device);
     if (pl->d_pat) DBGFREE(hipFree(pl->d_pat));
+    if (pl->d_pat_chunks) DBGFREE(hipFree(pl->d_pat_chunks));
     if (pl->d_ctr) DBGFREE(hipFree(pl->d_ctr));
     if (pl->h_ctr) DBGFREE(hipHostFree(pl->h_ctr));
     if (pl->ev0) DBGFREE(hipEventDestroy(pl->ev0));
@@ -620,6 +630,8 @@ static int lit_pass(krep_gpu_plan *pl, const Window &w, const LitPass &ps, hipSt
         a.p2 = pl->p2; a.p3 = pl->p3; a.k2 = pl->k2; a.k3 = pl->k3; a.l2 = pl->l2; a.l3 = pl->l3;
     }
     a.pat = pl->d_pat;
+    a.pat_chunks = pl->d_pat_chunks;
+    a.n_chunks = ps.first_byte ? 0 : pl->n_chunks;
     a.ctr = pl->d_ctr;
     a.flags = (pl->cs ? 0 : F_CI) | (ps.ww ? F_WW : 0) | (ps.lines ? F_LINES : 0) | (ps.sink != LitPass::COUNT ? F_POS : 0);
     const bool chain = (a.flags & (F_POS | F_LINES)) != 0;

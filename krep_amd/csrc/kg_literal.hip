@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 #include "kg_common.h"
 
 namespace kg {
@@ -372,23 +373,44 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
                             // inside [p, p + m) and therefore inside the text
                             struct __attribute__((packed)) U64p { unsigned long long v; };
                             const unsigned char *tp = a.text + p;
-                            auto chunk = [&](u32 q) -> unsigned long long {
-                                unsigned long long t = reinterpret_cast<const U64p *>(tp + q)->v;
-                                if (CI)
-                                    t = (unsigned long long)fold4((u32)t) | ((unsigned long long)fold4((u32)(t >> 32)) << 32);
-                                return t ^ reinterpret_cast<const U64p *>(a.pat + q)->v;
-                            };
-                            // (measured round 2: under the 128-VGPR cap the compiler gives this rare branch two register pairs
-                            //  and waits after every chunk — one memory round trip PER CHUNK, ~0.3 us of wave time each; issuing
-                            //  eight clamped chunks per group did not change that and cost m = 17..40 six extra round trips:
-                            //  5.1 -> 4.5 TB/s.  Hence the counted loop; the real fix is DESIGN.md §8 "long patterns".)
+                            // groups of eight chunks: the eight text loads are issued back to back and waited for ONCE.  Round 1's
+                            // counted loop cost one dependent memory round trip per chunk (two register pairs under the 128-VGPR
+                            // cap of the old kernel; ~0.3 us of wave time each): 4.8 TB/s at m = 32, 4.2 at m = 64.  The
+                            // pattern side comes as aligned 8-byte words (LitArgs::pat_chunks): uniform scalar loads, no
+                            // vector registers.  A chunk index past the end repeats the last chunk (always inside the match).
                             unsigned long long diff = 0;
-                            u32 q = 8;
-#pragma unroll 4
-                            for (; q + 8 <= a.m; q += 8)
-                                diff |= chunk(q);
-                            if (q < a.m)
-                                diff |= chunk(a.m - 8);
+                            const u32 last = a.n_chunks - 1u;
+                            // constant address space: tells the compiler the words are never written while the kernel runs,
+                            // which is what lets it use s_load (SMEM) for them
+                            typedef const __attribute__((address_space(4))) unsigned long long cu64;
+                            cu64 *pc = (cu64 *)(size_t)a.pat_chunks;
+                            auto group = [&](auto width_c, u32 g0) {
+                                constexpr u32 W = decltype(width_c)::value;
+                                unsigned long long t[W];
+#pragma unroll
+                                for (u32 i = 0; i < W; ++i)
+                                {
+                                    const u32 k = g0 + i < last ? g0 + i : last;
+                                    const u32 q = 8u + 8u * k < a.m - 8u ? 8u + 8u * k : a.m - 8u;
+                                    t[i] = reinterpret_cast<const U64p *>(tp + q)->v;
+                                }
+#pragma unroll
+                                for (u32 i = 0; i < W; ++i)
+                                {
+                                    const u32 k = g0 + i < last ? g0 + i : last;
+                                    unsigned long long x = t[i];
+                                    if (CI)
+                                        x = (unsigned long long)fold4((u32)x) | ((unsigned long long)fold4((u32)(x >> 32)) << 32);
+                                    diff |= x ^ pc[k];
+                                }
+                            };
+                            if (a.n_chunks <= 2u) // m <= 24
+                                group(std::integral_constant<u32, 2>{}, 0u);
+                            else if (a.n_chunks <= 4u) // m <= 40
+                                group(std::integral_constant<u32, 4>{}, 0u);
+                            else
+                                for (u32 g0 = 0; g0 < a.n_chunks; g0 += 8u)
+                                    group(std::integral_constant<u32, 8>{}, g0);
                             ok = diff == 0;
                         }
                         if (ok && ww)

@@ -25,6 +25,8 @@ struct krep_gpu_plan
     bool has_border = false;         // a proper prefix is also a suffix => all-occurrences != greedy
     bool has_newline = false;
     uint8_t *d_pat = nullptr;
+    unsigned long long *d_pat_chunks = nullptr; // see LitArgs::pat_chunks
+    uint32_t n_chunks = 0;
     // workspace
     kg::Counters *d_ctr = nullptr, *h_ctr = nullptr;
     int num_cu = 256;
