@@ -837,9 +837,15 @@ static u32 ac_lds_bytes(u32 filter_words, bool lines)
 template <bool CI, bool LN, bool SHORT, int STRIDE>
 static hipError_t ac_launch3(const AcArgs &a, u32 grid, u32 lds, hipStream_t st)
 {
-    // more than 64 KiB of dynamic LDS has to be requested explicitly
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ac_scan_kernel<CI, LN, SHORT, STRIDE>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // more than 64 KiB of dynamic LDS has to be requested explicitly — once per instantiation (and per larger request), not
+    // on every launch: the call sits on the latency path of small host buffers
+    static int granted = 0;
+    if ((int)lds > granted)
+    {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ac_scan_kernel<CI, LN, SHORT, STRIDE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        granted = (int)lds;
+    }
     hipLaunchKernelGGL((ac_scan_kernel<CI, LN, SHORT, STRIDE>), dim3(grid), dim3(kAcBlock), lds, st, a);
     return hipGetLastError();
 }

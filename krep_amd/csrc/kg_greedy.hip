@@ -23,6 +23,7 @@
 // split at gaps >= m exactly as in (1).
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstdlib>
 #include "kg_common.h"
 #include "kg_internal.h"
 
@@ -39,10 +40,42 @@ __device__ __forceinline__ bool g_wordc(u32 c) { return (c - '0' < 10u) || ((c |
 
 __device__ __forceinline__ uint8_t g_fold(uint8_t c) { return (c >= 'A' && c <= 'Z') ? (uint8_t)(c + 32) : c; }
 
-// mode kWalkGreedy: element = occurrence, a visited element is kept and consumes m.
-// mode kWalkShortO: element = first-byte candidate (record start), classified on the fly.
+// What visiting element j means: is it kept, and where does the walk look next (`consume` bytes behind its start).
+// kWalkGreedy: element = occurrence; kept, consumes m.  kWalkShortO: element = first-byte candidate, classified against the text.
+struct Visit { bool keep; u32 consume; };
+__device__ __forceinline__ Visit g_visit(const WalkSpec &ws, u64 sj, u64 base, const uint8_t *__restrict__ text, u64 text_len)
+{
+    const u32 m = ws.m;
+    if (ws.mode == kWalkGreedy)
+        return Visit{true, m};
+    const u64 p = sj - base; // offset inside the device buffer; p + m <= text_len by construction of the list
+    uint8_t c1 = text[p + 1], c2 = m > 2 ? text[p + 2] : 0;
+    if (ws.ci)
+    {
+        c1 = g_fold(c1);
+        c2 = g_fold(c2);
+    }
+    const bool full = c1 == ws.b1 && (m < 3 || c2 == ws.b2);
+    if (!full)
+        return Visit{false, m}; // krep.c:4495: pattern_len is skipped after a failed candidate as well
+    bool ok = true;
+    if (ws.ww)
+    {
+        if (p > 0 && g_wordc(text[p - 1]))
+            ok = false;
+        else if (p + m < text_len && g_wordc(text[p + m]))
+            ok = false;
+    }
+    return Visit{ok, ok ? m : 1u}; // krep.c:4441-4446: a -w rejected match resumes one byte further
+}
+
+constexpr u64 kWalkBound = 4096; // elements one head thread walks before the pass is handed to the parallel form below
+
+// The first thread of a cluster walks it (clusters split at gaps >= m: an element that far behind its predecessor is always
+// visited).  Typical clusters hold a handful of elements; a walk that reaches kWalkBound elements (text like "aaaa...") raises
+// *too_long and the host reruns the pass with g_next / g_jump.
 __global__ __launch_bounds__(kGB) void g_walk(const u64 *__restrict__ occ, u64 n, u64 base, const uint8_t *__restrict__ text,
-                                              u64 text_len, WalkSpec ws, uint8_t *__restrict__ keep)
+                                              u64 text_len, WalkSpec ws, uint8_t *__restrict__ keep, u32 *too_long)
 {
     const u64 i = (u64)blockIdx.x * kGB + threadIdx.x;
     if (i >= n)
@@ -57,43 +90,77 @@ __global__ __launch_bounds__(kGB) void g_walk(const u64 *__restrict__ occ, u64 n
         const u64 sj = occ[2 * j];
         if (j != i && sj - prev >= m)
             break; // next cluster: its own head thread takes over
+        if (j - i >= kWalkBound)
+        {
+            *too_long = 1u;
+            return;
+        }
         prev = sj;
         if (sj < cur)
         {
             keep[j] = 0;
             continue;
         }
-        if (ws.mode == kWalkGreedy)
-        {
-            keep[j] = 1;
-            cur = sj + m;
-            continue;
-        }
-        const u64 p = sj - base; // offset inside the device buffer; p + m <= text_len by construction of the list
-        uint8_t c1 = text[p + 1], c2 = m > 2 ? text[p + 2] : 0;
-        if (ws.ci)
-        {
-            c1 = g_fold(c1);
-            c2 = g_fold(c2);
-        }
-        const bool full = c1 == ws.b1 && (m < 3 || c2 == ws.b2);
-        if (!full)
-        {
-            keep[j] = 0;
-            cur = sj + m; // krep.c:4495
-            continue;
-        }
-        bool ok = true;
-        if (ws.ww)
-        {
-            if (p > 0 && g_wordc(text[p - 1]))
-                ok = false;
-            else if (p + m < text_len && g_wordc(text[p + m]))
-                ok = false;
-        }
-        keep[j] = ok ? 1 : 0;
-        cur = ok ? sj + m : sj + 1; // krep.c:4441-4446: a -w rejected match resumes one byte further
+        const Visit v = g_visit(ws, sj, base, text, text_len);
+        keep[j] = v.keep ? 1 : 0;
+        cur = sj + v.consume;
     }
+}
+
+// ---- the same walk without a serial chain (giant clusters): pointer jumping ---------------------------------------------------
+// Visiting element i sends the walk to nxt[i] = the first element starting at or behind s_i + consume_i — a function of element
+// i alone.  The visited set is what cluster heads reach through nxt; log2(n) rounds of pointer doubling mark it:
+//   round k: every visited i marks jump[i] (its 2^k-th successor) visited; then jump[i] <- jump[jump[i]].
+__global__ __launch_bounds__(kGB) void g_next(const u64 *__restrict__ occ, u64 n, u64 base, const uint8_t *__restrict__ text,
+                                              u64 text_len, WalkSpec ws, u64 *__restrict__ jump, uint8_t *__restrict__ visited,
+                                              uint8_t *__restrict__ accept)
+{
+    const u64 i = (u64)blockIdx.x * kGB + threadIdx.x;
+    if (i >= n)
+        return;
+    const u64 s = occ[2 * i];
+    const Visit v = g_visit(ws, s, base, text, text_len);
+    accept[i] = v.keep ? 1 : 0;
+    const u64 target = s + v.consume;
+    u64 lo = i + 1, hi = n; // first j > i with start >= target (starts ascend strictly)
+    while (lo < hi)
+    {
+        const u64 mid = lo + (hi - lo) / 2;
+        if (occ[2 * mid] < target)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    jump[i] = lo; // n = end of the list
+    visited[i] = (i == 0 || s - occ[2 * (i - 1)] >= ws.m) ? 1 : 0;
+}
+__global__ __launch_bounds__(kGB) void g_jump_mark(const u64 *__restrict__ jump, u64 n, const uint8_t *__restrict__ vin,
+                                                   uint8_t *__restrict__ vout)
+{
+    const u64 i = (u64)blockIdx.x * kGB + threadIdx.x;
+    if (i < n && vin[i])
+    {
+        vout[i] = 1;
+        const u64 j = jump[i];
+        if (j < n)
+            vout[j] = 1;
+    }
+}
+__global__ __launch_bounds__(kGB) void g_jump_double(const u64 *__restrict__ jin, u64 n, u64 *__restrict__ jout)
+{
+    const u64 i = (u64)blockIdx.x * kGB + threadIdx.x;
+    if (i < n)
+    {
+        const u64 j = jin[i];
+        jout[i] = j < n ? jin[j] : n;
+    }
+}
+__global__ __launch_bounds__(kGB) void g_keep_from(const uint8_t *__restrict__ visited, const uint8_t *__restrict__ accept, u64 n,
+                                                   uint8_t *__restrict__ keep)
+{
+    const u64 i = (u64)blockIdx.x * kGB + threadIdx.x;
+    if (i < n)
+        keep[i] = visited[i] && accept[i];
 }
 
 __global__ __launch_bounds__(kGB) void g_ww(const u64 *__restrict__ occ, u64 n, u64 base, const uint8_t *__restrict__ text,
@@ -261,7 +328,41 @@ int post_walk(PostScratch &s, const uint8_t *d_text, uint64_t text_len, uint64_t
     const u32 g1 = (u32)((n_occ + kGB - 1) / kGB);
     const u32 set_len = ws.mode == kWalkShortO ? ws.m : 0u;
     GCHK(hipMemsetAsync(s.d_keep, 0, n_occ, st));
-    hipLaunchKernelGGL(g_walk, dim3(g1), dim3(kGB), 0, st, occ, (u64)n_occ, (u64)global_base, d_text, (u64)text_len, ws, s.d_keep);
+    GCHK(hipMemsetAsync(&d_ctr->pad[1], 0, sizeof(u64), st));
+    hipLaunchKernelGGL(g_walk, dim3(g1), dim3(kGB), 0, st, occ, (u64)n_occ, (u64)global_base, d_text, (u64)text_len, ws, s.d_keep,
+                       (u32 *)&d_ctr->pad[1]);
+    GCHK(hipMemcpyAsync(h_ctr, d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, st));
+    GCHK(hipStreamSynchronize(st));
+    if (h_ctr->pad[1] || getenv("KREP_GPU_FORCE_POINTER_JUMPING"))
+    {
+        // a giant cluster: redo the pass in its parallel form (pointer jumping, ceil(log2 n) rounds)
+        u64 *jmp = nullptr;
+        uint8_t *flags = nullptr; // visited A | visited B | accept
+        GCHK(hipMalloc(&jmp, 2 * n_occ * sizeof(u64)));
+        if (hipMalloc(&flags, 3 * n_occ) != hipSuccess)
+        {
+            (void)hipFree(jmp);
+            return fail("pointer-jumping scratch allocation failed");
+        }
+        u64 *ja = jmp, *jb = jmp + n_occ;
+        uint8_t *va = flags, *vb = flags + n_occ, *acc = flags + 2 * n_occ;
+        hipLaunchKernelGGL(g_next, dim3(g1), dim3(kGB), 0, st, occ, (u64)n_occ, (u64)global_base, d_text, (u64)text_len, ws, ja, va, acc);
+        for (u64 span = 1; span < n_occ; span <<= 1)
+        {
+            (void)hipMemcpyAsync(vb, va, n_occ, hipMemcpyDeviceToDevice, st);
+            hipLaunchKernelGGL(g_jump_mark, dim3(g1), dim3(kGB), 0, st, (const u64 *)ja, (u64)n_occ, (const uint8_t *)va, vb);
+            hipLaunchKernelGGL(g_jump_double, dim3(g1), dim3(kGB), 0, st, (const u64 *)ja, (u64)n_occ, jb);
+            std::swap(ja, jb);
+            std::swap(va, vb);
+        }
+        hipLaunchKernelGGL(g_keep_from, dim3(g1), dim3(kGB), 0, st, (const uint8_t *)va, (const uint8_t *)acc, (u64)n_occ, s.d_keep);
+        const hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(st);
+        (void)hipFree(jmp);
+        (void)hipFree(flags);
+        if (e1 != hipSuccess || e2 != hipSuccess)
+            return fail("pointer-jumping pass failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+    }
+    GCHK(hipMemsetAsync(d_ctr, 0, sizeof(Counters), st));
     if (ws.ww && ws.mode == kWalkGreedy) // -w AFTER the selection: a rejected hit still consumed (krep.c:4767, :1684)
         hipLaunchKernelGGL(g_ww, dim3(g1), dim3(kGB), 0, st, occ, (u64)n_occ, (u64)global_base, d_text, (u64)text_len, ws.m, s.d_keep);
     hipLaunchKernelGGL(g_count, dim3((u32)nb), dim3(kGB), 0, st, (const uint8_t *)s.d_keep, (u64)n_occ, (u64 *)s.d_gblk);

@@ -83,3 +83,40 @@ def test_giant_cluster(gpu, oracle_engine):
     for pat in (b"aa", b"aaa", b"aaaaaaa"):
         _check(gpu, oracle_engine, text, pat, dict(), abi.REF_AVX2)
         _check(gpu, oracle_engine, text, pat, dict(max_count=1000), abi.REF_AVX2)
+
+
+def test_pointer_jumping_form_of_the_walks(gpu, oracle_engine, monkeypatch):
+    """A cluster longer than 4096 elements hands the pass to its parallel form (pointer jumping over nxt[i] = first element at
+    or behind start_i + consume_i).  Forced here for ordinary inputs as well: greedy SSE4.2/KMP selection, BMH under -o and
+    memchr_short_search's -o candidate walk must come out identical."""
+    monkeypatch.setenv("KREP_GPU_FORCE_POINTER_JUMPING", "1")
+    rng = np.random.RandomState(77)
+    for n in (50, 4000, 70001):
+        for alpha in (b"ab", b"ab\n", b"aab_ "):
+            text = cases.rand_text(rng, n, alpha)
+            for pat, kw, level in ((b"aa", dict(), abi.REF_AVX2), (b"abab", dict(whole_word=True), abi.REF_AVX2),
+                                   (b"aba", dict(max_count=7), abi.REF_SSE42), (b"abab", dict(count_lines=True, whole_word=True), abi.REF_AVX2),
+                                   (b"aaaa", dict(), abi.REF_SCALAR)):
+                _check(gpu, oracle_engine, text, pat, kw, level)
+            gpu.set_only_matching(True)
+            oracle_engine.set_only_matching(True)
+            try:
+                for pat, kw, level in ((b"ab", dict(case_sensitive=False), abi.REF_AVX2), (b"aab", dict(case_sensitive=False, whole_word=True), abi.REF_AVX2),
+                                       (b"aa", dict(), abi.REF_SCALAR), (b"abab", dict(case_sensitive=False), abi.REF_AVX2)):
+                    _check(gpu, oracle_engine, text, pat, kw, level)
+            finally:
+                gpu.set_only_matching(False)
+                oracle_engine.set_only_matching(False)
+    monkeypatch.delenv("KREP_GPU_FORCE_POINTER_JUMPING")
+    # and the natural trigger: one 300 000-element cluster, all three consumption rules
+    text = np.full(300_000, ord("a"), dtype=np.uint8)
+    text[123_456] = ord("b")
+    _check(gpu, oracle_engine, text, b"aa", dict(), abi.REF_AVX2)
+    gpu.set_only_matching(True)
+    oracle_engine.set_only_matching(True)
+    try:
+        _check(gpu, oracle_engine, text, b"ab", dict(case_sensitive=False), abi.REF_AVX2)   # every candidate fails: m skipped
+        _check(gpu, oracle_engine, text, b"aa", dict(case_sensitive=False, whole_word=True), abi.REF_AVX2)
+    finally:
+        gpu.set_only_matching(False)
+        oracle_engine.set_only_matching(False)

@@ -10,11 +10,17 @@ from krep_amd.engine import Engine
 import bench
 
 gib, kind, mode = float(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
-libs = sys.argv[4:]
+libs = sys.argv[4:]  # "<variant.so>" or "<variant.so>:ENV=VAL[,ENV=VAL]" (environment set around that variant's scans)
 n = int(gib * (1 << 30))
-engs = [(os.path.basename(p), Engine(p if os.path.isabs(p) else os.path.join(ROOT, "krep_amd", "lib", "variants", p))) for p in libs]
+def _eng(spec):
+    path, _, envs = spec.partition(":")
+    env = dict(kv.split("=", 1) for kv in envs.split(",") if kv)
+    return (spec, Engine(path if os.path.isabs(path) else os.path.join(ROOT, "krep_amd", "lib", "variants", path)), env)
+engs = [_eng(p) for p in libs]
 wl = bench.workload({2: "literal8", 3: "memchr1", 4: "ac1000"}[kind])
 buf = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+envs = {name: env for name, _, env in engs}
+engs = [(name, e) for name, e, _ in engs]
 engs[0][1].generate(buf.data_ptr(), n, 0, wl["kind"], 42, wl["plant"], wl["period"])
 kw = dict(count_lines=True, only_match=True) if mode == "count" else dict(count_lines=True) if mode == "lines" else {}
 cap = (n // 50 if kind == 3 else n // 1500) + 4096 if mode == "pos" else 0
@@ -23,9 +29,12 @@ plans = [(name, e.plan(abi.Params(wl["patterns"], **kw))) for name, e in engs]
 times = {name: [] for name, _ in plans}
 for rep in range(int(os.environ.get("AB_REPS", "9"))):
     for name, pl in plans:
+        os.environ.update(envs[name])
         out = pl.scan(buf.data_ptr(), n, 0, n, 0, pos.data_ptr() if cap else 0, cap, time_it=True)
+        for k in envs[name]:
+            os.environ.pop(k, None)
         if rep:
             times[name].append(out.kernel_ms)
 for name, _ in plans:
     t = times[name]
-    print(f"{name:16s} {mode:5s} kind={kind} median {statistics.median(t):7.3f} ms  min {min(t):7.3f}  {n / statistics.median(t) / 1e6:7.1f} GB/s   count={out.count}")
+    print(f"{name:40s} {mode:5s} kind={kind} median {statistics.median(t):7.3f} ms  min {min(t):7.3f}  {n / statistics.median(t) / 1e6:7.1f} GB/s   count={out.count}")
