@@ -839,12 +839,15 @@ static hipError_t ac_launch3(const AcArgs &a, u32 grid, u32 lds, hipStream_t st)
 {
     // more than 64 KiB of dynamic LDS has to be requested explicitly — once per instantiation (and per larger request), not
     // on every launch: the call sits on the latency path of small host buffers
-    static int granted = 0;
-    if ((int)lds > granted)
+    static int granted[64] = {0}; // per device (the attribute belongs to the function ON a device)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev &= 63;
+    if ((int)lds > granted[dev])
     {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ac_scan_kernel<CI, LN, SHORT, STRIDE>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        granted = (int)lds;
+        granted[dev] = (int)lds;
     }
     hipLaunchKernelGGL((ac_scan_kernel<CI, LN, SHORT, STRIDE>), dim3(grid), dim3(kAcBlock), lds, st, a);
     return hipGetLastError();
