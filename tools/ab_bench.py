@@ -22,6 +22,8 @@ buf = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
 envs = {name: env for name, _, env in engs}
 engs = [(name, e) for name, e, _ in engs]
 engs[0][1].generate(buf.data_ptr(), n, 0, wl["kind"], 42, wl["plant"], wl["period"])
+if os.environ.get("AB_PATTERN"):
+    wl["patterns"] = [os.environ["AB_PATTERN"].encode()]
 kw = dict(count_lines=True, only_match=True) if mode == "count" else dict(count_lines=True) if mode == "lines" else {}
 cap = (n // 50 if kind == 3 else n // 1500) + 4096 if mode == "pos" else 0
 pos = torch.empty(2 * cap, dtype=torch.int64, device="cuda") if cap else None
