@@ -17,6 +17,7 @@ def _eng(spec):
     env = dict(kv.split("=", 1) for kv in envs.split(",") if kv)
     return (spec, Engine(path if os.path.isabs(path) else os.path.join(ROOT, "krep_amd", "lib", "variants", path)), env)
 engs = [_eng(p) for p in libs]
+engs = [(f"{name}#{i}", e, env) for i, (name, e, env) in enumerate(engs)]
 wl = bench.workload({2: "literal8", 3: "memchr1", 4: "ac1000"}[kind])
 buf = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
 envs = {name: env for name, _, env in engs}
