@@ -54,6 +54,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
     const u32 fw = (a.filter_words + 3u) & ~3u;
     constexpr u32 kPerWave = kAcBitmapWords + (LINES ? 2u * kAcBitmapWords : 0u); // candidate | hit | newline bitmaps
     constexpr u32 XB = LINES ? kXBitsLines : kXBitsBig; // index bits of the exact-class table
+    constexpr bool PAIR = STRIDE == 2 && !LINES;        // pair-layout table, odd positions tested (see cell_body)
     // candidate bitmap of the unit: one bit per end position, written as the lane's 16-bit filter result per cell —
     // entry (r * 8 + j) * 64 + lane, so that index order is position order
     u32 *cbits = s_mem + fw + wave * kPerWave;
@@ -107,8 +108,24 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
         const u64 seg = useg + (u64)r * kSegBytes;
         const bool fast_now = seg + kSegBytes <= a.text_len;
         const bool interior = seg >= a.end_lo && seg + kSegBytes <= a.end_hi;
-        u32 before = 0; // the 4 bytes in front of the round
         const uint4 *src = reinterpret_cast<const uint4 *>(a.text + seg) + lane;
+        // `before` (the 4 bytes in front of the round) is settled BEFORE the round's loads are issued and kept SCALAR: as a
+        // vector register filled on a cold path it made the compiler wait vmcnt(0) where the paths join — at the start of
+        // EVERY round, draining the rolling prefetch the filter never needed to wait for
+        u32 before = 0;
+        if (have)
+            before = carry;
+        else
+        {
+            u32 bb = 0;
+            if (seg >= 4 && seg <= a.text_len)
+                bb = *reinterpret_cast<const u32 *>(a.text + seg - 4);
+            else
+                for (u32 b = 0; b < 4; ++b)
+                    if (seg + b >= 4 && seg + b - 4 < a.text_len)
+                        bb |= (u32)a.text[seg + b - 4] << (8 * b);
+            before = __builtin_amdgcn_readfirstlane(bb);
+        }
         if (fast_now && !have)
         {
 #pragma unroll
@@ -123,14 +140,6 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
         // always issued in the fast path (a uniform address select, not a branch: the s_waitcnt counts stay static);
         // without a next round every lane re-reads the first bytes of this one (one cached line per load, dropped)
         const uint4 *nsrc = pf_next ? src + kSegBytes / 16 : reinterpret_cast<const uint4 *>(a.text + seg);
-        if (have)
-            before = carry;
-        else if (seg >= 4 && seg <= a.text_len)
-            before = *reinterpret_cast<const u32 *>(a.text + seg - 4);
-        else
-            for (u32 b = 0; b < 4; ++b)
-                if (seg + b >= 4 && seg + b - 4 < a.text_len)
-                    before |= (u32)a.text[seg + b - 4] << (8 * b);
         // W[0] = the 4 bytes before the lane, W[1..4] = the lane's 16 bytes of cell j
         // have_c: the caller already holds the classes of W[0] and W[4] (fast path: it shuffles the 20-bit class word
         // of the neighbour lane instead of its raw bytes, which saves one compress per cell)
@@ -144,6 +153,39 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                     NL |= ac_movemask4(ac_eq_bytes(W[w + 1], 0x0a0a0a0au)) << (4 * w);
             }
             u32 cand = 0;
+            if constexpr (PAIR)
+            {
+                // ---- filter, pair layout (stride 2 without -c): the ODD positions are tested, so the gram of position k is two
+                //      16-bit-aligned byte pairs.  A dword becomes two 10-bit pair classes in its halves (3 VALU); the gram of
+                //      k = 3 (mod 4) is that register as it is, the gram of k = 1 (mod 4) one v_alignbit over two of them.  The
+                //      table slot is chosen for this register (ac_pair_slot): bit = the earliest class (the shifter reads the low
+                //      5 bits itself), byte address = ((u >> 3) ^ (u >> 13)) & 0x1fffc — two shifts and one v_bitop3, and the
+                //      LDS bank is the XOR of two classes (one class alone sends the 16 % blanks of a text to ONE bank: 10.6
+                //      instead of 7.2 cycles per 64-lane read).  Per tested position: 0.5 + 3 + 2 VALU and 1.5 for the
+                //      classes — 58 per 1-KiB cell where the 100-bit class stream took ~95 ----
+                u32 t[5];
+#pragma unroll
+                for (int w = 1; w < 4; ++w)
+                    t[w] = ac_pair(W[w]);
+                t[0] = have_c ? pc0 : ac_pair(W[0]);
+                t[4] = have_c ? pc4 : ac_pair(W[4]);
+                u32 xs[8], dws[8];
+                typedef __attribute__((address_space(3))) const u32 lds_u32;
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                {
+                    const int w = q / 2 + 1;
+                    xs[q] = (q & 1) ? t[w] : __builtin_amdgcn_alignbit(t[w], t[w - 1], 16u);
+                    dws[q] = *(lds_u32 *)(size_t)(((xs[q] >> 3) ^ (xs[q] >> 13)) & 0x1fffcu);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                u32 acc = 0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    acc = __builtin_amdgcn_alignbit(dws[q] >> (xs[q] & 31u), acc, 2u);
+                cand = (acc >> 16) & 0x5555u; // bit 2q <-> tested position 2q + 1 (the verify stage adds the 1)
+            }
+            else
             {
                 // ---- filter, exact-class table: the lane's 20 bytes as a 100-bit stream of 5-bit classes; the
                 //      index of end position k is the 20-bit window at bit 5(k+1): one v_alignbit, no hash ----
@@ -195,20 +237,60 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                     return khi > klo ? (((1u << khi) - 1u) & ~((1u << klo) - 1u)) : 0u;
                 };
                 const u32 endm = clip(a.end_lo, a.end_hi);
-                cand &= STRIDE == 2 ? (endm | (endm >> 1)) : endm; // stride 2: t or t + 1 is an end of this launch
+                if (!PAIR) // (pair layout: a bit stands for the ends k + 1 and k + 2, the second possibly in the next lane; the
+                           //  verify stage applies the exact window)
+                    cand &= STRIDE == 2 ? (endm | (endm >> 1)) : endm; // stride 2: t or t + 1 is an end of this launch
                 if (LINES)
                     nlm &= clip(a.own_lo, a.own_hi);
             }
             if (LINES) // kept in LDS, not in 16 registers, across the verify stage
                 nlmap[(u32)r * (kSegBytes / 16) + (u32)j * kWave + lane] = (unsigned short)nlm;
-            if (a.flags & (1u << 31)) // ablation hook (KREP_GPU_AC_NOVERIFY): filter cost only
-                cand = 0;
 
             // ---- the lane's candidates go into the unit's bitmap; they are enumerated once per unit (below) instead
             //      of ranked per cell (ballots + a divergent store loop: ~15 VALU per cell), and nothing overflows ----
             cbits16[(u32)r * (kSegBytes / 16) + (u32)j * kWave + lane] = (unsigned short)cand;
         };
-        if (fast_now)
+        if (PAIR && fast_now)
+        {
+            // Pair layout, software-pipelined over the cells of the round: the table reads of cell j + 1 are issued before the
+            // results of cell j are consumed, so a wave waits for LDS once per round instead of once per cell (the LDS pipe
+            // is ~50 % busy with 4 waves per SIMD: the exposed read latency, not its throughput, was the limit).
+            u32 xs[2][8], dw[2][8];
+            typedef __attribute__((address_space(3))) const u32 lds_u32;
+            auto issue = [&](const int j, u32 (&x)[8], u32 (&v)[8]) __attribute__((always_inline)) {
+                u32 t[5];
+                t[1] = ac_pair(d[j].x); t[2] = ac_pair(d[j].y); t[3] = ac_pair(d[j].z); t[4] = ac_pair(d[j].w);
+                const u32 last = d[j].w;
+                d[j] = nsrc[j * kWave];
+                t[0] = (u32)__builtin_amdgcn_update_dpp((int)ac_pair(before), (int)t[4], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+                before = __builtin_amdgcn_readlane(last, 63);
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                {
+                    const int w = q / 2 + 1;
+                    x[q] = (q & 1) ? t[w] : __builtin_amdgcn_alignbit(t[w], t[w - 1], 16u);
+                    v[q] = *(lds_u32 *)(size_t)(((x[q] >> 3) ^ (x[q] >> 13)) & 0x1fffcu);
+                }
+            };
+            auto finish = [&](const int j, const u32 (&x)[8], const u32 (&v)[8]) __attribute__((always_inline)) {
+                u32 acc = 0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    acc = __builtin_amdgcn_alignbit(v[q] >> (x[q] & 31u), acc, 2u);
+                cbits16[(u32)r * (kSegBytes / 16) + (u32)j * kWave + lane] = (unsigned short)((acc >> 16) & 0x5555u);
+            };
+            issue(0, xs[0], dw[0]);
+#pragma unroll
+            for (int j = 0; j < kCells; ++j)
+            {
+                if (j + 1 < kCells)
+                    issue(j + 1, xs[(j + 1) & 1], dw[(j + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                finish(j, xs[j & 1], dw[j & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        else if (fast_now)
         { // straight-line: no branch between a prefetch and the next cell's read of d[]
 #pragma unroll
             for (int j = 0; j < kCells; ++j)
@@ -217,9 +299,11 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 W[1] = d[j].x; W[2] = d[j].y; W[3] = d[j].z; W[4] = d[j].w;
                 d[j] = nsrc[j * kWave];
                 {
-                    const u32 c4 = ac_cls4(W[4]);
-                    const u32 up = __shfl_up(c4, 1);
-                    const u32 c0 = (lane == 0u) ? ac_cls4(before) : up; // `before` is uniform: scalar ALU
+                    // the class word of the 4 bytes in front of the lane = the left neighbour's last one: a DPP wave shift
+                    // (lane 0 keeps `old` = the classes of `before`, uniform: scalar ALU) — no LDS permute, no branch
+                    const u32 c4 = PAIR ? ac_pair(W[4]) : ac_cls4(W[4]);
+                    const u32 cb = PAIR ? ac_pair(before) : ac_cls4(before);
+                    const u32 c0 = (u32)__builtin_amdgcn_update_dpp((int)cb, (int)c4, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
                     W[0] = 0;
                     before = __builtin_amdgcn_readlane(W[4], 63); // the next cell's (and round's) left neighbour
                     cell_body(j, W, true, c0, c4);
@@ -276,7 +360,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 if (lane >= (u32)o)
                     incl += t;
             }
-            const u32 n = __shfl(incl, 63);
+            const u32 n = (a.flags & (1u << 31)) ? 0u : __shfl(incl, 63); // (ablation hook KREP_GPU_AC_NOVERIFY: filter cost only)
             constexpr bool pair = STRIDE == 2; // a candidate stands for the ends t and t + 1
             for (u32 b0 = 0; b0 < n; b0 += 64)
             {
@@ -313,7 +397,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                         rel = own * 256u + w * 32u + (u32)__builtin_ctz(word);
                     }
                 }
-                const u64 pos = useg + rel;
+                const u64 pos = useg + rel + (PAIR ? 1u : 0u); // pair layout: bit j of the bitmap is tested position j + 1
                 bool liveA = live, liveB = false;
                 if (STRIDE == 2)
                     liveA = live && pos >= a.end_lo && pos < a.end_hi;
@@ -719,7 +803,8 @@ AcTables *ac_build(const search_params_t &sp, int device)
         // ---- filter: exact-class table over the last 4 bytes; a pattern shorter than 4 sets every class of the
         //      bytes in front of it (32 / 1024 / 32768 entries) ----
         std::vector<u32> X20((1u << kXBitsBig) / 32, 0), X19((1u << kXBitsLines) / 32, 0), S20, S19;
-        auto expand = [&](std::vector<u32> &T20, std::vector<u32> *T19, const uint8_t *last, size_t known) {
+        // pair == true: the slot layout of the stride-2 kernel without -c (ac_pair_slot)
+        auto expand = [&](std::vector<u32> &T20, std::vector<u32> *T19, const uint8_t *last, size_t known, bool pair) {
             // the `known` (<= 4) classes next to the tested position are fixed (last[0..known), text order), the rest free
             u32 fixed = 0;
             for (size_t q = 0; q < known; ++q)
@@ -728,7 +813,14 @@ AcTables *ac_build(const search_params_t &sp, int device)
             for (u32 f = 0; f < nfree; ++f)
             {
                 const u32 x = fixed | f;
-                T20[x >> 5] |= 1u << (x & 31);
+                if (pair)
+                {
+                    u32 dw, bit;
+                    ac_pair_slot(x, dw, bit);
+                    T20[dw] |= 1u << bit;
+                }
+                else
+                    T20[x >> 5] |= 1u << (x & 31);
                 if (T19)
                 {
                     const u32 y = x & ((1u << kXBitsLines) - 1u);
@@ -739,7 +831,7 @@ AcTables *ac_build(const search_params_t &sp, int device)
         for (auto &p : pats)
         {
             const size_t n = p.size(), known = std::min<size_t>(n, 4);
-            expand(X20, &X19, p.data() + (n - known), known);
+            expand(X20, &X19, p.data() + (n - known), known, false);
         }
         ACHK(hipMalloc(&t->d_filterx20, X20.size() * sizeof(u32)));
         ACHK(hipMemcpy(t->d_filterx20, X20.data(), X20.size() * sizeof(u32), hipMemcpyHostToDevice));
@@ -749,12 +841,13 @@ AcTables *ac_build(const search_params_t &sp, int device)
         // one later: its last byte is not part of the tested gram, one class fewer is known)
         if (!t->has1)
         {
-            S20 = X20;
+            S20.assign(X20.size(), 0);
             S19 = X19;
             for (auto &p : pats)
             {
-                const size_t n = p.size(), known = std::min<size_t>(n - 1, 4);
-                expand(S20, &S19, p.data() + (n - 1 - known), known);
+                const size_t n = p.size(), k4 = std::min<size_t>(n, 4), known = std::min<size_t>(n - 1, 4);
+                expand(S20, nullptr, p.data() + (n - k4), k4, true);             // the match ends at the tested position
+                expand(S20, &S19, p.data() + (n - 1 - known), known, true);      // ... one byte behind it
             }
             u64 e1 = 0, e2 = 0;
             for (size_t w = 0; w < X20.size(); ++w)

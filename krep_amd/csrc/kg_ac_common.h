@@ -474,4 +474,20 @@ __host__ __device__ __forceinline__ u32 ac_cls4(u32 w)
     return ((t & 0x3ffu) | ((t >> 6) & ~0x3ffu)) & 0xfffffu;       // ... shifted out or masked here
 }
 
+
+// Pair layout of the stride-2 filter (kernel without -c): the ODD text positions are tested, so the suffix 4-gram of a
+// tested position is two 16-bit-aligned byte pairs of the lane's dwords.
+// ac_pair: dword -> {c(b0) | c(b1) << 5} in the low half, {c(b2) | c(b3) << 5} in the high half (bits 10-15 of each half 0).
+__host__ __device__ __forceinline__ u32 ac_pair(u32 w) { return (w & 0x001f001fu) | ((w >> 3) & 0x03e003e0u); }
+// Table slot of the gram with classes x = c0 | c1 << 5 | c2 << 10 | c3 << 15 (c3 = the tested position): chosen so that the
+// kernel gets it from the pair register u = {c0, c1 | c2, c3} with three VALU — bit = c0 = u & 31 (taken by the shifter),
+// byte address = ((u >> 3) ^ (u >> 13)) & 0x1fffc, i.e. dword = (c1 ^ (c2 & 15) << 1) | (c2 >> 4) << 5 | c3 << 6 | (c2 & 15) << 11:
+// a bijection of (c1, c2, c3) whose low five bits (the LDS bank) mix two classes.
+__host__ __device__ __forceinline__ void ac_pair_slot(u32 x, u32 &dword, u32 &bit)
+{
+    const u32 c1 = (x >> 5) & 31u, c2 = (x >> 10) & 31u, c3 = (x >> 15) & 31u;
+    bit = x & 31u;
+    dword = (c1 ^ ((c2 & 15u) << 1)) | ((c2 >> 4) << 5) | (c3 << 6) | ((c2 & 15u) << 11);
+}
+
 } // namespace kg
