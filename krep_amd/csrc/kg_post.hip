@@ -11,6 +11,8 @@
 //   K4 post_gather : coalesced copy staging slot -> match_position_t[offset ..]
 // All of it touches only O(units + matches) bytes — ~1 % of the scan for BASELINE config 2.
 #include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include "kg_common.h"
 #include "kg_internal.h"
@@ -322,6 +324,9 @@ int post_reserve(PostScratch &s, uint64_t n_units, uint64_t stage_words)
         PCHK(hipMalloc(&s.d_stage, stage_words * sizeof(u64)));
         s.stage_cap_words = stage_words;
     }
+    if (getenv("KREP_GPU_DEBUG_ALLOC")) // tools/placement_probe.py
+        fprintf(stderr, "[krep_gpu] scratch: unitinfo %p offsets %p blk %p stage %p (%llu units, %llu stage words)\n", (void *)s.d_unitinfo,
+                (void *)s.d_offsets, (void *)s.d_blk, (void *)s.d_stage, (unsigned long long)s.units_cap, (unsigned long long)s.stage_cap_words);
     return 0;
 }
 
