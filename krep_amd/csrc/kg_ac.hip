@@ -408,9 +408,10 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 bool simA = false, simB = false;
                 if (STRIDE == 2)
                 {
-                    bool slA, slB;
-                    u32 mA, mB;
-                    ac_walk_probe2<CI, SHORT>(a, pos, liveA, liveB, LINES, mA, slA, mB, slB);
+                    bool slA = false, slB = false;
+                    u32 mA = 0, mB = 0;
+                    if (!(a.flags & (1u << 30))) // (ablation hook KREP_GPU_AC_NOPROBE: candidate enumeration without the probes)
+                        ac_walk_probe2<CI, SHORT>(a, pos, liveA, liveB, LINES, mA, slA, mB, slB);
                     dmA = mA; dmB = mB;
                     cA = (u32)__popc(mA); cB = (u32)__popc(mB);
                     simA = simB = true;
@@ -1009,6 +1010,8 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
     a.flags = (t->ci ? F_CI : 0) | (ww ? F_WW : 0) | (lines ? F_LINES : 0);
     if (getenv("KREP_GPU_AC_NOVERIFY")) // measurement hook: filter cost only (wrong results by design)
         a.flags |= 1u << 31;
+    if (getenv("KREP_GPU_AC_NOPROBE")) // measurement hook: filter + candidate enumeration, no probes (wrong results by design)
+        a.flags |= 1u << 30;
     a.lmax = t->lmax;
     a.has1 = t->has1; a.has2 = t->has2; a.has3 = t->has3; a.has4 = t->has4;
     a.stride = 1;

@@ -160,7 +160,6 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
         u32 M[kInline ? 1 : R][kInline ? 1 : kCells];
         u32 wcnt = 0;     // unit total (uniform)
         LS wls{0, false, false, false};
-        bool nl_pend = false; // -c: some lane saw a newline in the hit-free interior cells since the last flush (per lane)
 
         // the rounds of a unit are a real loop for the sparse kinds (nothing is indexed by r any more): a quarter of the code
 #pragma unroll(KIND == 1 ? R : 1)
@@ -231,7 +230,6 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
                 // 16-bit mask (a multiply per dword) is computed where it is consumed: in cells that hold a hit, and in
                 // boundary cells, where it has to be clipped to the owned window
                 u32 NL = 0;
-                bool nl_any = false;
                 auto exact_nl = [&]() -> u32 {
                     u32 v = 0;
 #pragma unroll
@@ -239,22 +237,18 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
                         v |= movemask4(eq_bytes(D[w], 0x0a0a0a0au)) << (4 * w);
                     return v;
                 };
-                if (LINES)
-                {
-                    if (interior)
-                    {
-                        u32 z = 0;
+                auto has_nl = [&]() -> bool { // "does this lane hold a newline": a zero-byte test on D ^ '\n'
+                    u32 z = 0;
 #pragma unroll
-                        for (int w = 0; w < 4; ++w)
-                        {
-                            const u32 t = D[w] ^ 0x0a0a0a0au;
-                            z |= (t - 0x01010101u) & ~t;
-                        }
-                        nl_any = (z & 0x80808080u) != 0u;
+                    for (int w = 0; w < 4; ++w)
+                    {
+                        const u32 t = D[w] ^ 0x0a0a0a0au;
+                        z |= (t - 0x01010101u) & ~t;
                     }
-                    else
-                        NL = exact_nl();
-                }
+                    return (z & 0x80808080u) != 0u;
+                };
+                if (LINES && !interior)
+                    NL = exact_nl();
                 // -i: the text is NOT folded; a letter of the (folded) pattern is compared as (x | 0x20) == p, which
                 // holds exactly for its two cases (C locale) — one OR per compared dword instead of a SWAR fold of
                 // the whole window
@@ -492,22 +486,35 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
                     }
                 }
 
-                // A hit-free interior cell only matters through "was there a newline": remembered per lane and folded
-                // into the summary with ONE ballot when the next cell with a hit (or the unit's end) needs it —
-                // the per-cell ballot + scalar monoid update made -c VALU/SALU-bound (4.7 TB/s against 6.2 for -c -o).
+                // A hit-free interior cell only matters through "was there a newline", and only while that changes the running
+                // summary: a newline cell is {0, nl, -, -}, which sets nl and clears tail — idempotent.  Once the summary has
+                // nl && !tail, hit-free cells are not even looked at until the next hit (a wave-uniform test of two scalars):
+                // round 1 tested every cell and folded per-lane flags lazily (4.4-5.3 TB/s against 6.3-6.7 for -c -o).
                 if (LINES && interior && !anyhit)
-                    nl_pend = nl_pend || nl_any;
+                {
+                    if (!wls.nl || wls.tail)
+                        if (__ballot(has_nl()))
+                            wls = ls_combine(wls, LS{0, true, false, false});
+                }
                 else if (LINES)
                 {
-                    if (__ballot(nl_pend))
-                        wls = ls_combine(wls, LS{0, true, false, false});
-                    nl_pend = false;
+                    const bool nl_any = interior ? has_nl() : false;
                     // per-lane summary of its 16 bytes
                     const u32 H = m16;
                     const bool l_nl = interior ? nl_any : (nlm != 0u);
                     const u64 B_nl = __ballot(l_nl);
                     LS cell{0, B_nl != 0, false, false};
-                    if (anyhit)
+                    // the usual cell with a hit: ONE lane, one hit, no newline inside that lane's 16 bytes — then the summary is
+                    // three scalar mask tests (no exact newline mask, no further ballots)
+                    const int h1 = anyhit ? __builtin_ctzll(anyhit) : 0;
+                    const u32 hm = (u32)__builtin_amdgcn_readlane((int)H, h1);
+                    if (interior && anyhit && (anyhit & (anyhit - 1ull)) == 0ull && (hm & (hm - 1u)) == 0u && !((B_nl >> h1) & 1ull))
+                    {
+                        cell.cnt = 1;
+                        cell.head = (B_nl & ((1ull << h1) - 1ull)) == 0ull;
+                        cell.tail = h1 == 63 || (B_nl >> (h1 + 1)) == 0ull;
+                    }
+                    else if (anyhit)
                     {
                         // first hit of every newline-delimited segment: see DESIGN.md (line bookkeeping)
                         const u32 N = interior ? exact_nl() : nlm; // (folding never touches '\n')
@@ -551,8 +558,6 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
 
         }
 
-        if (LINES && __ballot(nl_pend))
-            wls = ls_combine(wls, LS{0, true, false, false});
         acc_total += wcnt;
         if (!chain)
             continue;
