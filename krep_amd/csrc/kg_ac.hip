@@ -54,7 +54,12 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
     const u32 fw = (a.filter_words + 3u) & ~3u;
     constexpr u32 kPerWave = kAcBitmapWords + (LINES ? 2u * kAcBitmapWords : 0u); // candidate | hit | newline bitmaps
     constexpr u32 XB = LINES ? kXBitsLines : kXBitsBig; // index bits of the exact-class table
-    constexpr bool PAIR = STRIDE == 2 && !LINES;        // pair-layout table, odd positions tested (see cell_body)
+    constexpr bool PAIR = STRIDE == 2;                  // pair-layout table, odd positions tested (see cell_body)
+    constexpr bool PIPE = PAIR && !LINES;               // ... with the table reads software-pipelined over the cells of a round
+    // -c owns a match by its END and records it in the unit's hit bitmap, so the end j + 2 of the unit's last candidate bit
+    // (= the first byte of the next unit) cannot be reported from here: every unit instead verifies one EXTRA candidate, the
+    // tested position in front of its first byte, for its second end only
+    constexpr bool XCAND = PAIR && LINES;
     // candidate bitmap of the unit: one bit per end position, written as the lane's 16-bit filter result per cell —
     // entry (r * 8 + j) * 64 + lane, so that index order is position order
     u32 *cbits = s_mem + fw + wave * kPerWave;
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
         // the next round of this ticket, if it is a full one, streams in behind this one
         // (not in the -c variant of the stride-2 kernel: with the prefetch registers live across the verify stage it
         //  spilled 50-69 VGPRs under the 128 cap)
-        const bool pf_next = !(LINES && STRIDE == 2) && fast_now && !emit_final && seg + 2 * (u64)kSegBytes <= a.text_len &&
+        const bool pf_next = fast_now && !emit_final && seg + 2 * (u64)kSegBytes <= a.text_len &&
                              (r + 1 < kAcRounds || unit + 1 < u_end);
         // always issued in the fast path (a uniform address select, not a branch: the s_waitcnt counts stay static);
         // without a next round every lane re-reads the first bytes of this one (one cached line per load, dropped)
@@ -148,6 +153,8 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
             u32 NL = 0;
             if (LINES)
             {
+                // (exact 16-bit mask in every cell, ~40 VALU: storing only a has-newline flag and fetching the hit lanes' bytes
+                //  in the line pass was measured — one more memory round trip per unit cost more than it saved: 10.15 -> 11.3 ms)
 #pragma unroll
                 for (int w = 0; w < 4; ++w)
                     NL |= ac_movemask4(ac_eq_bytes(W[w + 1], 0x0a0a0a0au)) << (4 * w);
@@ -176,7 +183,8 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 {
                     const int w = q / 2 + 1;
                     xs[q] = (q & 1) ? t[w] : __builtin_amdgcn_alignbit(t[w], t[w - 1], 16u);
-                    dws[q] = *(lds_u32 *)(size_t)(((xs[q] >> 3) ^ (xs[q] >> 13)) & 0x1fffcu);
+                    // (-c: a 2^19-bit table, address bit 16 = bit 3 of the class c2 dropped)
+                    dws[q] = *(lds_u32 *)(size_t)(((xs[q] >> 3) ^ (xs[q] >> 13)) & (XB == 20 ? 0x1fffcu : 0xfffcu));
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 u32 acc = 0;
@@ -250,7 +258,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
             //      of ranked per cell (ballots + a divergent store loop: ~15 VALU per cell), and nothing overflows ----
             cbits16[(u32)r * (kSegBytes / 16) + (u32)j * kWave + lane] = (unsigned short)cand;
         };
-        if (PAIR && fast_now)
+        if (PIPE && fast_now)
         {
             // Pair layout, software-pipelined over the cells of the round: the table reads of cell j + 1 are issued before the
             // results of cell j are consumed, so a wave waits for LDS once per round instead of once per cell (the LDS pipe
@@ -362,10 +370,12 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
             }
             const u32 n = (a.flags & (1u << 31)) ? 0u : __shfl(incl, 63); // (ablation hook KREP_GPU_AC_NOVERIFY: filter cost only)
             constexpr bool pair = STRIDE == 2; // a candidate stands for the ends t and t + 1
-            for (u32 b0 = 0; b0 < n; b0 += 64)
+            const u32 n_tot = n + ((XCAND && !(a.flags & (1u << 31)) && useg >= 1u) ? 1u : 0u); // rank n: the extra candidate
+            for (u32 b0 = 0; b0 < n_tot; b0 += 64)
             {
                 const u32 qi = b0 + lane;
                 const bool live = qi < n;
+                const bool isx = XCAND && qi == n && qi < n_tot;
                 u32 rel = 0;
                 {
                     // owner = first lane whose inclusive sum exceeds my rank
@@ -397,12 +407,14 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                         rel = own * 256u + w * 32u + (u32)__builtin_ctz(word);
                     }
                 }
-                const u64 pos = useg + rel + (PAIR ? 1u : 0u); // pair layout: bit j of the bitmap is tested position j + 1
+                // pair layout: bit j of the bitmap is tested position j + 1
+                const u64 pos = isx ? useg - 1u : useg + rel + (PAIR ? 1u : 0u);
                 bool liveA = live, liveB = false;
                 if (STRIDE == 2)
                     liveA = live && pos >= a.end_lo && pos < a.end_hi;
                 if (pair)
-                    liveB = live && pos + 1 >= a.end_lo && pos + 1 < a.end_hi;
+                    liveB = (live || isx) && pos + 1 >= a.end_lo && pos + 1 < a.end_hi &&
+                            (!XCAND || pos + 1 < useg + kAcUnitBytes); // (-c: that end belongs to the next unit's extra candidate)
                 u32 cA = 0, cB = 0;
                 u64 dmA = 0, dmB = 0;
                 bool simA = false, simB = false;
@@ -446,7 +458,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                     if (!ce)
                         continue;
                     const u64 pe = pos + (u64)e, dme = e ? dmB : dmA;
-                    const u32 re = rank0 + (e ? cA : 0u), rele = rel + (u32)e;
+                    const u32 re = rank0 + (e ? cA : 0u), rele = (u32)(pe - useg); // the END's bit in the unit's hit bitmap
                     const bool sime = e ? simB : simA;
                     if (LINES)
                         atomicOr(&bitmap[rele >> 5], 1u << (rele & 31u));
@@ -822,7 +834,13 @@ AcTables *ac_build(const search_params_t &sp, int device)
                 }
                 else
                     T20[x >> 5] |= 1u << (x & 31);
-                if (T19)
+                if (T19 && pair)
+                {
+                    u32 dw, bit;
+                    ac_pair_slot(x, dw, bit);
+                    (*T19)[dw & ((1u << (kXBitsLines - 5)) - 1u)] |= 1u << bit; // the kernel masks the byte address with 0xfffc
+                }
+                else if (T19)
                 {
                     const u32 y = x & ((1u << kXBitsLines) - 1u);
                     (*T19)[y >> 5] |= 1u << (y & 31);
@@ -843,11 +861,11 @@ AcTables *ac_build(const search_params_t &sp, int device)
         if (!t->has1)
         {
             S20.assign(X20.size(), 0);
-            S19 = X19;
+            S19.assign(X19.size(), 0);
             for (auto &p : pats)
             {
                 const size_t n = p.size(), k4 = std::min<size_t>(n, 4), known = std::min<size_t>(n - 1, 4);
-                expand(S20, nullptr, p.data() + (n - k4), k4, true);             // the match ends at the tested position
+                expand(S20, &S19, p.data() + (n - k4), k4, true);                // the match ends at the tested position
                 expand(S20, &S19, p.data() + (n - 1 - known), known, true);      // ... one byte behind it
             }
             u64 e1 = 0, e2 = 0;
