@@ -101,7 +101,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
         if (emit_final && (u32)(a.unitinfo[unit] & kUiCountMask) <= a.stage_cap)
             continue;
 
-        u64 *slot = reinterpret_cast<u64 *>(a.stage) + unit * (u64)a.stage_cap;
+        u32 *slot = reinterpret_cast<u32 *>(a.stage) + unit * (u64)a.stage_cap; // 32-bit staged words, see write() below
         const bool do_final = emit_final && want_pos;
         const bool do_stage = !emit_final && want_pos;
         const u64 fbase = do_final ? a.offsets[unit] : 0ull;
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                             if (do_stage)
                             {
                                 if (at < a.stage_cap)
-                                    slot[at] = ((s0 + a.global_base) << 11) | len;
+                                    slot[at] = ((u32)(s0 + 1024u - useg) << 11) | len; // start relative to the unit (>= -1023), length <= 1024
                             }
                             else
                             {
@@ -595,6 +595,7 @@ struct AcTables
     uint4 *d_g4x = nullptr; // chain-compressed entries, same slots as d_gram4
     u32 g4mask = 0;
     u32 g4x_mode = 0, g4x_mask = 0, g4x_mul = 0;
+    u32 stage_cap = 16; // staged matches per unit (16, raised to 64 by a scan whose units overflowed; see ac_scan)
 };
 
 #define ACHK(x)                                                                                \
@@ -1058,10 +1059,13 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
     a.pos_cap = want;
     const bool chain = want || lines;
     const u64 n_units = a.num_tiles;
-    a.stage_cap = want ? (g_ac_force_stage_cap ? (u32)g_ac_force_stage_cap : 64u) : 0u;
+    // 16 staged matches (32-bit words: unit-relative start + length) = one 64-byte slot per 16 KiB unit; BASELINE config 4 puts 5.3
+    // matches in a unit.  Units that hold more are re-scanned in emit mode, and a scan in which more than 1 in 64 units did
+    // raises the dictionary's slot to 64 for its next scans.  (Small slots keep the store stream dense: kg_host.hip, lit_pass.)
+    a.stage_cap = want ? (g_ac_force_stage_cap ? (u32)g_ac_force_stage_cap : t->stage_cap) : 0u;
     if (chain)
     {
-        if (post_reserve(post, n_units, n_units * a.stage_cap))
+        if (post_reserve(post, n_units, (n_units * a.stage_cap + 1) / 2))
             return 2;
         a.unitinfo = post.d_unitinfo;
         a.stage = (u64 *)post.d_stage;
@@ -1078,11 +1082,13 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
     if (time_it) SCHK(hipEventRecord(ev0, st));
     SCHK(hipMemsetAsync(d_ctr, 0, sizeof(Counters), st));
     SCHK(ac_launch(a, grid, lds, st));
-    if (chain && post_order(post, n_units, a.stage_cap, 0, 0, 0, lines, (uint64_t *)d_pos, want, d_ctr, num_cu, st))
+    if (chain && post_order(post, n_units, a.stage_cap, 0, a.anchor + global_base, unit_bytes, lines, (uint64_t *)d_pos, want, d_ctr, num_cu, st))
         return 2;
     if (time_it) SCHK(hipEventRecord(ev1, st));
     SCHK(hipMemcpyAsync(h_ctr, d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, st));
     SCHK(hipStreamSynchronize(st));
+    if (want && !g_ac_force_stage_cap && h_ctr->overflow_units * 64 > n_units)
+        t->stage_cap = 64; // a dense dictionary / text: the next scans stage 64 matches per unit
     if (want && h_ctr->overflow_units)
     {
         AcArgs e = a;

@@ -636,11 +636,17 @@ static int lit_pass(krep_gpu_plan *pl, const Window &w, const LitPass &ps, hipSt
     a.flags = (pl->cs ? 0 : F_CI) | (ps.ww ? F_WW : 0) | (ps.lines ? F_LINES : 0) | (ps.sink != LitPass::COUNT ? F_POS : 0);
     const bool chain = (a.flags & (F_POS | F_LINES)) != 0;
     const uint64_t n_units = a.num_tiles * kWavesPerBlk;
-    // staging slot per unit: sized for ~4x BASELINE's densities (1e-4/B literal, 1e-2/B single byte);
-    // denser units take the emit-mode re-scan
+    // Staging slot per unit.  Single byte: 512 offsets (1 KiB) per 32 KiB unit, ~1.5x BASELINE's 1 % density.  Sparse kinds:
+    // 16 offsets = ONE 32-byte slot per 32 KiB unit (BASELINE's 1e-4/B puts 3.3 hits in a unit); units that hold more take the
+    // emit-mode re-scan, and a scan in which more than 1 in 64 units did raises the plan's slot to 64 for its next scans.
+    // Why so small: every unit's slot is a store into a different place, and the 4096 units in flight walk through the
+    // staging array one slot each per step — with 128-byte slots through 128 pages of 4 KiB per step.  On boxes where the
+    // driver backs the scratch with small page-table fragments the offsets-producing scan ran 0.3-0.5 ms slower in every
+    // second process (store translation misses, coupled to the loads through the shared in-order vmcnt); 32-byte slots
+    // cut that to < 0.1 ms (same process, 32 GiB: 5.75/5.48/5.82/5.52 ms with 64 entries, 5.47/5.43/5.52/5.41 with 16).
     a.stage_cap = 0;
     if (a.flags & F_POS)
-        a.stage_cap = a.rounds == kRoundsBig ? (m_scan == 1 ? 512u : 64u) : (m_scan == 1 ? 256u : 32u);
+        a.stage_cap = a.rounds == kRoundsBig ? (m_scan == 1 ? 512u : pl->sparse_cap) : (m_scan == 1 ? 256u : 32u);
     const int fsc = g_force_stage_cap.load(std::memory_order_relaxed);
     if (fsc && (a.flags & F_POS))
         a.stage_cap = (uint32_t)fsc;
@@ -670,6 +676,8 @@ static int lit_pass(krep_gpu_plan *pl, const Window &w, const LitPass &ps, hipSt
         if (ps.ev_end) HIPCHK(hipEventRecord(ps.ev_end, st));
         HIPCHK(hipMemcpyAsync(pl->h_ctr, pl->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
+        if ((a.flags & F_POS) && m_scan != 1 && a.rounds == kRoundsBig && pl->h_ctr->overflow_units * 64 > n_units)
+            pl->sparse_cap = 64; // a dense input: the next scans of this plan stage 64 hits per unit
         if ((a.flags & F_POS) && pl->h_ctr->overflow_units)
         {
             // some units held more hits than their staging slot: re-scan exactly those, writing in place

@@ -35,6 +35,9 @@ struct krep_gpu_plan
     kg::AcTables *ac = nullptr;
     bool ac_has_newline = false; // some pattern of the set contains '\n' (-c then counts emission-order line changes)
     kg::PostScratch post; // ordering post-pass / sequential-family scratch of the main pass
+    uint32_t sparse_cap = 16; // staging entries per 32 KiB unit of the sparse literal kinds: 16, raised to 64 after a scan whose
+                              // units overflowed (see lit_pass); one 32-byte slot per unit keeps the store stream dense
+    uint32_t ac_cap = 16;     // the same for the multi-pattern scan (16 KiB units)
     kg::PostScratch aux;  // small auxiliary passes that must not disturb `post` (end-of-text replay)
     search_params_t sp{}; // shallow copy with patterns pointing into `pats`
     std::vector<const char *> pat_ptrs;

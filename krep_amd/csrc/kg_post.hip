@@ -220,7 +220,8 @@ __global__ __launch_bounds__(kPostBlock) void post_offsets(const u64 *__restrict
 
 // Staging -> final records.  fixed_len > 0 (single literal): the slot holds 16-bit offsets relative to the unit's
 // first byte, records are {unit_origin + rel, + fixed_len}; fixed_len == 0 (Aho-Corasick): the staged 64-bit word
-// is (start << 11 | len), len <= 1024.
+// (unit-relative start + 1024) << 11 | len, len <= 1024 (the start of a match that ends in the unit lies at most 1023 bytes
+// in front of it).
 __global__ __launch_bounds__(kPostBlock) void post_gather(const u64 *__restrict__ info, u64 n_units,
                                                           const u64 *__restrict__ offsets, const u64 *__restrict__ stage,
                                                           u32 stage_cap, u32 fixed_len, u64 origin, u64 unit_bytes,
@@ -230,17 +231,20 @@ __global__ __launch_bounds__(kPostBlock) void post_gather(const u64 *__restrict_
     const u32 lane = plane_id();
     const u64 n_waves = (u64)gridDim.x * (kPostBlock / 64);
     const u64 wid = (u64)blockIdx.x * (kPostBlock / 64) + (threadIdx.x >> 6);
-    auto put = [&](u64 idx, u64 word) {
+    const u32 *stage32 = reinterpret_cast<const u32 *>(stage);
+    // record i of the unit whose first byte is `org` and whose staging slot starts at entry `sbase`
+    auto put = [&](u64 idx, u64 org, u64 sbase, u32 i) {
         u64 s, e;
         if (fixed_len)
         {
-            s = word; // already absolute: unit origin + 16-bit offset
-            e = word + fixed_len;
+            s = org + stage16[sbase + i];
+            e = s + fixed_len;
         }
         else
         {
-            s = word >> 11;
-            e = s + (word & 2047ull);
+            const u32 w = stage32[sbase + i];
+            s = org + (u64)(w >> 11) - 1024ull;
+            e = s + (w & 2047u);
         }
         *reinterpret_cast<uint4 *>(positions + 2 * idx) = make_uint4((u32)s, (u32)(s >> 32), (u32)e, (u32)(e >> 32));
     };
@@ -262,7 +266,7 @@ __global__ __launch_bounds__(kPostBlock) void post_gather(const u64 *__restrict_
             const u64 sbase = u * (u64)stage_cap, org = origin + u * unit_bytes;
             for (u32 i = 0; i < cnt; ++i)
                 if (off + i < pos_cap)
-                    put(off + i, fixed_len ? org + stage16[sbase + i] : stage[sbase + i]);
+                    put(off + i, org, sbase, i);
             cnt = 0;
         }
         // many records: the whole wave copies one unit at a time (coalesced)
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(kPostBlock) void post_gather(const u64 *__restrict_
             const u64 sbase = (g + (u64)l) * (u64)stage_cap, org = origin + (g + (u64)l) * unit_bytes;
             for (u32 i = lane; i < c; i += 64)
                 if (o + i < pos_cap)
-                    put(o + i, fixed_len ? org + stage16[sbase + i] : stage[sbase + i]);
+                    put(o + i, org, sbase, i);
         }
     }
 }
