@@ -289,3 +289,40 @@ def test_thousand_patterns_32gib_full_size(gpu):
         idx = torch.sort(order[i0:i1]).values  # back to emission order
         got = rec[idx].cpu().numpy()
         assert np.array_equal(got, want), (wlo, len(got), len(want))
+
+
+def test_dense_literal_1gib_overflowing_slots(gpu):
+    """A text with ~47 hits per 32 KiB unit: every unit overflows the 16-entry staging slot (emit-mode re-scan), and the
+    plan moves to 64-entry slots for its second scan — both lists must be the planted one."""
+    import torch
+    n, period = GIB, 700
+    buf = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+    gpu.generate(buf.data_ptr(), n, 0, 2, SEED, PAT, period)
+    plan = gpu.plan(abi.Params([PAT]))
+    cnt = gpu.plan(abi.Params([PAT], count_lines=True, only_match=True)).scan(buf.data_ptr(), n)
+    cap = cnt.count + 4096
+    pos = torch.empty(2 * cap, dtype=torch.int64, device="cuda")
+    first = None
+    for rep in range(3):
+        pos.zero_()
+        out = plan.scan(buf.data_ptr(), n, 0, n, 0, pos.data_ptr(), cap)
+        assert out.count == out.stored == cnt.count and not out.overflow
+        assert out.count > n // period - 8  # (the generator drops the plants next to a GiB boundary)
+        rec = pos[: 2 * out.stored].view(-1, 2)
+        starts = rec[:, 0]
+        assert bool(torch.all(starts[1:] > starts[:-1]))
+        assert bool(torch.all(rec[:, 1] - rec[:, 0] == len(PAT)))
+        idx = starts[:, None] + torch.arange(len(PAT), device="cuda")[None, :]
+        assert bool(torch.all(buf[idx] == torch.tensor(list(PAT), dtype=torch.uint8, device="cuda")[None, :]))
+        if first is None:
+            first = starts.clone()
+        else:
+            assert torch.equal(first, starts)
+    # oracle on a window
+    o = ol.oracle()
+    win = buf[3 << 20: 5 << 20].cpu().numpy()
+    _, wpos = o.call(abi.RA_BMH, abi.Params([PAT]), win)
+    lo, hi = 3 << 20, 5 << 20
+    inside = first[(first >= lo) & (first + len(PAT) <= hi)].cpu().numpy()
+    assert np.array_equal(wpos[:, 0].astype(np.int64) + lo, inside)
+    plan.close()
