@@ -140,6 +140,33 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
     const u64 hi_match = (a.own_hi < a.text_len - a.m + 1) ? a.own_hi : (a.text_len - a.m + 1); // exclusive start bound
     constexpr u64 kUnitBytes = (u64)R * kSegBytes;
 
+    // Sparse kinds with 16-entry slots: NOTHING is stored while the wave streams.  Info words and staged offsets of up to
+    // kPark units are parked in LDS (2 + 8 KiB per wave: the four blocks of a CU use all 160 KiB) and written out in one burst
+    // of ~12 store instructions; at 32 GiB a wave scans 256 units, i.e. it stores once, at its end.
+    constexpr u32 kPark = (KIND == 4 || KIND == 8) ? 256u : 1u;
+    __shared__ u64 s_info[kWavesPerBlk][kPark];
+    __shared__ __attribute__((aligned(16))) unsigned short s_slots[kWavesPerBlk][kPark][16];
+    // (only the plain offsets-producing scan with its regular 16-entry slots: -c measured 1 % slower parked, 64-entry slots
+    //  would not fit, emit mode writes final records; m > 8 measured 3 % slower parked)
+    const bool park = (KIND == 4 || KIND == 8) && !LINES && want_pos && !a.emit_mode && a.stage_cap == 16u;
+    u32 n_park = 0;     // parked units (uniform)
+    u64 park_first = 0; // the first of them; the others follow at the wave's unit stride
+    const u64 unit_stride = (u64)gridDim.x * kWavesPerBlk;
+    auto flush_parked = [&]() __attribute__((always_inline)) {
+        for (u32 i = lane; i < n_park; i += 64u)
+        {
+            const u64 u = park_first + (u64)i * unit_stride;
+            a.unitinfo[u] = s_info[wave][i];
+            if (want_pos && (s_info[wave][i] & kUiCountMask))
+            {
+                uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<unsigned short *>(a.stage) + u * (u64)a.stage_cap);
+                const uint4 *src = reinterpret_cast<const uint4 *>(&s_slots[wave][i][0]);
+                dst[0] = src[0];
+                dst[1] = src[1];
+            }
+        }
+        n_park = 0;
+    };
     u64 acc_total = 0; // wave-uniform accumulator
     // Units are dealt out STATICALLY: wave w of block b scans units (i * gridDim.x + b) * 4 + w — the four waves of a block
     // read 4 x R x 8 KiB contiguous bytes per step, every wave runs on its own (no ticket, no barrier).  Round 1 drew one
@@ -455,7 +482,8 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
                         u32 rest = m16;
                         if (!a.emit_mode)
                         {
-                            unsigned short *slot = reinterpret_cast<unsigned short *>(a.stage) + unit * (u64)a.stage_cap;
+                            unsigned short *slot = park ? &s_slots[wave][n_park][0]
+                                                        : reinterpret_cast<unsigned short *>(a.stage) + unit * (u64)a.stage_cap;
                             const u32 rel0 = (u32)(r * kCells + j) * kCellBytes + lane * 16u;
                             while (rest)
                             {
@@ -572,12 +600,22 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
                     info |= ls_bits(wls) | ((u64)(wls.cnt & kUiLineMask) << kUiLineShift);
                 else if (wcnt)
                     info |= kLnHead | kLnTail;
-                a.unitinfo[unit] = info;
+                if (park)
+                    s_info[wave][n_park] = info;
+                else
+                    a.unitinfo[unit] = info;
                 if (want_pos && wcnt > a.stage_cap)
                 {
                     atomicAdd(&a.ctr->overflow_units, 1ull);
                     atomicMax(&a.ctr->max_unit_count, (u64)wcnt);
                 }
+            }
+            if (park)
+            {
+                if (n_park == 0)
+                    park_first = unit;
+                if (++n_park == kPark)
+                    flush_parked();
             }
             if (!kInline && want_pos && wcnt)
             {
@@ -661,6 +699,8 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
         }
     }
 
+    if (park && n_park)
+        flush_parked();
     if (lane == 0 && acc_total && !a.emit_mode)
         atomicAdd(&a.ctr->total, acc_total);
 }
