@@ -260,8 +260,9 @@ __global__ __launch_bounds__(kPostBlock) void post_gather(const u64 *__restrict_
             if (cnt > stage_cap || off >= pos_cap)
                 cnt = 0; // overflowed units are written by the scan kernel's emit mode
         }
-        // few records: the owning lane copies them itself
-        if (cnt && cnt <= 4)
+        // few records: the owning lane copies them itself (multi-pattern: up to a whole 16-entry slot — the per-unit loop below
+        // is a serial chain of ~35 wave steps per 64 units at 5.3 matches per unit: 0.235 ms for 11.2 M records)
+        if (cnt && cnt <= (fixed_len ? 4u : 16u))
         {
             const u64 sbase = u * (u64)stage_cap, org = origin + u * unit_bytes;
             for (u32 i = 0; i < cnt; ++i)
