@@ -64,6 +64,14 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
     // entry (r * 8 + j) * 64 + lane, so that index order is position order
     u32 *cbits = s_mem + fw + wave * kPerWave;
     unsigned short *cbits16 = reinterpret_cast<unsigned short *>(cbits);
+    // PIPE: the pair filter only ever sets the even bits of a lane's 16-bit result, so it stores EIGHT bits per lane and cell
+    // (bit q <-> tested position 2q + 1): the bitmap is 1 KiB, lane L owns 4 dwords, and the other KiB of the wave's bitmap
+    // area parks the info words and staging slots of a ticket's units until the ticket's end (store
+    // placement: the waves store nothing while they stream)
+    constexpr u32 kWPL = PIPE ? 4u : 8u; // bitmap dwords per enumerating lane (256 positions)
+    uint8_t *cbits8 = reinterpret_cast<uint8_t *>(cbits);
+    u32 *park_slots = cbits + 256;       // [kAcUnitsPerTicketMax][16] staged words
+    u64 *park_info = reinterpret_cast<u64 *>(cbits + 256 + kAcUnitsPerTicketMax * 16); // [kAcUnitsPerTicketMax]
     u32 *bitmap = cbits + kAcBitmapWords;
     unsigned short *nlmap = reinterpret_cast<unsigned short *>(bitmap + kAcBitmapWords); // 16 bits per lane and cell
     if (LINES)
@@ -101,7 +109,9 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
         if (emit_final && (u32)(a.unitinfo[unit] & kUiCountMask) <= a.stage_cap)
             continue;
 
-        u32 *slot = reinterpret_cast<u32 *>(a.stage) + unit * (u64)a.stage_cap; // 32-bit staged words, see write() below
+        const bool parked = PIPE && !emit_final && chain && a.stage_cap == 16u && a.upt <= kAcUnitsPerTicketMax;
+        u32 *slot = parked ? park_slots + (u32)(unit - u_begin) * 16u
+                           : reinterpret_cast<u32 *>(a.stage) + unit * (u64)a.stage_cap; // 32-bit staged words, see write() below
         const bool do_final = emit_final && want_pos;
         const bool do_stage = !emit_final && want_pos;
         const u64 fbase = do_final ? a.offsets[unit] : 0ull;
@@ -256,7 +266,16 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
 
             // ---- the lane's candidates go into the unit's bitmap; they are enumerated once per unit (below) instead
             //      of ranked per cell (ballots + a divergent store loop: ~15 VALU per cell), and nothing overflows ----
-            cbits16[(u32)r * (kSegBytes / 16) + (u32)j * kWave + lane] = (unsigned short)cand;
+            if (PIPE)
+            {
+                u32 x = cand & 0x5555u; // even bits -> 8 contiguous bits
+                x = (x | (x >> 1)) & 0x3333u;
+                x = (x | (x >> 2)) & 0x0f0fu;
+                x = (x | (x >> 4)) & 0x00ffu;
+                cbits8[(u32)r * (kSegBytes / 16) + (u32)j * kWave + lane] = (uint8_t)x;
+            }
+            else
+                cbits16[(u32)r * (kSegBytes / 16) + (u32)j * kWave + lane] = (unsigned short)cand;
         };
         if (PIPE && fast_now)
         {
@@ -284,8 +303,8 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 u32 acc = 0;
 #pragma unroll
                 for (int q = 0; q < 8; ++q)
-                    acc = __builtin_amdgcn_alignbit(v[q] >> (x[q] & 31u), acc, 2u);
-                cbits16[(u32)r * (kSegBytes / 16) + (u32)j * kWave + lane] = (unsigned short)((acc >> 16) & 0x5555u);
+                    acc = __builtin_amdgcn_alignbit(v[q] >> (x[q] & 31u), acc, 1u);
+                cbits8[(u32)r * (kSegBytes / 16) + (u32)j * kWave + lane] = (uint8_t)(acc >> 24); // bit q <-> tested position 2q + 1
             };
             issue(0, xs[0], dw[0]);
 #pragma unroll
@@ -350,15 +369,15 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
         //      range, and the lane verifying rank q finds its candidate by a binary search over those sums and a
         //      select of the t-th set bit in the owner's block ------------------------------------------------
         {
-            u32 myw[8];
             u32 mycnt = 0;
             {
-                const uint4 lo = *reinterpret_cast<const uint4 *>(cbits + lane * 8u), hi = *reinterpret_cast<const uint4 *>(cbits + lane * 8u + 4u);
-                myw[0] = lo.x; myw[1] = lo.y; myw[2] = lo.z; myw[3] = lo.w;
-                myw[4] = hi.x; myw[5] = hi.y; myw[6] = hi.z; myw[7] = hi.w;
-#pragma unroll
-                for (int w = 0; w < 8; ++w)
-                    mycnt += (u32)__popc(myw[w]);
+                const uint4 lo = *reinterpret_cast<const uint4 *>(cbits + lane * kWPL);
+                mycnt = (u32)(__popc(lo.x) + __popc(lo.y) + __popc(lo.z) + __popc(lo.w));
+                if (!PIPE)
+                {
+                    const uint4 hi = *reinterpret_cast<const uint4 *>(cbits + lane * kWPL + 4u);
+                    mycnt += (u32)(__popc(hi.x) + __popc(hi.y) + __popc(hi.z) + __popc(hi.w));
+                }
             }
             u32 incl = mycnt; // inclusive prefix of the candidate counts over lanes
 #pragma unroll
@@ -392,7 +411,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                     if (live)
                     {
                         u32 t = qi - (oincl - ocnt); // my candidate is the t-th set bit of the owner's block
-                        const u32 *blk = cbits + own * 8u;
+                        const u32 *blk = cbits + own * kWPL;
                         u32 w = 0, word = blk[0];
                         for (;;)
                         {
@@ -404,7 +423,8 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                         }
                         for (; t; --t)
                             word &= word - 1u;
-                        rel = own * 256u + w * 32u + (u32)__builtin_ctz(word);
+                        rel = PIPE ? 2u * (own * 128u + w * 32u + (u32)__builtin_ctz(word)) // (bit b <-> tested position 2b + 1)
+                                   : own * 256u + w * 32u + (u32)__builtin_ctz(word);
                     }
                 }
                 // pair layout: bit j of the bitmap is tested position j + 1
@@ -563,13 +583,25 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                         ((u64)(wls.cnt & kUiLineMask) << kUiLineShift);
             else if (wcnt)
                 info |= kLnHead | kLnTail;
-            a.unitinfo[unit] = info;
+            if (parked)
+                park_info[(u32)(unit - u_begin)] = info;
+            else
+                a.unitinfo[unit] = info;
             if (want_pos && wcnt > a.stage_cap)
             {
                 atomicAdd(&a.ctr->overflow_units, 1ull);
                 atomicMax(&a.ctr->max_unit_count, (u64)wcnt);
             }
         }
+      }
+      if (PIPE && !emit_final && chain && a.stage_cap == 16u && a.upt <= kAcUnitsPerTicketMax)
+      {
+        // the ticket's parked info words and slots (consecutive units: one contiguous 64-byte-per-unit region), two stores
+        const u32 nun = (u32)(u_end - u_begin);
+        if (lane < nun)
+            a.unitinfo[u_begin + lane] = park_info[lane];
+        if (want_pos && lane < nun * 4u)
+            reinterpret_cast<uint4 *>(reinterpret_cast<u32 *>(a.stage) + u_begin * 16u)[lane] = reinterpret_cast<const uint4 *>(park_slots)[lane];
       }
     }
     if (lane == 0 && acc_total && !a.emit_mode)
