@@ -76,6 +76,7 @@ struct LitArgs {
     Counters *ctr;
     uint64_t *stage;              // [num_tiles * 4 * stage_cap] ordered start offsets per unit (F_POS, scan mode)
     uint32_t stage_cap;           // staging records per unit
+    uint32_t upt;                 // units per wave ticket (1..8, by text size; divides 256)
     uint32_t emit_mode;           // 0: scan (count + stage); 1: re-scan the overflowed units and write records
     const uint64_t *offsets;      // [units] exclusive global index of each unit's first match (emit mode)
     uint64_t *positions;          // match_position_t records (2 x u64) or nullptr

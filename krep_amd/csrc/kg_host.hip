@@ -636,6 +636,11 @@ static int lit_pass(krep_gpu_plan *pl, const Window &w, const LitPass &ps, hipSt
     a.flags = (pl->cs ? 0 : F_CI) | (ps.ww ? F_WW : 0) | (ps.lines ? F_LINES : 0) | (ps.sink != LitPass::COUNT ? F_POS : 0);
     const bool chain = (a.flags & (F_POS | F_LINES)) != 0;
     const uint64_t n_units = a.num_tiles * kWavesPerBlk;
+    // units per wave ticket: 8 on large texts, fewer while that keeps >= ~4 tickets per resident wave (powers of two: the
+    // parked-store flush maps a parked unit to its ticket by division)
+    a.upt = 1;
+    while (a.upt < 8 && n_units / ((uint64_t)pl->num_cu * 16 * 4) >= 2 * a.upt)
+        a.upt *= 2;
     // Staging slot per unit.  Single byte: 512 offsets (1 KiB) per 32 KiB unit, ~1.5x BASELINE's 1 % density.  Sparse kinds:
     // 16 offsets = ONE 32-byte slot per 32 KiB unit (BASELINE's 1e-4/B puts 3.3 hits in a unit); units that hold more take the
     // emit-mode re-scan, and a scan in which more than 1 in 64 units did raises the plan's slot to 64 for its next scans.

@@ -140,22 +140,21 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
     const u64 hi_match = (a.own_hi < a.text_len - a.m + 1) ? a.own_hi : (a.text_len - a.m + 1); // exclusive start bound
     constexpr u64 kUnitBytes = (u64)R * kSegBytes;
 
-    // Sparse kinds with 16-entry slots: NOTHING is stored while the wave streams.  Info words and staged offsets of up to
-    // kPark units are parked in LDS (2 + 8 KiB per wave: the four blocks of a CU use all 160 KiB) and written out in one burst
-    // of ~12 store instructions; at 32 GiB a wave scans 256 units, i.e. it stores once, at its end.
-    constexpr u32 kPark = (KIND == 4 || KIND == 8) ? 256u : 1u;
+    // 2..8-byte kinds with 16-entry slots: NOTHING is stored while the wave streams.  Info words and staged offsets of up to
+    // kPark units (30 tickets of 8) are parked in LDS (~9.8 KiB per wave: the four blocks of a CU use 154 of the 160 KiB) and
+    // written out in one burst of ~12 store instructions; at 32 GiB a wave scans ~256 units, i.e. it stores twice.
+    constexpr u32 kPark = (KIND == 4 || KIND == 8) ? 240u : 8u; // 30 tickets of 8 units: 4 x (240 x 40 + 240) B x 4 blocks = 154 KiB
     __shared__ u64 s_info[kWavesPerBlk][kPark];
     __shared__ __attribute__((aligned(16))) unsigned short s_slots[kWavesPerBlk][kPark][16];
     // (only the plain offsets-producing scan with its regular 16-entry slots: -c measured 1 % slower parked, 64-entry slots
     //  would not fit, emit mode writes final records; m > 8 measured 3 % slower parked)
-    const bool park = (KIND == 4 || KIND == 8) && !LINES && want_pos && !a.emit_mode && a.stage_cap == 16u;
-    u32 n_park = 0;     // parked units (uniform)
-    u64 park_first = 0; // the first of them; the others follow at the wave's unit stride
-    const u64 unit_stride = (u64)gridDim.x * kWavesPerBlk;
+    const bool park = (KIND == 4 || KIND == 8) && !LINES && want_pos && !a.emit_mode && a.stage_cap == 16u && a.upt == 8u;
+    u32 n_park = 0;     // parked units (uniform); they are the units of the wave's last tickets, a.upt consecutive ones each
+    __shared__ u64 s_tk[kWavesPerBlk][kPark / 8u]; // first unit of each parked ticket
     auto flush_parked = [&]() __attribute__((always_inline)) {
         for (u32 i = lane; i < n_park; i += 64u)
         {
-            const u64 u = park_first + (u64)i * unit_stride;
+            const u64 u = s_tk[wave][i / 8u] + (u64)(i % 8u);
             a.unitinfo[u] = s_info[wave][i];
             if (want_pos && (s_info[wave][i] & kUiCountMask))
             {
@@ -168,15 +167,34 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
         n_park = 0;
     };
     u64 acc_total = 0; // wave-uniform accumulator
-    // Units are dealt out STATICALLY: wave w of block b scans units (i * gridDim.x + b) * 4 + w — the four waves of a block
-    // read 4 x R x 8 KiB contiguous bytes per step, every wave runs on its own (no ticket, no barrier).  Round 1 drew one
-    // atomic ticket per 128 KiB tile and broadcast it through LDS behind a __syncthreads(): measured in isolation
-    // (tools/ubench/read_ceiling.hip, 32 GiB) that skeleton alone caps a pure reader at 6.5 TB/s against 7.07 TB/s for
-    // static striding — the barrier makes every wave wait for the slowest of its tile, 262 144 times per scan.  The
-    // interleaved static deal keeps the blocks balanced on skewed inputs as well.
+    // Every WAVE draws its own ticket for a.upt consecutive units (8 = 256 KiB on large texts; ~26 fetch-adds/us on the one
+    // ticket word at 6.5 TB/s, a third of what it sustains) and runs on its own: no barrier, no LDS broadcast.  Round 1 drew one
+    // ticket per 128 KiB tile for the four waves of a block and broadcast it behind a __syncthreads(): measured in isolation
+    // (tools/ubench/read_ceiling.hip, 32 GiB) that skeleton alone caps a pure reader at 6.5 TB/s against 7.07 TB/s without
+    // the barrier — every wave waits for the slowest of its tile, 262 144 times per scan.  A static interleaved deal (wave w
+    // of block b scans units (i * grid + b) * 4 + w) was the first replacement; it leaves the waves that the store path
+    // slows down (4.1, store placement) as stragglers: per-wave tickets measured 5.39 -> 5.17 ms counting and 8.5 -> 7.9 ms
+    // on the single-byte workload on a box where that happens, and the same elsewhere.
     const u64 n_units = a.num_tiles * kWavesPerBlk;
-    for (u64 unit = (u64)blockIdx.x * kWavesPerBlk + wave; unit < n_units; unit += (u64)gridDim.x * kWavesPerBlk)
+    u64 tk_next = 0, tk_end = 0;
+    for (;;)
     {
+        if (tk_next == tk_end)
+        {
+            u64 tk = 0;
+            if (lane == 0)
+                tk = __hip_atomic_fetch_add(&a.ctr->ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tk_next = rfl64(tk) * (u64)a.upt;
+            tk_end = tk_next + a.upt;
+            if (park && tk_next < n_units)
+            {
+                if (lane == 0)
+                    s_tk[wave][n_park / 8u] = tk_next;
+            }
+        }
+        const u64 unit = tk_next++;
+        if (unit >= n_units)
+            break; // tickets ascend: nothing is left for this wave
         const u64 ubase = a.anchor + unit * kUnitBytes;
         if (a.emit_mode && (u32)(a.unitinfo[unit] & kUiCountMask) <= a.stage_cap)
             continue; // wave-uniform: only overflowed units are re-scanned
@@ -612,8 +630,6 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
             }
             if (park)
             {
-                if (n_park == 0)
-                    park_first = unit;
                 if (++n_park == kPark)
                     flush_parked();
             }
