@@ -636,11 +636,13 @@ static int lit_pass(krep_gpu_plan *pl, const Window &w, const LitPass &ps, hipSt
     a.flags = (pl->cs ? 0 : F_CI) | (ps.ww ? F_WW : 0) | (ps.lines ? F_LINES : 0) | (ps.sink != LitPass::COUNT ? F_POS : 0);
     const bool chain = (a.flags & (F_POS | F_LINES)) != 0;
     const uint64_t n_units = a.num_tiles * kWavesPerBlk;
-    // units per wave ticket: 8 on large texts, fewer while that keeps >= ~4 tickets per resident wave (powers of two: the
-    // parked-store flush maps a parked unit to its ticket by division)
-    a.upt = 1;
-    while (a.upt < 8 && n_units / ((uint64_t)pl->num_cu * 16 * 4) >= 2 * a.upt)
-        a.upt *= 2;
+    // Dealing: from ~24 GiB on every wave draws tickets of 8 units (>= 24 tickets per resident wave, ~26 fetch-adds/us on the
+    // ticket word); below that the static interleaved deal (upt = 0) is faster — measured at 8 GiB: 1.38 vs 1.41 ms with
+    // offsets, 1.29 vs 1.37 ms counting; at 16 GiB 2.58 vs 2.63 ms; at 2 GiB 0.37 vs 0.48 ms (the ticket word becomes the limit
+    // of a short scan); at 32 GiB tickets win: 5.20 vs 5.31 ms, and 7.1 vs 7.9 ms on the single-byte workload
+    a.upt = (a.rounds == kRoundsBig && n_units / ((uint64_t)pl->num_cu * 16) >= 192) ? 8 : 0;
+    if (const char *e = getenv("KREP_GPU_LIT_UPT")) // measurement aid
+        a.upt = (uint32_t)atoi(e);
     // Staging slot per unit.  Single byte: 512 offsets (1 KiB) per 32 KiB unit, ~1.5x BASELINE's 1 % density.  Sparse kinds:
     // 16 offsets = ONE 32-byte slot per 32 KiB unit (BASELINE's 1e-4/B puts 3.3 hits in a unit); units that hold more take the
     // emit-mode re-scan, and a scan in which more than 1 in 64 units did raises the plan's slot to 64 for its next scans.

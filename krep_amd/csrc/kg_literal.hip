@@ -148,13 +148,14 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
     __shared__ __attribute__((aligned(16))) unsigned short s_slots[kWavesPerBlk][kPark][16];
     // (only the plain offsets-producing scan with its regular 16-entry slots: -c measured 1 % slower parked, 64-entry slots
     //  would not fit, emit mode writes final records; m > 8 measured 3 % slower parked)
-    const bool park = (KIND == 4 || KIND == 8) && !LINES && want_pos && !a.emit_mode && a.stage_cap == 16u && a.upt == 8u;
+    const bool park = (KIND == 4 || KIND == 8) && !LINES && want_pos && !a.emit_mode && a.stage_cap == 16u && (a.upt == 0u || a.upt >= 4u) && a.num_tiles < (1ull << 29);
     u32 n_park = 0;     // parked units (uniform); they are the units of the wave's last tickets, a.upt consecutive ones each
-    __shared__ u64 s_tk[kWavesPerBlk][kPark / 8u]; // first unit of each parked ticket
+    __shared__ u32 s_tk[kWavesPerBlk][kPark / 4u]; // first unit of each parked ticket (4 or 8 units each)
+    u64 park_first = 0;                            // static deal: the first parked unit, the others follow at the wave's stride
     auto flush_parked = [&]() __attribute__((always_inline)) {
         for (u32 i = lane; i < n_park; i += 64u)
         {
-            const u64 u = s_tk[wave][i / 8u] + (u64)(i % 8u);
+            const u64 u = a.upt ? (u64)s_tk[wave][i / a.upt] + (u64)(i % a.upt) : park_first + (u64)i * ((u64)gridDim.x * kWavesPerBlk);
             a.unitinfo[u] = s_info[wave][i];
             if (want_pos && (s_info[wave][i] & kUiCountMask))
             {
@@ -176,10 +177,11 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
     // slows down (4.1, store placement) as stragglers: per-wave tickets measured 5.39 -> 5.17 ms counting and 8.5 -> 7.9 ms
     // on the single-byte workload on a box where that happens, and the same elsewhere.
     const u64 n_units = a.num_tiles * kWavesPerBlk;
-    u64 tk_next = 0, tk_end = 0;
+    // (a.upt == 0, texts below 512 MiB: the static interleaved deal — such a scan lasts < 100 us, the ticket word would be its limit)
+    u64 tk_next = (u64)blockIdx.x * kWavesPerBlk + wave, tk_end = a.upt ? tk_next : ~0ull;
     for (;;)
     {
-        if (tk_next == tk_end)
+        if (a.upt && tk_next == tk_end)
         {
             u64 tk = 0;
             if (lane == 0)
@@ -189,12 +191,13 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
             if (park && tk_next < n_units)
             {
                 if (lane == 0)
-                    s_tk[wave][n_park / 8u] = tk_next;
+                    s_tk[wave][n_park / a.upt] = (u32)tk_next;
             }
         }
-        const u64 unit = tk_next++;
+        const u64 unit = tk_next;
+        tk_next += a.upt ? 1ull : (u64)gridDim.x * kWavesPerBlk;
         if (unit >= n_units)
-            break; // tickets ascend: nothing is left for this wave
+            break; // tickets (and the static stride) ascend: nothing is left for this wave
         const u64 ubase = a.anchor + unit * kUnitBytes;
         if (a.emit_mode && (u32)(a.unitinfo[unit] & kUiCountMask) <= a.stage_cap)
             continue; // wave-uniform: only overflowed units are re-scanned
@@ -630,6 +633,8 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
             }
             if (park)
             {
+                if (n_park == 0)
+                    park_first = unit;
                 if (++n_park == kPark)
                     flush_parked();
             }
