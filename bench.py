@@ -30,7 +30,8 @@ PATTERN = b"Sherlock"
 PERIOD = 10000
 SEED = 20260925
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-HBM_MEASURED_GBS = 6290.0  # the same guide: measured streaming ceiling
+HBM_MEASURED_GBS = 6290.0  # the same guide: measured streaming (copy) ceiling
+HBM_READ_CEILING_GBS = 7070.0  # bare non-temporal 32 GiB reader on this part (tools/ubench/read_ceiling.hip, profiles/r02_read_ceiling_ubench.txt)
 
 
 def ac_patterns(n=1000, seed=1234):
@@ -287,6 +288,7 @@ def run_workload(name, args, eng, buf, dev, rank, world, local, use_dist):
                      # also against the measured streaming ceiling, and with the 16 B/match
                      # result writes counted (the figure that matters for the 1 % single-byte config)
                      "frac_of_measured_ceiling": round(achieved / HBM_MEASURED_GBS, 4),
+                     "frac_of_read_only_ceiling": round(achieved / HBM_READ_CEILING_GBS, 4),
                      "achieved_incl_result_writes": round((n + 16 * stored) / (k_avg * 1e-3) / 1e9, 1)},
     }
 
