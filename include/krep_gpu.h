@@ -9,12 +9,21 @@
  * against krep.h can pass its own objects straight through.  If krep.h was included first its
  * definitions are used and ours are skipped.
  *
- * Error behaviour mirrors the reference: the search_func_t-shaped entry points have no in-band
- * error channel (the reference's do not either: they print to stderr and return a partial count,
- * e.g. krep.c:1359-1362); on a device/launch failure they print "krep-gpu: ..." to stderr, set
- * krep_gpu_last_error() and return 0.  search_buffer() returns 0 match / 1 no match / 2 error
- * exactly like search_file()/search_string() (krep.h:159,168).  There is NO CPU fallback inside this
- * library: if no gfx950 device / code object is available every entry point fails loudly.
+ * Error behaviour: the search_func_t signature has no in-band error channel (the reference's functions
+ * print to stderr and return a partial count, e.g. krep.c:1359-1362), and a backend that answers 0
+ * when it could not look would turn "failed" into "no match".  So (SURVEY §8b "Errors"):
+ *   - without a usable gfx950 device krep_gpu_available() is 0, krep_gpu_can_accelerate() is 0 and
+ *     krep_gpu_select_search_algorithm() returns NULL: the caller keeps the CPU function pointer the
+ *     reference's own select_search_algorithm() gives it (krep.c:1944-1948);
+ *   - an operator that fails at run time (allocation, copy, launch, device lost) appends NOTHING to
+ *     `result`, prints "krep-gpu: ..." to stderr, sets krep_gpu_last_error() and
+ *     krep_gpu_last_status() != 0, and — when the host registered its CPU selector with
+ *     krep_gpu_set_cpu_fallback() — re-runs the search through the host's own CPU function and returns
+ *     THAT result (status KREP_GPU_FELL_BACK).  Without a registered selector it returns 0 with status
+ *     KREP_GPU_FAILED, which the caller must test (the error_flag path of krep.c:2940-2947).
+ * search_buffer() returns 0 match / 1 no match / 2 error exactly like search_file()/search_string()
+ * (krep.h:159,168).  The library itself contains no CPU implementation of any search: a fallback is
+ * always the CALLER's function.
  */
 #ifndef KREP_GPU_H
 #define KREP_GPU_H
@@ -117,11 +126,17 @@ typedef struct krep_gpu_config
     int result_order;          /* 1: multi-pattern records come back in (start, end) order (see below)                  */
     int device;                /* HIP device the host-buffer operators use (default: $KREP_GPU_DEVICE, else 0)          */
     size_t stream_chunk_bytes; /* piece size of the streamed host path (0 = default 128 MiB); texts > 2 pieces stream   */
+    int num_gpus;              /* devices the search_func_t operators shard a text over (default: $KREP_GPU_NUM, else 1;
+                                  0 or less = all visible devices); shards meet in one RCCL all-reduce of their counters  */
+    size_t min_text_bytes;     /* krep_gpu_worthwhile(): texts shorter than this stay on the CPU function (default:
+                                  $KREP_GPU_MIN_BYTES, else 1 MiB — one operator call costs 50-80 us)       */
 } krep_gpu_config_t;
 void krep_gpu_config_default(krep_gpu_config_t *out);           /* the current process-wide defaults */
 void krep_gpu_set_thread_config(const krep_gpu_config_t *cfg);  /* calling thread only; NULL clears   */
 void krep_gpu_set_device(int device);                           /* process-wide default device         */
 void krep_gpu_set_stream_chunk(size_t bytes);                   /* process-wide default piece size     */
+void krep_gpu_set_num_gpus(int n);                              /* process-wide default shard count    */
+void krep_gpu_set_min_text_bytes(size_t bytes);                 /* process-wide default size threshold */
 /* frees every per-device context of the host path (device buffers, pinned staging ring, cached plans) */
 void krep_gpu_release_device_resources(void);
 
@@ -145,6 +160,37 @@ int krep_gpu_mirror_select(const search_params_t *params, size_t text_len);
 const char *krep_gpu_algorithm_name(int krep_ref_algo); /* twin of get_algorithm_name(), krep.c:1964 */
 
 /* ------------------------------------------------------------------------------------------------
+ * Availability, failure status and the CPU fallback (SURVEY §8b "Errors", §5 "Failure detection").
+ * ---------------------------------------------------------------------------------------------- */
+/* 1 when the configured device exists, is a gfx950 and a probe kernel of this library's code object ran on it
+ * (checked once per device and process); 0 otherwise, with the reason in krep_gpu_unavailable_reason().
+ * $KREP_GPU_DISABLE=1 forces 0. */
+int krep_gpu_available(void);
+const char *krep_gpu_unavailable_reason(void); /* "" when available */
+/* The host's own selector of CPU functions — for the reference CLI a wrapper of select_search_algorithm() (krep.c:1771)
+ * that skips the GPU branch.  When registered, an operator that fails at run time calls
+ * select_cpu(params)(params, text, len, result) itself and returns that function's result (sorted into (start, end)
+ * order when result_order is set, so the promise of krep_gpu_set_result_order() holds either way). NULL unregisters. */
+typedef search_func_t (*krep_gpu_cpu_select_t)(const search_params_t *params);
+void krep_gpu_set_cpu_fallback(krep_gpu_cpu_select_t select_cpu);
+/* Outcome of the calling thread's LAST operator / search_buffer call. */
+enum krep_gpu_status
+{
+    KREP_GPU_OK = 0,        /* the scan ran on the GPU; the return value and `result` are the backend's             */
+    KREP_GPU_FELL_BACK = 1, /* the GPU path failed; the registered CPU function produced the return value / result */
+    KREP_GPU_FAILED = 2     /* the GPU path failed and no CPU function was available: the returned 0 means
+                               "could not look", NOT "no match" — nothing was appended to `result`                 */
+};
+int krep_gpu_last_status(void);
+/* Should a caller hand THIS text to the backend?  1 iff krep_gpu_available() && krep_gpu_can_accelerate(params) &&
+ * text_len >= min_text_bytes.  search_file() asks this once per file (krep.c:2404-2420 already special-cases small
+ * files): `krep -r` over many small files must not pay one device round trip per file. */
+int krep_gpu_worthwhile(const search_params_t *params, size_t text_len);
+/* test hook: make the next operator calls fail at a chosen point — 0 off, 1 device allocation, 2 host->device copy,
+ * 3 kernel launch, 4 device->host copy of the records.  Also read from $KREP_GPU_INJECT_FAILURE. */
+void krep_gpu_debug_inject_failure(int kind);
+
+/* ------------------------------------------------------------------------------------------------
  * Operator-level entry points (search_func_t-compatible).  `text_start` is a HOST pointer, exactly
  * as in the reference; the bytes are staged to HBM through pinned buffers, scanned by the HIP
  * kernels, and the results appended to `result` with the match_result_add() contract
@@ -156,16 +202,20 @@ uint64_t krep_gpu_literal_search(const search_params_t *params, const char *text
 uint64_t krep_gpu_aho_corasick_search(const search_params_t *params, const char *text_start,
                                       size_t text_len, match_result_t *result);
 /* Drop-in for select_search_algorithm(): returns one of the two functions above, or NULL when the backend does not
- * take the search — regex_search, and the two input classes krep_gpu_can_accelerate() names — so that the caller keeps
- * the CPU function pointer the reference's own select_search_algorithm() gives it. */
+ * take the search — no usable device (krep_gpu_available() == 0), regex_search, and the input classes
+ * krep_gpu_can_accelerate() names — so that the caller keeps the CPU function pointer the reference's own
+ * select_search_algorithm() gives it. */
 search_func_t krep_gpu_select_search_algorithm(const search_params_t *params);
-/* 1 when the backend reproduces the reference for `params` under the current configuration, 0 when not:
+/* 1 when the backend takes the search for `params` under the current configuration, 0 when not:
+ *   - no usable gfx950 device (krep_gpu_available() == 0);
+ *   - no pattern at all (num_patterns == 0 and pattern == NULL);
  *   - use_regex;
  *   - count_lines_mode with a '\n' inside a single pattern that the reference would run through simd_sse42_search or
  *     kmp_search (the -c line skip of simd_sse42_search depends on the phase of its 16-byte window grid, krep.c:4787-4793);
  *   - count_lines_mode together with only_matching through memchr_short_search (unreachable from the reference CLI,
  *     krep.c:3811-3814).
- * The operators refuse these loudly ("krep-gpu: ..." on stderr, return 0); nothing is silently approximated. */
+ * An operator called with such params anyway treats it like a run-time failure (see the top of this header): the
+ * registered CPU function answers, or status KREP_GPU_FAILED; nothing is silently approximated. */
 int krep_gpu_can_accelerate(const search_params_t *params);
 
 /* The in-memory twin of search_file()/search_string() that BASELINE.json calls search_buffer():

@@ -59,7 +59,10 @@ class Config(C.Structure):
     """krep_gpu_config_t: the reference's build level and file-static option globals, explicit."""
     _fields_ = [("reference_simd", C.c_int), ("only_matching", C.c_int), ("force_no_simd", C.c_int),
                 ("algo_override", C.c_int), ("result_order", C.c_int), ("device", C.c_int),
-                ("stream_chunk_bytes", C.c_size_t)]
+                ("stream_chunk_bytes", C.c_size_t), ("num_gpus", C.c_int), ("min_text_bytes", C.c_size_t)]
+
+
+STATUS_OK, STATUS_FELL_BACK, STATUS_FAILED = 0, 1, 2
 
 
 SEARCH_FUNC = C.CFUNCTYPE(C.c_uint64, C.POINTER(SearchParams), C.c_char_p, C.c_size_t,

@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <unordered_map>
@@ -979,20 +980,26 @@ static u32 ac_lds_bytes(u32 filter_words, bool lines)
     return (((filter_words + 3u) & ~3u) + kAcWaves * per_wave) * (u32)sizeof(u32);
 }
 
+constexpr u32 kAcMaxLds = 160u * 1024u; // LDS of a gfx950 CU: the most a launch of the scan kernel can ask for
 template <bool CI, bool LN, bool SHORT, int STRIDE>
 static hipError_t ac_launch3(const AcArgs &a, u32 grid, u32 lds, hipStream_t st)
 {
-    // more than 64 KiB of dynamic LDS has to be requested explicitly — once per instantiation (and per larger request), not
-    // on every launch: the call sits on the latency path of small host buffers
-    static int granted[64] = {0}; // per device (the attribute belongs to the function ON a device)
+    // more than 64 KiB of dynamic LDS has to be requested explicitly — once per instantiation and device, not on every launch
+    // (the call sits on the latency path of small host buffers), and always for the MOST this kernel can ask for (the whole
+    // 160 KiB of a CU), so that no later, larger request can find a stale grant.  Atomic flags: concurrent scans from several
+    // host threads may launch the same instantiation; devices beyond the table simply set it every time.
+    constexpr int kMaxDev = 64;
+    static std::atomic<bool> granted[kMaxDev];
     int dev = 0;
     (void)hipGetDevice(&dev);
-    dev &= 63;
-    if ((int)lds > granted[dev])
+    if (dev < 0 || dev >= kMaxDev || !granted[dev].load(std::memory_order_acquire))
     {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ac_scan_kernel<CI, LN, SHORT, STRIDE>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        granted[dev] = (int)lds;
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ac_scan_kernel<CI, LN, SHORT, STRIDE>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAcMaxLds);
+        if (e != hipSuccess)
+            return e;
+        if (dev >= 0 && dev < kMaxDev)
+            granted[dev].store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL((ac_scan_kernel<CI, LN, SHORT, STRIDE>), dim3(grid), dim3(kAcBlock), lds, st, a);
     return hipGetLastError();

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -48,7 +49,7 @@ bool have_error() { return !g_err.empty(); }
 
 extern "C" const char *krep_gpu_last_error(void) { return g_err.c_str(); }
 extern "C" void krep_gpu_clear_error(void) { g_err.clear(); }
-extern "C" const char *krep_gpu_version(void) { return "krep-gpu 0.2 (gfx950)"; }
+extern "C" const char *krep_gpu_version(void) { return "krep-gpu 0.3 (gfx950)"; }
 extern "C" int krep_gpu_device_count(void)
 {
     int n = 0;
@@ -66,6 +67,8 @@ extern "C" int krep_gpu_device_count(void)
 static std::atomic<int> g_simd{KREP_REF_AVX2}, g_only_matching{0}, g_no_simd{0}, g_algo_override{KREP_ALGO_AUTO},
     g_result_order{0}, g_device{-1};
 static std::atomic<size_t> g_stream_chunk{0};
+static std::atomic<int> g_num_gpus{INT32_MIN};            // INT32_MIN: not set -> $KREP_GPU_NUM, else 1
+static std::atomic<size_t> g_min_bytes{SIZE_MAX};         // SIZE_MAX: not set -> $KREP_GPU_MIN_BYTES, else 1 MiB
 static thread_local bool tl_cfg_set = false;
 static thread_local krep_gpu_config_t tl_cfg;
 
@@ -73,6 +76,16 @@ static int env_device()
 {
     const char *e = getenv("KREP_GPU_DEVICE");
     return e && *e ? atoi(e) : 0;
+}
+static int env_num_gpus()
+{
+    const char *e = getenv("KREP_GPU_NUM");
+    return e && *e ? atoi(e) : 1;
+}
+static size_t env_min_bytes()
+{
+    const char *e = getenv("KREP_GPU_MIN_BYTES");
+    return e && *e ? (size_t)strtoull(e, nullptr, 0) : ((size_t)1 << 20);
 }
 extern "C" void krep_gpu_config_default(krep_gpu_config_t *c)
 {
@@ -86,6 +99,10 @@ extern "C" void krep_gpu_config_default(krep_gpu_config_t *c)
     const int d = g_device.load(std::memory_order_relaxed);
     c->device = d >= 0 ? d : env_device();
     c->stream_chunk_bytes = g_stream_chunk.load(std::memory_order_relaxed);
+    const int ng = g_num_gpus.load(std::memory_order_relaxed);
+    c->num_gpus = ng != INT32_MIN ? ng : env_num_gpus();
+    const size_t mb = g_min_bytes.load(std::memory_order_relaxed);
+    c->min_text_bytes = mb != SIZE_MAX ? mb : env_min_bytes();
 }
 extern "C" void krep_gpu_set_thread_config(const krep_gpu_config_t *c)
 {
@@ -111,6 +128,118 @@ extern "C" void krep_gpu_set_force_no_simd(int on) { g_no_simd.store(on != 0, st
 extern "C" void krep_gpu_set_algo_override(int a) { g_algo_override.store(a, std::memory_order_relaxed); }
 extern "C" void krep_gpu_set_device(int d) { g_device.store(d, std::memory_order_relaxed); }
 extern "C" void krep_gpu_set_stream_chunk(size_t bytes) { g_stream_chunk.store(bytes, std::memory_order_relaxed); }
+extern "C" void krep_gpu_set_num_gpus(int n) { g_num_gpus.store(n, std::memory_order_relaxed); }
+extern "C" void krep_gpu_set_min_text_bytes(size_t b) { g_min_bytes.store(b, std::memory_order_relaxed); }
+
+// ------------------------------------------------------------------------------------ availability
+// "Is there a device this library can run on" is asked by the SELECTOR, before any operator is handed out (SURVEY §8b:
+// a backend must be able to fail BEFORE producing output): device count, range of the configured device, gfx950, and one
+// probe kernel of this code object launched and read back.  Once per device and process.
+__global__ void kg_probe_kernel(unsigned *out) { *out = 0x950u; }
+namespace {
+struct Avail
+{
+    std::mutex mu;
+    std::vector<int> state;           // per device: 0 unknown, 1 usable, 2 not usable
+    std::vector<std::string> reason;  // why not
+};
+Avail &avail()
+{
+    static Avail *a = new Avail(); // leaked: may be consulted from atexit paths
+    return *a;
+}
+thread_local std::string tl_unavail;
+bool probe_device(int device, std::string &why)
+{
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    auto done = [&](bool ok) {
+        if (prev >= 0)
+            (void)hipSetDevice(prev);
+        (void)hipGetLastError();
+        return ok;
+    };
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess)
+    {
+        why = "hipGetDeviceProperties failed";
+        return done(false);
+    }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    {
+        why = std::string("device is ") + prop.gcnArchName + ", this library holds gfx950 code only";
+        return done(false);
+    }
+    unsigned *d = nullptr, h = 0;
+    if (hipSetDevice(device) != hipSuccess || hipMalloc(&d, sizeof(unsigned)) != hipSuccess)
+    {
+        why = "cannot allocate on the device";
+        return done(false);
+    }
+    hipLaunchKernelGGL(kg_probe_kernel, dim3(1), dim3(1), 0, nullptr, d);
+    const bool ok = hipGetLastError() == hipSuccess && hipMemcpy(&h, d, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h == 0x950u;
+    (void)hipFree(d);
+    if (!ok)
+        why = "the gfx950 code object of this library does not run on the device";
+    return done(ok);
+}
+} // namespace
+namespace kg {
+// NULL = usable; otherwise the reason (valid until the calling thread asks again)
+const char *device_unusable(int device)
+{
+    if (const char *e = getenv("KREP_GPU_DISABLE"))
+        if (*e && *e != '0')
+            return "disabled by KREP_GPU_DISABLE";
+    if (const char *e = getenv("KREP_GPU_ASSUME_AVAILABLE")) // test hook: skip the probe, so that a box WITHOUT a device
+        if (*e && *e != '0')                                  // reaches the operators and exercises their run-time failure paths
+            return nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    {
+        (void)hipGetLastError();
+        return "no HIP device available";
+    }
+    if (device < 0 || device >= ndev)
+    {
+        tl_unavail = "device " + std::to_string(device) + " out of range (have " + std::to_string(ndev) + ")";
+        return tl_unavail.c_str();
+    }
+    Avail &a = avail();
+    std::lock_guard<std::mutex> lk(a.mu);
+    if ((size_t)ndev > a.state.size())
+    {
+        a.state.resize((size_t)ndev, 0);
+        a.reason.resize((size_t)ndev);
+    }
+    if (a.state[device] == 0)
+        a.state[device] = probe_device(device, a.reason[device]) ? 1 : 2;
+    if (a.state[device] == 1)
+        return nullptr;
+    tl_unavail = a.reason[device];
+    return tl_unavail.c_str();
+}
+// ---- failure injection (test hook): the failure paths of the operators must be reachable on a healthy box
+static std::atomic<int> g_inject{-1};
+bool inject(int kind)
+{
+    int v = g_inject.load(std::memory_order_relaxed);
+    if (v < 0)
+    {
+        const char *e = getenv("KREP_GPU_INJECT_FAILURE");
+        v = e && *e ? atoi(e) : 0;
+        g_inject.store(v, std::memory_order_relaxed);
+    }
+    return v == kind;
+}
+} // namespace kg
+extern "C" void krep_gpu_debug_inject_failure(int kind) { kg::g_inject.store(kind < 0 ? 0 : kind, std::memory_order_relaxed); }
+extern "C" int krep_gpu_available(void) { return kg::device_unusable(kg::current_config().device) == nullptr ? 1 : 0; }
+extern "C" const char *krep_gpu_unavailable_reason(void)
+{
+    const char *r = kg::device_unusable(kg::current_config().device);
+    return r ? r : "";
+}
 
 static std::atomic<int> g_force_rounds{0};    // test hook: 0 = auto, 1 / 4 = force the tile shape
 static std::atomic<int> g_force_stage_cap{0}; // test hook: staging records per unit (0 = auto)
@@ -265,8 +394,17 @@ const char *unsupported_reason(const search_params_t *p, const krep_gpu_config_t
         return "NULL params";
     if (p->use_regex)
         return "regex search is not part of the accelerated path (keep krep's regex_search)";
-    if (p->num_patterns != 1 || !p->pattern)
-        return nullptr;
+    if (p->num_patterns > 1)
+        return (p->patterns && p->pattern_lens) ? nullptr : "several patterns announced but patterns / pattern_lens are NULL";
+    if (!p->pattern && !(p->num_patterns == 1 && p->patterns && p->pattern_lens && p->patterns[0]))
+        return "no pattern";
+    search_params_t q = *p; // legacy callers fill only pattern / pattern_len (test/test_krep.c:233-235); others only the arrays
+    if (p->num_patterns == 1 && p->patterns && p->pattern_lens && p->patterns[0])
+    {
+        q.pattern = p->patterns[0];
+        q.pattern_len = p->pattern_lens[0];
+    }
+    p = &q;
     const int top = mirror_top(p, c);
     const int eff = mirror_effective(top, p, SIZE_MAX / 2);
     const bool has_nl = p->pattern_len && memchr(p->pattern, '\n', p->pattern_len) != nullptr;
@@ -281,7 +419,13 @@ const char *unsupported_reason(const search_params_t *p, const krep_gpu_config_t
 } // namespace kg
 extern "C" int krep_gpu_can_accelerate(const search_params_t *p)
 {
-    return kg::unsupported_reason(p, kg::current_config()) == nullptr ? 1 : 0;
+    const krep_gpu_config_t c = kg::current_config();
+    return kg::unsupported_reason(p, c) == nullptr && kg::device_unusable(c.device) == nullptr ? 1 : 0;
+}
+extern "C" int krep_gpu_worthwhile(const search_params_t *p, size_t text_len)
+{
+    const krep_gpu_config_t c = kg::current_config();
+    return text_len >= c.min_text_bytes && kg::unsupported_reason(p, c) == nullptr && kg::device_unusable(c.device) == nullptr ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------ result container (krep.c:139-251 contract)
@@ -343,15 +487,14 @@ extern "C" krep_gpu_plan_t *krep_gpu_plan_create_ex(const search_params_t *p, co
     }
     const krep_gpu_config_t cfg = cfg_in ? *cfg_in : kg::current_config();
     const int device = cfg.device;
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    if (const char *why = kg::device_unusable(device))
     {
-        kg::fail("no HIP device available (this library has no CPU fallback)");
+        kg::fail("%s", why);
         return nullptr;
     }
-    if (device < 0 || device >= ndev)
+    if (kg::inject(1))
     {
-        kg::fail("device %d out of range (have %d)", device, ndev);
+        kg::fail("injected failure: device allocation (plan)");
         return nullptr;
     }
     if (hipSetDevice(device) != hipSuccess)
@@ -641,8 +784,12 @@ static int lit_pass(krep_gpu_plan *pl, const Window &w, const LitPass &ps, hipSt
     // offsets, 1.29 vs 1.37 ms counting; at 16 GiB 2.58 vs 2.63 ms; at 2 GiB 0.37 vs 0.48 ms (the ticket word becomes the limit
     // of a short scan); at 32 GiB tickets win: 5.20 vs 5.31 ms, and 7.1 vs 7.9 ms on the single-byte workload
     a.upt = (a.rounds == kRoundsBig && n_units / ((uint64_t)pl->num_cu * 16) >= 192) ? 8 : 0;
-    if (const char *e = getenv("KREP_GPU_LIT_UPT")) // measurement aid
-        a.upt = (uint32_t)atoi(e);
+    if (const char *e = getenv("KREP_GPU_LIT_UPT")) // measurement aid; only the values the kernel's parked-store bookkeeping
+    {                                               // is built for (kPark = 240 must be a multiple)
+        const int v = atoi(e);
+        if (v == 0 || v == 1 || v == 2 || v == 4 || v == 8)
+            a.upt = (uint32_t)v;
+    }
     // Staging slot per unit.  Single byte: 512 offsets (1 KiB) per 32 KiB unit, ~1.5x BASELINE's 1 % density.  Sparse kinds:
     // 16 offsets = ONE 32-byte slot per 32 KiB unit (BASELINE's 1e-4/B puts 3.3 hits in a unit); units that hold more take the
     // emit-mode re-scan, and a scan in which more than 1 in 64 units did raises the plan's slot to 64 for its next scans.
@@ -1157,6 +1304,8 @@ extern "C" int krep_gpu_scan_device_ex(krep_gpu_plan_t *pl, const void *d_text, 
     hipStream_t st = (hipStream_t)stream;
     if (pl->unsupported)
         return kg::fail("%s", pl->unsupported);
+    if (kg::inject(3))
+        return kg::fail("injected failure: kernel launch");
     if (pl->ref_algo == KREP_RA_AHO_CORASICK && pl->lines && pl->ac_has_newline)
     {
         Window w{(const uint8_t *)d_text, text_len, own_lo, own_hi, global_base, global_len};

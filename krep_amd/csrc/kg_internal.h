@@ -7,6 +7,8 @@
 namespace kg {
 
 int fail(const char *fmt, ...); // records krep_gpu_last_error(), prints "krep-gpu: ..." and returns 2
+const char *device_unusable(int device); // NULL: a gfx950 device this code object runs on; else why not
+bool inject(int kind);                   // test hook: is failure `kind` being injected (krep_gpu_debug_inject_failure)
 
 // kg_literal.hip
 hipError_t launch_literal(const LitArgs &a, uint32_t num_cu, hipStream_t st); // grid = resident blocks of the variant x CUs
@@ -80,12 +82,6 @@ bool result_reserve(match_result_t *r, uint64_t extra);
 bool have_error();
 
 // kg_ops.hip — host-buffer side
-int stage_to_device(uint8_t *d_dst, const char *src, size_t len, int device); // pinned double-buffered H2D
-void stage_release();
 void memchr_batch_quirk(match_position_t *recs, uint64_t have, size_t maxc);
-
-// kg_multi.hip — one process driving several devices (search_buffer(num_gpus > 1))
-uint64_t multi_gpu_search(const search_params_t *params, const char *buf, size_t len, int num_gpus,
-                          const krep_gpu_config_t &cfg, match_result_t *out, int *status);
 
 } // namespace kg

@@ -13,6 +13,7 @@
 #include <pthread.h>
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -52,6 +53,8 @@ struct DevBuf
         release();
         HIPCHK(hipSetDevice(device));
         const size_t want = std::max<size_t>(n, 1 << 20);
+        if (kg::inject(1))
+            return kg::fail("injected failure: device allocation of %zu bytes", want);
         if (hipMalloc(&p, want) != hipSuccess)
         {
             p = nullptr;
@@ -88,8 +91,10 @@ struct Stager
     hipStream_t st = nullptr;
     hipEvent_t done[2] = {nullptr, nullptr};
     int dev = -1;
+    bool ready = false; // every resource below exists (set last by init(); a half-built stager is torn down)
     void release()
     {
+        ready = false;
         if (dev < 0)
             return;
         (void)hipSetDevice(dev);
@@ -107,17 +112,23 @@ struct Stager
     }
     int init(int device)
     {
-        if (dev == device && pin[0])
+        if (dev == device && ready)
             return 0;
         release();
         HIPCHK(hipSetDevice(device));
         dev = device;
-        for (int i = 0; i < 2; ++i)
+        bool ok = true;
+        for (int i = 0; i < 2 && ok; ++i)
+            ok = hipHostMalloc(&pin[i], kChunk + kSlack) == hipSuccess &&
+                 hipEventCreateWithFlags(&done[i], hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+        if (!ok)
         {
-            HIPCHK(hipHostMalloc(&pin[i], kChunk + kSlack));
-            HIPCHK(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+            (void)hipGetLastError();
+            release(); // a recoverable out-of-memory must not leave NULL buffers behind for the next call
+            return kg::fail("cannot create the pinned staging ring on device %d", device);
         }
-        HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        ready = true;
         return 0;
     }
     uint64_t seq = 0; // staging chunks issued so far: the ring runs on across calls (no drain between the pieces of a stream)
@@ -126,6 +137,10 @@ struct Stager
     // piece k+1's first chunk is staged while piece k's last DMA is still running.
     int copy_async(uint8_t *d_dst, const char *src, size_t len, hipEvent_t after)
     {
+        if (!ready)
+            return kg::fail("staging ring not initialised");
+        if (kg::inject(2))
+            return kg::fail("injected failure: host->device copy");
         HIPCHK(hipSetDevice(dev));
         for (size_t off = 0, n = 0; off < len; off += n, ++seq)
         {
@@ -158,6 +173,10 @@ struct Stager
     }
     int copy(uint8_t *d_dst, const char *src, size_t len)
     {
+        if (!ready)
+            return kg::fail("staging ring not initialised");
+        if (kg::inject(2))
+            return kg::fail("injected failure: host->device copy");
         HIPCHK(hipSetDevice(dev));
         if (len < (4u << 20)) // small buffers: one synchronous copy is cheaper than the pipeline
         {
@@ -293,17 +312,6 @@ extern "C" void krep_gpu_release_device_resources(void)
 }
 
 namespace kg {
-// pinned, double-buffered host -> device copy through the device's staging ring (caller holds no context lock)
-int stage_to_device(uint8_t *d_dst, const char *src, size_t len, int device)
-{
-    DeviceCtx *cx = ctx_for(device);
-    std::lock_guard<std::mutex> lk(cx->mu);
-    if (cx->stager.init(device))
-        return 2;
-    return cx->stager.copy(d_dst, src, len);
-}
-void stage_release() {}
-
 // memchr_search's final flush (krep.c:3976-3991 + :4026-4038): when max_count is a multiple of the
 // 4096-entry batch and more matches exist, the (max_count+1)-th record is stored FIRST (in front of
 // the last batch) and the max_count-th is dropped.
@@ -366,8 +374,8 @@ static int run_whole(DeviceCtx &cx, const search_params_t *params, const krep_gp
             krep_gpu_order_by_start((match_position_t *)cx.pos.p, so.stored, text_len, nullptr))
             return 2;
         std::vector<match_position_t> tmp(so.stored);
-        if (hipMemcpy(tmp.data(), cx.pos.p, so.stored * sizeof(match_position_t), hipMemcpyDeviceToHost) != hipSuccess)
-            return kg::fail("D2H copy failed");
+        if (kg::inject(4) || hipMemcpy(tmp.data(), cx.pos.p, so.stored * sizeof(match_position_t), hipMemcpyDeviceToHost) != hipSuccess)
+            return kg::fail("D2H copy of the records failed");
         uint64_t n = so.stored;
         const int algo = pl->ref_algo == KREP_RA_AHO_CORASICK ? KREP_RA_AHO_CORASICK : mirror_effective(pl->ref_algo, &pl->sp, text_len);
         if (algo == KREP_RA_MEMCHR && params->max_count != SIZE_MAX)
@@ -528,9 +536,10 @@ void run_device(DeviceRun *dr)
         if (!rc && dr->want_pos && p->out.stored)
         {
             p->recs.resize(p->out.stored);
-            if (hipMemcpy(p->recs.data(), cx.pos.p, p->out.stored * sizeof(match_position_t), hipMemcpyDeviceToHost) != hipSuccess)
+            if (kg::inject(4) ||
+                hipMemcpy(p->recs.data(), cx.pos.p, p->out.stored * sizeof(match_position_t), hipMemcpyDeviceToHost) != hipSuccess)
             {
-                kg::fail("D2H copy failed");
+                kg::fail("D2H copy of the records failed");
                 rc = 2;
             }
         }
@@ -556,7 +565,7 @@ static int run_pieces(const search_params_t *params, const krep_gpu_config_t &cf
     *ret_out = 0;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-        return kg::fail("no HIP device available (this library has no CPU fallback)");
+        return kg::fail("no HIP device available");
     size_t lmax = 1;
     for (size_t i = 0; i < params->num_patterns; ++i)
         lmax = std::max(lmax, params->pattern_lens[i]);
@@ -677,43 +686,110 @@ static int run_pieces(const search_params_t *params, const krep_gpu_config_t &cf
 }
 
 // ------------------------------------------------------------------------------------------------ dispatcher
-static uint64_t run_host_operator(const search_params_t *params, const char *text, size_t text_len, match_result_t *result,
+namespace {
+// One view of the caller's params for everything below: legacy callers fill only pattern / pattern_len (the reference's own
+// tests, test/test_krep.c:233-235), the CLI fills the arrays as well.  After this, num_patterns >= 1, patterns / pattern_lens
+// are valid and pattern / pattern_len name the first one (run_pieces read pattern_lens[] of the raw struct).
+struct NormParams
+{
+    search_params_t sp{};
+    const char *one_pat = nullptr;
+    size_t one_len = 0;
+    bool valid = false;
+    explicit NormParams(const search_params_t *p)
+    {
+        sp = *p;
+        if (p->num_patterns > 1)
+        {
+            valid = p->patterns && p->pattern_lens;
+            return;
+        }
+        if (p->num_patterns == 1 && p->patterns && p->pattern_lens && p->patterns[0])
+        {
+            one_pat = p->patterns[0];
+            one_len = p->pattern_lens[0];
+        }
+        else if (p->pattern)
+        {
+            one_pat = p->pattern;
+            one_len = p->pattern_len;
+        }
+        else
+            return;
+        sp.pattern = one_pat;
+        sp.pattern_len = one_len;
+        sp.patterns = &one_pat;
+        sp.pattern_lens = &one_len;
+        sp.num_patterns = 1;
+        valid = true;
+    }
+    NormParams(const NormParams &) = delete;
+    NormParams &operator=(const NormParams &) = delete;
+};
+
+// restores the calling thread's current HIP device: the operators are called on the HOST's threads (krep.c:1950), and a
+// library must not leave their device changed
+struct DeviceGuard
+{
+    int prev = -1;
+    DeviceGuard() { (void)hipGetDevice(&prev); (void)hipGetLastError(); }
+    ~DeviceGuard()
+    {
+        if (prev >= 0)
+            (void)hipSetDevice(prev);
+    }
+};
+thread_local int tl_status = KREP_GPU_OK;
+std::atomic<krep_gpu_cpu_select_t> g_cpu_select{nullptr};
+} // namespace
+
+extern "C" int krep_gpu_last_status(void) { return tl_status; }
+extern "C" void krep_gpu_set_cpu_fallback(krep_gpu_cpu_select_t f) { g_cpu_select.store(f); }
+
+// the GPU attempt: *status 0 = the return value and `result` are good; 2 = failed, nothing appended
+static uint64_t run_host_operator(const search_params_t *raw, const char *text, size_t text_len, match_result_t *result,
                                   const krep_gpu_config_t &cfg, int num_gpus, int *status)
 {
-    if (status)
-        *status = 2;
-    if (!params || (!text && text_len))
+    *status = 2;
+    if (!raw || (!text && text_len))
     {
         kg::fail("NULL params/text");
         return 0;
     }
+    NormParams np(raw);
+    if (!np.valid)
+    {
+        kg::fail("no pattern");
+        return 0;
+    }
+    const search_params_t *params = &np.sp;
     if (const char *why = kg::unsupported_reason(params, cfg))
     {
         kg::fail("%s", why);
         return 0;
     }
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    if (const char *why = kg::device_unusable(cfg.device))
     {
-        kg::fail("no HIP device available (this library has no CPU fallback)");
-        return 0;
-    }
-    if (cfg.device < 0 || cfg.device >= ndev)
-    {
-        kg::fail("device %d out of range (have %d)", cfg.device, ndev);
+        kg::fail("%s", why);
         return 0;
     }
     if (params->num_patterns > 1 && !params->ac_trie)
     { // aho_corasick.c:306: no trie, no matches
-        if (status) *status = 0;
+        *status = 0;
         return 0;
     }
+    DeviceGuard guard;
+    int ndev = 1;
+    (void)hipGetDeviceCount(&ndev);
+    if (num_gpus <= 0)
+        num_gpus = ndev; // "all visible devices"
     // streaming threshold: pieces of `chunk` bytes once the text is larger than two of them
     const size_t chunk = cfg.stream_chunk_bytes ? cfg.stream_chunk_bytes : ((size_t)128 << 20);
     const bool can_split = kg::shardable(params, cfg, text_len);
     const bool split = can_split && (num_gpus > 1 || text_len > 2 * chunk);
     uint64_t ret = 0;
     int rc;
+    const uint64_t count0 = result ? result->count : 0;
     if (!split)
     {
         DeviceCtx *cx = ctx_for(cfg.device);
@@ -723,25 +799,76 @@ static uint64_t run_host_operator(const search_params_t *params, const char *tex
     else
         rc = run_pieces(params, cfg, text, text_len, num_gpus, text_len > 2 * chunk ? chunk : 0, result, &ret);
     if (rc)
+    {
+        if (result)
+            result->count = count0; // a failed attempt leaves the caller's list as it found it
         return 0;
-    if (status)
-        *status = 0;
+    }
+    *status = 0;
     return ret;
+}
+
+// GPU attempt, then — on ANY failure (no device, refused input class, allocation, copy, launch) — the host's own CPU
+// function, if it registered its selector.  A 0 that means "could not look" is never returned with status OK
+// (SURVEY §8b "Errors"; the reference's fallback idiom krep.c:1944-1948, its error channel krep.c:2940-2947).
+static uint64_t run_with_fallback(const search_params_t *params, const char *text, size_t text_len, match_result_t *result,
+                                  const krep_gpu_config_t &cfg, int num_gpus, int *status_out, bool allow_fallback = true)
+{
+    int st = 2;
+    krep_gpu_clear_error();
+    const uint64_t n = run_host_operator(params, text, text_len, result, cfg, num_gpus, &st);
+    if (st == 0)
+    {
+        tl_status = KREP_GPU_OK;
+        if (status_out) *status_out = 0;
+        return n;
+    }
+    const krep_gpu_cpu_select_t sel = g_cpu_select.load();
+    search_func_t cpu = (sel && params && allow_fallback) ? sel(params) : nullptr;
+    if (cpu == krep_gpu_literal_search || cpu == krep_gpu_aho_corasick_search)
+        cpu = nullptr; // a selector that hands our own operators back would recurse
+    if (!cpu)
+    {
+        tl_status = KREP_GPU_FAILED;
+        if (status_out) *status_out = 2;
+        return 0;
+    }
+    static std::atomic<bool> warned{false};
+    if (!warned.exchange(true))
+        fprintf(stderr, "krep-gpu: falling back to the CPU function for this search (reported once)\n");
+    const uint64_t count0 = result ? result->count : 0;
+    const uint64_t r = cpu(params, text, text_len, result);
+    if (result && cfg.result_order && result->count > count0 + 1)
+        // krep_gpu_set_result_order(1) promises the formatter's (start, end) order (krep.c:420-434) whoever produced the records
+        std::stable_sort(result->positions + count0, result->positions + result->count,
+                         [](const match_position_t &a, const match_position_t &b) {
+                             return a.start_offset != b.start_offset ? a.start_offset < b.start_offset : a.end_offset < b.end_offset;
+                         });
+    tl_status = KREP_GPU_FELL_BACK;
+    if (status_out) *status_out = 0;
+    return r;
 }
 
 extern "C" uint64_t krep_gpu_literal_search(const search_params_t *params, const char *text, size_t len, match_result_t *result)
 {
-    return run_host_operator(params, text, len, result, kg::current_config(), 1, nullptr);
+    const krep_gpu_config_t cfg = kg::current_config();
+    return run_with_fallback(params, text, len, result, cfg, cfg.num_gpus, nullptr);
 }
 extern "C" uint64_t krep_gpu_aho_corasick_search(const search_params_t *params, const char *text, size_t len,
                                                  match_result_t *result)
 {
-    return run_host_operator(params, text, len, result, kg::current_config(), 1, nullptr);
+    const krep_gpu_config_t cfg = kg::current_config();
+    return run_with_fallback(params, text, len, result, cfg, cfg.num_gpus, nullptr);
 }
 extern "C" search_func_t krep_gpu_select_search_algorithm(const search_params_t *params)
 {
-    if (!params || kg::unsupported_reason(params, kg::current_config()))
-        return nullptr; // the caller keeps the CPU function pointer select_search_algorithm() gives it
+    if (!params)
+        return nullptr;
+    const krep_gpu_config_t cfg = kg::current_config();
+    // NULL: the caller keeps the CPU function pointer select_search_algorithm() gives it — for an input class that is not
+    // reproduced, and when there is no device this library can run on (asked HERE, before any operator is handed out)
+    if (kg::unsupported_reason(params, cfg) || kg::device_unusable(cfg.device))
+        return nullptr;
     return params->num_patterns > 1 ? krep_gpu_aho_corasick_search : krep_gpu_literal_search;
 }
 
@@ -751,7 +878,8 @@ extern "C" int search_buffer_ex(const search_params_t *params, const char *buf, 
 {
     if (count_out)
         *count_out = 0;
-    if (!params || params->num_patterns == 0)
+    tl_status = KREP_GPU_FAILED; // until the search below says otherwise
+    if (!params || params->num_patterns == 0 || !params->patterns || !params->pattern_lens)
         return kg::fail("Error: No pattern specified.");
     if (!buf && len)
         return kg::fail("Error: NULL text in search_buffer.");
@@ -771,9 +899,11 @@ extern "C" int search_buffer_ex(const search_params_t *params, const char *buf, 
     int st = 2;
     search_params_t local = *params;
     static int dummy_trie;
-    if (local.num_patterns > 1 && !local.ac_trie)
+    const bool no_trie = local.num_patterns > 1 && !local.ac_trie;
+    if (no_trie)
         local.ac_trie = (ac_trie_t *)&dummy_trie; // search_string builds the trie itself (krep.c:2067-2078)
-    uint64_t n = run_host_operator(&local, buf, len, out, cfg, num_gpus, &st);
+    // (a CPU function could not use that placeholder: the fallback needs the caller's real trie)
+    uint64_t n = run_with_fallback(&local, buf, len, out, cfg, num_gpus, &st, !no_trie);
     if (st)
         return 2;
     const size_t maxc = params->max_count;

@@ -90,10 +90,19 @@ class Engine:
         L.krep_gpu_line_numbers.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
         for n in ("krep_gpu_set_reference_simd", "krep_gpu_set_only_matching", "krep_gpu_set_force_no_simd",
                   "krep_gpu_set_algo_override", "krep_gpu_debug_force_rounds", "krep_gpu_debug_force_stage_cap",
-                  "krep_gpu_set_result_order", "krep_gpu_set_device"):
+                  "krep_gpu_set_result_order", "krep_gpu_set_device", "krep_gpu_set_num_gpus", "krep_gpu_debug_inject_failure"):
             getattr(L, n).restype = None
             getattr(L, n).argtypes = [C.c_int]
         L.krep_gpu_get_reference_simd.restype = C.c_int
+        L.krep_gpu_available.restype = C.c_int
+        L.krep_gpu_unavailable_reason.restype = C.c_char_p
+        L.krep_gpu_last_status.restype = C.c_int
+        L.krep_gpu_set_cpu_fallback.restype = None
+        L.krep_gpu_set_cpu_fallback.argtypes = [C.c_void_p]
+        L.krep_gpu_worthwhile.restype = C.c_int
+        L.krep_gpu_worthwhile.argtypes = [C.POINTER(abi.SearchParams), C.c_size_t]
+        L.krep_gpu_set_min_text_bytes.restype = None
+        L.krep_gpu_set_min_text_bytes.argtypes = [C.c_size_t]
         L.krep_gpu_device_count.restype = C.c_int
         L.krep_gpu_last_error.restype = C.c_char_p
         L.krep_gpu_clear_error.restype = None
@@ -135,6 +144,29 @@ class Engine:
     def select(self, params: abi.Params):
         """krep_gpu_select_search_algorithm(): the operator's address, or None (the caller keeps its CPU function)."""
         return self.lib.krep_gpu_select_search_algorithm(params.ref)
+
+    # ---- availability, failure status, CPU fallback (SURVEY §8b "Errors") ----
+    def available(self) -> bool:
+        return bool(self.lib.krep_gpu_available())
+
+    def unavailable_reason(self) -> str:
+        return (self.lib.krep_gpu_unavailable_reason() or b"").decode()
+
+    def last_status(self) -> int:
+        return int(self.lib.krep_gpu_last_status())
+
+    def set_cpu_fallback(self, selector_address):
+        """selector_address: address of a `search_func_t (*)(const search_params_t *)` (or None to unregister)."""
+        self.lib.krep_gpu_set_cpu_fallback(C.c_void_p(selector_address) if selector_address else None)
+
+    def worthwhile(self, params: abi.Params, text_len: int) -> bool:
+        return bool(self.lib.krep_gpu_worthwhile(params.ref, text_len))
+
+    def inject_failure(self, kind: int):
+        self.lib.krep_gpu_debug_inject_failure(kind)
+
+    def set_num_gpus(self, n: int):
+        self.lib.krep_gpu_set_num_gpus(n)
 
     def release_device_resources(self):
         self.lib.krep_gpu_release_device_resources()
@@ -181,8 +213,8 @@ class Engine:
         try:
             self.lib.krep_gpu_clear_error()
             ret = fn(params.ref, ptr, n, res)
-            if self.last_error():
-                raise KrepGpuError(self.last_error())
+            if self.last_status() == abi.STATUS_FAILED:
+                raise KrepGpuError(self.last_error() or "krep-gpu operator failed")
             pos = abi.result_positions(res) if res else None
         finally:
             if res:
