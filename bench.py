@@ -230,14 +230,20 @@ def run_workload(name, args, eng, buf, dev, rank, world, local, use_dist):
     counts = torch.zeros(2, dtype=torch.int64, device=dev)
     host_counts = torch.zeros(2, dtype=torch.int64).pin_memory()
 
+    reduced = [0, 0]
+
     def step():
         out = plan.scan(buf.data_ptr(), text_len, 0, n, shard_off, pos.data_ptr(), cap, stream, True,
                         global_len=world * n)
-        if use_dist:
+        if use_dist == "c":
+            # the one collective of the path, from C: krep_gpu_comm_allreduce_u64 = ncclAllReduce(uint64, sum) on the
+            # library's rank communicator (kg_comm.hip) — the same call the in-process multi-device path makes
+            reduced[:] = eng.comm_allreduce([out.count, out.total_matches])
+        elif use_dist:
             host_counts[0] = out.count
             host_counts[1] = out.total_matches
             counts.copy_(host_counts, non_blocking=True)
-            dist.all_reduce(counts)           # the one RCCL all-reduce of the per-GPU counts
+            dist.all_reduce(counts)           # (torch.distributed's RCCL: only when the C-level communicator is unavailable)
         return out
 
     for _ in range(args.warmup):
@@ -258,7 +264,7 @@ def run_workload(name, args, eng, buf, dev, rank, world, local, use_dist):
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        total_matches = int(counts[1].item())
+        total_matches = reduced[1] if use_dist == "c" else int(counts[1].item())
     else:
         total_matches = int(out.total_matches)
     assert not out.overflow, "position buffer too small"
@@ -272,7 +278,7 @@ def run_workload(name, args, eng, buf, dev, rank, world, local, use_dist):
     k_avg, k_med = sum(k_ms) / len(k_ms), statistics.median(k_ms)
     achieved = n / (k_avg * 1e-3) / 1e9
     return {
-        "wl": wl,
+        "wl": wl, "collective": use_dist if use_dist else None,
         "value": round(value, 1), "ms_per_step": round(ms_step, 4), "matches": total_matches,
         "matches_per_s": round(total_matches / (dt / args.steps), 1),
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -298,7 +304,9 @@ def config_of(name, wl, args, world, n, res):
                         f"{' x' + str(world) + ' shards = configs[4] shape' if world > 1 else ''})",
             "pattern": wl["patterns"][0].decode("latin-1") if len(wl["patterns"]) == 1 else f"{len(wl['patterns'])} patterns",
             "bytes_per_gpu": n, "matches": res["matches"], "matches_per_s": res["matches_per_s"],
-            "parallelism": f"contiguous shards x{world}, start-offset ownership, 1 RCCL all-reduce of counts"}
+            "parallelism": f"contiguous shards x{world}, start-offset ownership, 1 RCCL all-reduce of counts"
+                           + (" (krep_gpu_comm_allreduce_u64: ncclAllReduce from the C library)" if res.get("collective") == "c"
+                              else " (torch.distributed)" if res.get("collective") else "")}
 
 
 def dry_run(args, rank, world):
@@ -342,6 +350,8 @@ def main():
     ap.add_argument("--cpu-sample-gib", type=float, default=4.0)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo = CPU dry run of the plumbing")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and all-reduce even with one rank (self-test)")
+    ap.add_argument("--collective", default="c", choices=["c", "torch"],
+                    help="who issues the count all-reduce: the C library's own RCCL communicator (default) or torch.distributed")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -365,9 +375,28 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = args.gpus > 1 or world > 1 or args.force_dist
-    if use_dist:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     eng = krep_amd.load()
+    if use_dist:
+        # torch.distributed carries the rendezvous, the barrier and the MAX-over-ranks of the timing; the data-path collective
+        # is the library's own rank communicator (RCCL from C) whose 128-byte id rides on that bootstrap
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        use_dist = "torch"
+        if args.collective == "c":
+            ok = 1
+            try:
+                box = [eng.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                eng.comm_init_rank(box[0], world, rank, local)
+            except Exception as e:  # every rank must take the same road: agree below
+                print(f"bench.py: rank {rank}: C-level communicator unavailable ({e}); torch.distributed all-reduce instead",
+                      file=sys.stderr)
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                use_dist = "c"
+            elif ok:
+                eng.comm_destroy()
     n = int(args.gib * (1 << 30))
     buf = torch.empty(n + 64, dtype=torch.uint8, device=dev)
 
@@ -412,6 +441,11 @@ def main():
     if rank == 0:
         print(json.dumps(line), flush=True)
     if use_dist:
+        if use_dist == "c":
+            if rank == 0 and line is not None:
+                print(f"bench.py: {eng.rccl_calls()} all-reduces issued through the C library's communicator (RCCL "
+                      f"{eng.rccl_version()})", file=sys.stderr)
+            eng.comm_destroy()
         dist.destroy_process_group()
     return 0
 

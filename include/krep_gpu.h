@@ -279,11 +279,40 @@ int krep_gpu_scan_device(krep_gpu_plan_t *plan, const void *d_text, size_t text_
  * the WHOLE text (the block simd_avx512_search leaves unexamined, krep.c:5171; the first byte of the scalar tail calls,
  * which has no left neighbour for -w, krep.c:5059-5097): with global_len those land where the reference puts them, in
  * whichever shard holds them.  The sequential match-set families (greedy SSE4.2/KMP selection of a bordered pattern,
- * -o through BMH / memchr_short, -c through the AVX-512 / NEON / AVX2 -w block loops) need the whole text in ONE window
- * and refuse anything else. */
+ * -o through BMH / memchr_short) accept a window inside the text only through krep_gpu_scan_device_seq() below; -c through
+ * the AVX-512 / NEON / AVX2 -w block loops needs the END of the text in a whole-text window (krep_gpu_split_mode()). */
 int krep_gpu_scan_device_ex(krep_gpu_plan_t *plan, const void *d_text, size_t text_len, size_t own_lo,
                             size_t own_hi, size_t global_base, size_t global_len, match_position_t *d_positions,
                             uint64_t position_capacity, void *stream, int time_it, krep_gpu_scan_out_t *out);
+
+/* ---- the sequential match-set families in pieces ("one boundary record per shard ... one exchange step") ----
+ * The greedy left-to-right selection of simd_sse42_search / kmp_search (krep.c:4839-4848, :1741), boyer_moore_search under
+ * -o (:1371) and memchr_short_search's -o walk (:4495) couple a match to the one before it; across a cut of the text the
+ * whole coupling is ONE number: where the reference's scan stands when it enters the right-hand piece. */
+typedef struct krep_gpu_seq_carry
+{
+    uint64_t resume;      /* global offset from which the reference's scan continues: starts in front of it are consumed,
+                             the first occurrence / candidate at or behind it is looked at afresh (0: nothing consumed)   */
+    uint64_t reserved[3]; /* zero */
+} krep_gpu_seq_carry_t;
+/* krep_gpu_scan_device_ex() for the pieces of one text IN TEXT ORDER: carry_in = the record the previous piece left
+ * (NULL: nothing in front of this window is consumed — the piece that starts the text, or an optimistic first pass of a
+ * shard whose left neighbour is still running: compare its assumption with the neighbour's carry_out afterwards and re-run
+ * the piece if they differ), carry_out (nullable) = this piece's record.  Families without a sequential dependency pass
+ * the record through unchanged. */
+int krep_gpu_scan_device_seq(krep_gpu_plan_t *plan, const void *d_text, size_t text_len, size_t own_lo, size_t own_hi,
+                             size_t global_base, size_t global_len, match_position_t *d_positions, uint64_t position_capacity,
+                             void *stream, int time_it, const krep_gpu_seq_carry_t *carry_in, krep_gpu_seq_carry_t *carry_out,
+                             krep_gpu_scan_out_t *out);
+/* How a text of text_len bytes may be cut for `params` under the current configuration. */
+enum krep_gpu_split
+{
+    KREP_GPU_SPLIT_WHOLE = 0,  /* one window only: -c through the block-structured bodies (end-of-text replay),
+                                  neon_search's max_count == 0 corner, multi-pattern -c with a newline inside a pattern   */
+    KREP_GPU_SPLIT_PIECES = 1, /* independent pieces: start-offset ownership + halo, results concatenate / merge          */
+    KREP_GPU_SPLIT_CHAIN = 2   /* pieces in text order through krep_gpu_scan_device_seq()                                 */
+};
+int krep_gpu_split_mode(const search_params_t *params, size_t text_len);
 
 /* Deterministic synthetic haystacks, generated directly in HBM by a counter-based
  * PRNG so that any [global_off, global_off+len) slice is reproducible on any rank.
@@ -299,6 +328,21 @@ void krep_gpu_generate_host(void *dst, size_t len, size_t global_off, int kind, 
 /* Combine per-shard line bookkeeping left-to-right (the one "exchange step" of the multi-GPU path):
  * returns the global distinct-line count given shard outputs in shard order. */
 uint64_t krep_gpu_combine_line_counts(const krep_gpu_scan_out_t *shards, int n);
+
+/* ---- the collective of the multi-GPU path: per-shard counters meet in ONE RCCL all-reduce over xGMI -------
+ * One process driving several devices (search_buffer(num_gpus > 1), the operators with cfg.num_gpus > 1) does this
+ * internally (ncclCommInitAll over the devices used).  One process PER GPU (bench.py under torch.distributed.run) uses the
+ * rank-level calls below: rank 0 draws an id, the host program's own bootstrap carries its 128 bytes to the other ranks,
+ * every rank joins, and each scan ends with one all-reduce of its counters {matches, lines, ...}.  librccl is opened on
+ * first use (dlopen); all return 0, or 2 with krep_gpu_last_error() set. */
+#define KREP_GPU_COMM_ID_BYTES 128
+int krep_gpu_comm_unique_id(void *id128);
+int krep_gpu_comm_init_rank(const void *id128, int nranks, int rank, int device);
+int krep_gpu_comm_allreduce_u64(uint64_t *values, int n);                         /* host values, in place; synchronous  */
+int krep_gpu_comm_allreduce_device_u64(void *d_values, int n, void *stream);      /* device-resident, in place, async    */
+void krep_gpu_comm_destroy(void);
+uint64_t krep_gpu_rccl_calls(void); /* collectives this process has issued through RCCL (diagnostic / self-test) */
+int krep_gpu_rccl_version(void);    /* ncclGetVersion(), 0 when librccl cannot be loaded */
 
 /* ---- formatter-side post-processing in HBM (what search_file() does on one host thread after the scan) --------------
  * krep_gpu_order_by_start: the (start, end) order of compare_match_positions (krep.c:420-434) that search_file()

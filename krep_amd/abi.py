@@ -63,6 +63,12 @@ class Config(C.Structure):
 
 
 STATUS_OK, STATUS_FELL_BACK, STATUS_FAILED = 0, 1, 2
+SPLIT_WHOLE, SPLIT_PIECES, SPLIT_CHAIN = 0, 1, 2
+
+
+class SeqCarry(C.Structure):
+    """krep_gpu_seq_carry_t: the boundary record of the sequential match-set families."""
+    _fields_ = [("resume", C.c_uint64), ("reserved", C.c_uint64 * 3)]
 
 
 SEARCH_FUNC = C.CFUNCTYPE(C.c_uint64, C.POINTER(SearchParams), C.c_char_p, C.c_size_t,

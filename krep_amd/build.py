@@ -71,5 +71,33 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_variant(name: str, defines, verbose: bool = False) -> str:
+    """Development aid: the same sources with extra -D switches, as krep_amd/lib/exp/libkrep_gpu_<name>.so — an A/B partner
+    for one GPU session (KREP_GPU_LIB=<path> selects it in krep_amd.load(), tools/ab_bench.py).  Never the shipped library."""
+    out_dir = os.path.join(LIBDIR, "exp")
+    obj_dir = os.path.join(out_dir, "obj_" + name)
+    os.makedirs(obj_dir, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+
+    def compile_one(src):
+        o = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o")
+        cmd = [hipcc] + FLAGS + list(defines) + ["-c", src, "-o", o]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True, cwd=CSRC)
+        return o
+
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        objs = list(ex.map(compile_one, sources()))
+    lib = os.path.join(out_dir, f"libkrep_gpu_{name}.so")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + sorted(objs), check=True, cwd=CSRC)
+    return lib
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--variant" in sys.argv:
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], [a for a in sys.argv[i + 2:] if a.startswith("-D")], verbose=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

@@ -69,6 +69,10 @@ __device__ __forceinline__ Visit g_visit(const WalkSpec &ws, u64 sj, u64 base, c
     return Visit{ok, ok ? m : 1u}; // krep.c:4441-4446: a -w rejected match resumes one byte further
 }
 
+// flags of one list element after the walk
+constexpr uint8_t kKeep = 1;    // reported (after -w)
+constexpr uint8_t kVisited = 2; // the reference's scan stood on it (kept or not): it moved the resume point
+
 constexpr u64 kWalkBound = 4096; // elements one head thread walks before the pass is handed to the parallel form below
 
 // The first thread of a cluster walks it (clusters split at gaps >= m: an element that far behind its predecessor is always
@@ -102,7 +106,7 @@ __global__ __launch_bounds__(kGB) void g_walk(const u64 *__restrict__ occ, u64 n
             continue;
         }
         const Visit v = g_visit(ws, sj, base, text, text_len);
-        keep[j] = v.keep ? 1 : 0;
+        keep[j] = (v.keep ? kKeep : 0) | kVisited;
         cur = sj + v.consume;
     }
 }
@@ -160,14 +164,33 @@ __global__ __launch_bounds__(kGB) void g_keep_from(const uint8_t *__restrict__ v
 {
     const u64 i = (u64)blockIdx.x * kGB + threadIdx.x;
     if (i < n)
-        keep[i] = visited[i] && accept[i];
+        keep[i] = (uint8_t)(((visited[i] && accept[i]) ? kKeep : 0) | (visited[i] ? kVisited : 0));
+}
+
+// Where the reference's scan stands behind the list: start + consume of the LAST visited element — the boundary record a
+// following piece of the text resumes from (krep.c:4839-4848, :1741, :1371, :4495).  The elements behind the last visited one
+// all start in front of that point, so there are fewer than m of them: one thread walks back.
+__global__ void g_resume(const u64 *__restrict__ occ, u64 n, u64 base, const uint8_t *__restrict__ text, u64 text_len, WalkSpec ws,
+                         const uint8_t *__restrict__ keep, u64 *out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0)
+        return;
+    u64 r = 0;
+    for (u64 j = n; j-- > 0;)
+        if (keep[j] & kVisited)
+        {
+            const u64 sj = occ[2 * j];
+            r = sj + g_visit(ws, sj, base, text, text_len).consume;
+            break;
+        }
+    *out = r;
 }
 
 __global__ __launch_bounds__(kGB) void g_ww(const u64 *__restrict__ occ, u64 n, u64 base, const uint8_t *__restrict__ text,
                                             u64 text_len, u32 m, uint8_t *__restrict__ keep)
 {
     const u64 i = (u64)blockIdx.x * kGB + threadIdx.x;
-    if (i >= n || !keep[i])
+    if (i >= n || !(keep[i] & kKeep))
         return;
     const u64 p = occ[2 * i] - base; // offset inside the device buffer
     bool ok = true;
@@ -176,7 +199,7 @@ __global__ __launch_bounds__(kGB) void g_ww(const u64 *__restrict__ occ, u64 n, 
     else if (p + m < text_len && g_wordc(text[p + m]))
         ok = false;
     if (!ok)
-        keep[i] = 0;
+        keep[i] &= (uint8_t)~kKeep; // still visited: a rejected hit consumed (krep.c:4767, :1684)
 }
 
 __global__ __launch_bounds__(kGB) void g_count(const uint8_t *__restrict__ keep, u64 n, u64 *__restrict__ blk)
@@ -186,7 +209,7 @@ __global__ __launch_bounds__(kGB) void g_count(const uint8_t *__restrict__ keep,
     u32 c = 0;
 #pragma unroll
     for (int k = 0; k < kGPer; ++k)
-        c += (i0 + k < n && keep[i0 + k]) ? 1u : 0u;
+        c += (i0 + k < n && (keep[i0 + k] & kKeep)) ? 1u : 0u;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1)
         c += __shfl_xor(c, o);
@@ -234,7 +257,7 @@ __global__ __launch_bounds__(kGB) void g_scatter(const u64 *__restrict__ occ, co
 #pragma unroll
     for (int q = 0; q < kGPer; ++q)
     {
-        k[q] = i0 + q < n && keep[i0 + q];
+        k[q] = i0 + q < n && (keep[i0 + q] & kKeep);
         c += k[q] ? 1u : 0u;
     }
     u32 incl = c;
@@ -304,12 +327,15 @@ __global__ __launch_bounds__(kGB) void g_lines(const u64 *__restrict__ lst, u64 
 
 // occ: n_occ records already in s.d_occ.  Results: *total kept matches; records into d_pos (<= want);
 // with ws.lines the distinct-line count (the survivors are compacted into scratch for that).
+// *resume (may be NULL): start + consume of the last element the walk visited (0 for an empty list).
 int post_walk(PostScratch &s, const uint8_t *d_text, uint64_t text_len, uint64_t global_base, const WalkSpec &ws,
               uint64_t n_occ, uint64_t *d_pos, uint64_t want, Counters *d_ctr, Counters *h_ctr, hipStream_t st,
-              uint64_t *total, uint64_t *nlines)
+              uint64_t *total, uint64_t *nlines, uint64_t *resume)
 {
     *total = 0;
     *nlines = 0;
+    if (resume)
+        *resume = 0;
     if (n_occ == 0)
         return 0;
     const u64 nb = (n_occ + kGBlockElems - 1) / kGBlockElems;
@@ -363,6 +389,9 @@ int post_walk(PostScratch &s, const uint8_t *d_text, uint64_t text_len, uint64_t
             return fail("pointer-jumping pass failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
     }
     GCHK(hipMemsetAsync(d_ctr, 0, sizeof(Counters), st));
+    if (resume)
+        hipLaunchKernelGGL(g_resume, dim3(1), dim3(64), 0, st, occ, (u64)n_occ, (u64)global_base, d_text, (u64)text_len, ws,
+                           (const uint8_t *)s.d_keep, (u64 *)&d_ctr->pad[1]);
     if (ws.ww && ws.mode == kWalkGreedy) // -w AFTER the selection: a rejected hit still consumed (krep.c:4767, :1684)
         hipLaunchKernelGGL(g_ww, dim3(g1), dim3(kGB), 0, st, occ, (u64)n_occ, (u64)global_base, d_text, (u64)text_len, ws.m, s.d_keep);
     hipLaunchKernelGGL(g_count, dim3((u32)nb), dim3(kGB), 0, st, (const uint8_t *)s.d_keep, (u64)n_occ, (u64 *)s.d_gblk);
@@ -389,6 +418,8 @@ int post_walk(PostScratch &s, const uint8_t *d_text, uint64_t text_len, uint64_t
     GCHK(hipStreamSynchronize(st));
     *total = h_ctr->total;
     *nlines = ws.lines ? h_ctr->lines : 0;
+    if (resume)
+        *resume = h_ctr->pad[1];
     return 0;
 }
 

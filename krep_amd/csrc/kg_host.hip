@@ -915,25 +915,28 @@ Family family_of(int algo, bool only_matching, bool lines, bool ww, bool track, 
 }
 } // namespace
 namespace kg {
-// May the text be scanned in pieces (start-offset ownership + halo) whose results are merged?  Not for the sequential
-// families above, and not for multi-pattern -c with a '\n' inside a pattern (emission-order line transitions).
-bool shardable(const search_params_t *p, const krep_gpu_config_t &c, size_t text_len)
+// How may the text be cut?  kSplitPieces: independent pieces (start-offset ownership + halo) whose results merge.
+// kSplitChain: pieces in text order, each taking the boundary record of the one before it (the greedy / -o walks: where the
+// reference's scan stands, krep_gpu_seq_carry_t).  kSplitWhole: one window only — -c through the block-structured bodies
+// (their end-of-text replay), neon_search's max_count == 0 corner, multi-pattern -c with a '\n' inside a pattern
+// (emission-order line transitions).
+int split_mode(const search_params_t *p, const krep_gpu_config_t &c, size_t text_len)
 {
     if (!p || p->use_regex || p->num_patterns == 0)
-        return false;
+        return kSplitWhole;
     if (p->num_patterns > 1)
     {
         if (!p->count_lines_mode)
-            return true;
+            return kSplitPieces;
         for (size_t i = 0; i < p->num_patterns; ++i)
             if (p->pattern_lens[i] && memchr(p->patterns[i], '\n', p->pattern_lens[i]))
-                return false;
-        return true;
+                return kSplitWhole;
+        return kSplitPieces;
     }
     const char *pat = p->patterns && p->pattern_lens ? p->patterns[0] : p->pattern;
     const size_t m = p->patterns && p->pattern_lens ? p->pattern_lens[0] : p->pattern_len;
     if (!pat || m == 0)
-        return true;
+        return kSplitPieces;
     search_params_t q = *p;
     q.pattern = pat;
     q.pattern_len = m;
@@ -944,9 +947,16 @@ bool shardable(const search_params_t *p, const krep_gpu_config_t &c, size_t text
             b = lo8(b);
     const Family fam = family_of(algo, c.only_matching != 0, p->count_lines_mode, p->whole_word, p->track_positions, p->max_count,
                                  pattern_has_border(f.data(), m), (uint32_t)m);
-    return !fam.whole_text();
+    if (fam.replay || fam.neon_zero)
+        return kSplitWhole;
+    return fam.need_walk ? kSplitChain : kSplitPieces;
 }
+bool shardable(const search_params_t *p, const krep_gpu_config_t &c, size_t text_len) { return split_mode(p, c, text_len) != kSplitWhole; }
 } // namespace kg
+extern "C" int krep_gpu_split_mode(const search_params_t *p, size_t text_len)
+{
+    return kg::split_mode(p, kg::current_config(), text_len);
+}
 
 // Where the reference's block loop stands when it enters the last kReplayWindow bytes (kg_replay.h): `cur`, and for
 // neon_search whether the (unterminated) line holding `cur` is already counted.  Uses the per-unit info words the
@@ -1037,10 +1047,12 @@ static int replay_entry(krep_gpu_plan *pl, int algo, const Window &w, const LitR
 }
 
 static int scan_literal(krep_gpu_plan *pl, int algo, const Window &w, match_position_t *d_pos, uint64_t cap, hipStream_t st,
-                        int time_it, krep_gpu_scan_out_t *out)
+                        int time_it, const krep_gpu_seq_carry_t *carry_in, krep_gpu_seq_carry_t *carry_out, krep_gpu_scan_out_t *out)
 {
     const uint32_t m = pl->m;
     memset(out, 0, sizeof *out);
+    if (carry_out)
+        *carry_out = carry_in ? *carry_in : krep_gpu_seq_carry_t{};
     // the reference function sees the WHOLE text: its length decides the delegation and every early-out
     if (m == 0 || w.global_len < m || w.text_len < m || w.own_lo >= w.own_hi)
         return 0;
@@ -1049,9 +1061,12 @@ static int scan_literal(krep_gpu_plan *pl, int algo, const Window &w, match_posi
 
     const Family fam = family_of(algo, pl->only_matching, pl->lines, pl->ww, pl->track, pl->max_count, pl->has_border, m);
     const bool mshort_o = fam.mshort_o, need_walk = fam.need_walk, replay = fam.replay;
-    if (need_walk && !whole)
-        return kg::fail("the greedy / only-matching families couple neighbouring matches: scan the whole text in one window "
-                        "(%s, pattern length %u)", krep_gpu_algorithm_name(algo), m);
+    // the walks couple neighbouring matches: a window that does not start the text needs the boundary record of the text
+    // in front of it (where the reference's scan stands: krep_gpu_seq_carry_t::resume)
+    if (need_walk && !whole && !carry_in && w.global_base + w.own_lo != 0)
+        return kg::fail("the greedy / only-matching families couple neighbouring matches: scan the whole text in one window, or "
+                        "its pieces in text order through krep_gpu_scan_device_seq() (%s, pattern length %u)",
+                        krep_gpu_algorithm_name(algo), m);
 
     // ---- where the block-structured functions put their quirks: positions in the WHOLE text, translated to the buffer
     uint64_t excl_lo = 0, excl_hi = 0, ww_exempt = ~0ull;
@@ -1170,31 +1185,67 @@ static int scan_literal(krep_gpu_plan *pl, int algo, const Window &w, match_posi
     else
     {
         // sequential families on the ordered list (kg_greedy.hip): greedy non-overlapping selection (SSE4.2 / KMP, and BMH
-        // under -o) over all occurrences, or memchr_short's -o walk over the first-byte candidates
+        // under -o) over all occurrences, or memchr_short's -o walk over the first-byte candidates.  A window inside the text
+        // starts where the reference's scan stands (carry_in->resume): starts in front of that point are consumed, the first
+        // one at or behind it is looked at afresh — exactly what the reference's loop does after `advance`.
         const bool ww_first = pl->ww && algo == KREP_RA_BMH; // BMH -o: a -w rejected hit does not consume (krep.c:1323-1329)
+        const uint64_t resume_in = carry_in ? carry_in->resume : 0;
+        size_t lo_eff = w.own_lo;
+        if (resume_in > w.global_base + w.own_lo)
+            lo_eff = (size_t)std::min<uint64_t>(own_hi, resume_in - w.global_base);
         LitPass ps;
-        ps.own_lo = w.own_lo; ps.own_hi = own_hi; ps.sink = LitPass::OCC; ps.post = &pl->post;
+        ps.own_lo = lo_eff; ps.own_hi = own_hi; ps.sink = LitPass::OCC; ps.post = &pl->post;
         ps.first_byte = mshort_o;
         ps.ww = ww_first;
         if (lit_pass(pl, w, ps, st, &lr))
             return 2;
+        uint64_t resume_out = 0;
+        WalkSpec ws{};
+        ws.mode = mshort_o ? kWalkShortO : kWalkGreedy;
+        ws.m = m;
+        ws.ww = pl->ww && !ww_first;
+        ws.lines = pl->lines;
+        ws.ci = !pl->cs;
+        ws.b1 = m > 1 ? pl->pat_folded[1] : 0;
+        ws.b2 = m > 2 ? pl->pat_folded[2] : 0;
         if (lr.total)
         {
-            WalkSpec ws{};
-            ws.mode = mshort_o ? kWalkShortO : kWalkGreedy;
-            ws.m = m;
-            ws.ww = pl->ww && !ww_first;
-            ws.lines = pl->lines;
-            ws.ci = !pl->cs;
-            ws.b1 = m > 1 ? pl->pat_folded[1] : 0;
-            ws.b2 = m > 2 ? pl->pat_folded[2] : 0;
             HIPCHK(hipMemsetAsync(pl->d_ctr, 0, sizeof(Counters), st));
             int rc = post_walk(pl->post, w.d_text, w.text_len, w.global_base, ws, lr.total, (uint64_t *)d_pos, want, pl->d_ctr,
-                               pl->h_ctr, st, &total, &lines);
+                               pl->h_ctr, st, &total, &lines, &resume_out);
             if (rc)
                 return rc;
         }
-        summary = total ? (kLnHead | kLnTail) : 0; // shard line bits are not produced on this path
+        if (carry_out)
+            carry_out->resume = std::max(resume_in, resume_out);
+        summary = total ? (kLnHead | kLnTail) : 0;
+        if (pl->lines && !whole)
+        {
+            // line bits of the owned window for the left-to-right fold over the pieces (krep_gpu_combine_line_counts): is there
+            // a '\n' in [own_lo, own_hi), does a survivor start at or before the first / behind the last one
+            unsigned long long *d_slot = &pl->d_ctr->pad[0], *h_slot = &pl->h_ctr->pad[0];
+            uint64_t first_nl = own_hi, last_p1 = 0;
+            if (tail_find_next_newline(w.d_text, w.own_lo, own_hi, d_slot, h_slot, st, &first_nl))
+                return 2;
+            summary = 0;
+            if (first_nl < own_hi)
+            {
+                if (tail_find_prev_newline(w.d_text, own_hi, d_slot, h_slot, st, &last_p1))
+                    return 2;
+                summary |= kLnNl;
+            }
+            if (total)
+            {
+                uint64_t s_first[2], s_last[2]; // the survivors were compacted into post.d_surv for the line count
+                HIPCHK(hipMemcpy(s_first, pl->post.d_surv, sizeof s_first, hipMemcpyDeviceToHost));
+                HIPCHK(hipMemcpy(s_last, pl->post.d_surv + 2 * (total - 1), sizeof s_last, hipMemcpyDeviceToHost));
+                const uint64_t f = s_first[0] - w.global_base, l = s_last[0] - w.global_base;
+                if (!(summary & kLnNl))
+                    summary |= kLnHead | kLnTail;
+                else
+                    summary |= (f <= first_nl ? kLnHead : 0) | (l >= last_p1 ? kLnTail : 0);
+            }
+        }
     }
     if (time_it)
     {
@@ -1280,14 +1331,17 @@ static int scan_ac_newline_lines(krep_gpu_plan *pl, const Window &w, hipStream_t
     return 0;
 }
 
-extern "C" int krep_gpu_scan_device_ex(krep_gpu_plan_t *pl, const void *d_text, size_t text_len, size_t own_lo, size_t own_hi,
-                                       size_t global_base, size_t global_len, match_position_t *d_positions,
-                                       uint64_t position_capacity, void *stream, int time_it, krep_gpu_scan_out_t *out)
+static int scan_device_impl(krep_gpu_plan_t *pl, const void *d_text, size_t text_len, size_t own_lo, size_t own_hi,
+                            size_t global_base, size_t global_len, match_position_t *d_positions, uint64_t position_capacity,
+                            void *stream, int time_it, const krep_gpu_seq_carry_t *carry_in, krep_gpu_seq_carry_t *carry_out,
+                            krep_gpu_scan_out_t *out)
 {
     krep_gpu_scan_out_t tmp;
     if (!out)
         out = &tmp;
     memset(out, 0, sizeof *out);
+    if (carry_out)
+        *carry_out = carry_in ? *carry_in : krep_gpu_seq_carry_t{};
     if (!pl || (!d_text && text_len))
         return kg::fail("scan_device: bad arguments");
     if (global_len == 0)
@@ -1319,7 +1373,26 @@ extern "C" int krep_gpu_scan_device_ex(krep_gpu_plan_t *pl, const void *d_text, 
         return kg::fail("scan_device: no pattern");
     const int algo = mirror_effective(pl->ref_algo, &pl->sp, global_len);
     Window w{(const uint8_t *)d_text, text_len, own_lo, own_hi, global_base, global_len};
-    return scan_literal(pl, algo, w, d_positions, position_capacity, st, time_it, out);
+    return scan_literal(pl, algo, w, d_positions, position_capacity, st, time_it, carry_in, carry_out, out);
+}
+extern "C" int krep_gpu_scan_device_ex(krep_gpu_plan_t *pl, const void *d_text, size_t text_len, size_t own_lo, size_t own_hi,
+                                       size_t global_base, size_t global_len, match_position_t *d_positions,
+                                       uint64_t position_capacity, void *stream, int time_it, krep_gpu_scan_out_t *out)
+{
+    return scan_device_impl(pl, d_text, text_len, own_lo, own_hi, global_base, global_len, d_positions, position_capacity, stream,
+                            time_it, nullptr, nullptr, out);
+}
+// The pieces of one text, scanned in text order: each call takes the boundary record the previous one left (NULL for the
+// piece that starts the text) and leaves its own.  For the families without a sequential dependency the record passes through.
+extern "C" int krep_gpu_scan_device_seq(krep_gpu_plan_t *pl, const void *d_text, size_t text_len, size_t own_lo, size_t own_hi,
+                                        size_t global_base, size_t global_len, match_position_t *d_positions,
+                                        uint64_t position_capacity, void *stream, int time_it,
+                                        const krep_gpu_seq_carry_t *carry_in, krep_gpu_seq_carry_t *carry_out,
+                                        krep_gpu_scan_out_t *out)
+{
+    krep_gpu_seq_carry_t zero{};
+    return scan_device_impl(pl, d_text, text_len, own_lo, own_hi, global_base, global_len, d_positions, position_capacity, stream,
+                            time_it, carry_in ? carry_in : &zero, carry_out, out);
 }
 extern "C" int krep_gpu_scan_device(krep_gpu_plan_t *pl, const void *d_text, size_t text_len, size_t own_lo, size_t own_hi,
                                     size_t global_base, match_position_t *d_positions, uint64_t position_capacity,

@@ -1,6 +1,9 @@
 // kg_internal.h — internal (C++) interfaces between the translation units of libkrep_gpu.so.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <vector>
+
 #include "../../include/krep_gpu.h"
 #include "kg_common.h"
 
@@ -49,7 +52,7 @@ struct WalkSpec
 };
 int post_walk(PostScratch &s, const uint8_t *d_text, uint64_t text_len, uint64_t global_base, const WalkSpec &ws,
               uint64_t n_occ, uint64_t *d_pos, uint64_t want, Counters *d_ctr, Counters *h_ctr, hipStream_t st,
-              uint64_t *total, uint64_t *nlines);
+              uint64_t *total, uint64_t *nlines, uint64_t *resume);
 
 // kg_tail.hip — end-of-text replay of the block-structured -c paths (kg_replay.h)
 struct ReplayIn;
@@ -77,9 +80,14 @@ krep_gpu_config_t current_config(); // the calling thread's override, else the p
 int mirror_top(const search_params_t *p, const krep_gpu_config_t &c);
 int mirror_effective(int top, const search_params_t *p, size_t text_len);
 const char *unsupported_reason(const search_params_t *p, const krep_gpu_config_t &c); // NULL = accelerated
-bool shardable(const search_params_t *p, const krep_gpu_config_t &c, size_t text_len); // pieces + merge reproduce the result
+constexpr int kSplitWhole = 0, kSplitPieces = 1, kSplitChain = 2; // enum krep_gpu_split (include/krep_gpu.h)
+int split_mode(const search_params_t *p, const krep_gpu_config_t &c, size_t text_len);
+bool shardable(const search_params_t *p, const krep_gpu_config_t &c, size_t text_len); // split_mode != whole
 bool result_reserve(match_result_t *r, uint64_t extra);
 bool have_error();
+
+// kg_comm.hip — the RCCL all-reduce of the per-shard counters (one process driving several devices)
+int allreduce_across_devices(const std::vector<int> &devs, std::vector<std::vector<unsigned long long>> &vecs);
 
 // kg_ops.hip — host-buffer side
 void memchr_batch_quirk(match_position_t *recs, uint64_t have, size_t maxc);

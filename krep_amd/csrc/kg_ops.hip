@@ -402,8 +402,12 @@ struct Piece
     size_t lo = 0, hi = 0; // owned window in the text
     size_t b0 = 0, b1 = 0; // bytes staged: [b0, b1) superset of [lo, hi)
     int device = 0;
+    int shard = 0; // logical shard (one per requested GPU) this piece belongs to
     krep_gpu_scan_out_t out{};
     std::vector<match_position_t> recs;
+    // kSplitChain (the greedy / -o walks): the boundary record this piece was scanned with and the one it leaves
+    uint64_t resume_used = 0;
+    krep_gpu_seq_carry_t carry_out{};
 };
 inline bool rec_less(const match_position_t &a, const match_position_t &b) // emission order of aho_corasick_search
 {
@@ -420,9 +424,40 @@ struct DeviceRun
     const char *buf = nullptr;
     size_t len = 0;
     bool want_pos = false;
+    bool chain = false; // kSplitChain: pieces in text order, each with its predecessor's boundary record
     int rc = 0;
     std::string err;
 };
+
+// one piece, resident in d_text: scan (second pass with an exact buffer when the position buffer was too small), records to
+// the host.  carry_in == NULL: nothing in front of the piece is consumed.
+int scan_one_piece(DeviceCtx &cx, krep_gpu_plan_t *pl, const uint8_t *d_text, Piece *p, size_t global_len, bool want_pos,
+                   const krep_gpu_seq_carry_t *carry_in)
+{
+    const size_t nb = p->b1 - p->b0;
+    uint64_t cap = want_pos ? std::max<uint64_t>(1u << 16, nb / 64) : 0;
+    p->resume_used = carry_in ? carry_in->resume : 0;
+    p->recs.clear();
+    for (int attempt = 0;; ++attempt)
+    {
+        if (cap && cx.pos.ensure(cap * sizeof(match_position_t), cx.device))
+            return 2;
+        if (krep_gpu_scan_device_seq(pl, d_text, nb, p->lo - p->b0, p->hi - p->b0, p->b0, global_len,
+                                     cap ? (match_position_t *)cx.pos.p : nullptr, cap, nullptr, 0, carry_in, &p->carry_out, &p->out))
+            return 2;
+        if (!p->out.overflow || attempt == 1)
+            break;
+        cap = p->out.total_matches + 1;
+    }
+    if (want_pos && p->out.stored)
+    {
+        p->recs.resize(p->out.stored);
+        if (kg::inject(4) ||
+            hipMemcpy(p->recs.data(), cx.pos.p, p->out.stored * sizeof(match_position_t), hipMemcpyDeviceToHost) != hipSuccess)
+            return kg::fail("D2H copy of the records failed");
+    }
+    return 0;
+}
 
 void run_device(DeviceRun *dr)
 {
@@ -517,33 +552,13 @@ void run_device(DeviceRun *dr)
             return;
         }
         Piece *p = dr->pieces[k];
-        const size_t nb = p->b1 - p->b0;
-        uint64_t cap = dr->want_pos ? std::max<uint64_t>(1u << 16, nb / 64) : 0;
-        int rc = 0;
-        for (int attempt = 0;; ++attempt)
-        {
-            if (cap && cx.pos.ensure(cap * sizeof(match_position_t), cx.device))
-            {
-                rc = 2;
-                break;
-            }
-            rc = krep_gpu_scan_device_ex(pl, cx.text[k & 1].p, nb, p->lo - p->b0, p->hi - p->b0, p->b0, dr->len,
-                                         cap ? (match_position_t *)cx.pos.p : nullptr, cap, nullptr, 0, &p->out);
-            if (rc || !p->out.overflow || attempt == 1)
-                break;
-            cap = p->out.total_matches + 1;
-        }
-        if (!rc && dr->want_pos && p->out.stored)
-        {
-            p->recs.resize(p->out.stored);
-            if (kg::inject(4) ||
-                hipMemcpy(p->recs.data(), cx.pos.p, p->out.stored * sizeof(match_position_t), hipMemcpyDeviceToHost) != hipSuccess)
-            {
-                kg::fail("D2H copy of the records failed");
-                rc = 2;
-            }
-        }
-        if (rc)
+        // chain: inside a shard every piece takes its predecessor's boundary record; the FIRST piece of a shard is scanned
+        // optimistically — its left neighbour is another device's work, still running — and checked by run_pieces afterwards
+        // (one rule for every layout: shards that share a device on a small box take the same road as eight devices)
+        const krep_gpu_seq_carry_t *cin = nullptr;
+        if (dr->chain && k > 0 && dr->pieces[k - 1]->shard == p->shard)
+            cin = &dr->pieces[k - 1]->carry_out;
+        if (scan_one_piece(cx, pl, cx.text[k & 1].p, p, dr->len, dr->want_pos, cin))
         {
             dr->err = krep_gpu_last_error();
             finish(false);
@@ -591,11 +606,13 @@ static int run_pieces(const search_params_t *params, const krep_gpu_config_t &cf
             p.b0 = p.lo > ctx ? p.lo - ctx : 0;
             p.b1 = std::min(len, p.hi + ctx);
             p.device = (cfg.device + g) % ndev;
+            p.shard = g;
             pcs.push_back(std::move(p));
             lo += step;
         } while (lo < ghi);
     }
     const bool want_pos = params->track_positions && out != nullptr && !params->count_lines_mode;
+    const bool chain = kg::split_mode(params, cfg, len) == kSplitChain;
     // one worker per PHYSICAL device (several logical shards may share one on a small box)
     std::vector<DeviceRun> runs;
     for (Piece &p : pcs)
@@ -614,6 +631,7 @@ static int run_pieces(const search_params_t *params, const krep_gpu_config_t &cf
             dr->buf = buf;
             dr->len = len;
             dr->want_pos = want_pos;
+            dr->chain = chain;
         }
         dr->pieces.push_back(&p);
     }
@@ -630,15 +648,87 @@ static int run_pieces(const search_params_t *params, const krep_gpu_config_t &cf
     for (auto &r : runs)
         if (r.rc)
             return kg::fail("device %d failed: %s", r.cx->device, r.err.c_str());
-
-    uint64_t total = 0;
-    std::vector<krep_gpu_scan_out_t> outs;
-    for (auto &p : pcs)
+    if (chain)
     {
-        total += p.out.total_matches;
-        outs.push_back(p.out);
+        // The one exchange step of the sequential families: walk the pieces in text order and compare what each
+        // was scanned with against what its left neighbour really left.  They differ only where a cluster of overlapping
+        // occurrences straddles a cut between two devices (the last consumed occurrence reaches < m bytes into the next
+        // shard); that piece is staged and scanned again with the true record — and, should its own record change, the one
+        // behind it.
+        uint64_t true_resume = 0;
+        for (Piece &p : pcs)
+        {
+            if (std::max<uint64_t>(p.resume_used, p.lo) != std::max<uint64_t>(true_resume, p.lo))
+            {
+                DeviceCtx &cx = *ctx_for(p.device);
+                std::lock_guard<std::mutex> lk(cx.mu);
+                search_params_t local = *params;
+                local.max_count = SIZE_MAX;
+                krep_gpu_plan_t *pl = cx.plan_for(&local, cfg);
+                krep_gpu_seq_carry_t cin{};
+                cin.resume = true_resume;
+                if (!pl || cx.text[0].ensure(p.b1 - p.b0 + 64, cx.device) || cx.stager.init(cx.device) ||
+                    cx.stager.copy(cx.text[0].p, buf + p.b0, p.b1 - p.b0) || scan_one_piece(cx, pl, cx.text[0].p, &p, len, want_pos, &cin))
+                    return 2;
+            }
+            true_resume = std::max<uint64_t>(true_resume, p.carry_out.resume);
+        }
     }
-    const uint64_t lines = krep_gpu_combine_line_counts(outs.data(), (int)outs.size());
+
+    // ---- the shards' counters meet: per logical shard one slot {matches, lines, head, tail, has_nl}, each
+    // device fills the slots of its own shards, ONE RCCL all-reduce (uint64 sum over xGMI) makes every device hold all of them
+    // — the sum doubles as the all-gather the left-to-right line fold needs.  The reference's counterpart is the host loop
+    // over thread_args[] (krep.c:2930-3016).  A single shard has nothing to reduce.
+    constexpr size_t kSlot = 5;
+    std::vector<std::vector<unsigned long long>> vecs(runs.size(), std::vector<unsigned long long>(kSlot * (size_t)G, 0ull));
+    for (size_t r = 0; r < runs.size(); ++r)
+        for (int g = 0; g < G; ++g)
+        {
+            std::vector<krep_gpu_scan_out_t> outs;
+            for (Piece *p : runs[r].pieces)
+                if (p->shard == g)
+                    outs.push_back(p->out);
+            if (outs.empty())
+                continue;
+            unsigned long long *slot = &vecs[r][kSlot * (size_t)g];
+            for (auto &o : outs)
+                slot[0] += o.total_matches;
+            slot[1] = krep_gpu_combine_line_counts(outs.data(), (int)outs.size());
+            for (size_t i = 0; i < outs.size(); ++i) // a match before the shard's first newline
+            {
+                slot[2] |= outs[i].head_line_hit;
+                if (outs[i].has_newline)
+                    break;
+            }
+            for (size_t i = outs.size(); i-- > 0;) // ... after its last
+            {
+                slot[3] |= outs[i].tail_line_hit;
+                if (outs[i].has_newline)
+                    break;
+            }
+            for (auto &o : outs)
+                slot[4] |= o.has_newline;
+        }
+    if (G > 1)
+    {
+        std::vector<int> devs;
+        for (auto &r : runs)
+            devs.push_back(r.cx->device);
+        if (kg::allreduce_across_devices(devs, vecs))
+            return 2;
+    }
+    uint64_t total = 0;
+    std::vector<krep_gpu_scan_out_t> shard_outs((size_t)G);
+    for (int g = 0; g < G; ++g)
+    {
+        const unsigned long long *slot = &vecs[0][kSlot * (size_t)g];
+        total += slot[0];
+        shard_outs[g].line_count = slot[1];
+        shard_outs[g].head_line_hit = slot[2] != 0;
+        shard_outs[g].tail_line_hit = slot[3] != 0;
+        shard_outs[g].has_newline = slot[4] != 0;
+    }
+    const uint64_t lines = krep_gpu_combine_line_counts(shard_outs.data(), G);
     const size_t maxc = params->max_count;
     uint64_t ret;
     if (maxc == 0)

@@ -59,6 +59,12 @@ class Engine:
         L.krep_gpu_scan_device_ex.restype = C.c_int
         L.krep_gpu_scan_device_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t,
                                               C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.POINTER(abi.ScanOut)]
+        L.krep_gpu_scan_device_seq.restype = C.c_int
+        L.krep_gpu_scan_device_seq.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t,
+                                               C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.POINTER(abi.SeqCarry),
+                                               C.POINTER(abi.SeqCarry), C.POINTER(abi.ScanOut)]
+        L.krep_gpu_split_mode.restype = C.c_int
+        L.krep_gpu_split_mode.argtypes = [C.POINTER(abi.SearchParams), C.c_size_t]
         L.krep_gpu_match_result_init.restype = C.POINTER(abi.MatchResult)
         L.krep_gpu_match_result_init.argtypes = [C.c_uint64]
         L.krep_gpu_match_result_free.restype = None
@@ -94,6 +100,17 @@ class Engine:
             getattr(L, n).restype = None
             getattr(L, n).argtypes = [C.c_int]
         L.krep_gpu_get_reference_simd.restype = C.c_int
+        L.krep_gpu_comm_unique_id.restype = C.c_int
+        L.krep_gpu_comm_unique_id.argtypes = [C.c_void_p]
+        L.krep_gpu_comm_init_rank.restype = C.c_int
+        L.krep_gpu_comm_init_rank.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.krep_gpu_comm_allreduce_u64.restype = C.c_int
+        L.krep_gpu_comm_allreduce_u64.argtypes = [C.POINTER(C.c_uint64), C.c_int]
+        L.krep_gpu_comm_allreduce_device_u64.restype = C.c_int
+        L.krep_gpu_comm_allreduce_device_u64.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.krep_gpu_comm_destroy.restype = None
+        L.krep_gpu_rccl_calls.restype = C.c_uint64
+        L.krep_gpu_rccl_version.restype = C.c_int
         L.krep_gpu_available.restype = C.c_int
         L.krep_gpu_unavailable_reason.restype = C.c_char_p
         L.krep_gpu_last_status.restype = C.c_int
@@ -167,6 +184,38 @@ class Engine:
 
     def set_num_gpus(self, n: int):
         self.lib.krep_gpu_set_num_gpus(n)
+
+    # ---- the collective of the multi-GPU path, C level (kg_comm.hip: RCCL, dlopen'd on first use) ----
+    def comm_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        if self.lib.krep_gpu_comm_unique_id(buf):
+            raise KrepGpuError("krep_gpu_comm_unique_id failed: " + self.last_error())
+        return buf.raw
+
+    def comm_init_rank(self, id128: bytes, nranks: int, rank: int, device: int):
+        assert len(id128) == 128
+        buf = C.create_string_buffer(id128, 128)
+        if self.lib.krep_gpu_comm_init_rank(buf, nranks, rank, device):
+            raise KrepGpuError("krep_gpu_comm_init_rank failed: " + self.last_error())
+
+    def comm_allreduce(self, values):
+        """ONE ncclAllReduce(uint64, sum) of the rank's counters; returns the summed values."""
+        arr = (C.c_uint64 * len(values))(*[int(v) for v in values])
+        if self.lib.krep_gpu_comm_allreduce_u64(arr, len(values)):
+            raise KrepGpuError("krep_gpu_comm_allreduce_u64 failed: " + self.last_error())
+        return [int(v) for v in arr]
+
+    def comm_destroy(self):
+        self.lib.krep_gpu_comm_destroy()
+
+    def rccl_calls(self) -> int:
+        return int(self.lib.krep_gpu_rccl_calls())
+
+    def rccl_version(self) -> int:
+        return int(self.lib.krep_gpu_rccl_version())
+
+    def split_mode(self, params: abi.Params, text_len: int) -> int:
+        return int(self.lib.krep_gpu_split_mode(params.ref, text_len))
 
     def release_device_resources(self):
         self.lib.krep_gpu_release_device_resources()
@@ -279,6 +328,18 @@ class Plan:
         if rc:
             raise KrepGpuError("krep_gpu_scan_device failed: " + self.eng.last_error())
         return out
+
+    def scan_seq(self, d_text: int, text_len: int, own_lo, own_hi, global_base=0, d_positions: int = 0, capacity: int = 0,
+                 global_len=0, carry_in: "abi.SeqCarry | None" = None):
+        """krep_gpu_scan_device_seq(): one piece of a text scanned in text order -> (ScanOut, SeqCarry it leaves)."""
+        out, cout = abi.ScanOut(), abi.SeqCarry()
+        rc = self.eng.lib.krep_gpu_scan_device_seq(self.h, C.c_void_p(d_text), text_len, own_lo, own_hi, global_base, global_len,
+                                                   C.c_void_p(d_positions) if d_positions else None, capacity, None, 0,
+                                                   C.byref(carry_in) if carry_in is not None else None, C.byref(cout),
+                                                   C.byref(out))
+        if rc:
+            raise KrepGpuError("krep_gpu_scan_device_seq failed: " + self.eng.last_error())
+        return out, cout
 
     def close(self):
         if self.h:

@@ -15,5 +15,7 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def oracle_engine():
+    """The parity checker of the `-m gpu` tests: the compiled, unmodified reference (oracle/_ref/libkrep_ref_*.so), function
+    by function; the restatement (oracle/krep_oracle.c, pinned to it differentially) under -o and where a build is absent."""
     import oracle_lib
-    return oracle_lib.oracle()
+    return oracle_lib.checker()

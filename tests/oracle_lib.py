@@ -203,6 +203,61 @@ def ref(level: int):
     return _cache[level]
 
 
+# which compiled reference build a direct function call goes to: every _ref library holds the same source, so any build
+# that exports the function is the reference for it; spread over all five so that each is exercised
+_DIRECT = {abi.RA_BMH: (abi.REF_SCALAR, abi.REF_SSE42), abi.RA_KMP: (abi.REF_SCALAR, abi.REF_SSE42),
+           abi.RA_MEMCHR: (abi.REF_SSE42, abi.REF_SCALAR), abi.RA_MEMCHR_SHORT: (abi.REF_SSE42, abi.REF_SCALAR),
+           abi.RA_SSE42: (abi.REF_SSE42, abi.REF_AVX2), abi.RA_AVX2: (abi.REF_AVX2, abi.REF_AVX512),
+           abi.RA_AHO_CORASICK: (abi.REF_AVX2, abi.REF_SCALAR), abi.RA_AVX512: (abi.REF_AVX512,),
+           abi.RA_NEON: (abi.REF_NEON,)}
+
+
+class Checker:
+    """What the `-m gpu` parity tests compare the HIP path with: the UNMODIFIED reference compiled into oracle/_ref
+    (called function by function), and the restatement only where the compiled reference cannot be asked — under the
+    file-static `only_matching` (-o: not settable through a shared object; pinned against the stock CLI in
+    tests/test_oracle_cli_only_matching.py), or where a build is absent / needs CPU features this host lacks.
+    `direct_calls` / `restatement_calls` say which one answered."""
+
+    def __init__(self):
+        self.o = oracle()
+        self._om = False
+        self.direct_calls = 0
+        self.restatement_calls = 0
+        self.used = set()
+
+    def _direct(self, algo):
+        if self._om:
+            return None
+        for level in _DIRECT.get(algo, ()):
+            r = ref(level)
+            if r is not None and r.has(algo):
+                return r
+        return None
+
+    def call(self, algo, params, text, want_result=True):
+        r = self._direct(algo)
+        if r is not None:
+            self.direct_calls += 1
+            self.used.add(r.name)
+            return r.call(algo, params, text, want_result)
+        self.restatement_calls += 1
+        return self.o.call(algo, params, text, want_result)
+
+    def set_only_matching(self, on: bool):
+        self._om = bool(on)
+        self.o.set_only_matching(on)
+
+    def __getattr__(self, name):  # select(), lib, fn, ... of the restatement
+        return getattr(self.o, name)
+
+
+def checker() -> Checker:
+    if "chk" not in _cache:
+        _cache["chk"] = Checker()
+    return _cache["chk"]
+
+
 def ref_cli() -> str | None:
     p = os.path.join(REF_DIR, "krep")
     return p if os.path.exists(p) and {"avx2", "sse4_2"} <= _cpu_flags() else None

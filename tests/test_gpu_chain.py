@@ -1,0 +1,195 @@
+"""The SEQUENTIAL match-set families cut into pieces (SURVEY §8e "one boundary record per shard ... one exchange step"):
+greedy non-overlapping selection of a bordered pattern (simd_sse42_search krep.c:4839-4848, kmp_search :1741,
+boyer_moore_search under -o :1371) and memchr_short_search's -o walk (:4495).  Across a cut the whole coupling is where the
+reference's scan stands (krep_gpu_seq_carry_t::resume); shards on different devices start optimistically and the one whose
+assumption was wrong is re-scanned.  Every layout must give the single-chunk reference result, offsets and order included.
+Also here: the C-level RCCL all-reduce of the shard counters really runs (1-rank self-tests on a 1-GPU box)."""
+import numpy as np
+import pytest
+
+import cases
+import oracle_lib as ol
+from krep_amd import abi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import krep_amd
+    e = krep_amd.load()
+    assert e.device_count() >= 1
+    yield e
+    e.set_stream_chunk(0)
+    e.set_reference_simd(abi.REF_AVX2)
+
+
+# (level, pattern, params kwargs, only_matching) — every family that needs the chain, plus neighbours that do not
+JOBS = [
+    (abi.REF_AVX2, b"abab", dict(), False),                                # simd_sse42_search, greedy, border 2
+    (abi.REF_AVX2, b"aa", dict(), False),                                  # ... border 1: runs of a's are one giant cluster
+    (abi.REF_AVX2, b"aba", dict(whole_word=True), False),                  # -w after the selection: a rejected hit consumes
+    (abi.REF_AVX2, b"abab", dict(count_lines=True, whole_word=True), False),  # -c -w: distinct lines among the survivors
+    (abi.REF_AVX2, b"aa", dict(max_count=700), False),
+    (abi.REF_SCALAR, b"abab", dict(), False),                              # kmp_search (repetitive, m < 8)
+    (abi.REF_SCALAR, b"aaa", dict(max_count=300), False),                  # ... and its (max_count+1)-th record
+    (abi.REF_AVX2, b"ab", dict(case_sensitive=False), True),               # memchr_short_search under -o
+    (abi.REF_AVX2, b"aba", dict(case_sensitive=False), True),              # ... m = 3
+    (abi.REF_AVX2, b"ab", dict(case_sensitive=False, whole_word=True), True),
+    (abi.REF_AVX2, b"abab", dict(case_sensitive=False), True),             # boyer_moore_search under -o: greedy
+    (abi.REF_AVX2, b"aabaa", dict(case_sensitive=False, whole_word=True), True),  # ... -w BEFORE the selection
+    (abi.REF_AVX2, b"abba", dict(), True),                                 # SSE4.2 under -o: all occurrences (no chain)
+]
+
+
+def _text(rng, n, cuts):
+    text = cases.rand_text(rng, n, b"aab _\n")
+    text[: n // 3] = cases.rand_text(rng, n // 3, b"ab")  # a third of it is one dense field of overlapping occurrences
+    for c in cuts:  # runs and periodic stretches across every cut: clusters that straddle it by every phase
+        for k, run in enumerate((b"a" * 61, b"ab" * 33, b"aab" * 21, b"abba" * 9)):
+            s = c - 17 - 5 * k + (k % 2) * 40
+            if 0 <= s and s + len(run) <= n:
+                text[s:s + len(run)] = np.frombuffer(run, dtype=np.uint8)
+    return text
+
+
+def _want(o, gpu, level, pat, kw, om, text):
+    gpu.set_reference_simd(level)
+    p = abi.Params([pat], **kw)
+    algo = gpu.mirror_select(p, text.size)
+    chk = o
+    o.set_only_matching(om)
+    try:
+        return algo, chk.call(algo, abi.Params([pat], **kw), text)
+    finally:
+        o.set_only_matching(False)
+
+
+def _compare(gpu, level, pat, kw, om, text, want, shards, tag):
+    gpu.set_reference_simd(level)
+    p = abi.Params([pat], **kw)
+    rc, cnt, pos = gpu.search_buffer(p, text, only_matching=om, num_gpus=shards)
+    want_ret, want_pos = want
+    maxc = kw.get("max_count", abi.SIZE_MAX)
+    if kw.get("count_lines") and not om:
+        assert cnt == min(want_ret, maxc), (tag, pat, kw, om, shards, cnt, want_ret)
+    else:
+        keep = min(len(want_pos), maxc)
+        assert len(pos) == keep and np.array_equal(pos, want_pos[:keep]), (tag, pat, kw, om, shards, len(pos), keep)
+
+
+@pytest.mark.parametrize("shards", [2, 3, 8])
+def test_sharded_sequential_families_equal_the_whole_text(gpu, oracle_engine, shards):
+    rng = np.random.RandomState(500 + shards)
+    n = 300_007
+    share = (n + shards - 1) // shards
+    text = _text(rng, n, [g * share for g in range(1, shards)])
+    chains = 0
+    for level, pat, kw, om in JOBS:
+        algo, want = _want(oracle_engine, gpu, level, pat, kw, om, text)
+        cfg = gpu.default_config()
+        cfg.reference_simd, cfg.only_matching = level, int(om)
+        gpu.set_thread_config(cfg)
+        try:
+            chains += gpu.split_mode(abi.Params([pat], **kw), n) == abi.SPLIT_CHAIN
+        finally:
+            gpu.set_thread_config(None)
+        _compare(gpu, level, pat, kw, om, text, want, shards, "sharded")
+        _compare(gpu, level, pat, kw, om, text, want, 1, "one piece")
+    assert chains >= 10  # the families above really take the chained road
+
+
+def test_streamed_sequential_families_equal_the_whole_text(gpu, oracle_engine):
+    """The same through the streamed host path: 1 MiB pieces on one device (every piece takes its predecessor's record), and
+    1 MiB pieces of three shards (the first piece of a shard is optimistic)."""
+    rng = np.random.RandomState(77)
+    n = 5 * (1 << 20) + 12345
+    text = _text(rng, n, [k << 20 for k in range(1, 6)] + [(n + 2) // 3, 2 * ((n + 2) // 3)])
+    gpu.set_stream_chunk(1 << 20)
+    try:
+        for level, pat, kw, om in JOBS:
+            algo, want = _want(oracle_engine, gpu, level, pat, kw, om, text)
+            _compare(gpu, level, pat, kw, om, text, want, 1, "streamed")
+            _compare(gpu, level, pat, kw, om, text, want, 3, "streamed x3")
+    finally:
+        gpu.set_stream_chunk(0)
+
+
+def test_a_text_that_is_one_cluster(gpu, oracle_engine):
+    """'aaaa...' under 'aa': one cluster from the first byte to the last — every optimistic shard start is wrong whenever the
+    shard offset is odd, and the correction of one piece changes the record of the next."""
+    n = 200_001
+    text = np.full(n, ord("a"), dtype=np.uint8)
+    for shards in (2, 3, 7):
+        for level, pat, kw, om in ((abi.REF_AVX2, b"aa", dict(), False), (abi.REF_AVX2, b"aaa", dict(), False),
+                                   (abi.REF_AVX2, b"aa", dict(case_sensitive=False), True)):
+            algo, want = _want(oracle_engine, gpu, level, pat, kw, om, text)
+            _compare(gpu, level, pat, kw, om, text, want, shards, "one cluster")
+
+
+def test_device_windows_with_the_boundary_record(gpu, oracle_engine):
+    """krep_gpu_scan_device_seq(): windows of a resident text in text order; a window inside the text without a record is
+    refused by the plain entry point, and an optimistic scan (carry_in = NULL) differs exactly when a cluster straddles."""
+    import torch
+    import krep_amd
+    gpu.set_reference_simd(abi.REF_AVX2)
+    text = np.frombuffer(b"ababababab " * 1000 + b"a" * 999, dtype=np.uint8).copy()
+    d = torch.from_numpy(text).cuda()
+    n = text.size
+    for pat in (b"abab", b"aa"):
+        plan = gpu.plan(abi.Params([pat]))
+        want = oracle_engine.call(gpu.mirror_select(abi.Params([pat]), n), abi.Params([pat]), text)
+        whole = plan.scan(d.data_ptr(), n)
+        assert whole.count == want[0]
+        with pytest.raises(krep_amd.KrepGpuError):
+            plan.scan(d.data_ptr(), n, 5003, n)  # no record: refused, never approximated
+        cuts = [0, 1, 4099, 5003, 11_002, 11_503, n]
+        pos = torch.zeros(2 * 20_000, dtype=torch.int64, device="cuda")
+        got, carry = [], None
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            o, carry = plan.scan_seq(d.data_ptr(), n, lo, hi, 0, pos.data_ptr(), 20_000, carry_in=carry)
+            got.append(pos[: 2 * o.stored].cpu().numpy().astype(np.uint64).reshape(-1, 2))
+        assert np.array_equal(np.concatenate(got), want[1]), pat
+        plan.close()
+
+
+def test_rccl_all_reduce_really_runs(gpu, oracle_engine):
+    """The shard counters meet in ONE ncclAllReduce issued from C (kg_comm.hip).  1-GPU box: a clique of one device."""
+    assert gpu.rccl_version() > 0
+    rng = np.random.RandomState(3)
+    text = cases.rand_text(rng, 200_003, b"abcd \n")
+    gpu.set_reference_simd(abi.REF_AVX2)
+    for pats, kw in (([b"abcd"], dict()), ([b"d"], dict(count_lines=True)), ([b"ab", b"bcd", b"d a"], dict())):
+        p = abi.Params(pats, **kw)
+        algo = abi.RA_AHO_CORASICK if len(pats) > 1 else gpu.mirror_select(p, text.size)
+        want = oracle_engine.call(algo, abi.Params(pats, **kw), text)
+        before = gpu.rccl_calls()
+        rc, cnt, pos = gpu.search_buffer(p, text, num_gpus=3)
+        assert gpu.rccl_calls() == before + 1, "search_buffer(num_gpus=3) must issue exactly one all-reduce"
+        assert cnt == want[0] if kw.get("count_lines") else np.array_equal(pos, want[1])
+        before = gpu.rccl_calls()
+        gpu.search_buffer(p, text, num_gpus=1)
+        assert gpu.rccl_calls() == before  # a single shard has nothing to reduce
+    # the search_func_t operators shard by configuration (the reference CLI: KREP_GPU_NUM)
+    gpu.set_num_gpus(4)
+    try:
+        before = gpu.rccl_calls()
+        p = abi.Params([b"abcd"])
+        got = gpu.search(p, text)
+        want = oracle_engine.call(gpu.mirror_select(p, text.size), abi.Params([b"abcd"]), text)
+        assert gpu.rccl_calls() == before + 1 and got[0] == want[0] and np.array_equal(got[1], want[1])
+    finally:
+        gpu.set_num_gpus(1)
+
+
+def test_rank_communicator_one_rank(gpu):
+    """The one-process-per-GPU entry points bench.py uses: unique id -> init_rank -> all-reduce -> destroy."""
+    ident = gpu.comm_unique_id()
+    assert len(ident) == 128
+    gpu.comm_init_rank(ident, 1, 0, 0)
+    try:
+        before = gpu.rccl_calls()
+        assert gpu.comm_allreduce([5, 7, 2**40 + 3]) == [5, 7, 2**40 + 3]
+        assert gpu.rccl_calls() == before + 1
+    finally:
+        gpu.comm_destroy()

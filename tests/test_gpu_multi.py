@@ -131,8 +131,9 @@ def test_bench_rank_scheme_reproduces_the_single_buffer(gpu, workload):
 
 
 def test_partial_windows_refused_for_sequential_families(gpu):
-    """A bordered pattern through simd_sse42_search is a greedy chain over neighbouring occurrences: a partial ownership
-    window cannot reproduce it, and says so instead of returning an approximation."""
+    """A bordered pattern through simd_sse42_search is a greedy chain over neighbouring occurrences: a window INSIDE the text
+    cannot reproduce it without the boundary record of the text in front of it (krep_gpu_scan_device_seq,
+    tests/test_gpu_chain.py), and the plain entry point says so instead of returning an approximation."""
     import torch
     import krep_amd
     gpu.set_reference_simd(abi.REF_AVX2)
@@ -142,5 +143,7 @@ def test_partial_windows_refused_for_sequential_families(gpu):
     whole = plan.scan(d.data_ptr(), text.size)
     assert whole.count == 2000
     with pytest.raises(krep_amd.KrepGpuError):
-        plan.scan(d.data_ptr(), text.size, 0, 5000)
+        plan.scan(d.data_ptr(), text.size, 5000, text.size)
+    head = plan.scan(d.data_ptr(), text.size, 0, 5000)  # the piece that starts the text needs no record
+    assert head.count == 2 * (5000 // 11) + (1 if 5000 % 11 > 0 else 0) + (1 if 5000 % 11 > 4 else 0)
     plan.close()
