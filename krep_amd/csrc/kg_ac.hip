@@ -42,19 +42,6 @@ namespace kg {
 // pattern's final 4-gram (a match ends at the tested position t), the 4-gram one byte earlier (the match ends at t + 1;
 // for a 4-byte pattern that gram has an unknown first byte: all 32 classes are set).  Half the LDS lookups — the
 // bank-conflict wall of 4.2 — and half the lookup VALU; a candidate verifies both ends, with both probes in flight.
-// the streaming load of the filter: 16 B per lane.  KG_AC_NT (experiment): non-temporal, so that the stream does not
-// evict the verifier's table buckets from L2
-__device__ __forceinline__ uint4 ac_ld16(const uint4 *p)
-{
-#ifdef KG_AC_NT
-    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
-    return make_uint4(v.x, v.y, v.z, v.w);
-#else
-    return *p;
-#endif
-}
-
 template <bool CI, bool LINES, bool SHORT, int STRIDE>
 __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
 {
@@ -159,7 +146,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
         {
 #pragma unroll
             for (int j = 0; j < kCells; ++j)
-                d[j] = ac_ld16(src + j * kWave);
+                d[j] = src[j * kWave]; // (temporal on purpose: non-temporal stream loads measured 7.45 vs 6.87 ms, the verifier's text windows hit in cache)
         }
         // the next round of this ticket, if it is a full one, streams in behind this one
         // (not in the -c variant of the stride-2 kernel: with the prefetch registers live across the verify stage it
@@ -302,7 +289,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 u32 t[5];
                 t[1] = ac_pair(d[j].x); t[2] = ac_pair(d[j].y); t[3] = ac_pair(d[j].z); t[4] = ac_pair(d[j].w);
                 const u32 last = d[j].w;
-                d[j] = ac_ld16(nsrc + j * kWave);
+                d[j] = nsrc[j * kWave];
                 t[0] = (u32)__builtin_amdgcn_update_dpp((int)ac_pair(before), (int)t[4], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
                 before = __builtin_amdgcn_readlane(last, 63);
 #pragma unroll
@@ -338,7 +325,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
             {
                 u32 W[5];
                 W[1] = d[j].x; W[2] = d[j].y; W[3] = d[j].z; W[4] = d[j].w;
-                d[j] = ac_ld16(nsrc + j * kWave);
+                d[j] = nsrc[j * kWave];
                 {
                     // the class word of the 4 bytes in front of the lane = the left neighbour's last one: a DPP wave shift
                     // (lane 0 keeps `old` = the classes of `before`, uniform: scalar ALU) — no LDS permute, no branch

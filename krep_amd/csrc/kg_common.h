@@ -71,7 +71,8 @@ struct LitArgs {
                                   // is the C-locale case-insensitive compare of that byte (one OR instead of folding the text)
     const uint8_t *pat;           // device copy of the (folded) pattern, for m > 8
     const unsigned long long *pat_chunks; // m > 8: (folded) pattern bytes [q_k, q_k + 8), q_k = min(8 + 8k, m - 8), 8-byte aligned
-    uint32_t n_chunks;            //   ceil((m - 8) / 8) of them: scalar loads for the verify (an unaligned pattern read is a vector load)
+    uint32_t n_chunks;            //   ceil((m - 8) / 8) of them: scalar loads for the verify (an unaligned pattern read is a vector load);
+                                  //   followed by n_chunks letter masks (0x20 where the folded pattern holds a letter, F_CI)
     unsigned long long *unitinfo; // [num_tiles * 4] per-unit info words (F_POS | F_LINES)
     Counters *ctr;
     uint64_t *stage;              // [num_tiles * 4 * stage_cap] ordered start offsets per unit (F_POS, scan mode)

@@ -589,9 +589,16 @@ extern "C" krep_gpu_plan_t *krep_gpu_plan_create_ex(const search_params_t *p, co
         if (ok && pl->m > 8)
         {
             pl->n_chunks = (pl->m - 8 + 7) / 8;
-            std::vector<unsigned long long> ch(pl->n_chunks);
+            std::vector<unsigned long long> ch(2 * pl->n_chunks, 0ull); // pattern words, then their letter masks (-i)
             for (uint32_t k = 0; k < pl->n_chunks; ++k)
-                memcpy(&ch[k], pl->pat_folded.data() + std::min<uint32_t>(8 + 8 * k, pl->m - 8), 8);
+            {
+                const uint8_t *src = pl->pat_folded.data() + std::min<uint32_t>(8 + 8 * k, pl->m - 8);
+                memcpy(&ch[k], src, 8);
+                uint8_t l[8];
+                for (int b = 0; b < 8; ++b)
+                    l[b] = (!pl->cs && src[b] >= 'a' && src[b] <= 'z') ? 0x20 : 0;
+                memcpy(&ch[pl->n_chunks + k], l, 8);
+            }
             ok = hipMalloc(&pl->d_pat_chunks, ch.size() * 8) == hipSuccess &&
                  hipMemcpy(pl->d_pat_chunks, ch.data(), ch.size() * 8, hipMemcpyHostToDevice) == hipSuccess;
         }
@@ -804,6 +811,42 @@ static int lit_pass(krep_gpu_plan *pl, const Window &w, const LitPass &ps, hipSt
     const int fsc = g_force_stage_cap.load(std::memory_order_relaxed);
     if (fsc && (a.flags & F_POS))
         a.stage_cap = (uint32_t)fsc;
+    const uint32_t grid = (uint32_t)pl->num_cu; // the launchers size the grid: resident blocks of the chosen variant x CUs
+    const uint64_t unit_bytes = (uint64_t)a.rounds * kSegBytes, origin = a.anchor + w.global_base;
+    res->n_units = n_units;
+    res->unit_bytes = unit_bytes;
+    res->anchor = a.anchor;
+    // ---- single byte with records (memchr_search, BASELINE config 3): ONE pass, the records written by the scanning waves
+    // at their final index (kg_single.hip) — no staging, no info words, no post-pass.  Too dense for its LDS rings (> ~1.5 %
+    // hits): counted but not recorded; the two-pass kernels below take this scan and the plan's later ones.
+    if (m_scan == 1 && ps.sink == LitPass::RECORDS && !ps.ww && !ps.lines && !ps.first_byte && a.rounds == kRoundsBig && fsc == 0 &&
+        ps.excl_lo == ps.excl_hi && pl->fused1_ok && w.text_len >= 2 * (size_t)kSegBytes && !getenv("KREP_GPU_NO_FUSED1"))
+    {
+        const uint64_t n_tk = single_fused_tickets(n_units);
+        if (n_tk > post.tk_cap)
+        {
+            if (post.d_tk) (void)hipFree(post.d_tk);
+            post.d_tk = nullptr;
+            post.tk_cap = 0;
+            HIPCHK(hipMalloc(&post.d_tk, 2 * n_tk * sizeof(unsigned long long)));
+            post.tk_cap = n_tk;
+        }
+        a.positions = ps.d_out;
+        a.pos_cap = ps.out_cap;
+        HIPCHK(hipMemsetAsync(pl->d_ctr, 0, sizeof(Counters), st));
+        HIPCHK(hipMemsetAsync(post.d_tk, 0, 2 * n_tk * sizeof(unsigned long long), st));
+        HIPCHK(launch_single_fused(a, post.d_tk, post.d_tk + n_tk, n_tk, grid, st));
+        if (ps.ev_end) HIPCHK(hipEventRecord(ps.ev_end, st));
+        HIPCHK(hipMemcpyAsync(pl->h_ctr, pl->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (!pl->h_ctr->overflow_units)
+        {
+            res->total = pl->h_ctr->total;
+            res->summary = res->total ? (kLnHead | kLnTail) : 0;
+            return 0;
+        }
+        pl->fused1_ok = false;
+    }
     if (chain)
     {
         if (post_reserve(post, n_units, (n_units * a.stage_cap + 3) / 4)) // 16-bit staging entries
@@ -812,12 +855,6 @@ static int lit_pass(krep_gpu_plan *pl, const Window &w, const LitPass &ps, hipSt
         a.stage = (uint64_t *)post.d_stage;
         a.offsets = (const uint64_t *)post.d_offsets;
     }
-    const uint32_t grid = (uint32_t)pl->num_cu; // launch_literal sizes the grid: resident blocks of the chosen variant x CUs
-    const uint64_t unit_bytes = (uint64_t)a.rounds * kSegBytes, origin = a.anchor + w.global_base;
-    res->n_units = n_units;
-    res->unit_bytes = unit_bytes;
-    res->anchor = a.anchor;
-
     HIPCHK(hipMemsetAsync(pl->d_ctr, 0, sizeof(Counters), st));
     if (ps.sink != LitPass::OCC)
     {

@@ -16,6 +16,11 @@ bool inject(int kind);                   // test hook: is failure `kind` being i
 // kg_literal.hip
 hipError_t launch_literal(const LitArgs &a, uint32_t num_cu, hipStream_t st); // grid = resident blocks of the variant x CUs
 
+// kg_single.hip — single byte with records in one pass (counts resolved by one wave, records written a ticket later)
+uint64_t single_fused_tickets(uint64_t n_units);
+hipError_t launch_single_fused(const LitArgs &a, unsigned long long *d_agg, unsigned long long *d_pref, uint64_t n_tickets,
+                               uint32_t num_cu, hipStream_t st);
+
 // kg_post.hip — ordering post-pass shared by the literal and Aho-Corasick scans
 struct PostScratch
 {
@@ -31,6 +36,8 @@ struct PostScratch
     unsigned long long *d_gblk = nullptr;     // compaction block counts
     unsigned long long *d_surv = nullptr;     // compacted survivors (line counting)
     uint64_t keep_cap = 0;
+    unsigned long long *d_tk = nullptr;       // kg_single.hip: per-ticket hit counts | their exclusive prefixes
+    uint64_t tk_cap = 0;                      // in tickets
 };
 void post_free(PostScratch &s);
 int post_reserve(PostScratch &s, uint64_t n_units, uint64_t stage_words);

@@ -45,14 +45,6 @@ __device__ __forceinline__ u64 rfl64(u64 v)
     return ((u64)hi << 32) | lo;
 }
 
-// C-locale tolower on 4 packed bytes: 'A'..'Z' -> +0x20, everything else untouched
-__device__ __forceinline__ u32 fold4(u32 x)
-{
-    u32 t = x & 0x7f7f7f7fu;
-    u32 ge = t + 0x3f3f3f3fu; // bit7 <=> t >= 'A'
-    u32 gt = t + 0x25252525u; // bit7 <=> t >  'Z'
-    return x | ((ge & ~gt & ~x & 0x80808080u) >> 2);
-}
 // 0x80 in every byte of x that equals the byte replicated in c4 (exact, no false positives)
 __device__ __forceinline__ u32 eq_bytes(u32 x, u32 c4)
 {
@@ -314,15 +306,26 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
                     auto A = [&](int k) -> u32 {
                         return ((k & 3) == 0) ? D[k >> 2] : __builtin_amdgcn_alignbyte(D[(k >> 2) + 1], D[k >> 2], (u32)(k & 3));
                     };
+                    // -i, common path: a SUPERSET filter on the window with 0x20 set in every byte, compared with the pattern's
+                    // first word treated the same way — 6 ORs per cell where the exact compare ((x | letter mask) == p, the
+                    // mask aligned to the candidate) costs one per position.  It also passes '@' for '`', '[' for '{' ...; the
+                    // exact compare runs below, in the cells that hold a candidate.
+                    u32 Dq[6];
+#pragma unroll
+                    for (int w = 0; w < 6; ++w)
+                        Dq[w] = CI ? (D[w] | 0x20202020u) : D[w];
+                    auto Aq = [&](int k) -> u32 {
+                        return ((k & 3) == 0) ? Dq[k >> 2] : __builtin_amdgcn_alignbyte(Dq[(k >> 2) + 1], Dq[k >> 2], (u32)(k & 3));
+                    };
+                    const u32 p0q = CI ? (a.p0 | 0x20202020u) : a.p0;
                     u32 A0[16];
                     bool c[16];
                     u64 any = 0;
 #pragma unroll
                     for (int k = 0; k < 16; ++k)
                     {
-                        A0[k] = A(k);
-                        const u32 x0 = CI ? (A0[k] | a.l0) : A0[k];
-                        c[k] = (KIND == 4 && MASKED) ? (((x0 ^ a.p0) & a.k0) == 0u) : (x0 == a.p0);
+                        A0[k] = Aq(k);
+                        c[k] = (KIND == 4 && MASKED) ? (((A0[k] ^ p0q) & a.k0) == 0u) : (A0[k] == p0q);
                         any |= __ballot(c[k]);
                     }
                     if (any) // wave-uniform: almost never taken for a selective 4-byte prefix
@@ -331,9 +334,14 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
                         for (int k = 0; k < 16; ++k)
                         {
                             bool h = c[k];
+                            if (CI)
+                            {
+                                const u32 e0 = A(k) | a.l0; // exact: (x | 0x20 in the pattern's letter lanes) == folded pattern
+                                h = h && ((KIND == 4 && MASKED) ? (((e0 ^ a.p0) & a.k0) == 0u) : (e0 == a.p0));
+                            }
                             if (KIND >= 8)
                             {
-                                const u32 a4 = ((k < 12) ? A0[k + 4] : A(k + 4)) | (CI ? a.l1 : 0u);
+                                const u32 a4 = (CI ? A(k + 4) : ((k < 12) ? A0[k + 4] : A(k + 4))) | (CI ? a.l1 : 0u);
                                 h = h && ((KIND == 8 && MASKED) ? (((a4 ^ a.p1) & a.k1) == 0u) : (a4 == a.p1));
                             }
                             m16 |= h ? (1u << k) : 0u;
@@ -440,9 +448,10 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
                                 for (u32 i = 0; i < W; ++i)
                                 {
                                     const u32 k = g0 + i < last ? g0 + i : last;
-                                    unsigned long long x = t[i];
-                                    if (CI)
-                                        x = (unsigned long long)fold4((u32)x) | ((unsigned long long)fold4((u32)(x >> 32)) << 32);
+                                    // -i: the text is not folded — (x | letter mask) == pattern word is the C-locale compare of the
+                                    // eight bytes (0x20 where the folded pattern holds a letter; the masks follow the pattern
+                                    // words in the same scalar-loaded array): one OR where a SWAR fold cost ~16 VALU per chunk
+                                    const unsigned long long x = CI ? (t[i] | pc[a.n_chunks + k]) : t[i];
                                     diff |= x ^ pc[k];
                                 }
                             };
@@ -450,9 +459,11 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
                                 group(std::integral_constant<u32, 2>{}, 0u);
                             else if (a.n_chunks <= 4u) // m <= 40
                                 group(std::integral_constant<u32, 4>{}, 0u);
-                            else
-                                for (u32 g0 = 0; g0 < a.n_chunks; g0 += 8u)
-                                    group(std::integral_constant<u32, 8>{}, g0);
+                            else if (a.n_chunks <= 8u) // m <= 72
+                                group(std::integral_constant<u32, 8>{}, 0u);
+                            else // sixteen loads in flight, waited for once: two groups of eight cost m = 128 a second round trip per candidate
+                                for (u32 g0 = 0; g0 < a.n_chunks; g0 += 16u)
+                                    group(std::integral_constant<u32, 16>{}, g0);
                             ok = diff == 0;
                         }
                         if (ok && ww)

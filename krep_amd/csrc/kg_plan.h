@@ -38,6 +38,7 @@ struct krep_gpu_plan
     uint32_t sparse_cap = 16; // staging entries per 32 KiB unit of the sparse literal kinds: 16, raised to 64 after a scan whose
                               // units overflowed (see lit_pass); one 32-byte slot per unit keeps the store stream dense
     uint32_t ac_cap = 16;     // the same for the multi-pattern scan (16 KiB units)
+    bool fused1_ok = true;    // single byte with records: the one-pass kernel (kg_single.hip) until a scan proves too dense for it
     kg::PostScratch aux;  // small auxiliary passes that must not disturb `post` (end-of-text replay)
     search_params_t sp{}; // shallow copy with patterns pointing into `pats`
     std::vector<const char *> pat_ptrs;

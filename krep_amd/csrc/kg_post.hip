@@ -329,6 +329,7 @@ void post_free(PostScratch &s)
     if (s.d_keep) (void)hipFree(s.d_keep);
     if (s.d_gblk) (void)hipFree(s.d_gblk);
     if (s.d_surv) (void)hipFree(s.d_surv);
+    if (s.d_tk) (void)hipFree(s.d_tk);
     s = PostScratch{};
 }
 

@@ -1,0 +1,373 @@
+// kg_single.hip — memchr_search (krep.c:3891-4041) with its match_position_t records in ONE pass over the text (gfx950).
+//
+// A single byte at 1 % density (BASELINE config 3: 343.6 M records per 32 GiB) is the worst case of the two-pass scheme of
+// kg_literal.hip + kg_post.hip: the scan stages 0.7 GB of unit-relative offsets, publishes 1 M info words, and a second
+// kernel turns the staging into 5.5 GB of records — 5.8-6.9 ms of scan (depending on where the driver places the staging
+// stores) plus 1.4 ms of gather for a workload whose bytes (34.4 GB read + 5.5 GB written) fit into ~6 ms.
+// Here the records are written by the wave that found the hits, at their FINAL index, and nothing else is stored:
+//   * a wave draws a ticket of kUpt units (128 KiB), scans it exactly as lit_scan<1> does (SWAR byte equality, 16 start
+//     positions per lane in registers) and puts every hit, already ranked inside the ticket (ballot bit-planes + v_mbcnt),
+//     as a 16-bit unit-relative offset into its LDS ring — nothing goes to memory while it streams;
+//   * it publishes the ticket's hit count (one 8-byte store) and goes on to the NEXT ticket;
+//   * one RESOLVER wave (wave 0 of block 0; it does not scan) turns the published counts, 256 tickets per step, into their
+//     exclusive prefix — the global index of each ticket's first record;
+//   * only after scanning that next ticket (~80 us later) does the wave pick up its previous ticket's prefix — by then the
+//     resolver has long passed it, nobody waits — and writes that ticket's records from the ring: coalesced 1-KiB stores,
+//     21 KiB per ticket, ascending with the ticket number.
+// This is the chained scan that round 1 measured at 2.9 TB/s (every tile waited for its predecessor's status) with the wait
+// taken out of it: counts flow forward through one wave, the consumers are a whole ticket period behind.
+// Residency: the grid is exactly the resident blocks (as for every kernel of this library), so the resolver and every wave
+// that holds a ticket are running; a wave publishes its count BEFORE it waits for anything, so no wait can be circular.
+// A ticket with more hits than the ring holds (denser than ~1.5 %) raises ctr->overflow_units: the host falls back to the
+// two-pass kernels for that scan and for the plan's later ones.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdlib>
+#include "kg_common.h"
+#include "kg_internal.h"
+
+namespace kg {
+
+using u32 = uint32_t;
+using u64 = unsigned long long;
+
+constexpr u32 kUpt = 4;                       // units (32 KiB each) per ticket: 128 KiB
+constexpr u32 kRing = 4096;                   // 16-bit entries per wave (8 KiB): the ticket being scanned + the one waiting
+constexpr u64 kReady = 1ull << 63;
+constexpr u32 kResolveChunk = 4;              // tickets per resolver lane and step (256 per wave step)
+constexpr u64 kUnitBytes1 = (u64)kRoundsBig * kSegBytes;
+
+__device__ __forceinline__ u32 s_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ u32 s_mbcnt(u64 m) { return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)); }
+__device__ __forceinline__ u64 s_rfl64(u64 v)
+{
+    const u32 lo = __builtin_amdgcn_readfirstlane((u32)v), hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u32 s_eq_bytes(u32 x, u32 c4)
+{
+    const u32 y = x ^ c4;
+    const u32 t = (y & 0x7f7f7f7fu) + 0x7f7f7f7fu;
+    return ~(t | y | 0x7f7f7f7fu);
+}
+__device__ __forceinline__ u32 s_movemask4(u32 t) { return (((t >> 7) * 0x00204081u) >> 21) & 0xfu; }
+
+// the (at most one) round that touches the end of the buffer: byte-wise, bounds-checked, out of line
+__device__ __noinline__ uint4 s_load16_guarded(const uint8_t *text, u64 text_len, u64 off)
+{
+    u32 w[4] = {0, 0, 0, 0};
+    for (u32 b = 0; b < 16; ++b)
+        if (off + b < text_len)
+            w[b >> 2] |= (u32)text[off + b] << (8 * (b & 3u));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+template <bool CI>
+__global__ __launch_bounds__(kBlock, 4) void single_fused(const LitArgs a, u64 *__restrict__ agg, u64 *__restrict__ pref,
+                                                          const u64 n_tickets)
+{
+    const u32 lane = s_lane();
+    const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const u64 n_units = a.num_tiles * kWavesPerBlk;
+
+    // ---- the resolver: counts -> exclusive prefixes, in ticket order ----------------------------------------------------
+    if (blockIdx.x == 0 && wave == 0)
+    {
+        u64 running = 0;
+        for (u64 t0 = 0; t0 < n_tickets; t0 += 64u * kResolveChunk)
+        {
+            const u64 mine = t0 + (u64)lane * kResolveChunk;
+            u64 v[kResolveChunk];
+            for (;;)
+            {
+                bool ok = true;
+#pragma unroll
+                for (u32 k = 0; k < kResolveChunk; ++k)
+                {
+                    v[k] = mine + k < n_tickets ? __hip_atomic_load(&agg[mine + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kReady;
+                    ok = ok && (v[k] & kReady);
+                }
+                if (__ballot(!ok) == 0ull)
+                    break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+            u64 s = 0;
+#pragma unroll
+            for (u32 k = 0; k < kResolveChunk; ++k)
+                s += v[k] & ~kReady;
+            u64 incl = s;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1)
+            {
+                const u64 up = __shfl_up(incl, o);
+                if (lane >= (u32)o)
+                    incl += up;
+            }
+            u64 e = running + incl - s;
+#pragma unroll
+            for (u32 k = 0; k < kResolveChunk; ++k)
+            {
+                if (mine + k < n_tickets)
+                    __hip_atomic_store(&pref[mine + k], e | kReady, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                e += v[k] & ~kReady;
+            }
+            running += __shfl(incl, 63);
+        }
+        if (lane == 0)
+            a.ctr->total = running;
+        return;
+    }
+
+    __shared__ unsigned short s_ring[kWavesPerBlk][kRing];
+    unsigned short *ring = s_ring[wave];
+    const u64 hi_match = a.own_hi < a.text_len ? a.own_hi : a.text_len; // exclusive start bound (m == 1)
+
+    // the ticket whose records are still in the ring (uniform)
+    bool pend = false;
+    u64 pend_t = 0;
+    u32 pend_at = 0, pend_cnt = 0, pend_c0 = 0, pend_c1 = 0, pend_c2 = 0;
+    u32 wp = 0; // ring write position (uniform, modulo kRing at use)
+    bool overflowed = false;
+
+    auto flush = [&]() __attribute__((always_inline)) {
+        u64 p = 0;
+#ifdef KG_S1_NOWAIT // (ablation build: records at a made-up index, nobody waits for the resolver)
+        p = pend_t * 1400ull;
+#else
+        if (lane == 0)
+        {
+            for (;;)
+            {
+                p = __hip_atomic_load(&pref[pend_t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (p & kReady)
+                    break;
+                __builtin_amdgcn_s_sleep(4);
+            }
+        }
+#endif
+        const u64 first = s_rfl64(p) & ~kReady;
+        const u64 tbase = a.anchor + pend_t * (u64)kUpt * kUnitBytes1 + a.global_base;
+        const u32 b1 = pend_c0, b2 = pend_c0 + pend_c1, b3 = pend_c0 + pend_c1 + pend_c2;
+        // Lanes are mapped to GLOBAL record indices rounded down to 8 (= one 128-byte line), so every store instruction covers
+        // whole lines except at the two ends of the ticket's run; the stores are NON-TEMPORAL: next to the streaming reads that
+        // is worth 9 % of the kernel (tools/ubench/write_ceiling.hip: 34.4 GB read + 5.5 GB written in 7.30 ms with plain
+        // stores, 6.64 ms non-temporal; line-aligned runs another 0.1-0.3 ms).
+        const u32 pad = (u32)(first & 7ull);
+        for (u32 g = lane; g < pend_cnt + pad; g += 64u)
+        {
+            if (g < pad)
+                continue;
+            const u32 i = g - pad;
+            const u32 off = ring[(pend_at + i) & (kRing - 1u)];
+            const u32 unit = (i >= b1 ? 1u : 0u) + (i >= b2 ? 1u : 0u) + (i >= b3 ? 1u : 0u);
+            const u64 idx = first + i;
+#ifdef KG_S1_NOSTORE // (ablation build: everything but the record stores)
+            if (idx == ~0ull)
+#else
+            if (idx < a.pos_cap)
+#endif
+            {
+                const u64 st = tbase + (u64)unit * kUnitBytes1 + off, en = st + 1;
+                typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 rec = {(u32)st, (u32)(st >> 32), (u32)en, (u32)(en >> 32)};
+#ifdef KG_S1_PLAIN_STORES
+                *reinterpret_cast<u32x4 *>(a.positions + 2 * idx) = rec;
+#else
+                __builtin_nontemporal_store(rec, reinterpret_cast<u32x4 *>(a.positions + 2 * idx));
+#endif
+            }
+        }
+        pend = false;
+    };
+
+    // ---- the rounds of a ticket (16 x 8 KiB, contiguous).  The first round of the NEXT ticket is requested before the previous
+    // ticket's records are written, so the flush runs under load latency.  (A rolling prefetch of every next round into a
+    // second register set — 123 instead of 59 VGPRs — was built and measured: 7.23 vs 7.20 ms, nothing; the kernel is bound by
+    // the mixed read/write traffic, not by exposed load latency: without its record stores it runs at 5.4 ms.)  Loads whose
+    // target may not exist are issued unconditionally at a fallback address (uniform select: a conditional load makes the
+    // compiler wait vmcnt(0) at the join); a round that touches the end of the buffer is loaded byte-wise.
+    constexpr u32 kRoundsPerTicket = kUpt * kRoundsBig;
+    constexpr u64 kTicketBytes = (u64)kUpt * kUnitBytes1;
+    const u64 scan_end = a.anchor + n_units * kUnitBytes1 < a.text_len ? a.anchor + n_units * kUnitBytes1 : a.text_len;
+    const u64 fb = (a.text_len - kSegBytes) & ~15ull; // a round that is always inside the buffer (the host guarantees text_len >= 8 KiB):
+                                                      // where a prefetch with nothing to fetch points, so that it stays unconditional
+    auto issue = [&](uint4 (&X)[kCells], u64 seg) __attribute__((always_inline)) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.text + seg) + lane;
+#pragma unroll
+        for (int j = 0; j < kCells; ++j)
+        {
+            typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src + j * kWave));
+            X[j] = make_uint4(v.x, v.y, v.z, v.w);
+        }
+    };
+    u32 cnt = 0;  // hits of the ticket so far (uniform)
+    u32 at = 0, room = 0;
+    auto process = [&](uint4 (&X)[kCells], u64 seg, bool have, u32 rr) __attribute__((always_inline)) {
+        if (!have)
+        {
+            if (seg + kSegBytes <= a.text_len)
+                issue(X, seg);
+            else
+            {
+#pragma unroll
+                for (int j = 0; j < kCells; ++j)
+                    X[j] = s_load16_guarded(a.text, a.text_len, seg + (u64)j * kCellBytes + (u64)lane * 16u);
+            }
+        }
+        const bool interior = seg >= a.own_lo && seg + kSegBytes <= hi_match;
+#pragma unroll
+        for (int j = 0; j < kCells; ++j)
+        {
+            const u32 D[4] = {X[j].x, X[j].y, X[j].z, X[j].w};
+            u32 m16 = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+                m16 |= s_movemask4(s_eq_bytes(CI ? (D[w] | a.l0) : D[w], a.p0)) << (4 * w);
+            if (!interior)
+            {
+                const u64 lbase = seg + (u64)j * kCellBytes + (u64)lane * 16u;
+                const u32 klo = a.own_lo > lbase ? (u32)((a.own_lo - lbase) < 16 ? (a.own_lo - lbase) : 16) : 0u;
+                const u32 khi = hi_match > lbase ? (u32)((hi_match - lbase) < 16 ? (hi_match - lbase) : 16) : 0u;
+                m16 &= khi > klo ? (((1u << khi) - 1u) & ~((1u << klo) - 1u)) : 0u;
+            }
+            if (__ballot(m16 != 0u))
+            {
+                // rank inside the ticket: hits so far (uniform) + exclusive lane prefix, from the same ballot bit-planes
+                const u32 c = __popc(m16);
+                u32 idx = cnt, tot = 0;
+                auto plane = [&](int b) {
+                    const u64 bm = __ballot((c >> b) & 1u);
+                    idx += s_mbcnt(bm) << b;
+                    tot += (u32)__popcll(bm) << b;
+                };
+                plane(0);
+                plane(1);
+                if (__ballot(c > 3u))
+                {
+                    plane(2);
+                    plane(3);
+                    plane(4);
+                }
+                cnt += tot;
+                const u32 rel0 = ((rr & (kRoundsBig - 1u)) * kCells + (u32)j) * kCellBytes + lane * 16u; // unit-relative
+                u32 rest = m16;
+                while (rest)
+                {
+                    const u32 k = __builtin_ctz(rest);
+                    rest &= rest - 1u;
+                    if (idx < room)
+                        ring[(at + idx) & (kRing - 1u)] = (unsigned short)(rel0 + k);
+                    ++idx;
+                }
+            }
+        }
+    };
+
+    uint4 A[kCells];
+    u64 t;
+    {
+        u64 tk = 0;
+        if (lane == 0)
+            tk = __hip_atomic_fetch_add(&a.ctr->ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t = s_rfl64(tk);
+    }
+    bool haveA = t < n_tickets && a.anchor + t * kTicketBytes + kSegBytes <= a.text_len;
+    issue(A, haveA ? a.anchor + t * kTicketBytes : fb);
+    while (t < n_tickets)
+    {
+        const u64 tbase = a.anchor + t * kTicketBytes;
+        at = wp;
+        room = kRing - pend_cnt; // entries this ticket may use while the previous one is still parked
+        cnt = 0;
+        u32 c0 = 0, c1 = 0, c2 = 0, before = 0, units_done = 0; // hits of the ticket's first three units
+#pragma unroll 1
+        for (u32 rr = 0; rr < kRoundsPerTicket; ++rr)
+        {
+            const u64 seg = tbase + (u64)rr * kSegBytes;
+            if (seg >= scan_end)
+                break;
+            process(A, seg, haveA, rr);
+            haveA = false;
+            if ((rr & (kRoundsBig - 1u)) == kRoundsBig - 1u)
+            { // a unit is complete (selects, not an indexed array: that would live in scratch)
+                const u32 cu = cnt - before, uu = rr / kRoundsBig;
+                before = cnt;
+                units_done = uu + 1u;
+                c0 = uu == 0u ? cu : c0;
+                c1 = uu == 1u ? cu : c1;
+                c2 = uu == 2u ? cu : c2;
+            }
+        }
+        {
+            // a ticket cut short by the end of the text: what was found behind the last complete unit belongs to the next one
+            const u32 cu = cnt - before;
+            c0 = units_done == 0u ? cu : c0;
+            c1 = units_done == 1u ? cu : c1;
+            c2 = units_done == 2u ? cu : c2;
+        }
+        if (cnt > room)
+            overflowed = true; // too dense for the ring: counted, not recorded — the host re-runs the two-pass kernels
+        // publish the count BEFORE waiting for anything (see the header: no wait can be circular)
+        if (lane == 0)
+            __hip_atomic_store(&agg[t], (u64)cnt | kReady, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the next ticket, and its first round on the way, before the previous ticket's records are written
+        u64 tk = 0;
+        if (lane == 0)
+            tk = __hip_atomic_fetch_add(&a.ctr->ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const u64 tn = s_rfl64(tk);
+        haveA = tn < n_tickets && a.anchor + tn * kTicketBytes + kSegBytes <= a.text_len;
+        issue(A, haveA ? a.anchor + tn * kTicketBytes : fb);
+        if (pend)
+            flush();
+        if (cnt && cnt <= room)
+        {
+            pend = true;
+            pend_t = t;
+            pend_at = at;
+            pend_cnt = cnt;
+            pend_c0 = c0;
+            pend_c1 = c1;
+            pend_c2 = c2;
+            wp = (at + cnt) & (kRing - 1u);
+        }
+        else
+            pend_cnt = 0;
+        t = tn;
+    }
+    if (pend)
+        flush();
+    if (overflowed && lane == 0)
+        atomicAdd(&a.ctr->overflow_units, 1ull);
+}
+
+// grid = the resident blocks of the instantiation x CUs (never more: see the header on residency)
+template <bool CI>
+static hipError_t launch_fused(const LitArgs &a, u64 *agg, u64 *pref, u64 n_tickets, u32 num_cu, hipStream_t st)
+{
+    static const u32 bpc = [] {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, single_fused<CI>, kBlock, 0) != hipSuccess || n < 1)
+        {
+            (void)hipGetLastError();
+            n = 1;
+        }
+        return (u32)std::min(n, 4);
+    }();
+    // one block more than the tickets need is never useful; at least 1 scanning wave next to the resolver
+    const u64 want = (n_tickets + kWavesPerBlk - 1) / kWavesPerBlk + 1;
+    const u32 grid = (u32)std::max<u64>(1, std::min<u64>(want, (u64)num_cu * bpc));
+    hipLaunchKernelGGL((single_fused<CI>), dim3(grid), dim3(kBlock), 0, st, a, agg, pref, n_tickets);
+    return hipGetLastError();
+}
+
+uint64_t single_fused_tickets(uint64_t n_units) { return (n_units + kUpt - 1) / kUpt; }
+
+hipError_t launch_single_fused(const LitArgs &a, unsigned long long *d_agg, unsigned long long *d_pref, uint64_t n_tickets,
+                               uint32_t num_cu, hipStream_t st)
+{
+    return (a.flags & F_CI) ? launch_fused<true>(a, d_agg, d_pref, n_tickets, num_cu, st)
+                            : launch_fused<false>(a, d_agg, d_pref, n_tickets, num_cu, st);
+}
+
+} // namespace kg
