@@ -199,11 +199,17 @@ def self_launch(args):
 
 
 def traffic_for(name):
+    """(HBM bytes per launch of the dominant kernel, where that figure comes from).  The PMC counters cannot be read from
+    inside this process: the figure is the one the last committed profile round measured for THIS command with separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile_round.sh + tools/collect_profiles.py) — a pointer to that
+    measurement, not a measurement of this run, and the line says so (`traffic_source`)."""
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     try:
-        return json.load(open(tpath)).get(name, {}).get("hbm_bytes_per_launch")
+        ent = json.load(open(tpath)).get(name, {})
+        src = f"profiles/traffic.json[{name}] (round {ent.get('measured_by', '?')}: separate rocprofv3 --pmc passes of this command; not of this run)"
+        return ent.get("hbm_bytes_per_launch"), src
     except Exception:
-        return None
+        return None, None
 
 
 # ---------------------------------------------------------------------------------------------- one workload on this rank
@@ -282,9 +288,11 @@ def run_workload(name, args, eng, buf, dev, rank, world, local, use_dist):
         "value": round(value, 1), "ms_per_step": round(ms_step, 4), "matches": total_matches,
         "matches_per_s": round(total_matches / (dt / args.steps), 1),
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic_for(name),
-                     "kernel": ("kg::ac_scan_kernel" if len(wl["patterns"]) > 1 else "kg::lit_scan")
-                     + " + post-pass, hipEvent-timed on the launch stream",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic_for(name)[0],
+                     "traffic_source": traffic_for(name)[1],
+                     "kernel": ("kg::ac_scan_kernel + post-pass" if len(wl["patterns"]) > 1 else
+                                "kg::single_fused (one pass, records included)" if wl["kind"] == 3 else "kg::lit_scan + post-pass")
+                     + ", hipEvent-timed on the launch stream",
                      # `achieved` uses the AVERAGE launch duration (comparable with rocprofv3's kernel-trace average in
                      # profiles/); the median over the timed steps is next to it
                      "kernel_ms": round(k_avg, 4), "kernel_ms_median": round(k_med, 4),

@@ -279,8 +279,8 @@ int krep_gpu_scan_device(krep_gpu_plan_t *plan, const void *d_text, size_t text_
  * the WHOLE text (the block simd_avx512_search leaves unexamined, krep.c:5171; the first byte of the scalar tail calls,
  * which has no left neighbour for -w, krep.c:5059-5097): with global_len those land where the reference puts them, in
  * whichever shard holds them.  The sequential match-set families (greedy SSE4.2/KMP selection of a bordered pattern,
- * -o through BMH / memchr_short) accept a window inside the text only through krep_gpu_scan_device_seq() below; -c through
- * the AVX-512 / NEON / AVX2 -w block loops needs the END of the text in a whole-text window (krep_gpu_split_mode()). */
+ * -o through BMH / memchr_short; -c through the AVX-512 / AVX2 -w block loops) accept a window inside the text only through
+ * krep_gpu_scan_device_seq() below; -c through neon_search needs the whole text in one window (krep_gpu_split_mode()). */
 int krep_gpu_scan_device_ex(krep_gpu_plan_t *plan, const void *d_text, size_t text_len, size_t own_lo,
                             size_t own_hi, size_t global_base, size_t global_len, match_position_t *d_positions,
                             uint64_t position_capacity, void *stream, int time_it, krep_gpu_scan_out_t *out);
@@ -291,15 +291,25 @@ int krep_gpu_scan_device_ex(krep_gpu_plan_t *plan, const void *d_text, size_t te
  * whole coupling is ONE number: where the reference's scan stands when it enters the right-hand piece. */
 typedef struct krep_gpu_seq_carry
 {
-    uint64_t resume;      /* global offset from which the reference's scan continues: starts in front of it are consumed,
-                             the first occurrence / candidate at or behind it is looked at afresh (0: nothing consumed)   */
-    uint64_t reserved[3]; /* zero */
+    uint64_t resume;      /* greedy / -o walks: global offset from which the reference's scan continues — starts in front of
+                             it are consumed, the first occurrence / candidate at or behind it is looked at afresh (0: nothing
+                             consumed)                                                                                      */
+    /* -c through simd_avx512_search / simd_avx2_search -w (krep.c:5203-5218, :5000-5013): the line-skip history that decides
+     * where the block grid stands when it enters the last 256 bytes of the text (the end-of-text replay, kg_replay.h).
+     * All offsets are global and stored + 1 (0 = none).                                                                    */
+    uint64_t q1;          /* start of the last accepted occurrence in the text so far                                        */
+    uint64_t nl1;         /* first '\n' at or behind it                                                                      */
+    uint64_t local_q1;    /* the same for THIS piece alone: a caller that scanned its pieces out of order (shards on       */
+    uint64_t local_nl1;   /* different devices) folds them afterwards: q1 = local_q1 ? local_q1 : in.q1,                   */
+    uint64_t local_first_nl1; /* nl1 = local_q1 ? local_nl1 : in.nl1 ? in.nl1 : in.q1 ? local_first_nl1 : 0                 */
+    uint64_t reserved[2]; /* zero */
 } krep_gpu_seq_carry_t;
 /* krep_gpu_scan_device_ex() for the pieces of one text IN TEXT ORDER: carry_in = the record the previous piece left
  * (NULL: nothing in front of this window is consumed — the piece that starts the text, or an optimistic first pass of a
  * shard whose left neighbour is still running: compare its assumption with the neighbour's carry_out afterwards and re-run
  * the piece if they differ), carry_out (nullable) = this piece's record.  Families without a sequential dependency pass
- * the record through unchanged. */
+ * the record through unchanged.  For the -c block-loop family only the piece that ENDS the text depends on the record (it
+ * must be at least 4 KiB long); the others only extend it. */
 int krep_gpu_scan_device_seq(krep_gpu_plan_t *plan, const void *d_text, size_t text_len, size_t own_lo, size_t own_hi,
                              size_t global_base, size_t global_len, match_position_t *d_positions, uint64_t position_capacity,
                              void *stream, int time_it, const krep_gpu_seq_carry_t *carry_in, krep_gpu_seq_carry_t *carry_out,
@@ -307,8 +317,8 @@ int krep_gpu_scan_device_seq(krep_gpu_plan_t *plan, const void *d_text, size_t t
 /* How a text of text_len bytes may be cut for `params` under the current configuration. */
 enum krep_gpu_split
 {
-    KREP_GPU_SPLIT_WHOLE = 0,  /* one window only: -c through the block-structured bodies (end-of-text replay),
-                                  neon_search's max_count == 0 corner, multi-pattern -c with a newline inside a pattern   */
+    KREP_GPU_SPLIT_WHOLE = 0,  /* one window only: -c through neon_search (arm64 builds), neon_search's max_count == 0
+                                  corner, multi-pattern -c with a newline inside a pattern                                */
     KREP_GPU_SPLIT_PIECES = 1, /* independent pieces: start-offset ownership + halo, results concatenate / merge          */
     KREP_GPU_SPLIT_CHAIN = 2   /* pieces in text order through krep_gpu_scan_device_seq()                                 */
 };
@@ -355,7 +365,8 @@ int krep_gpu_rccl_version(void);    /* ncclGetVersion(), 0 when librccl cannot b
  *   reference's emission order (end ascending, longest first).
  * All return 0, or 2 with krep_gpu_last_error() set. */
 /* max_offset: upper bound of every start offset in the list (the WHOLE text's length when the records carry a
- * global_base) — the radix key is sized from it. */
+ * global_base) — the radix key is sized from it.  Limit: n <= 2^31 - 1 records (34 GB of match_position_t; the device
+ * radix sort counts its items in an int) — a longer list is refused with an error, never truncated. */
 int krep_gpu_order_by_start(match_position_t *d_positions, uint64_t n, size_t max_offset, void *stream);
 /* records must be relative to d_text[0]; use the _ex form (records minus global_base) for shard lists.  A record outside
  * [global_base, global_base + text_len] gets line number 0. */

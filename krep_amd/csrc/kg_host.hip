@@ -647,6 +647,8 @@ extern "C" void krep_gpu_plan_destroy(krep_gpu_plan_t *pl)
     if (pl->ev0) DBGFREE(hipEventDestroy(pl->ev0));
     if (pl->ev1) DBGFREE(hipEventDestroy(pl->ev1));
     if (pl->ac) ac_free(pl->ac);
+    if (pl->d_nl_rec) DBGFREE(hipFree(pl->d_nl_rec));
+    if (pl->d_nl_ln) DBGFREE(hipFree(pl->d_nl_ln));
     post_free(pl->post);
     post_free(pl->aux);
     delete pl;
@@ -954,9 +956,9 @@ Family family_of(int algo, bool only_matching, bool lines, bool ww, bool track, 
 namespace kg {
 // How may the text be cut?  kSplitPieces: independent pieces (start-offset ownership + halo) whose results merge.
 // kSplitChain: pieces in text order, each taking the boundary record of the one before it (the greedy / -o walks: where the
-// reference's scan stands, krep_gpu_seq_carry_t).  kSplitWhole: one window only — -c through the block-structured bodies
-// (their end-of-text replay), neon_search's max_count == 0 corner, multi-pattern -c with a '\n' inside a pattern
-// (emission-order line transitions).
+// reference's scan stands; -c through simd_avx512_search / simd_avx2_search -w: the line-skip history the end-of-text replay
+// needs — krep_gpu_seq_carry_t).  kSplitWhole: one window only — -c through neon_search (a second level of line history),
+// its max_count == 0 corner, multi-pattern -c with a '\n' inside a pattern (emission-order line transitions).
 int split_mode(const search_params_t *p, const krep_gpu_config_t &c, size_t text_len)
 {
     if (!p || p->use_regex || p->num_patterns == 0)
@@ -984,9 +986,9 @@ int split_mode(const search_params_t *p, const krep_gpu_config_t &c, size_t text
             b = lo8(b);
     const Family fam = family_of(algo, c.only_matching != 0, p->count_lines_mode, p->whole_word, p->track_positions, p->max_count,
                                  pattern_has_border(f.data(), m), (uint32_t)m);
-    if (fam.replay || fam.neon_zero)
+    if (fam.neon_zero || (fam.replay && algo == KREP_RA_NEON))
         return kSplitWhole;
-    return fam.need_walk ? kSplitChain : kSplitPieces;
+    return (fam.need_walk || fam.replay) ? kSplitChain : kSplitPieces;
 }
 bool shardable(const search_params_t *p, const krep_gpu_config_t &c, size_t text_len) { return split_mode(p, c, text_len) != kSplitWhole; }
 } // namespace kg
@@ -998,45 +1000,53 @@ extern "C" int krep_gpu_split_mode(const search_params_t *p, size_t text_len)
 // Where the reference's block loop stands when it enters the last kReplayWindow bytes (kg_replay.h): `cur`, and for
 // neon_search whether the (unterminated) line holding `cur` is already counted.  Uses the per-unit info words the
 // canonical -c pass over [0, X) just left in pl->post.
+// last accepted occurrence with (buffer-relative) start < limit among the starts the canonical -c pass `lr` covered: the last
+// unit reporting hits in its info word, re-scanned with records (pl->aux)
+static int last_accepted_before(krep_gpu_plan *pl, const Window &w, const LitResult &lr, uint64_t own_lo, uint64_t limit,
+                                hipStream_t st, bool *found, uint64_t *q)
+{
+    unsigned long long *d_slot = &pl->d_ctr->pad[0], *h_slot = &pl->h_ctr->pad[0];
+    *found = false;
+    if (limit <= lr.anchor || lr.n_units == 0)
+        return 0;
+    uint64_t lim_units = std::min<uint64_t>(lr.n_units, (limit - lr.anchor + lr.unit_bytes - 1) / lr.unit_bytes);
+    while (lim_units)
+    {
+        uint64_t up1 = 0;
+        if (tail_last_hit(pl->post.d_unitinfo, lim_units, d_slot, h_slot, st, &up1))
+            return 2;
+        if (!up1)
+            return 0;
+        const uint64_t u = up1 - 1, ulo = lr.anchor + u * lr.unit_bytes;
+        LitPass ps;
+        ps.ww = pl->ww;
+        ps.own_lo = std::max<uint64_t>(ulo, own_lo);
+        ps.own_hi = std::min<uint64_t>(ulo + lr.unit_bytes, limit);
+        ps.sink = LitPass::OCC;
+        ps.post = &pl->aux;
+        LitResult r2;
+        if (lit_pass(pl, w, ps, st, &r2))
+            return 2;
+        if (r2.total)
+        {
+            uint64_t rec[2];
+            HIPCHK(hipMemcpy(rec, pl->aux.d_occ + 2 * (r2.total - 1), sizeof rec, hipMemcpyDeviceToHost));
+            *found = true;
+            *q = rec[0] - w.global_base;
+            return 0;
+        }
+        lim_units = u; // every hit of that unit starts at or after `limit`: look further left
+    }
+    return 0;
+}
+
 static int replay_entry(krep_gpu_plan *pl, int algo, const Window &w, const LitResult &lr, uint64_t X, hipStream_t st,
                         uint64_t *cur_out, int *open_out)
 {
     const uint64_t n = w.text_len, B = algo == KREP_RA_AVX512 ? 64 : algo == KREP_RA_AVX2 ? 32 : 16;
     unsigned long long *d_slot = &pl->d_ctr->pad[0], *h_slot = &pl->h_ctr->pad[0];
-    // last accepted occurrence with start < limit (limit <= X): the last unit reporting hits, re-scanned with records
     auto last_accepted_before = [&](uint64_t limit, bool *found, uint64_t *q) -> int {
-        *found = false;
-        if (limit == 0 || lr.n_units == 0)
-            return 0;
-        uint64_t lim_units = std::min<uint64_t>(lr.n_units, (limit - lr.anchor + lr.unit_bytes - 1) / lr.unit_bytes);
-        while (lim_units)
-        {
-            uint64_t up1 = 0;
-            if (tail_last_hit(pl->post.d_unitinfo, lim_units, d_slot, h_slot, st, &up1))
-                return 2;
-            if (!up1)
-                return 0;
-            const uint64_t u = up1 - 1, ulo = lr.anchor + u * lr.unit_bytes;
-            LitPass ps;
-            ps.ww = pl->ww;
-            ps.own_lo = ulo;
-            ps.own_hi = std::min<uint64_t>(ulo + lr.unit_bytes, limit);
-            ps.sink = LitPass::OCC;
-            ps.post = &pl->aux;
-            LitResult r2;
-            if (lit_pass(pl, w, ps, st, &r2))
-                return 2;
-            if (r2.total)
-            {
-                uint64_t rec[2];
-                HIPCHK(hipMemcpy(rec, pl->aux.d_occ + 2 * (r2.total - 1), sizeof rec, hipMemcpyDeviceToHost));
-                *found = true;
-                *q = rec[0] - w.global_base;
-                return 0;
-            }
-            lim_units = u; // every hit of that unit starts at or after `limit`: look further left
-        }
-        return 0;
+        return ::last_accepted_before(pl, w, lr, 0, limit, st, found, q);
     };
     bool have_q = false;
     uint64_t q = 0;
@@ -1149,14 +1159,77 @@ static int scan_literal(krep_gpu_plan *pl, int algo, const Window &w, match_posi
         const uint64_t G = w.global_len, X = G > kReplayWindow ? G - kReplayWindow : 0;
         if (!whole)
         {
-            if (w.global_base + own_hi > X)
-                return kg::fail("-c through %s restarts its block grid at every counted line: the window that reaches the "
-                                "end of the text must be the whole text", krep_gpu_algorithm_name(algo));
-            LitPass ps;
-            ps.ww = pl->ww; ps.lines = true; ps.own_lo = w.own_lo; ps.own_hi = own_hi; ps.post = &pl->post;
-            if (lit_pass(pl, w, ps, st, &lr))
+            // ---- a PIECE of the text (krep_gpu_scan_device_seq).  Only the piece that ends the text runs the replay; what it
+            // needs from the text in front of it is the line-skip history {last accepted occurrence q, first '\n' behind it},
+            // which every piece extends (krep_gpu_seq_carry_t) — the piece's own contribution is reported next to the folded
+            // state, so that shards scanned out of order can be folded afterwards.
+            const uint64_t base = w.global_base, B = algo == KREP_RA_AVX512 ? 64 : 32;
+            const bool final_piece = base + own_hi >= G;
+            if (algo == KREP_RA_NEON)
+                return kg::fail("-c through neon_search keeps a second level of line history: scan the whole text in one window");
+            if (base + w.own_lo != 0 && !carry_in)
+                return kg::fail("-c through %s restarts its block grid at every counted line: scan the whole text in one window, "
+                                "or its pieces in text order through krep_gpu_scan_device_seq()", krep_gpu_algorithm_name(algo));
+            if (final_piece && (base + w.text_len != G || X < base + w.own_lo + B))
+                return kg::fail("-c through %s: the piece that ends the text must hold its last %llu bytes", krep_gpu_algorithm_name(algo),
+                                (unsigned long long)(kReplayWindow + B));
+            const uint64_t lim = final_piece ? X - base : own_hi; // the canonical pass covers the starts in [own_lo, lim)
+            const uint64_t nl_end = final_piece ? w.text_len : own_hi; // where this piece's newline searches stop
+            unsigned long long *d_slot = &pl->d_ctr->pad[0], *h_slot = &pl->h_ctr->pad[0];
+            if (lim > w.own_lo)
+            {
+                LitPass ps;
+                ps.ww = pl->ww; ps.lines = true; ps.own_lo = w.own_lo; ps.own_hi = lim; ps.post = &pl->post;
+                if (lit_pass(pl, w, ps, st, &lr))
+                    return 2;
+            }
+            krep_gpu_seq_carry_t in = carry_in ? *carry_in : krep_gpu_seq_carry_t{}, co = in;
+            co.local_q1 = co.local_nl1 = co.local_first_nl1 = 0;
+            bool have_q = false;
+            uint64_t q = 0;
+            if (lim > w.own_lo && last_accepted_before(pl, w, lr, w.own_lo, lim, st, &have_q, &q))
                 return 2;
+            if (have_q)
+            {
+                uint64_t nl = nl_end;
+                if (tail_find_next_newline(w.d_text, q, nl_end, d_slot, h_slot, st, &nl))
+                    return 2;
+                co.local_q1 = base + q + 1;
+                co.local_nl1 = nl < nl_end ? base + nl + 1 : 0;
+            }
+            else
+            {
+                uint64_t nl = nl_end;
+                if (tail_find_next_newline(w.d_text, w.own_lo, nl_end, d_slot, h_slot, st, &nl))
+                    return 2;
+                co.local_first_nl1 = nl < nl_end ? base + nl + 1 : 0;
+            }
+            co.q1 = co.local_q1 ? co.local_q1 : in.q1;
+            co.nl1 = co.local_q1 ? co.local_nl1 : in.nl1 ? in.nl1 : in.q1 ? co.local_first_nl1 : 0;
+            if (carry_out)
+                *carry_out = co;
             total = lr.total; lines = lr.lines; summary = lr.summary;
+            if (final_piece)
+            {
+                // where the reference's block loop stands when it enters the last kReplayWindow bytes (replay_entry, global offsets)
+                uint64_t cur, extra = 0;
+                if (!co.q1)
+                    cur = (X / B) * B; // the block grid never left offset 0
+                else if (co.nl1)
+                    cur = co.nl1 <= X ? co.nl1 + ((X - co.nl1) / B) * B : co.nl1; // restarted at the line start behind q
+                else
+                    cur = G; // unterminated line counted: the clamped advance ended the scan (krep.c:5006-5008, :5211-5213)
+                ReplayIn r{};
+                r.algo = algo; r.m = m; r.ww = pl->ww; r.n = G; r.cur = cur; r.open = 0;
+                r.text = w.d_text - base; // indexed with global offsets >= cur - 1 >= base: inside the buffer
+                r.pat = pl->d_pat;
+                if (cur < G && tail_run_replay(r, d_slot, h_slot, st, &extra))
+                    return 2;
+                // the lines the replay counts are new ones (it starts behind the line of q), and the line open at the piece's
+                // start can only be among them when nothing in front of the piece counted it: the canonical head bit stands
+                lines = lr.lines + extra;
+                total = lines;
+            }
         }
         else
         {
@@ -1334,22 +1407,26 @@ static int scan_ac_newline_lines(krep_gpu_plan *pl, const Window &w, hipStream_t
     uint64_t changes = 0;
     if (total)
     {
-        match_position_t *d_rec = nullptr;
-        uint64_t *d_ln = nullptr;
-        HIPCHK(hipMalloc(&d_rec, total * sizeof(match_position_t)));
-        if (hipMalloc(&d_ln, total * sizeof(uint64_t)) != hipSuccess)
+        if (total > pl->nl_cap) // grow-only scratch of the plan (no allocation per call)
         {
-            (void)hipFree(d_rec);
-            return kg::fail("line-number buffer allocation failed");
+            if (pl->d_nl_rec) (void)hipFree(pl->d_nl_rec);
+            if (pl->d_nl_ln) (void)hipFree(pl->d_nl_ln);
+            pl->d_nl_rec = nullptr;
+            pl->d_nl_ln = nullptr;
+            pl->nl_cap = 0;
+            const uint64_t want = total + total / 4 + 1024;
+            HIPCHK(hipMalloc(&pl->d_nl_rec, want * sizeof(match_position_t)));
+            HIPCHK(hipMalloc(&pl->d_nl_ln, want * sizeof(uint64_t)));
+            pl->nl_cap = want;
         }
+        match_position_t *d_rec = pl->d_nl_rec;
+        uint64_t *d_ln = pl->d_nl_ln;
         rc = ac_scan(pl->ac, pl->d_ctr, pl->h_ctr, pl->post, pl->num_cu, w.d_text, w.text_len, 0, w.text_len, 0, d_rec, total, pl->ww,
                      false, true, SIZE_MAX, st, 0, pl->ev0, pl->ev1, &o1);
         if (!rc)
             rc = krep_gpu_line_numbers(w.d_text, w.text_len, d_rec, total, d_ln, st);
         if (!rc)
             rc = tail_count_changes(d_ln, total, &pl->d_ctr->pad[0], &pl->h_ctr->pad[0], st, &changes);
-        (void)hipFree(d_rec);
-        (void)hipFree(d_ln);
         if (rc)
             return rc;
     }

@@ -93,6 +93,9 @@ bool shardable(const search_params_t *p, const krep_gpu_config_t &c, size_t text
 bool result_reserve(match_result_t *r, uint64_t extra);
 bool have_error();
 
+// kg_format.hip
+void format_release(); // frees the formatter scratch of every device
+
 // kg_comm.hip — the RCCL all-reduce of the per-shard counters (one process driving several devices)
 int allreduce_across_devices(const std::vector<int> &devs, std::vector<std::vector<unsigned long long>> &vecs);
 

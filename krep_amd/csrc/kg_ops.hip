@@ -309,6 +309,7 @@ extern "C" void krep_gpu_release_device_resources(void)
         std::lock_guard<std::mutex> lk(c->mu);
         c->release();
     }
+    kg::format_release();
 }
 
 namespace kg {
@@ -405,9 +406,8 @@ struct Piece
     int shard = 0; // logical shard (one per requested GPU) this piece belongs to
     krep_gpu_scan_out_t out{};
     std::vector<match_position_t> recs;
-    // kSplitChain (the greedy / -o walks): the boundary record this piece was scanned with and the one it leaves
-    uint64_t resume_used = 0;
-    krep_gpu_seq_carry_t carry_out{};
+    // kSplitChain: the boundary record this piece was scanned with and the one it leaves
+    krep_gpu_seq_carry_t carry_used{}, carry_out{};
 };
 inline bool rec_less(const match_position_t &a, const match_position_t &b) // emission order of aho_corasick_search
 {
@@ -436,7 +436,7 @@ int scan_one_piece(DeviceCtx &cx, krep_gpu_plan_t *pl, const uint8_t *d_text, Pi
 {
     const size_t nb = p->b1 - p->b0;
     uint64_t cap = want_pos ? std::max<uint64_t>(1u << 16, nb / 64) : 0;
-    p->resume_used = carry_in ? carry_in->resume : 0;
+    p->carry_used = carry_in ? *carry_in : krep_gpu_seq_carry_t{};
     p->recs.clear();
     for (int attempt = 0;; ++attempt)
     {
@@ -611,6 +611,13 @@ static int run_pieces(const search_params_t *params, const krep_gpu_config_t &cf
             lo += step;
         } while (lo < ghi);
     }
+    if (pcs.size() >= 2 && pcs.back().hi - pcs.back().lo < 4096)
+    { // a sliver at the end joins its neighbour (the piece that ends the text must hold the end-of-text replay window)
+        Piece &prev = pcs[pcs.size() - 2];
+        prev.hi = pcs.back().hi;
+        prev.b1 = pcs.back().b1;
+        pcs.pop_back();
+    }
     const bool want_pos = params->track_positions && out != nullptr && !params->count_lines_mode;
     const bool chain = kg::split_mode(params, cfg, len) == kSplitChain;
     // one worker per PHYSICAL device (several logical shards may share one on a small box)
@@ -655,26 +662,34 @@ static int run_pieces(const search_params_t *params, const krep_gpu_config_t &cf
         // occurrences straddles a cut between two devices (the last consumed occurrence reaches < m bytes into the next
         // shard); that piece is staged and scanned again with the true record — and, should its own record change, the one
         // behind it.
-        uint64_t true_resume = 0;
+        krep_gpu_seq_carry_t tc{}; // what the text in front of the current piece REALLY leaves
         for (Piece &p : pcs)
         {
-            if (std::max<uint64_t>(p.resume_used, p.lo) != std::max<uint64_t>(true_resume, p.lo))
+            // walks: the piece's own list depends on where the scan stands at its start; block-loop -c: only the piece that
+            // ends the text depends on the line-skip history
+            const bool stale = std::max<uint64_t>(p.carry_used.resume, p.lo) != std::max<uint64_t>(tc.resume, p.lo) ||
+                               (p.hi == len && (p.carry_used.q1 != tc.q1 || p.carry_used.nl1 != tc.nl1));
+            if (stale)
             {
                 DeviceCtx &cx = *ctx_for(p.device);
                 std::lock_guard<std::mutex> lk(cx.mu);
                 search_params_t local = *params;
                 local.max_count = SIZE_MAX;
                 krep_gpu_plan_t *pl = cx.plan_for(&local, cfg);
-                krep_gpu_seq_carry_t cin{};
-                cin.resume = true_resume;
                 if (!pl || cx.text[0].ensure(p.b1 - p.b0 + 64, cx.device) || cx.stager.init(cx.device) ||
-                    cx.stager.copy(cx.text[0].p, buf + p.b0, p.b1 - p.b0) || scan_one_piece(cx, pl, cx.text[0].p, &p, len, want_pos, &cin))
+                    cx.stager.copy(cx.text[0].p, buf + p.b0, p.b1 - p.b0) || scan_one_piece(cx, pl, cx.text[0].p, &p, len, want_pos, &tc))
                     return 2;
             }
-            true_resume = std::max<uint64_t>(true_resume, p.carry_out.resume);
+            // fold this piece's own contribution onto the true record (for a piece scanned with the true record this
+            // reproduces its carry_out)
+            const krep_gpu_seq_carry_t &o = p.carry_out;
+            krep_gpu_seq_carry_t n = tc;
+            n.resume = std::max<uint64_t>(tc.resume, o.resume);
+            n.q1 = o.local_q1 ? o.local_q1 : tc.q1;
+            n.nl1 = o.local_q1 ? o.local_nl1 : tc.nl1 ? tc.nl1 : tc.q1 ? o.local_first_nl1 : 0;
+            tc = n;
         }
     }
-
     // ---- the shards' counters meet: per logical shard one slot {matches, lines, head, tail, has_nl}, each
     // device fills the slots of its own shards, ONE RCCL all-reduce (uint64 sum over xGMI) makes every device hold all of them
     // — the sum doubles as the all-gather the left-to-right line fold needs.  The reference's counterpart is the host loop

@@ -153,6 +153,59 @@ def test_device_windows_with_the_boundary_record(gpu, oracle_engine):
         plan.close()
 
 
+@pytest.mark.parametrize("shards", [2, 3, 8])
+def test_block_loop_count_lines_in_pieces(gpu, oracle_engine, shards):
+    """-c through simd_avx512_search (33..64 B) and simd_avx2_search -w (17..32 B): the block grid restarts at every counted
+    line (krep.c:5203-5218, :5000-5013), so the END of the scan depends on the line-skip history of the whole text.  In pieces
+    only the last one replays the end; the history {last accepted occurrence, first newline behind it} rides on the boundary
+    record.  Sharded and streamed, against the compiled reference."""
+    rng = np.random.RandomState(900 + shards)
+    jobs = [(abi.REF_AVX512, 40, dict(count_lines=True)), (abi.REF_AVX512, 64, dict(count_lines=True, whole_word=True)),
+            (abi.REF_AVX2, 20, dict(count_lines=True, whole_word=True)), (abi.REF_AVX2, 32, dict(count_lines=True, whole_word=True)),
+            (abi.REF_AVX512, 33, dict(count_lines=True))]
+    for n in (150_003, 64 * 2500 + 17, 3 * (1 << 20) + 99):
+        share = (n + shards - 1) // shards
+        for variant in range(4):
+            # newline-free text / sparse newlines / dense newlines / newlines only in the first half (long open last line)
+            alpha = [b"abcd_ ", b"abcd_ " * 40 + b"\n", b"abcd_ \n", b"abcd_ " * 40 + b"\n"][variant]
+            text = cases.rand_text(rng, n, alpha)
+            if variant == 3:
+                text[n // 2:][text[n // 2:] == 10] = ord("_")
+            for level, m, kw in jobs:
+                pat = cases.rand_text(rng, m, b"abcd").tobytes()
+                spots = [n - m, n - 100, n - 255 - m, n - 257, n - 300, n - 700, 5, n // 2] + \
+                        [g * share - d for g in range(1, shards) for d in (0, 9, m - 1, m + 3)]
+                if variant == 2:
+                    spots = spots[:3]  # few occurrences: the last one lies far in front of the end
+                for sp in spots:
+                    if 0 <= sp and sp + m <= n and rng.rand() < 0.8:
+                        text[sp:sp + m] = np.frombuffer(pat, dtype=np.uint8)
+                gpu.set_reference_simd(level)
+                p = abi.Params([pat], **kw)
+                algo = gpu.mirror_select(p, n)
+                assert algo in (abi.RA_AVX512, abi.RA_AVX2)
+                cfg = gpu.default_config()
+                cfg.reference_simd = level
+                gpu.set_thread_config(cfg)
+                try:
+                    assert gpu.split_mode(p, n) == abi.SPLIT_CHAIN
+                finally:
+                    gpu.set_thread_config(None)
+                want_ret, _ = oracle_engine.call(algo, abi.Params([pat], **kw), text)
+                rc, cnt, _ = gpu.search_buffer(p, text, num_gpus=shards)
+                assert cnt == want_ret, ("sharded", abi.RA_NAMES[algo], m, kw, n, variant, shards, cnt, want_ret)
+                if n > (2 << 20):
+                    gpu.set_stream_chunk(1 << 20)
+                    try:
+                        rc, cnt, _ = gpu.search_buffer(p, text, num_gpus=1)
+                        assert cnt == want_ret, ("streamed", abi.RA_NAMES[algo], m, kw, n, variant, cnt, want_ret)
+                        rc, cnt, _ = gpu.search_buffer(p, text, num_gpus=2)
+                        assert cnt == want_ret, ("streamed x2", abi.RA_NAMES[algo], m, kw, n, variant, cnt, want_ret)
+                    finally:
+                        gpu.set_stream_chunk(0)
+    gpu.set_reference_simd(abi.REF_AVX2)
+
+
 def test_rccl_all_reduce_really_runs(gpu, oracle_engine):
     """The shard counters meet in ONE ncclAllReduce issued from C (kg_comm.hip).  1-GPU box: a clique of one device."""
     assert gpu.rccl_version() > 0

@@ -194,3 +194,20 @@ def test_nine_to_sixteen_byte_verify_in_registers(gpu, oracle_engine, m):
     for cs in (True, False):
         for kw in (dict(), dict(count_lines=True), dict(whole_word=True)):
             _check(gpu, oracle_engine, text, pat, dict(case_sensitive=cs, **kw), abi.REF_SCALAR)
+
+
+def test_the_parity_checker_is_the_compiled_reference(gpu, oracle_engine):
+    """the -m gpu tests compared the HIP path with the RESTATEMENT.  They now ask the unmodified reference
+    compiled into oracle/_ref, function by function (tests/oracle_lib.py: Checker); the restatement only answers under -o
+    and where a build cannot run on this host."""
+    text = cases.rand_text(np.random.RandomState(5), 60_000, b"abcd \n")
+    jobs = [(abi.REF_SCALAR, b"cab", {}), (abi.REF_SCALAR, b"abab", {}), (abi.REF_SSE42, b"d", {}),
+            (abi.REF_SSE42, b"ab", dict(case_sensitive=False)), (abi.REF_SSE42, b"abcd", {}),
+            (abi.REF_AVX2, b"abcd abcd abcd abcd ", {}), (abi.REF_AVX512, b"abcd " * 9, {}), (abi.REF_NEON, b"dab", {})]
+    before = oracle_engine.direct_calls
+    for level, pat, kw in jobs:
+        text[1000:1000 + len(pat)] = np.frombuffer(pat, dtype=np.uint8)
+        _check(gpu, oracle_engine, text, pat, kw, level)
+    want = {f"ref:{ol._REF_FILES[lv]}" for lv in ol._REF_FILES if ol.ref_available(lv)}
+    assert oracle_engine.direct_calls - before >= len([lv for lv, _, _ in jobs if ol.ref_available(lv)])
+    assert want <= oracle_engine.used, (want, oracle_engine.used)

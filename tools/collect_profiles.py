@@ -16,7 +16,29 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT, PROF = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
-DOMINANT = {"literal8": "kg::lit_scan", "memchr1": "kg::lit_scan", "ac1000": "kg::ac_scan_kernel"}
+DOMINANT = {"literal8": "kg::lit_scan", "memchr1": "kg::single_fused", "ac1000": "kg::ac_scan_kernel"}
+WARMUP_DROPPED = 3  # launches of every kernel left out of the steady-state statistics (tools/profile_round.sh runs --warmup 3)
+
+
+def steady_stats(trace_csv, out_csv):
+    """rocprofv3's *_kernel_stats.csv averages EVERY launch, the cold first one included (literal8 avg 5.274 ms
+    with it, 5.144 without).  From the per-dispatch kernel trace: the same statistics without the first WARMUP_DROPPED
+    launches of each kernel."""
+    import statistics
+    per = {}
+    for row in csv.DictReader(open(trace_csv)):
+        name = short(row["Kernel_Name"])
+        if not name.startswith("kg::"):
+            continue
+        per.setdefault(name, []).append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]) - int(row["Start_Timestamp"])))
+    with open(out_csv, "w") as f:
+        f.write("kernel,calls,warmup_dropped,avg_ns_steady,median_ns_steady,min_ns,max_ns_steady,avg_ns_all\n")
+        for name, lst in sorted(per.items()):
+            lst.sort()
+            d = [x[1] for x in lst]
+            st = d[WARMUP_DROPPED:] if len(d) > WARMUP_DROPPED else d
+            f.write(f'"{name}",{len(d)},{len(d) - len(st)},{sum(st) / len(st):.0f},{statistics.median(st):.0f},{min(d)},{max(st)},'
+                    f'{sum(d) / len(d):.0f}\n')
 
 
 def short(name):
@@ -37,6 +59,9 @@ def main():
         ks = glob.glob(os.path.join(OUT, f"{tag}_{w}_kt", "**", "*kernel_stats.csv"), recursive=True)
         if ks:
             shutil.copy(ks[0], os.path.join(PROF, f"{tag}_{w}_kernel_stats.csv"))
+        kt = glob.glob(os.path.join(OUT, f"{tag}_{w}_kt", "**", "*kernel_trace.csv"), recursive=True)
+        if kt:
+            steady_stats(kt[0], os.path.join(PROF, f"{tag}_{w}_kernel_steady.csv"))
         agg = {}
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
             for f in glob.glob(os.path.join(OUT, f"{tag}_{w}_{c}", "**", "*counter_collection.csv"), recursive=True):
@@ -61,7 +86,7 @@ def main():
             hbm = int((2 * fetch + write) * 1024)
             traffic[w] = {
                 "hbm_bytes_per_launch": hbm, "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write,
-                "algorithmic_bytes": alg, "ratio": round(hbm / alg, 4), "kernel": dom,
+                "algorithmic_bytes": alg, "ratio": round(hbm / alg, 4), "kernel": dom, "measured_by": tag,
                 "method": f"tools/profile_round.sh {tag}: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate "
                           f"passes of `python bench.py --workload {w} --steps 2 --warmup 1 --no-cpu-baseline`; "
                           "FETCH_SIZE doubled (16 B/lane streams on gfx950, MI355X_MICROARCH.md HBM section); counters "

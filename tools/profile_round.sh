@@ -12,7 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 for w in $WL; do
   timeout 600 python $R/bench.py --workload $w --no-extra > $O/${TAG}_${w}_bench.json 2> $O/${TAG}_${w}_bench.err
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_${w}_kt -o kt -- \
-      python $R/bench.py --workload $w --steps 5 --warmup 1 --no-cpu-baseline --no-extra > $O/${TAG}_${w}_kt.log 2>&1
+      python $R/bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline --no-extra > $O/${TAG}_${w}_kt.log 2>&1
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout 600 rocprofv3 --pmc $c --output-format csv -d $O/${TAG}_${w}_$c -o pmc -- \
         python $R/bench.py --workload $w --steps 2 --warmup 1 --no-cpu-baseline --no-extra > $O/${TAG}_${w}_$c.log 2>&1
