@@ -260,9 +260,45 @@ __global__ __launch_bounds__(kPostBlock) void post_gather(const u64 *__restrict_
             if (cnt > stage_cap || off >= pos_cap)
                 cnt = 0; // overflowed units are written by the scan kernel's emit mode
         }
-        // few records: the owning lane copies them itself (multi-pattern: up to a whole 16-entry slot — the per-unit loop below
-        // is a serial chain of ~35 wave steps per 64 units at 5.3 matches per unit: 0.235 ms for 11.2 M records)
-        if (cnt && cnt <= (fixed_len ? 4u : 16u))
+        if (!fixed_len)
+        {
+            // multi-pattern (5.3 matches per 16 KiB unit): the 64 units of the wave are one contiguous run of records — the
+            // offsets of consecutive units follow each other — so lane j takes record j of the RUN: which unit it belongs to is
+            // a 6-step search over the wave's inclusive counts, its staged word one scattered 4-byte read (L2), and the 16-byte
+            // stores of a wave instruction are consecutive.  (Round 2 let every lane copy its own unit's records: 64 serial
+            // little loops with scattered stores, 0.23 ms for 11.2 M records.)
+            const u32 raw = u < n_units ? (u32)(info[u] & kUiCountMask) : 0u; // counts as the offsets saw them (overflowed units too)
+            u32 incl = raw;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1)
+            {
+                const u32 t = __shfl_up(incl, o);
+                if (lane >= (u32)o)
+                    incl += t;
+            }
+            const u32 total = __shfl(incl, 63);
+            const u64 off0 = __shfl(u < n_units ? offsets[u] : 0ull, 0); // g < n_units: lane 0 is a real unit
+            for (u32 j = lane; j < total; j += 64u)
+            {
+                u32 own = 0; // first lane whose inclusive count exceeds j
+#pragma unroll
+                for (u32 step = 32; step; step >>= 1)
+                {
+                    const u32 t = __shfl(incl, (own + step - 1u) & 63u);
+                    if (t <= j)
+                        own += step;
+                }
+                own &= 63u;
+                const u32 oincl = __shfl(incl, own), oraw = __shfl(raw, own);
+                const u32 i = j - (oincl - oraw);
+                const u64 idx = off0 + j;
+                if (oraw <= stage_cap && idx < pos_cap) // (an overflowed unit's records come from the scan kernel's emit mode)
+                    put(idx, origin + (g + (u64)own) * unit_bytes, (g + (u64)own) * (u64)stage_cap, i);
+            }
+            continue;
+        }
+        // few records: the owning lane copies them itself
+        if (cnt && cnt <= 4u)
         {
             const u64 sbase = u * (u64)stage_cap, org = origin + u * unit_bytes;
             for (u32 i = 0; i < cnt; ++i)

@@ -84,13 +84,25 @@ def main():
             write = sum(v[1] for _, v in wk) / sum(v[0] for _, v in wk)
             alg = bench["roofline"]["algorithmic_bytes_per_launch"]
             hbm = int((2 * fetch + write) * 1024)
+            note = ""
+            filt = []
+            for f in glob.glob(os.path.join(OUT, f"{tag}_{w}_FETCH_SIZE_filter", "**", "*counter_collection.csv"), recursive=True):
+                filt += [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
+                         if short(r["Kernel_Name"]).startswith(dom) and r["Counter_Name"] == "FETCH_SIZE"]
+            if filt:
+                # streamed reads (the filter-only pass) are under-reported 2x, the verify stage's gathers are exact
+                # (tools/ubench/fetch_calib.hip): traffic = 2 x filter + 1 x (full - filter) + writes
+                ff = sum(filt) / len(filt)
+                hbm = int((2 * ff + max(0.0, fetch - ff) + write) * 1024)
+                note = (f"; streamed part {ff:.0f} KiB (KREP_GPU_AC_NOVERIFY pass) doubled, the verify stage's gathers "
+                        f"({fetch - ff:.0f} KiB) counted as reported (profiles/r03_fetch_size_calibration.txt)")
             traffic[w] = {
                 "hbm_bytes_per_launch": hbm, "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write,
                 "algorithmic_bytes": alg, "ratio": round(hbm / alg, 4), "kernel": dom, "measured_by": tag,
                 "method": f"tools/profile_round.sh {tag}: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate "
                           f"passes of `python bench.py --workload {w} --steps 2 --warmup 1 --no-cpu-baseline`; "
                           "FETCH_SIZE doubled (16 B/lane streams on gfx950, MI355X_MICROARCH.md HBM section); counters "
-                          "in KiB (the generator's WRITE_SIZE calibrates to exactly the bytes it fills)"}
+                          "in KiB (the generator's WRITE_SIZE calibrates to exactly the bytes it fills)" + note}
             bench["roofline"]["traffic"] = hbm          # the PMC passes of this very run
             open(os.path.join(PROF, f"{tag}_{w}_bench.json"), "w").write(json.dumps(bench) + "\n")
             print(w, "traffic ratio", traffic[w]["ratio"], "value", bench["value"], "frac", bench["roofline"]["frac"])

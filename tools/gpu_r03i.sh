@@ -1,0 +1,6 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out
+timeout 1200 python -m pytest tests -m gpu -x -q > gpurun_out/r03i_pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r03i_pytest.log
+tail -4 gpurun_out/r03i_pytest.log | cut -c1-300
+bash tools/gpu_batch_r03.sh
