@@ -1,11 +1,15 @@
 // kg_ops.hip — the host-buffer side of the C-ABI: the search_func_t operators, search_buffer[_ex](), the drop-in for
 // select_search_algorithm(), and the executor that brings a host buffer through HBM:
-//   * ONE PIECE (the whole text staged, then scanned) for small inputs and for the sequential match-set families;
+//   * ONE PIECE (the whole text staged, then scanned) for small inputs and for the three input classes that need the whole
+//     text in one window (kg::split_mode() == whole);
 //   * PIECES otherwise — contiguous chunks with start-offset ownership and Lmax+1 bytes of halo, spread over the requested
-//     devices (search_buffer(num_gpus > 1): the reference's chunk loop, krep.c:2816-2905, without its double counting) and,
-//     per device, STREAMED: piece k+1 is copied through the pinned staging ring (mmap'd / pageable source -> pinned ->
-//     DMA) while piece k is scanned, two device buffers per device, so a haystack larger than HBM works and the scan time
-//     hides under the PCIe time (the reference's counterpart is mmap + MAP_POPULATE, krep.c:2630-2726).
+//     devices (search_buffer(num_gpus > 1), the operators with cfg.num_gpus > 1: the reference's chunk loop,
+//     krep.c:2816-2905, without its double counting; the shards' counters meet in ONE RCCL all-reduce, kg_comm.hip) and, per
+//     device, STREAMED: piece k+1 is copied through the pinned staging ring (mmap'd / pageable source -> pinned -> DMA) while
+//     piece k is scanned, two device buffers per device, so a haystack larger than HBM works and the scan time hides under
+//     the PCIe time (the reference's counterpart is mmap + MAP_POPULATE, krep.c:2630-2726).  The sequential
+//     match-set families run as CHAINED pieces: each takes the boundary record of the one before it (krep_gpu_seq_carry_t).
+//   * FAILURE: an attempt that fails appends nothing; the host's registered CPU function answers (run_with_fallback).
 // Every device has ONE context (buffers, staging ring, a small plan cache) behind a mutex: the operators are re-entrant
 // from any number of threads (SURVEY §8b "Threading", krep.c:1950), calls on one device serialise.  The configuration
 // travels explicitly (krep_gpu_config_t); nothing here writes a global.

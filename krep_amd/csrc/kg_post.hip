@@ -278,8 +278,9 @@ __global__ __launch_bounds__(kPostBlock) void post_gather(const u64 *__restrict_
             }
             const u32 total = __shfl(incl, 63);
             const u64 off0 = __shfl(u < n_units ? offsets[u] : 0ull, 0); // g < n_units: lane 0 is a real unit
-            for (u32 j = lane; j < total; j += 64u)
+            for (u32 j0 = 0; j0 < total; j0 += 64u) // wave-uniform trip count: every lane takes part in the shuffles below
             {
+                const u32 j = j0 + lane;
                 u32 own = 0; // first lane whose inclusive count exceeds j
 #pragma unroll
                 for (u32 step = 32; step; step >>= 1)
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(kPostBlock) void post_gather(const u64 *__restrict_
                 const u32 oincl = __shfl(incl, own), oraw = __shfl(raw, own);
                 const u32 i = j - (oincl - oraw);
                 const u64 idx = off0 + j;
-                if (oraw <= stage_cap && idx < pos_cap) // (an overflowed unit's records come from the scan kernel's emit mode)
+                if (j < total && oraw <= stage_cap && idx < pos_cap) // (an overflowed unit's records come from the scan kernel's emit mode)
                     put(idx, origin + (g + (u64)own) * unit_bytes, (g + (u64)own) * (u64)stage_cap, i);
             }
             continue;

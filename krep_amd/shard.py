@@ -62,3 +62,32 @@ def allgather_line_summaries(mine: LineSummary, device=None) -> list[LineSummary
     out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(out, t)
     return [LineSummary(int(o[0]), bool(o[1]), bool(o[2]), bool(o[3])) for o in out]
+
+
+def allgather_ints(values: Sequence[int], device=None) -> list[list[int]]:
+    """One all-gather of a few integers per rank (the boundary records of the sequential families)."""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor(list(values), dtype=torch.int64, device=device)
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return [[int(x) for x in t.tolist()]]
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [[int(x) for x in o.tolist()] for o in out]
+
+
+def true_resumes(lows: Sequence[int], resume_used: Sequence[int], resume_out: Sequence[int]) -> tuple[list[int], list[bool]]:
+    """The exchange step of the chained families (krep_gpu_seq_carry_t::resume, kg_ops.hip::run_pieces): given, per shard in
+    text order, the record it was scanned with and the record it left, the record each shard SHOULD have been scanned with and
+    whether its scan has to be repeated.  A repeated shard's own record is unknown until it has been re-scanned, so the walk
+    stops at the first stale shard: call again after re-scanning it (a text that is one cluster re-scans every shard)."""
+    true_in, stale = [], []
+    cur = 0
+    for lo, used, out in zip(lows, resume_used, resume_out):
+        true_in.append(cur)
+        bad = max(used, lo) != max(cur, lo)
+        stale.append(bad)
+        if bad:
+            break
+        cur = max(cur, out)
+    return true_in, stale

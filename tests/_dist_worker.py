@@ -54,6 +54,40 @@ def main():
             if total != want_n or lines != want_lines:
                 print("MISMATCH", pats, total, want_n, lines, want_lines, flush=True)
                 fails += 1
+    # ---- the chained families across ranks (krep_gpu_seq_carry_t::resume): greedy non-overlapping selection of a bordered
+    # pattern.  Every rank scans its shard optimistically (nothing consumed in front of it), the boundary records meet in ONE
+    # all-gather, and a rank whose assumption was wrong scans again — until no record changes (here the oracle's
+    # simd_sse42_search on the slice that starts at the resume point stands in for the GPU walk, which owns the starts from
+    # max(lo, resume): the reference's loop after `advance` IS a fresh scan from that point).
+    pat = b"aa"
+    m = len(pat)
+    ctext = text.copy()
+    ctext[: ctext.size // 2] = ord("a")  # one giant cluster across the first cuts, random text behind it
+    lo, hi = shard.shard_bounds(ctext.size, world, rank)
+
+    def greedy_scan(resume):
+        s0 = min(max(lo, resume), hi)
+        ret, pos = o.call(abi.RA_SSE42, abi.Params([pat]), ctext[s0:min(ctext.size, hi + m)].copy())
+        pos = pos + np.uint64(s0)
+        pos = pos[pos[:, 0] < hi]
+        return pos, (int(pos[-1, 0]) + m if len(pos) else 0)
+
+    used = 0
+    mine, out = greedy_scan(used)
+    for _ in range(world + 1):
+        recs = shard.allgather_ints([lo, used, out])
+        true_in, stale = shard.true_resumes([r[0] for r in recs], [r[1] for r in recs], [r[2] for r in recs])
+        if not any(stale):
+            break
+        if len(stale) > rank and stale[rank]:
+            used = true_in[rank]
+            mine, out = greedy_scan(used)
+    total, = shard.allreduce_counts([len(mine)])
+    if rank == 0:
+        want_n, want_pos = o.call(abi.RA_SSE42, abi.Params([pat]), ctext)
+        if total != want_n or any(stale):
+            print("MISMATCH chained", total, want_n, stale, flush=True)
+            fails += 1
     if rank == 0:
         print("DIST_OK" if fails == 0 else "DIST_FAIL", flush=True)
     dist.destroy_process_group()

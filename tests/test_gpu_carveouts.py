@@ -209,7 +209,8 @@ def test_classes_left_to_the_cpu_are_refused_loudly(gpu):
 @pytest.mark.parametrize("shards", [2, 3, 8])
 def test_sharded_quirks_follow_the_whole_text(gpu, oracle_engine, shards):
     """ADVICE r01: the AVX-512 unexamined block and the AVX tail's -w exemption are functions of the WHOLE text's length;
-    a bordered pattern under -o is a sequential family and stays in one piece."""
+    -c through the block loops and bordered patterns under -o are sequential families: chained pieces since round 3
+    (tests/test_gpu_chain.py has the dedicated cases)."""
     rng = np.random.RandomState(90 + shards)
     for n in (100_003, 64 * 1700 + 20, 32 * 3100 + 25):
         text = cases.rand_text(rng, n, b"abcd_ \n")
@@ -231,7 +232,7 @@ def test_sharded_quirks_follow_the_whole_text(gpu, oracle_engine, shards):
                     assert cnt == want_ret, (abi.RA_NAMES[algo], m, kw, shards, cnt, want_ret)
                 else:
                     assert np.array_equal(pos, want_pos), (abi.RA_NAMES[algo], m, kw, shards)
-    # bordered patterns with -o: BMH becomes greedy (krep.c:1371) -> one piece, same answer as the single-buffer call
+    # bordered patterns with -o: BMH becomes greedy (krep.c:1371) -> chained pieces, same answer as the single-buffer call
     text = cases.rand_text(rng, 90_000, b"ab")
     for pat, kw in ((b"abab", dict(case_sensitive=False)), (b"aa", dict(case_sensitive=False)), (b"ab", dict(case_sensitive=False))):
         gpu.set_reference_simd(abi.REF_AVX2)
