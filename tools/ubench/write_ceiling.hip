@@ -15,8 +15,20 @@
 #define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-// MODE bit0: read, bit1: write.  NTS: non-temporal stores.
-template <int MODE, bool NTS>
+// the record store with explicit cache-control bits (gfx942/950: sc0 / sc1 = write-through scope, nt = streaming hint)
+template <int ST>
+__device__ __forceinline__ void store16(u32x4 *p, u32x4 v)
+{
+    if (ST == 0) *p = v;
+    else if (ST == 1) __builtin_nontemporal_store(v, p);
+    else if (ST == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(v) : "memory");
+    else if (ST == 3) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
+    else if (ST == 4) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off sc0 nt" ::"v"(p), "v"(v) : "memory");
+}
+
+// MODE bit0: read, bit1: write.  NTS: 0 plain stores, 1 non-temporal (builtin: nt), 2..5 explicit bit combinations.
+template <int MODE, int NTS>
 __global__ __launch_bounds__(256, 4) void rw(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, size_t n_tickets,
                                              size_t rd_bytes, size_t chunk, size_t skew, unsigned long long *ticket, uint32_t *out)
 {
@@ -50,10 +62,7 @@ __global__ __launch_bounds__(256, 4) void rw(const uint8_t *__restrict__ src, ui
             for (size_t i = lane * 16; i + 16 <= chunk; i += 1024)
             {
                 const u32x4 v = {(uint32_t)i, acc, (uint32_t)t, 7u};
-                if (NTS)
-                    __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(q + i));
-                else
-                    *reinterpret_cast<u32x4 *>(q + i) = v;
+                store16<NTS>(reinterpret_cast<u32x4 *>(q + i), v);
             }
         }
     }
@@ -61,7 +70,7 @@ __global__ __launch_bounds__(256, 4) void rw(const uint8_t *__restrict__ src, ui
         out[0] = acc;
 }
 
-template <int MODE, bool NTS>
+template <int MODE, int NTS>
 static float run(const uint8_t *src, uint8_t *dst, size_t n_tickets, size_t rd, size_t chunk, size_t skew, unsigned long long *tk,
                  uint32_t *out, int grid)
 {
@@ -102,18 +111,22 @@ int main(int argc, char **argv)
     const int grid = 256 * 4;
     const double rgb = n_tickets * (double)rd / 1e9;
     printf("tickets %zu x %zu KiB read (%.1f GB)\n", n_tickets, rd >> 10, rgb);
-    printf("read only                          : %7.3f ms  %7.1f GB/s\n", run<1, false>(src, dst, n_tickets, rd, 0, 0, tk, out, grid),
-           rgb / run<1, false>(src, dst, n_tickets, rd, 0, 0, tk, out, grid) * 1e3);
+    printf("read only                          : %7.3f ms  %7.1f GB/s\n", run<1, 0>(src, dst, n_tickets, rd, 0, 0, tk, out, grid),
+           rgb / run<1, 0>(src, dst, n_tickets, rd, 0, 0, tk, out, grid) * 1e3);
     for (size_t chunk : {(size_t)20976, (size_t)21504, (size_t)16384})
         for (size_t skew : {(size_t)0, (size_t)48})
         {
             const double wgb = n_tickets * (double)(chunk / 16 * 16) / 1e9;
-            const float f = run<2, false>(src, dst, n_tickets, rd, chunk, skew, tk, out, grid);
-            const float fn = run<2, true>(src, dst, n_tickets, rd, chunk, skew, tk, out, grid);
-            const float b = run<3, false>(src, dst, n_tickets, rd, chunk, skew, tk, out, grid);
-            const float bn = run<3, true>(src, dst, n_tickets, rd, chunk, skew, tk, out, grid);
+            const float f = run<2, 0>(src, dst, n_tickets, rd, chunk, skew, tk, out, grid);
+            const float fn = run<2, 1>(src, dst, n_tickets, rd, chunk, skew, tk, out, grid);
+            const float b = run<3, 0>(src, dst, n_tickets, rd, chunk, skew, tk, out, grid);
+            const float bn = run<3, 1>(src, dst, n_tickets, rd, chunk, skew, tk, out, grid);
             printf("chunk %6zu skew %2zu (%.2f GB): fill %6.3f ms %6.1f GB/s | nt %6.3f ms | read+fill %6.3f ms (%6.1f GB/s total) | nt %6.3f ms\n",
                    chunk, skew, wgb, f, wgb / f * 1e3, fn, b, (rgb + wgb) / b * 1e3, bn);
+            if (chunk == 20976 && skew == 48)
+                printf("   read+fill with explicit bits: sc0 sc1 nt %6.3f ms | sc1 nt %6.3f ms | sc0 sc1 %6.3f ms | sc0 nt %6.3f ms\n",
+                       run<3, 2>(src, dst, n_tickets, rd, chunk, skew, tk, out, grid), run<3, 3>(src, dst, n_tickets, rd, chunk, skew, tk, out, grid),
+                       run<3, 4>(src, dst, n_tickets, rd, chunk, skew, tk, out, grid), run<3, 5>(src, dst, n_tickets, rd, chunk, skew, tk, out, grid));
         }
     return 0;
 }
