@@ -28,10 +28,11 @@ class Engine:
         # When torch is used in the same process (tests, bench.py: device memory + torch.distributed), its
         # bundled HIP runtime must be the one the process binds first; loading ours first makes torch see
         # "No HIP GPUs".  Importing torch here is plumbing only — nothing in the library needs it.
-        try:
-            import torch  # noqa: F401
-        except Exception:
-            pass
+        if not os.environ.get("KREP_GPU_NO_TORCH"):  # (tools/notorch_bench.py: the library on the system HIP runtime alone)
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         L = self.lib = C.CDLL(path)
         sf = [C.POINTER(abi.SearchParams), C.c_void_p, C.c_size_t, C.POINTER(abi.MatchResult)]
         for n in ("krep_gpu_literal_search", "krep_gpu_aho_corasick_search"):
