@@ -283,12 +283,20 @@ extern "C" int krep_gpu_comm_allreduce_u64(uint64_t *values, int n)
 {
     if (!values || n <= 0)
         return kg::fail("comm_allreduce: bad arguments");
+    struct Restore // the communicator's device for the whole call, the caller's device afterwards
+    {
+        int prev = -1;
+        Restore() { (void)hipGetDevice(&prev); }
+        ~Restore()
+        {
+            if (prev >= 0)
+                (void)hipSetDevice(prev);
+        }
+    } restore;
     {
         std::lock_guard<std::mutex> lk(g_mu);
         if (!g_rank.comm)
             return kg::fail("comm_allreduce: no rank communicator (krep_gpu_comm_init_rank)");
-        int prev = -1;
-        (void)hipGetDevice(&prev);
         HCHK(hipSetDevice(g_rank.device));
         if (g_rank.cap < (size_t)n)
         {
@@ -299,8 +307,6 @@ extern "C" int krep_gpu_comm_allreduce_u64(uint64_t *values, int n)
             g_rank.cap = (size_t)n;
         }
         HCHK(hipMemcpyAsync(g_rank.d_vec, values, (size_t)n * sizeof(uint64_t), hipMemcpyHostToDevice, g_rank.stream));
-        if (prev >= 0)
-            (void)hipSetDevice(prev);
     }
     if (krep_gpu_comm_allreduce_device_u64(g_rank.d_vec, n, nullptr))
         return 2;
