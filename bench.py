@@ -213,7 +213,13 @@ def traffic_for(name):
 
 
 # ---------------------------------------------------------------------------------------------- one workload on this rank
-def run_workload(name, args, eng, buf, dev, rank, world, local, use_dist):
+def positions_capacity(name, n):
+    wl = WORKLOADS[name]
+    density = 1.0 / 100 if wl["kind"] == 3 else 1.0 / wl["period"] + (2.5e-4 if wl["kind"] == 4 else 0)
+    return int(n * density * 1.25) + 4096
+
+
+def run_workload(name, args, eng, buf, pos, dev, rank, world, local, use_dist):
     """Generates the rank's shard, runs warmup + EXACTLY args.steps timed steps (barrier + synchronize on both sides, MAX over
     ranks) and returns the measurement dict (rank 0) incl. the roofline object of the dominant kernel."""
     import torch
@@ -229,9 +235,8 @@ def run_workload(name, args, eng, buf, dev, rank, world, local, use_dist):
     text_len = n if last else n + halo        # the global text ends with the last shard
     params = abi.Params(wl["patterns"], **wl["kw"])
     plan = eng.plan(params, device=local)
-    density = 1.0 / 100 if wl["kind"] == 3 else 1.0 / wl["period"] + (2.5e-4 if wl["kind"] == 4 else 0)
-    cap = int(n * density * 1.25) + 4096
-    pos = torch.empty(cap * 2, dtype=torch.int64, device=dev)
+    cap = positions_capacity(name, n)
+    assert pos.numel() >= 2 * cap
     stream = torch.cuda.current_stream().cuda_stream
     counts = torch.zeros(2, dtype=torch.int64, device=dev)
     host_counts = torch.zeros(2, dtype=torch.int64).pin_memory()
@@ -276,7 +281,6 @@ def run_workload(name, args, eng, buf, dev, rank, world, local, use_dist):
     assert not out.overflow, "position buffer too small"
     stored = int(out.stored)
     plan.close()
-    del pos
     if rank != 0:
         return None
     ms_step = dt / args.steps * 1e3
@@ -407,8 +411,15 @@ def main():
                 eng.comm_destroy()
     n = int(args.gib * (1 << 30))
     buf = torch.empty(n + 64, dtype=torch.uint8, device=dev)
+    # ONE record buffer for every workload of this run, allocated right behind the text while the device memory is pristine:
+    # where the driver places a buffer physically moves the offsets-producing scans by several per cent (DESIGN.md 6,
+    # profiles/r03_box_to_box.txt: re-allocating it inside one process draws 6.58 ... 7.42 ms for the single byte), and
+    # freeing / re-allocating it between workloads is what churns the placement
+    names = [args.workload] + ([w for w in ("literal8", "memchr1", "ac1000") if w != args.workload]
+                               if (world == 1 and not args.no_extra) else [])
+    pos = torch.empty(2 * max(positions_capacity(w, n) for w in names), dtype=torch.int64, device=dev)
 
-    res = run_workload(args.workload, args, eng, buf, dev, rank, world, local, use_dist)
+    res = run_workload(args.workload, args, eng, buf, pos, dev, rank, world, local, use_dist)
     line = None
     if rank == 0:
         wl = res["wl"]
@@ -433,7 +444,7 @@ def main():
             if name == args.workload:
                 continue
             try:
-                r = run_workload(name, args, eng, buf, dev, rank, world, local, use_dist)
+                r = run_workload(name, args, eng, buf, pos, dev, rank, world, local, use_dist)
                 e = {"value": r["value"], "unit": "GB/s", "ms_per_step": r["ms_per_step"],
                      "config": config_of(name, r["wl"], args, world, n, r), "roofline": r["roofline"]}
                 if not args.no_cpu_baseline:
