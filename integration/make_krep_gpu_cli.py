@@ -42,7 +42,7 @@ def main():
     #                           (krep_gpu_worthwhile: device usable, input class reproduced, size >= threshold).
     globals_ = r"""
 #ifdef KREP_WITH_GPU
-static bool use_gpu = false;             /* KREP_GPU=1 and a usable device */
+static bool use_gpu = false;             /* KREP_GPU=1 */
 static __thread bool gpu_bypass = false; /* this thread is selecting a CPU function */
 static search_func_t krep_cpu_select(const search_params_t *p)
 {
@@ -104,12 +104,13 @@ static bool krep_is_gpu_fn(search_func_t f) { return f == krep_gpu_literal_searc
         raise SystemExit("anchor not found: search_string's selection")
     src = re.sub(pat, '\n#ifdef KREP_WITH_GPU\n    search_func_t search_algo = krep_select_for(&current_params, text_len);\n#else\n'
                       '    search_func_t search_algo = select_search_algorithm(&current_params);\n#endif\n', src, count=1)
-    # 5. the CLI switch: environment variable, read at the top of main() (krep.c:3451).  Without a usable device the
-    #    switch stays off and every path is the reference's own; with one, the backend learns the CPU selector so that a
-    #    run-time failure of an operator is answered by the CPU function instead of "no match".
+    # 5. the CLI switch: environment variable, read at the top of main() (krep.c:3451).  No device is touched here — a run
+    #    over small files never initialises the HIP runtime: krep_gpu_worthwhile() looks at the size first, and without a
+    #    usable device it (and the selector) say no, so every path is the reference's own.  The backend learns the CPU
+    #    selector so that a run-time failure of an operator is answered by the CPU function instead of "no match".
     main_switch = r"""
 #ifdef KREP_WITH_GPU
-    use_gpu = getenv("KREP_GPU") != NULL && krep_gpu_available();
+    use_gpu = getenv("KREP_GPU") != NULL;
     if (use_gpu && !getenv("KREP_GPU_NO_FALLBACK_HOOK")) /* (test switch: exercises steps 7/8 instead) */
         krep_gpu_set_cpu_fallback(krep_cpu_select);
 #endif
