@@ -204,14 +204,13 @@ uint64_t krep_gpu_aho_corasick_search(const search_params_t *params, const char 
 /* Drop-in for select_search_algorithm(): returns one of the two functions above, or NULL when the backend does not
  * take the search — no usable device (krep_gpu_available() == 0), regex_search, and the input classes
  * krep_gpu_can_accelerate() names — so that the caller keeps the CPU function pointer the reference's own
- * select_search_algorithm() gives it. */
+ * select_search_algorithm() gives it.  (-c through simd_sse42_search / kmp_search with a newline inside the pattern, refused
+ * until round 3, is reproduced: one device thread walks the ordered occurrence list the way the reference's loop moves.) */
 search_func_t krep_gpu_select_search_algorithm(const search_params_t *params);
 /* 1 when the backend takes the search for `params` under the current configuration, 0 when not:
  *   - no usable gfx950 device (krep_gpu_available() == 0);
  *   - no pattern at all (num_patterns == 0 and pattern == NULL);
  *   - use_regex;
- *   - count_lines_mode with a '\n' inside a single pattern that the reference would run through simd_sse42_search or
- *     kmp_search (the -c line skip of simd_sse42_search depends on the phase of its 16-byte window grid, krep.c:4787-4793);
  *   - count_lines_mode together with only_matching through memchr_short_search (unreachable from the reference CLI,
  *     krep.c:3811-3814).
  * An operator called with such params anyway treats it like a run-time failure (see the top of this header): the

@@ -21,6 +21,7 @@
 // it, classifies every visited candidate against the text (bytes 1..m-1, -w) and keeps the accepted matches.  A candidate
 // at least m bytes behind its predecessor is always visited (the resume point never passes candidate + m), so clusters
 // split at gaps >= m exactly as in (1).
+// (3) -c through simd_sse42_search / kmp_search with a newline inside the pattern: g_nlwalk below.
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdlib>
@@ -317,6 +318,106 @@ __global__ __launch_bounds__(kGB) void g_lines(const u64 *__restrict__ lst, u64 
         atomicAdd(&ctr->lines, (u64)__popcll(bal));
 }
 
+
+// ---- (3) -c through simd_sse42_search / kmp_search with a '\n' INSIDE the pattern -------------------------------------------
+// After counting a line both functions jump towards the next line start — but with a newline inside the pattern that point
+// lies INSIDE the match, and simd_sse42_search adds the jump to its 16-byte WINDOW start instead of to the match
+// (krep.c:4787-4793), so where the scan resumes depends on the phase of its window grid (a full window without a hit
+// advances 17 - m bytes, :4858), which every earlier match has shifted.  A chain over all visited matches: one thread walks
+// the ordered occurrence list.  Everything it needs per occurrence is precomputed in parallel: the line number of its start
+// (kg_format.hip), the -w verdict (g_ww), and the first '\n' at or behind the start of its line, which is start + k0 (k0 = offset
+// of the first newline in the pattern: the line start has no newline up to the match, and the match spells the pattern).
+// Visits are ~2 per counted line (the jump skips the rest of the line), found by galloping from the current list index.
+//   kNlWalkSse42: cp = window + (le + 1 - at) after a newly counted line, else at + m (at + 1 under -o);  window = cp + j * (17 - m),
+//             j = (at - cp) / (17 - m) capped at the first window with fewer than 16 bytes left (krep.c:4739-4750)
+//   kNlWalkKmp  : cp = le + 1 after a newly counted line (krep.c:1703-1707), else at + m; a -w rejected match: at + m (:1684-1688)
+struct NlWalkSpec
+{
+    u32 mode, m, k0; // kNlWalkSse42 / kNlWalkKmp; pattern length; offset of the first '\n' in the pattern
+    bool ww, om;     // -w; only_matching (simd_sse42_search advances by 1 instead of m)
+    u64 n, maxc;     // text length; max_count (SIZE_MAX = unlimited)
+};
+
+__global__ void g_nlwalk(const u64 *__restrict__ occ, u64 n_occ, const u64 *__restrict__ lineno, const uint8_t *__restrict__ keep,
+                         NlWalkSpec ws, u64 *out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0)
+        return;
+    const u64 n = ws.n, m = ws.m, step = 17ull - m;
+    u64 cp = 0, cnt = 0, seen = ~0ull, i = 0;
+    while (n - cp >= m)
+    {
+        // first occurrence with start >= cp: gallop from the current index, then bisect
+        if (i < n_occ && occ[2 * i] < cp)
+        {
+            u64 lo = i, hop = 1;
+            while (lo + hop < n_occ && occ[2 * (lo + hop)] < cp)
+            {
+                lo += hop;
+                hop <<= 1;
+            }
+            u64 hi = lo + hop < n_occ ? lo + hop : n_occ; // occ[lo] < cp <= occ[hi] (or hi == n_occ)
+            ++lo;
+            while (lo < hi)
+            {
+                const u64 mid = lo + (hi - lo) / 2;
+                if (occ[2 * mid] < cp)
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+            i = lo;
+        }
+        if (i >= n_occ)
+            break;
+        const u64 at = occ[2 * i];
+        const bool ok = !ws.ww || (keep[i] & kKeep);
+        if (ws.mode == kNlWalkKmp)
+        {
+            if (ok && lineno[i] != seen)
+            {
+                if (ws.maxc != ~0ull && cnt >= ws.maxc)
+                    break;
+                ++cnt;
+                seen = lineno[i];
+                const u64 le = at + ws.k0;
+                cp = le < n ? le + 1 : n;
+            }
+            else
+                cp = at + m;
+            continue;
+        }
+        u64 j = (at - cp) / step;
+        if (n - cp < 16)
+            j = 0;
+        else
+        {
+            const u64 jt = (n - 16 - cp) / step + 1;
+            j = jt < j ? jt : j;
+        }
+        const u64 win = cp + j * step;
+        if (ok && lineno[i] != seen)
+        {
+            if (cnt >= ws.maxc)
+                break;
+            ++cnt;
+            seen = lineno[i];
+            const u64 le = at + ws.k0;
+            if (le < n)
+            {
+                cp = win + (le + 1 - at);
+                continue;
+            }
+            if (cnt >= ws.maxc)
+                break;
+        }
+        cp = at + (ws.om ? 1 : m);
+        if (cp > n)
+            cp = n;
+    }
+    out[0] = cnt;
+}
+
 #define GCHK(x)                                                                                \
     do                                                                                         \
     {                                                                                          \
@@ -420,6 +521,42 @@ int post_walk(PostScratch &s, const uint8_t *d_text, uint64_t text_len, uint64_t
     *nlines = ws.lines ? h_ctr->lines : 0;
     if (resume)
         *resume = h_ctr->pad[1];
+    return 0;
+}
+
+// occ: n_occ ALL-occurrence records in s.d_occ (whole text, global_base 0); d_lineno[n_occ] = line number of every start.
+int post_nlwalk(PostScratch &s, const uint8_t *d_text, uint64_t text_len, uint32_t mode, uint32_t m, uint32_t k0, bool ww, bool om,
+                uint64_t maxc, uint64_t n_occ, const uint64_t *d_lineno, Counters *d_ctr, Counters *h_ctr, hipStream_t st,
+                uint64_t *count)
+{
+    *count = 0;
+    if (n_occ == 0)
+        return 0;
+    if (n_occ > s.keep_cap)
+    {
+        const u64 nb = (n_occ + kGBlockElems - 1) / kGBlockElems;
+        if (s.d_keep) (void)hipFree(s.d_keep);
+        if (s.d_gblk) (void)hipFree(s.d_gblk);
+        if (s.d_surv) (void)hipFree(s.d_surv);
+        s.d_keep = nullptr; s.d_gblk = nullptr; s.d_surv = nullptr; s.keep_cap = 0;
+        GCHK(hipMalloc(&s.d_keep, n_occ));
+        GCHK(hipMalloc(&s.d_gblk, nb * sizeof(u64)));
+        GCHK(hipMalloc(&s.d_surv, n_occ * 2 * sizeof(u64)));
+        s.keep_cap = n_occ;
+    }
+    const u64 *occ = (const u64 *)s.d_occ;
+    GCHK(hipMemsetAsync(s.d_keep, kKeep, n_occ, st));
+    if (ww)
+        hipLaunchKernelGGL(g_ww, dim3((u32)((n_occ + kGB - 1) / kGB)), dim3(kGB), 0, st, occ, (u64)n_occ, 0ull, d_text, (u64)text_len, m,
+                           s.d_keep);
+    NlWalkSpec ws{};
+    ws.mode = mode; ws.m = m; ws.k0 = k0; ws.ww = ww; ws.om = om; ws.n = text_len; ws.maxc = maxc;
+    hipLaunchKernelGGL(g_nlwalk, dim3(1), dim3(64), 0, st, occ, (u64)n_occ, (const u64 *)d_lineno, (const uint8_t *)s.d_keep, ws,
+                       (u64 *)&d_ctr->pad[1]);
+    GCHK(hipGetLastError());
+    GCHK(hipMemcpyAsync(h_ctr, d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, st));
+    GCHK(hipStreamSynchronize(st));
+    *count = h_ctr->pad[1];
     return 0;
 }
 

@@ -371,15 +371,12 @@ extern "C" const char *krep_gpu_algorithm_name(int a)
 }
 
 // ------------------------------------------------------------------------------------ what is accelerated
-// Two input classes are NOT reproduced; for them krep_gpu_can_accelerate() says 0, krep_gpu_select_search_algorithm()
-// returns NULL (the caller keeps its CPU function pointer, exactly like the regex case) and the operators refuse loudly:
-//  * simd_sse42_search in -c mode with a pattern that contains '\n': its line skip adds (line_end + 1 - match) to the
-//    16-byte WINDOW start instead of to the match (krep.c:4787-4793), so where the scan resumes depends on the phase of
-//    the 17-m-byte window grid, which every earlier match has shifted — a sequential chain over the whole text.
-//    kmp_search -c with such a pattern resumes exactly behind the first '\n' (krep.c:1703-1707); it is kept off the
-//    GPU with it (same rarity: `--algo=kmp -c $'a\nb'`).
+// ONE input class is not taken; for it krep_gpu_can_accelerate() says 0, krep_gpu_select_search_algorithm() returns NULL (the
+// caller keeps its CPU function pointer, exactly like the regex case) and an operator called with it anyway takes the failure road:
 //  * memchr_short_search in -c mode while the file-static only_matching is set: main() never produces that
 //    combination (krep.c:3811-3814 clears count_lines_mode under -o), so it has no reference behaviour to pin.
+// (Round 3: -c through simd_sse42_search / kmp_search with a '\n' inside the pattern — refused until then — is reproduced by a
+//  walk over the ordered occurrence list, kg_greedy.hip (3).)
 static bool pattern_has_border(const uint8_t *p, size_t m)
 {
     for (size_t k = 1; k < m; ++k)
@@ -407,10 +404,6 @@ const char *unsupported_reason(const search_params_t *p, const krep_gpu_config_t
     p = &q;
     const int top = mirror_top(p, c);
     const int eff = mirror_effective(top, p, SIZE_MAX / 2);
-    const bool has_nl = p->pattern_len && memchr(p->pattern, '\n', p->pattern_len) != nullptr;
-    if (p->count_lines_mode && has_nl && (eff == KREP_RA_SSE42 || eff == KREP_RA_KMP))
-        return "-c through simd_sse42_search / kmp_search with a pattern containing a newline is not accelerated "
-               "(window-phase dependent line skip, krep.c:4787-4793)";
     if (p->count_lines_mode && c.only_matching && eff == KREP_RA_MEMCHR_SHORT)
         return "memchr_short_search with count_lines_mode AND only_matching is not accelerated (unreachable from the "
                "reference CLI, krep.c:3811-3814)";
@@ -928,11 +921,18 @@ struct Family
     bool need_walk = false; // a sequential pass over the ordered list is required (kg_greedy.hip)
     bool replay = false;    // -c through a block-structured function: end-of-text replay (kg_replay.h)
     bool neon_zero = false; // neon_search, count-only, max_count == 0 (tail-call convention)
-    bool whole_text() const { return need_walk || replay || neon_zero; } // cannot be scanned in pieces
+    bool nlwalk = false;    // -c through simd_sse42_search / kmp_search with a '\n' inside the pattern (kg_greedy.hip (3))
+    bool whole_text() const { return need_walk || replay || neon_zero || nlwalk; } // cannot be scanned in independent pieces
 };
-Family family_of(int algo, bool only_matching, bool lines, bool ww, bool track, size_t maxc, bool has_border, uint32_t m)
+Family family_of(int algo, bool only_matching, bool lines, bool ww, bool track, size_t maxc, bool has_border, uint32_t m,
+                 bool pat_has_newline = false)
 {
     Family f;
+    if (lines && pat_has_newline && (algo == KREP_RA_SSE42 || algo == KREP_RA_KMP))
+    {
+        f.nlwalk = true; // the line jump lands inside the match: a chain over every visited match, nothing else applies
+        return f;
+    }
     f.greedy = (algo == KREP_RA_SSE42 || algo == KREP_RA_KMP);
     if (only_matching)
     {
@@ -985,8 +985,8 @@ int split_mode(const search_params_t *p, const krep_gpu_config_t &c, size_t text
         for (auto &b : f)
             b = lo8(b);
     const Family fam = family_of(algo, c.only_matching != 0, p->count_lines_mode, p->whole_word, p->track_positions, p->max_count,
-                                 pattern_has_border(f.data(), m), (uint32_t)m);
-    if (fam.neon_zero || (fam.replay && algo == KREP_RA_NEON))
+                                 pattern_has_border(f.data(), m), (uint32_t)m, memchr(pat, '\n', m) != nullptr);
+    if (fam.neon_zero || fam.nlwalk || (fam.replay && algo == KREP_RA_NEON))
         return kSplitWhole;
     return (fam.need_walk || fam.replay) ? kSplitChain : kSplitPieces;
 }
@@ -1106,8 +1106,60 @@ static int scan_literal(krep_gpu_plan *pl, int algo, const Window &w, match_posi
     const size_t own_hi = std::min(w.own_hi, w.text_len);
     const bool whole = w.global_base == 0 && w.own_lo == 0 && own_hi + m > w.text_len && w.global_len == w.text_len;
 
-    const Family fam = family_of(algo, pl->only_matching, pl->lines, pl->ww, pl->track, pl->max_count, pl->has_border, m);
+    const Family fam = family_of(algo, pl->only_matching, pl->lines, pl->ww, pl->track, pl->max_count, pl->has_border, m,
+                                 pl->has_newline);
     const bool mshort_o = fam.mshort_o, need_walk = fam.need_walk, replay = fam.replay;
+    if (fam.nlwalk)
+    {
+        // -c through simd_sse42_search / kmp_search with a newline inside the pattern: all occurrences, the line number of every
+        // start, the -w verdicts — then ONE thread walks the list the way the reference's loop moves (kg_greedy.hip (3))
+        if (!whole)
+            return kg::fail("-c through %s with a newline inside the pattern is a chain over every counted match: scan the whole "
+                            "text in one window", krep_gpu_algorithm_name(algo));
+        if (pl->max_count == 0)
+            return 0; // krep.c:4713, :1634
+        HIPCHK(hipSetDevice(pl->device));
+        if (time_it) HIPCHK(hipEventRecord(pl->ev0, st));
+        LitPass ps;
+        ps.own_lo = 0; ps.own_hi = own_hi; ps.sink = LitPass::OCC; ps.post = &pl->post;
+        LitResult lr0;
+        if (lit_pass(pl, w, ps, st, &lr0))
+            return 2;
+        uint64_t lines_counted = 0;
+        if (lr0.total)
+        {
+            if (lr0.total > pl->nl_cap)
+            {
+                if (pl->d_nl_rec) (void)hipFree(pl->d_nl_rec);
+                if (pl->d_nl_ln) (void)hipFree(pl->d_nl_ln);
+                pl->d_nl_rec = nullptr; pl->d_nl_ln = nullptr; pl->nl_cap = 0;
+                const uint64_t want_n = lr0.total + lr0.total / 4 + 1024;
+                HIPCHK(hipMalloc(&pl->d_nl_rec, want_n * sizeof(match_position_t)));
+                HIPCHK(hipMalloc(&pl->d_nl_ln, want_n * sizeof(uint64_t)));
+                pl->nl_cap = want_n;
+            }
+            if (krep_gpu_line_numbers(w.d_text, w.text_len, (const match_position_t *)pl->post.d_occ, lr0.total, pl->d_nl_ln, st))
+                return 2;
+            const uint32_t k0 = (uint32_t)((const uint8_t *)memchr(pl->pats[0].data(), '\n', m) - pl->pats[0].data());
+            if (post_nlwalk(pl->post, w.d_text, w.text_len, algo == KREP_RA_KMP ? kNlWalkKmp : kNlWalkSse42, m, k0, pl->ww,
+                            pl->only_matching, pl->max_count == SIZE_MAX ? ~0ull : (uint64_t)pl->max_count, lr0.total, pl->d_nl_ln,
+                            pl->d_ctr, pl->h_ctr, st, &lines_counted))
+                return 2;
+        }
+        if (time_it)
+        {
+            HIPCHK(hipEventRecord(pl->ev1, st));
+            HIPCHK(hipStreamSynchronize(st));
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, pl->ev0, pl->ev1));
+            out->kernel_ms = ms;
+        }
+        out->total_matches = lines_counted;
+        out->line_count = lines_counted;
+        out->head_line_hit = out->tail_line_hit = lines_counted != 0;
+        out->count = lines_counted; // the walk applies max_count the way the functions do (a break before the increment)
+        return 0;
+    }
     // the walks couple neighbouring matches: a window that does not start the text needs the boundary record of the text
     // in front of it (where the reference's scan stands: krep_gpu_seq_carry_t::resume)
     if (need_walk && !whole && !carry_in && w.global_base + w.own_lo != 0)

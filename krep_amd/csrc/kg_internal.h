@@ -61,6 +61,11 @@ int post_walk(PostScratch &s, const uint8_t *d_text, uint64_t text_len, uint64_t
               uint64_t n_occ, uint64_t *d_pos, uint64_t want, Counters *d_ctr, Counters *h_ctr, hipStream_t st,
               uint64_t *total, uint64_t *nlines, uint64_t *resume);
 
+constexpr uint32_t kNlWalkSse42 = 0, kNlWalkKmp = 1; // post_nlwalk modes
+int post_nlwalk(PostScratch &s, const uint8_t *d_text, uint64_t text_len, uint32_t mode, uint32_t m, uint32_t k0, bool ww, bool om,
+                uint64_t maxc, uint64_t n_occ, const uint64_t *d_lineno, Counters *d_ctr, Counters *h_ctr, hipStream_t st,
+                uint64_t *count);
+
 // kg_tail.hip — end-of-text replay of the block-structured -c paths (kg_replay.h)
 struct ReplayIn;
 int tail_last_hit(const unsigned long long *d_unitinfo, uint64_t limit_units, unsigned long long *d_slot,

@@ -48,7 +48,7 @@ def test_gpu_reproduces_reference_vectors():
             if not e.can_accelerate(p):
                 assert e.select(p) is None
                 e.set_algo_override(abi.ALGO_AUTO)
-                continue  # left to the CPU by contract (krep_gpu_can_accelerate): SSE4.2/KMP -c with '\n' in the pattern
+                continue  # left to the CPU by contract (krep_gpu_can_accelerate): memchr_short -c under -o
         ret, pos = e.search(p, text)
         e.set_algo_override(abi.ALGO_AUTO)
         assert _same(v, ret, pos), (cid, v["algo"], pats, kw, ret, v["ret"])

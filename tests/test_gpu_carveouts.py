@@ -188,22 +188,54 @@ def test_classes_left_to_the_cpu_are_refused_loudly(gpu):
     import krep_amd
     t = np.frombuffer(b"a\nb a\nb\n" * 50, dtype=np.uint8)
     gpu.set_reference_simd(abi.REF_AVX2)
-    p = abi.Params([b"a\nb"], count_lines=True)  # simd_sse42_search -c with '\n' in the pattern
-    assert not gpu.can_accelerate(p) and gpu.select(p) is None
-    with pytest.raises(krep_amd.KrepGpuError):
-        gpu.search(p, t)
-    assert gpu.search_buffer(p, t)[0] == 2
+    assert gpu.can_accelerate(abi.Params([b"a\nb"], count_lines=True))     # round 3: the newline-pattern -c walk
     assert gpu.can_accelerate(abi.Params([b"a\nb"]))                      # positions: reproduced
     assert gpu.can_accelerate(abi.Params([b"a\nb" * 7], count_lines=True))  # 21 bytes -> AVX2 body: reproduced
     gpu.set_only_matching(True)
     try:
         q = abi.Params([b"ab"], case_sensitive=False, count_lines=True)   # memchr_short -c with -o: unreachable from the CLI
         assert not gpu.can_accelerate(q) and gpu.select(q) is None
+        with pytest.raises(krep_amd.KrepGpuError):
+            gpu.search(q, t)
+        assert gpu.search_buffer(q, t, only_matching=True)[0] == 2
     finally:
         gpu.set_only_matching(False)
     r = abi.Params([b"a.*b"])
     r.s.use_regex = True
     assert not gpu.can_accelerate(r) and gpu.select(r) is None
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_count_lines_with_a_newline_inside_the_pattern(gpu, oracle_engine, seed):
+    """-c through simd_sse42_search / kmp_search with a '\\n' inside the pattern (krep.c:4785-4795, :1703-1707): after a
+    counted line the scan resumes INSIDE the match — for SSE4.2 at a point that depends on the phase of its 17-m-byte window
+    grid.  The last input class that was left to the CPU until round 3: one device thread walks the ordered occurrence list
+    (kg_greedy.hip (3)).  Against the compiled reference, every flag and max_count, texts with dense newlines."""
+    rng = np.random.RandomState(700 + seed)
+    n_cases = 0
+    for n in (1, 5, 17, 40, 1000, 40_000, 300_001):
+        for alpha in (b"ab\n", b"ab \n\n", b"a\n"):
+            text = cases.rand_text(rng, n, alpha)
+            for pat in (b"a\nb", b"\n", b"a\n", b"\na", b"ab\nab", b"\n\n", b"b\na\nb", b"aa\n", b"a\na\na", b"\n\n\n\n"):
+                # the four x86 builds, and --algo=kmp (krep.c:1790), which sends every pattern through kmp_search
+                for level, override in ((abi.REF_AVX2, abi.ALGO_AUTO), (abi.REF_SSE42, abi.ALGO_AUTO), (abi.REF_SCALAR, abi.ALGO_AUTO),
+                                        (abi.REF_AVX512, abi.ALGO_AUTO), (abi.REF_AVX2, abi.ALGO_KMP)):
+                    for kw in (dict(), dict(whole_word=True), dict(max_count=3), dict(max_count=1, whole_word=True),
+                               dict(case_sensitive=False)):
+                        gpu.set_reference_simd(level)
+                        gpu.set_algo_override(override)
+                        p = abi.Params([pat], count_lines=True, **kw)
+                        algo = gpu.mirror_select(p, text.size)
+                        if algo not in (abi.RA_SSE42, abi.RA_KMP):
+                            continue
+                        assert gpu.can_accelerate(p) and gpu.split_mode(p, text.size) == abi.SPLIT_WHOLE
+                        want = oracle_engine.call(algo, abi.Params([pat], count_lines=True, **kw), text)
+                        got = gpu.search(p, text)
+                        assert got[0] == want[0], (abi.RA_NAMES[algo], pat, kw, n, alpha, got[0], want[0])
+                        n_cases += 1
+    gpu.set_reference_simd(abi.REF_AVX2)
+    gpu.set_algo_override(abi.ALGO_AUTO)
+    assert n_cases > 300
 
 
 @pytest.mark.parametrize("shards", [2, 3, 8])

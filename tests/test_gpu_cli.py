@@ -47,8 +47,8 @@ def test_cli_gpu_equals_cpu(tmp_path):
         # memchr_search with max_count a multiple of its 4096-entry batch: the displaced record (krep.c:3976-3991) must
         # still come out in file order although the patched CLI skips its qsort for GPU results
         (["-o", "-m", "4096", "e"], f_big),
-        # the input class left to the CPU (krep_gpu_can_accelerate() == 0): -c through simd_sse42_search with a newline in
-        # the pattern — the selector falls through to the reference's own function, output unchanged, nothing on stderr
+        # -c through simd_sse42_search with a newline in the pattern (left to the CPU until round 3, now the walk of
+        # kg_greedy.hip (3)): output unchanged, nothing on stderr
         (["-c", "fox\nSherlock"], f_small), (["-c", "e\nS"], f_big),
     ]
     for args, path in cases:

@@ -27,7 +27,7 @@ def _check(gpu, o, text, pat, kw, level):
     p = abi.Params([pat], **kw)
     algo = gpu.mirror_select(p, text.size)
     if not gpu.can_accelerate(p):
-        # the two input classes the backend leaves to the CPU (include/krep_gpu.h: krep_gpu_can_accelerate): the selector
+        # the input class the backend leaves to the CPU (include/krep_gpu.h: krep_gpu_can_accelerate): the selector
         # hands back NULL and the operator refuses loudly — never a silent approximation
         assert gpu.select(p) is None
         with pytest.raises(krep_amd.KrepGpuError):
