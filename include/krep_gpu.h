@@ -278,8 +278,8 @@ int krep_gpu_scan_device(krep_gpu_plan_t *plan, const void *d_text, size_t text_
  * the WHOLE text (the block simd_avx512_search leaves unexamined, krep.c:5171; the first byte of the scalar tail calls,
  * which has no left neighbour for -w, krep.c:5059-5097): with global_len those land where the reference puts them, in
  * whichever shard holds them.  The sequential match-set families (greedy SSE4.2/KMP selection of a bordered pattern,
- * -o through BMH / memchr_short; -c through the AVX-512 / AVX2 -w block loops) accept a window inside the text only through
- * krep_gpu_scan_device_seq() below; -c through neon_search needs the whole text in one window (krep_gpu_split_mode()). */
+ * -o through BMH / memchr_short; -c through the AVX-512 / AVX2 -w / NEON block loops) accept a window inside the text only
+ * through krep_gpu_scan_device_seq() below; krep_gpu_split_mode() names the few classes that need the whole text in one window. */
 int krep_gpu_scan_device_ex(krep_gpu_plan_t *plan, const void *d_text, size_t text_len, size_t own_lo,
                             size_t own_hi, size_t global_base, size_t global_len, match_position_t *d_positions,
                             uint64_t position_capacity, void *stream, int time_it, krep_gpu_scan_out_t *out);
@@ -293,7 +293,7 @@ typedef struct krep_gpu_seq_carry
     uint64_t resume;      /* greedy / -o walks: global offset from which the reference's scan continues — starts in front of
                              it are consumed, the first occurrence / candidate at or behind it is looked at afresh (0: nothing
                              consumed)                                                                                      */
-    /* -c through simd_avx512_search / simd_avx2_search -w (krep.c:5203-5218, :5000-5013): the line-skip history that decides
+    /* -c through simd_avx512_search / simd_avx2_search -w / neon_search (krep.c:5203-5218, :5000-5013, :4590-4611): the line-skip history that decides
      * where the block grid stands when it enters the last 256 bytes of the text (the end-of-text replay, kg_replay.h).
      * All offsets are global and stored + 1 (0 = none).                                                                    */
     uint64_t q1;          /* start of the last accepted occurrence in the text so far                                        */
@@ -301,7 +301,12 @@ typedef struct krep_gpu_seq_carry
     uint64_t local_q1;    /* the same for THIS piece alone: a caller that scanned its pieces out of order (shards on       */
     uint64_t local_nl1;   /* different devices) folds them afterwards: q1 = local_q1 ? local_q1 : in.q1,                   */
     uint64_t local_first_nl1; /* nl1 = local_q1 ? local_nl1 : in.nl1 ? in.nl1 : in.q1 ? local_first_nl1 : 0                 */
-    uint64_t reserved[2]; /* zero */
+    /* neon_search only (krep.c:4590-4611: no restart on an unterminated line, so its block grid is still the one the previous
+     * counted line set): g0 = the grid origin in effect for q's line — (first '\n' behind the last accepted occurrence on an
+     * EARLIER line) + 1, or 0.  local_g0_kind: 0 no occurrence in this piece; 1 g0 = local_g0; 2 q's line starts in this piece
+     * but the earlier occurrence lies in front of it: g0 = in.q1 ? (in.nl1 ? in.nl1 : local_first_nl1) : 0; 3 q's line started
+     * in front of this piece: g0 = in.q1 ? (in.nl1 ? in.nl1 : in.g0) : 0.                                                    */
+    uint64_t g0, local_g0, local_g0_kind;
 } krep_gpu_seq_carry_t;
 /* krep_gpu_scan_device_ex() for the pieces of one text IN TEXT ORDER: carry_in = the record the previous piece left
  * (NULL: nothing in front of this window is consumed — the piece that starts the text, or an optimistic first pass of a
@@ -316,8 +321,8 @@ int krep_gpu_scan_device_seq(krep_gpu_plan_t *plan, const void *d_text, size_t t
 /* How a text of text_len bytes may be cut for `params` under the current configuration. */
 enum krep_gpu_split
 {
-    KREP_GPU_SPLIT_WHOLE = 0,  /* one window only: -c through neon_search (arm64 builds), neon_search's max_count == 0
-                                  corner, multi-pattern -c with a newline inside a pattern                                */
+    KREP_GPU_SPLIT_WHOLE = 0,  /* one window only: -c through simd_sse42_search / kmp_search with a newline inside the pattern,
+                                  neon_search's max_count == 0 corner, multi-pattern -c with a newline inside a pattern   */
     KREP_GPU_SPLIT_PIECES = 1, /* independent pieces: start-offset ownership + halo, results concatenate / merge          */
     KREP_GPU_SPLIT_CHAIN = 2   /* pieces in text order through krep_gpu_scan_device_seq()                                 */
 };

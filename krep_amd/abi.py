@@ -69,7 +69,8 @@ SPLIT_WHOLE, SPLIT_PIECES, SPLIT_CHAIN = 0, 1, 2
 class SeqCarry(C.Structure):
     """krep_gpu_seq_carry_t: the boundary record of the sequential match-set families."""
     _fields_ = [("resume", C.c_uint64), ("q1", C.c_uint64), ("nl1", C.c_uint64), ("local_q1", C.c_uint64),
-                ("local_nl1", C.c_uint64), ("local_first_nl1", C.c_uint64), ("reserved", C.c_uint64 * 2)]
+                ("local_nl1", C.c_uint64), ("local_first_nl1", C.c_uint64), ("g0", C.c_uint64), ("local_g0", C.c_uint64),
+                ("local_g0_kind", C.c_uint64)]
 
 
 SEARCH_FUNC = C.CFUNCTYPE(C.c_uint64, C.POINTER(SearchParams), C.c_char_p, C.c_size_t,

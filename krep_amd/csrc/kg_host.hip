@@ -957,8 +957,8 @@ namespace kg {
 // How may the text be cut?  kSplitPieces: independent pieces (start-offset ownership + halo) whose results merge.
 // kSplitChain: pieces in text order, each taking the boundary record of the one before it (the greedy / -o walks: where the
 // reference's scan stands; -c through simd_avx512_search / simd_avx2_search -w: the line-skip history the end-of-text replay
-// needs — krep_gpu_seq_carry_t).  kSplitWhole: one window only — -c through neon_search (a second level of line history),
-// its max_count == 0 corner, multi-pattern -c with a '\n' inside a pattern (emission-order line transitions).
+// needs, for neon_search with its grid origin — krep_gpu_seq_carry_t).  kSplitWhole: one window only — the newline-pattern -c
+// walk of kg_greedy.hip (3), neon_search's max_count == 0 corner, multi-pattern -c with a '\n' inside a pattern.
 int split_mode(const search_params_t *p, const krep_gpu_config_t &c, size_t text_len)
 {
     if (!p || p->use_regex || p->num_patterns == 0)
@@ -986,11 +986,35 @@ int split_mode(const search_params_t *p, const krep_gpu_config_t &c, size_t text
             b = lo8(b);
     const Family fam = family_of(algo, c.only_matching != 0, p->count_lines_mode, p->whole_word, p->track_positions, p->max_count,
                                  pattern_has_border(f.data(), m), (uint32_t)m, memchr(pat, '\n', m) != nullptr);
-    if (fam.neon_zero || fam.nlwalk || (fam.replay && algo == KREP_RA_NEON))
+    if (fam.neon_zero || fam.nlwalk)
         return kSplitWhole;
     return (fam.need_walk || fam.replay) ? kSplitChain : kSplitPieces;
 }
 bool shardable(const search_params_t *p, const krep_gpu_config_t &c, size_t text_len) { return split_mode(p, c, text_len) != kSplitWhole; }
+// The left fold of the boundary record (include/krep_gpu.h, krep_gpu_seq_carry_t): used by a piece that knows its predecessor's
+// record, and by the host after shards were scanned out of order.
+krep_gpu_seq_carry_t fold_carry(const krep_gpu_seq_carry_t &in, const krep_gpu_seq_carry_t &pc)
+{
+    krep_gpu_seq_carry_t o = pc; // keeps the piece's local_* fields
+    o.resume = std::max<uint64_t>(in.resume, pc.resume);
+    if (!pc.local_q1)
+    {
+        o.q1 = in.q1;
+        o.nl1 = in.nl1 ? in.nl1 : in.q1 ? pc.local_first_nl1 : 0;
+        o.g0 = in.g0;
+        return o;
+    }
+    o.q1 = pc.local_q1;
+    o.nl1 = pc.local_nl1;
+    switch (pc.local_g0_kind)
+    {
+    case 1: o.g0 = pc.local_g0; break;
+    case 2: o.g0 = in.q1 ? (in.nl1 ? in.nl1 : pc.local_first_nl1) : 0; break; // nl1 is stored + 1: it IS the next line start
+    case 3: o.g0 = in.q1 ? (in.nl1 ? in.nl1 : in.g0) : 0; break;
+    default: o.g0 = 0;
+    }
+    return o;
+}
 } // namespace kg
 extern "C" int krep_gpu_split_mode(const search_params_t *p, size_t text_len)
 {
@@ -1215,10 +1239,8 @@ static int scan_literal(krep_gpu_plan *pl, int algo, const Window &w, match_posi
             // needs from the text in front of it is the line-skip history {last accepted occurrence q, first '\n' behind it},
             // which every piece extends (krep_gpu_seq_carry_t) — the piece's own contribution is reported next to the folded
             // state, so that shards scanned out of order can be folded afterwards.
-            const uint64_t base = w.global_base, B = algo == KREP_RA_AVX512 ? 64 : 32;
+            const uint64_t base = w.global_base, B = algo == KREP_RA_AVX512 ? 64 : algo == KREP_RA_AVX2 ? 32 : 16;
             const bool final_piece = base + own_hi >= G;
-            if (algo == KREP_RA_NEON)
-                return kg::fail("-c through neon_search keeps a second level of line history: scan the whole text in one window");
             if (base + w.own_lo != 0 && !carry_in)
                 return kg::fail("-c through %s restarts its block grid at every counted line: scan the whole text in one window, "
                                 "or its pieces in text order through krep_gpu_scan_device_seq()", krep_gpu_algorithm_name(algo));
@@ -1235,29 +1257,54 @@ static int scan_literal(krep_gpu_plan *pl, int algo, const Window &w, match_posi
                 if (lit_pass(pl, w, ps, st, &lr))
                     return 2;
             }
-            krep_gpu_seq_carry_t in = carry_in ? *carry_in : krep_gpu_seq_carry_t{}, co = in;
-            co.local_q1 = co.local_nl1 = co.local_first_nl1 = 0;
+            const krep_gpu_seq_carry_t in = carry_in ? *carry_in : krep_gpu_seq_carry_t{};
+            krep_gpu_seq_carry_t pc{}; // this piece's own contribution
             bool have_q = false;
             uint64_t q = 0;
             if (lim > w.own_lo && last_accepted_before(pl, w, lr, w.own_lo, lim, st, &have_q, &q))
                 return 2;
+            {
+                uint64_t nl = nl_end; // first newline of the piece (the record of a piece without an occurrence; neon_search's kind 2)
+                if ((!have_q || algo == KREP_RA_NEON) && tail_find_next_newline(w.d_text, w.own_lo, nl_end, d_slot, h_slot, st, &nl))
+                    return 2;
+                pc.local_first_nl1 = nl < nl_end ? base + nl + 1 : 0;
+            }
             if (have_q)
             {
                 uint64_t nl = nl_end;
                 if (tail_find_next_newline(w.d_text, q, nl_end, d_slot, h_slot, st, &nl))
                     return 2;
-                co.local_q1 = base + q + 1;
-                co.local_nl1 = nl < nl_end ? base + nl + 1 : 0;
+                pc.local_q1 = base + q + 1;
+                pc.local_nl1 = nl < nl_end ? base + nl + 1 : 0;
+                if (algo == KREP_RA_NEON)
+                {
+                    // the grid origin in effect for q's line: (first newline behind the last accepted occurrence on an earlier
+                    // line) + 1 — from this piece if that occurrence lies in it, else from the record in front of it
+                    uint64_t lsp1 = 0;
+                    if (tail_find_prev_newline(w.d_text, q, d_slot, h_slot, st, &lsp1))
+                        return 2;
+                    if (lsp1 <= w.own_lo) // no newline in [own_lo, q): q's line started in front of this piece
+                        pc.local_g0_kind = 3;
+                    else
+                    {
+                        bool have_q2 = false;
+                        uint64_t q2 = 0;
+                        if (last_accepted_before(pl, w, lr, w.own_lo, lsp1, st, &have_q2, &q2))
+                            return 2;
+                        if (!have_q2)
+                            pc.local_g0_kind = 2;
+                        else
+                        {
+                            uint64_t nl2 = nl_end;
+                            if (tail_find_next_newline(w.d_text, q2, nl_end, d_slot, h_slot, st, &nl2))
+                                return 2;
+                            pc.local_g0_kind = 1;
+                            pc.local_g0 = base + nl2 + 1; // nl2 < lsp1 <= q: it exists
+                        }
+                    }
+                }
             }
-            else
-            {
-                uint64_t nl = nl_end;
-                if (tail_find_next_newline(w.d_text, w.own_lo, nl_end, d_slot, h_slot, st, &nl))
-                    return 2;
-                co.local_first_nl1 = nl < nl_end ? base + nl + 1 : 0;
-            }
-            co.q1 = co.local_q1 ? co.local_q1 : in.q1;
-            co.nl1 = co.local_q1 ? co.local_nl1 : in.nl1 ? in.nl1 : in.q1 ? co.local_first_nl1 : 0;
+            const krep_gpu_seq_carry_t co = kg::fold_carry(in, pc);
             if (carry_out)
                 *carry_out = co;
             total = lr.total; lines = lr.lines; summary = lr.summary;
@@ -1265,14 +1312,20 @@ static int scan_literal(krep_gpu_plan *pl, int algo, const Window &w, match_posi
             {
                 // where the reference's block loop stands when it enters the last kReplayWindow bytes (replay_entry, global offsets)
                 uint64_t cur, extra = 0;
+                int open = 0;
                 if (!co.q1)
                     cur = (X / B) * B; // the block grid never left offset 0
                 else if (co.nl1)
                     cur = co.nl1 <= X ? co.nl1 + ((X - co.nl1) / B) * B : co.nl1; // restarted at the line start behind q
+                else if (algo == KREP_RA_NEON)
+                {
+                    cur = co.g0 + ((X - co.g0) / B) * B; // no restart on an unterminated line: the previous counted line's grid
+                    open = 1;
+                }
                 else
                     cur = G; // unterminated line counted: the clamped advance ended the scan (krep.c:5006-5008, :5211-5213)
                 ReplayIn r{};
-                r.algo = algo; r.m = m; r.ww = pl->ww; r.n = G; r.cur = cur; r.open = 0;
+                r.algo = algo; r.m = m; r.ww = pl->ww; r.n = G; r.cur = cur; r.open = open;
                 r.text = w.d_text - base; // indexed with global offsets >= cur - 1 >= base: inside the buffer
                 r.pat = pl->d_pat;
                 if (cur < G && tail_run_replay(r, d_slot, h_slot, st, &extra))

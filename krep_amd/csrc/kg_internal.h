@@ -95,6 +95,8 @@ const char *unsupported_reason(const search_params_t *p, const krep_gpu_config_t
 constexpr int kSplitWhole = 0, kSplitPieces = 1, kSplitChain = 2; // enum krep_gpu_split (include/krep_gpu.h)
 int split_mode(const search_params_t *p, const krep_gpu_config_t &c, size_t text_len);
 bool shardable(const search_params_t *p, const krep_gpu_config_t &c, size_t text_len); // split_mode != whole
+// a piece's own contribution (the local_* fields of `piece`) folded onto the record of the text in front of it
+krep_gpu_seq_carry_t fold_carry(const krep_gpu_seq_carry_t &in, const krep_gpu_seq_carry_t &piece);
 bool result_reserve(match_result_t *r, uint64_t extra);
 bool have_error();
 

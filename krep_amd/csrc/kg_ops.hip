@@ -672,7 +672,7 @@ static int run_pieces(const search_params_t *params, const krep_gpu_config_t &cf
             // walks: the piece's own list depends on where the scan stands at its start; block-loop -c: only the piece that
             // ends the text depends on the line-skip history
             const bool stale = std::max<uint64_t>(p.carry_used.resume, p.lo) != std::max<uint64_t>(tc.resume, p.lo) ||
-                               (p.hi == len && (p.carry_used.q1 != tc.q1 || p.carry_used.nl1 != tc.nl1));
+                               (p.hi == len && (p.carry_used.q1 != tc.q1 || p.carry_used.nl1 != tc.nl1 || p.carry_used.g0 != tc.g0));
             if (stale)
             {
                 DeviceCtx &cx = *ctx_for(p.device);
@@ -686,12 +686,7 @@ static int run_pieces(const search_params_t *params, const krep_gpu_config_t &cf
             }
             // fold this piece's own contribution onto the true record (for a piece scanned with the true record this
             // reproduces its carry_out)
-            const krep_gpu_seq_carry_t &o = p.carry_out;
-            krep_gpu_seq_carry_t n = tc;
-            n.resume = std::max<uint64_t>(tc.resume, o.resume);
-            n.q1 = o.local_q1 ? o.local_q1 : tc.q1;
-            n.nl1 = o.local_q1 ? o.local_nl1 : tc.nl1 ? tc.nl1 : tc.q1 ? o.local_first_nl1 : 0;
-            tc = n;
+            tc = kg::fold_carry(tc, p.carry_out);
         }
     }
     // ---- the shards' counters meet: per logical shard one slot {matches, lines, head, tail, has_nl}, each

@@ -155,14 +155,18 @@ def test_device_windows_with_the_boundary_record(gpu, oracle_engine):
 
 @pytest.mark.parametrize("shards", [2, 3, 8])
 def test_block_loop_count_lines_in_pieces(gpu, oracle_engine, shards):
-    """-c through simd_avx512_search (33..64 B) and simd_avx2_search -w (17..32 B): the block grid restarts at every counted
+    """-c through simd_avx512_search (33..64 B), simd_avx2_search -w (17..32 B) and neon_search (2..16 B): the block grid restarts at every counted
     line (krep.c:5203-5218, :5000-5013), so the END of the scan depends on the line-skip history of the whole text.  In pieces
     only the last one replays the end; the history {last accepted occurrence, first newline behind it} rides on the boundary
     record.  Sharded and streamed, against the compiled reference."""
     rng = np.random.RandomState(900 + shards)
     jobs = [(abi.REF_AVX512, 40, dict(count_lines=True)), (abi.REF_AVX512, 64, dict(count_lines=True, whole_word=True)),
             (abi.REF_AVX2, 20, dict(count_lines=True, whole_word=True)), (abi.REF_AVX2, 32, dict(count_lines=True, whole_word=True)),
-            (abi.REF_AVX512, 33, dict(count_lines=True))]
+            (abi.REF_AVX512, 33, dict(count_lines=True)),
+            # neon_search (arm64 builds): no restart on an unterminated line — the grid origin of the previous counted line
+            # rides on the record as well
+            (abi.REF_NEON, 3, dict(count_lines=True)), (abi.REF_NEON, 9, dict(count_lines=True, whole_word=True)),
+            (abi.REF_NEON, 16, dict(count_lines=True))]
     for n in (150_003, 64 * 2500 + 17, 3 * (1 << 20) + 99):
         share = (n + shards - 1) // shards
         for variant in range(4):
@@ -183,7 +187,7 @@ def test_block_loop_count_lines_in_pieces(gpu, oracle_engine, shards):
                 gpu.set_reference_simd(level)
                 p = abi.Params([pat], **kw)
                 algo = gpu.mirror_select(p, n)
-                assert algo in (abi.RA_AVX512, abi.RA_AVX2)
+                assert algo in (abi.RA_AVX512, abi.RA_AVX2, abi.RA_NEON)
                 cfg = gpu.default_config()
                 cfg.reference_simd = level
                 gpu.set_thread_config(cfg)

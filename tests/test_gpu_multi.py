@@ -147,3 +147,38 @@ def test_partial_windows_refused_for_sequential_families(gpu):
     head = plan.scan(d.data_ptr(), text.size, 0, 5000)  # the piece that starts the text needs no record
     assert head.count == 2 * (5000 // 11) + (1 if 5000 % 11 > 0 else 0) + (1 if 5000 % 11 > 4 else 0)
     plan.close()
+
+
+def test_legacy_single_pattern_params_through_every_host_path(gpu, oracle_engine):
+    """callers in the reference's own style fill only pattern / pattern_len (test/test_krep.c:233-235) — patterns and
+    pattern_lens NULL, num_patterns 0 or 1.  One normalised view serves the selector, the one-piece path, the sharded path and
+    the streamed path (run_pieces used to read pattern_lens[] of the raw struct)."""
+    import ctypes as C
+    rng = np.random.RandomState(12)
+    text = cases.rand_text(rng, 3 * (1 << 20) + 11, b"abcd \n")
+    gpu.set_reference_simd(abi.REF_AVX2)
+    want = oracle_engine.call(gpu.mirror_select(abi.Params([b"abcd"]), text.size), abi.Params([b"abcd"]), text)
+    for npat in (0, 1):
+        p = abi.Params([b"abcd"])
+        p.s.patterns = None
+        p.s.pattern_lens = None
+        p.s.num_patterns = npat
+        assert gpu.can_accelerate(p) and gpu.select(p) is not None
+        for shards, chunk in ((1, 0), (3, 0), (1, 1 << 20)):
+            gpu.set_num_gpus(shards)
+            gpu.set_stream_chunk(chunk)
+            try:
+                res = gpu.lib.krep_gpu_match_result_init(16)
+                ret = gpu.lib.krep_gpu_literal_search(p.ref, C.c_void_p(text.ctypes.data), text.size, res)
+                pos = abi.result_positions(res)
+                gpu.lib.krep_gpu_match_result_free(res)
+            finally:
+                gpu.set_num_gpus(1)
+                gpu.set_stream_chunk(0)
+            assert gpu.last_status() == abi.STATUS_OK and ret == want[0] and np.array_equal(pos, want[1]), (npat, shards, chunk)
+    empty = abi.Params([b"x"])
+    empty.s.pattern = None
+    empty.s.patterns = None
+    empty.s.pattern_lens = None
+    empty.s.num_patterns = 0
+    assert not gpu.can_accelerate(empty) and gpu.select(empty) is None
