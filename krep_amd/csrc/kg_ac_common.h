@@ -401,11 +401,21 @@ __device__ __forceinline__ void ac_walk_probe2(const AcArgs &a, u64 i, bool live
         slowB = liveB;
         return;
     }
+    // ONE 20-byte window serves both ends: A = its first 16 bytes (the text up to i), B = the same one byte further (up to
+    // i + 1) by funnel shifts — five loads where two windows took eight.  Only the byte text[i + 1] is read behind A, and
+    // only when it exists (liveB): nothing is touched past the end of the buffer.
     struct __attribute__((packed)) U32p { u32 v; };
     const U32p *qa = reinterpret_cast<const U32p *>(a.text + (i - 15));
-    const U32p *qb = reinterpret_cast<const U32p *>(a.text + (i - 15) + (liveB ? 1 : 0)); // i + 1 < text_len iff liveB
-    u32 TA[4] = {qa[0].v, qa[1].v, qa[2].v, qa[3].v};
-    u32 TB[4] = {qb[0].v, qb[1].v, qb[2].v, qb[3].v};
+    const u32 w0 = qa[0].v, w1 = qa[1].v, w2 = qa[2].v, w3 = qa[3].v, w4 = liveB ? (u32)a.text[i + 1] : 0u;
+    u32 TA[4] = {w0, w1, w2, w3};
+    u32 TB[4] = {w0, w1, w2, w3};
+    if (liveB)
+    {
+        TB[0] = __builtin_amdgcn_alignbyte(w1, w0, 1);
+        TB[1] = __builtin_amdgcn_alignbyte(w2, w1, 1);
+        TB[2] = __builtin_amdgcn_alignbyte(w3, w2, 1);
+        TB[3] = __builtin_amdgcn_alignbyte(w4, w3, 1);
+    }
     if (CI)
     {
 #pragma unroll
