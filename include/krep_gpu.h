@@ -327,6 +327,10 @@ enum krep_gpu_split
     KREP_GPU_SPLIT_CHAIN = 2   /* pieces in text order through krep_gpu_scan_device_seq()                                 */
 };
 int krep_gpu_split_mode(const search_params_t *params, size_t text_len);
+/* test hook (host only, no GPU needed): the left fold of the boundary record exactly as the library applies it — a piece's
+ * own contribution (its local_* fields) onto the record of the text in front of it — so that the CPU test-suite can pin the
+ * chained-pieces algebra against the oracle (tests/test_replay_cpu.py) */
+void krep_gpu_debug_fold_carry(const krep_gpu_seq_carry_t *in, const krep_gpu_seq_carry_t *piece, krep_gpu_seq_carry_t *out);
 
 /* Deterministic synthetic haystacks, generated directly in HBM by a counter-based
  * PRNG so that any [global_off, global_off+len) slice is reproducible on any rank.

@@ -1016,6 +1016,11 @@ krep_gpu_seq_carry_t fold_carry(const krep_gpu_seq_carry_t &in, const krep_gpu_s
     return o;
 }
 } // namespace kg
+extern "C" void krep_gpu_debug_fold_carry(const krep_gpu_seq_carry_t *in, const krep_gpu_seq_carry_t *piece, krep_gpu_seq_carry_t *out)
+{
+    if (in && piece && out)
+        *out = kg::fold_carry(*in, *piece);
+}
 extern "C" int krep_gpu_split_mode(const search_params_t *p, size_t text_len)
 {
     return kg::split_mode(p, kg::current_config(), text_len);

@@ -23,6 +23,8 @@ def lib():
     L = C.CDLL(build.build())
     L.krep_gpu_debug_replay_host.restype = C.c_uint64
     L.krep_gpu_debug_replay_host.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.c_char_p, C.c_uint32, C.c_int, C.c_size_t, C.c_int]
+    L.krep_gpu_debug_fold_carry.restype = None
+    L.krep_gpu_debug_fold_carry.argtypes = [C.POINTER(abi.SeqCarry)] * 3
     return L
 
 
@@ -112,3 +114,77 @@ def test_replay_plus_canonical_prefix_equals_reference_function(lib, algo, seed)
             assert got == want, (abi.RA_NAMES[algo], pat, ww, maxc, len(text), K, cur, opn, extra, want, text)
             checked += 1
     assert checked > 400
+
+
+# ---- the same in PIECES (round 3): every piece contributes its own part of the line-skip history, the product's fold
+# (kg::fold_carry, exported as krep_gpu_debug_fold_carry) combines them in text order — whatever order they were scanned in —
+# and only the piece that ends the text replays.  The per-piece quantities below restate what the device side derives
+# (kg_host.hip, the replay branch of scan_literal for a window inside the text).
+def piece_record(text, acc, lo, hi, X, final, algo):
+    n = len(text)
+    lim, nl_end = (X, n) if final else (hi, hi)
+    pc = abi.SeqCarry()
+    mine = [i for i in acc if lo <= i < lim]
+    first_nl = text.find(b"\n", lo, nl_end)
+    pc.local_first_nl1 = first_nl + 1 if first_nl != -1 else 0
+    if not mine:
+        return pc
+    q = mine[-1]
+    nl = text.find(b"\n", q, nl_end)
+    pc.local_q1 = q + 1
+    pc.local_nl1 = nl + 1 if nl != -1 else 0
+    if algo == abi.RA_NEON:
+        p = text.rfind(b"\n", 0, q)
+        if p < lo:  # q's line started in front of this piece (a newline in the halo belongs to the piece before)
+            pc.local_g0_kind = 3
+        else:
+            ls = p + 1
+            b2 = [i for i in mine if i < ls]
+            if not b2:
+                pc.local_g0_kind = 2
+            else:
+                pc.local_g0_kind = 1
+                pc.local_g0 = text.find(b"\n", b2[-1]) + 1
+    return pc
+
+
+@pytest.mark.parametrize("algo", [abi.RA_AVX2, abi.RA_AVX512, abi.RA_NEON])
+@pytest.mark.parametrize("seed", range(3))
+def test_chained_pieces_fold_equals_reference_function(lib, algo, seed):
+    rng = random.Random(7000 + 10 * algo + seed)
+    o = ol.checker()
+    B = BLOCK[algo]
+    checked = 0
+    for _ in range(500):
+        text, pat = make_case(rng, algo)
+        n = len(text)
+        X = n - W if n > W else 0
+        if n < len(pat) or X < B + 2 or (algo != abi.RA_NEON and pat[-1] == 0):
+            continue
+        for ww in ((True,) if algo == abi.RA_AVX2 else (False, True)):
+            want, _ = o.call(algo, abi.Params([pat], count_lines=True, whole_word=ww), text)
+            acc = accepted(text, pat, ww)
+            cuts = sorted({0, n} | {rng.randrange(1, X - B + 1) for _ in range(rng.choice([1, 2, 3, 6]))})
+            pieces = list(zip(cuts[:-1], cuts[1:]))
+            recs = [piece_record(text, acc, lo, hi, X, hi == n, algo) for lo, hi in pieces]
+            tc = abi.SeqCarry()
+            for pc in recs:  # the left fold, with the product's own function
+                out = abi.SeqCarry()
+                lib.krep_gpu_debug_fold_carry(C.byref(tc), C.byref(pc), C.byref(out))
+                tc = out
+            if not tc.q1:
+                cur, opn = (X // B) * B, 0
+            elif tc.nl1:
+                cur, opn = (tc.nl1 + ((X - tc.nl1) // B) * B if tc.nl1 <= X else tc.nl1), 0
+            elif algo == abi.RA_NEON:
+                cur, opn = tc.g0 + ((X - tc.g0) // B) * B, 1
+            else:
+                cur, opn = n, 0
+            K = len({text.rfind(b"\n", 0, i) + 1 for i in acc if i < X})
+            extra = lib.krep_gpu_debug_replay_host(algo, text, n, pat, len(pat), int(ww), cur, opn) if cur < n else 0
+            assert K + extra == want, (abi.RA_NAMES[algo], pat, ww, n, cuts, K, cur, opn, extra, want, text)
+            # ... and the folded record is the one the whole-text derivation arrives at
+            wK, wcur, wopn = decompose(text, pat, ww, algo)
+            assert (cur, opn) == (wcur, wopn), (abi.RA_NAMES[algo], pat, ww, n, cuts, cur, opn, wcur, wopn, text)
+            checked += 1
+    assert checked > 150
