@@ -86,3 +86,21 @@ def test_host_generator_is_deterministic_and_sliceable():
     assert bytes(a).count(b"Sherlock") == 5
     c = e.generate_host(200_000, 0, 3, 7, b"#", 0)
     assert 1500 < int((c == ord("#")).sum()) < 2500
+
+
+def test_header_is_plain_c_and_python_mirrors_its_structs(tmp_path):
+    """include/krep_gpu.h is the boundary a C host (krep.c) compiles against: C11, -pedantic clean, and the ctypes mirrors of
+    the configuration / boundary-record structs have the C layout (a silent mismatch would corrupt the caller's stack)."""
+    import subprocess
+    src = tmp_path / "abi_check.c"
+    src.write_text('#include "krep_gpu.h"\n#include <stdio.h>\n#include <stddef.h>\n'
+                   'int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(search_params_t), sizeof(match_result_t), '
+                   'sizeof(krep_gpu_config_t), sizeof(krep_gpu_seq_carry_t), sizeof(krep_gpu_scan_out_t), '
+                   'offsetof(krep_gpu_config_t, min_text_bytes), offsetof(krep_gpu_seq_carry_t, local_g0_kind)); return 0; }\n')
+    exe = tmp_path / "abi_check"
+    r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-pedantic", "-Werror", f"-I{os.path.join(ROOT, 'include')}",
+                        str(src), "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    sizes = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    assert sizes == [C.sizeof(abi.SearchParams), C.sizeof(abi.MatchResult), C.sizeof(abi.Config), C.sizeof(abi.SeqCarry),
+                     C.sizeof(abi.ScanOut), abi.Config.min_text_bytes.offset, abi.SeqCarry.local_g0_kind.offset], sizes
