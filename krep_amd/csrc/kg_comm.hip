@@ -15,11 +15,14 @@
 // single-GPU invocation of the CLI would pay for nothing; in a process that already holds an RCCL (PyTorch bundles one,
 // same soname) that copy is the one found, so there are never two.
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <unistd.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
 #include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -102,6 +105,35 @@ const char *rccl_why() { return g_rccl && !g_rccl->why.empty() ? g_rccl->why.c_s
             return kg::fail("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
+// RCCL prints a banner ("RCCL version : ... Hostname ... Librccl path ...") to STDOUT when a process creates its first
+// communicator.  A drop-in must not add a byte to its host's output (krep's stdout IS its result): file descriptor 1 points
+// to /dev/null while a communicator is created.  stdio is flushed on both sides of the switch, so the host's pending output
+// reaches the real stdout and whatever RCCL left in a stdio buffer goes down the drain.  ($KREP_GPU_RCCL_BANNER=1 keeps it.)
+struct StdoutMute
+{
+    int saved = -1;
+    StdoutMute()
+    {
+        if (getenv("KREP_GPU_RCCL_BANNER"))
+            return;
+        fflush(stdout);
+        saved = dup(1);
+        const int nul = open("/dev/null", O_WRONLY);
+        if (saved >= 0 && nul >= 0)
+            (void)dup2(nul, 1);
+        if (nul >= 0)
+            close(nul);
+    }
+    ~StdoutMute()
+    {
+        if (saved < 0)
+            return;
+        fflush(stdout);
+        (void)dup2(saved, 1);
+        close(saved);
+    }
+};
+
 // ---- one process, several devices ---------------------------------------------------------------------------------
 struct Clique
 {
@@ -123,7 +155,11 @@ int clique_for(Rccl *R, const std::vector<int> &devs, size_t n, Clique **out) //
         Clique *nc = new Clique();
         nc->devs = devs;
         nc->comms.resize(devs.size());
-        ncclResult_t e = R->CommInitAll(nc->comms.data(), (int)devs.size(), devs.data());
+        ncclResult_t e;
+        {
+            StdoutMute mute;
+            e = R->CommInitAll(nc->comms.data(), (int)devs.size(), devs.data());
+        }
         if (e != ncclSuccess)
         {
             delete nc;
@@ -254,7 +290,12 @@ extern "C" int krep_gpu_comm_init_rank(const void *id128, int nranks, int rank, 
     HCHK(hipSetDevice(device));
     ncclUniqueId id;
     memcpy(&id, id128, sizeof id);
-    NCHK(R, R->CommInitRank(&g_rank.comm, nranks, id, rank));
+    {
+        StdoutMute mute;
+        const ncclResult_t e = R->CommInitRank(&g_rank.comm, nranks, id, rank);
+        if (e != ncclSuccess)
+            return kg::fail("ncclCommInitRank failed: %s", R->GetErrorString(e));
+    }
     HCHK(hipStreamCreateWithFlags(&g_rank.stream, hipStreamNonBlocking));
     g_rank.device = device;
     g_rank.nranks = nranks;

@@ -13,11 +13,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLI = os.path.join(ROOT, "oracle", "_ref", "krep_gpu_cli")
 
 
-def run(args, gpu):
+def run(args, gpu, **extra):
     env = dict(os.environ)
-    env.pop("KREP_GPU", None)
+    for k in ("KREP_GPU", "KREP_GPU_NUM", "KREP_GPU_MIN_BYTES", "KREP_GPU_DISABLE", "KREP_GPU_INJECT_FAILURE"):
+        env.pop(k, None)
     if gpu:
         env["KREP_GPU"] = "1"
+        env["KREP_GPU_MIN_BYTES"] = "0"  # the small fixtures go through the backend too (the size policy has its own test)
+    env.update({k: str(v) for k, v in extra.items()})
     r = subprocess.run([CLI] + args, env=env, capture_output=True, timeout=300)
     return r.returncode, r.stdout, r.stderr
 
@@ -56,6 +59,13 @@ def test_cli_gpu_equals_cpu(tmp_path):
         gpu = run(["-t", "1", "--color=never"] + args + [str(path)], gpu=True)
         assert b"krep-gpu:" not in gpu[2], gpu[2]
         assert gpu[0] == cpu[0] and gpu[1] == cpu[1], (args, cpu[:2], gpu[:2])
+    # KREP_GPU_NUM=3: the operators shard every text over three devices of the process (one physical device here: a clique of
+    # one), the shards' counters meet in the RCCL all-reduce issued from C; sequential families take the chained road
+    for args, path in cases[:8] + cases[13:18]:
+        cpu = run(["-t", "1", "--color=never"] + args + [str(path)], gpu=False)
+        gpu3 = run(["-t", "1", "--color=never"] + args + [str(path)], gpu=True, KREP_GPU_NUM=3)
+        assert b"krep-gpu:" not in gpu3[2], gpu3[2]
+        assert gpu3[:2] == cpu[:2], ("KREP_GPU_NUM=3", args, cpu[:2], gpu3[:2])
     # and the GPU path really ran: the algorithm is no CPU function -> no chunking, same answer with -t 8
     multi = run(["-t", "8", "-c", "Sherlock", str(f_big)], gpu=True)
     single = run(["-t", "1", "-c", "Sherlock", str(f_big)], gpu=False)
