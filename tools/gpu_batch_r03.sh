@@ -4,6 +4,7 @@
 # TLB / write-stall counters of the literal scan with and without offsets, memchr1 run-to-run over six processes,
 # read/write ceilings, dictionaries, host path.
 set -u
+ulimit -c 0   # a faulting kernel must not fill the box's disk with core dumps (it cost the first run of this batch 37 minutes)
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; mkdir -p $O; cd $R
 timeout 600 python bench.py > $O/r03_default_bench.json 2> $O/r03_default_bench.err; tail -c 300 $O/r03_default_bench.json; echo
 timeout 300 python bench.py --force-dist --no-extra --no-cpu-baseline --steps 5 > $O/r03_force_dist_1rank_rccl.json 2> $O/r03_force_dist_1rank_rccl.err; tail -1 $O/r03_force_dist_1rank_rccl.err
