@@ -823,13 +823,13 @@ static int lit_pass(krep_gpu_plan *pl, const Window &w, const LitPass &ps, hipSt
             if (post.d_tk) (void)hipFree(post.d_tk);
             post.d_tk = nullptr;
             post.tk_cap = 0;
-            HIPCHK(hipMalloc(&post.d_tk, 2 * n_tk * sizeof(unsigned long long)));
+            HIPCHK(hipMalloc(&post.d_tk, single_fused_scratch_words(n_tk) * sizeof(unsigned long long)));
             post.tk_cap = n_tk;
         }
         a.positions = ps.d_out;
         a.pos_cap = ps.out_cap;
         HIPCHK(hipMemsetAsync(pl->d_ctr, 0, sizeof(Counters), st));
-        HIPCHK(hipMemsetAsync(post.d_tk, 0, 2 * n_tk * sizeof(unsigned long long), st));
+        HIPCHK(hipMemsetAsync(post.d_tk, 0, single_fused_scratch_words(n_tk) * sizeof(unsigned long long), st));
         HIPCHK(launch_single_fused(a, post.d_tk, post.d_tk + n_tk, n_tk, grid, st));
         if (ps.ev_end) HIPCHK(hipEventRecord(ps.ev_end, st));
         HIPCHK(hipMemcpyAsync(pl->h_ctr, pl->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, st));

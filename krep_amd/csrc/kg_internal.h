@@ -18,6 +18,7 @@ hipError_t launch_literal(const LitArgs &a, uint32_t num_cu, hipStream_t st); //
 
 // kg_single.hip — single byte with records in one pass (counts resolved by one wave, records written a ticket later)
 uint64_t single_fused_tickets(uint64_t n_units);
+uint64_t single_fused_scratch_words(uint64_t n_tickets);
 hipError_t launch_single_fused(const LitArgs &a, unsigned long long *d_agg, unsigned long long *d_pref, uint64_t n_tickets,
                                uint32_t num_cu, hipStream_t st);
 

@@ -5,15 +5,15 @@
 // kernel turns the staging into 5.5 GB of records — 5.8-6.9 ms of scan (depending on where the driver places the staging
 // stores) plus 1.4 ms of gather for a workload whose bytes (34.4 GB read + 5.5 GB written) fit into ~6 ms.
 // Here the records are written by the wave that found the hits, at their FINAL index, and nothing else is stored:
-//   * a wave draws a ticket of kUpt units (128 KiB), scans it exactly as lit_scan<1> does (SWAR byte equality, 16 start
+//   * a wave draws a ticket of kUpt units (64 KiB; eight interleaved counters), scans it exactly as lit_scan<1> does (SWAR byte equality, 16 start
 //     positions per lane in registers) and puts every hit, already ranked inside the ticket (ballot bit-planes + v_mbcnt),
 //     as a 16-bit unit-relative offset into its LDS ring — nothing goes to memory while it streams;
 //   * it publishes the ticket's hit count (one 8-byte store) and goes on to the NEXT ticket;
-//   * one RESOLVER wave (wave 0 of block 0; it does not scan) turns the published counts, 256 tickets per step, into their
+//   * one RESOLVER wave (wave 0 of block 0; it does not scan) turns the published counts, 512 tickets per step, into their
 //     exclusive prefix — the global index of each ticket's first record;
-//   * only after scanning that next ticket (~80 us later) does the wave pick up its previous ticket's prefix — by then the
+//   * only after scanning that next ticket (~40 us later) does the wave pick up its previous ticket's prefix — by then the
 //     resolver has long passed it, nobody waits — and writes that ticket's records from the ring: coalesced 1-KiB stores,
-//     21 KiB per ticket, ascending with the ticket number.
+//     10 KiB per ticket, ascending with the ticket number.
 // This is the chained scan that round 1 measured at 2.9 TB/s (every tile waited for its predecessor's status) with the wait
 // taken out of it: counts flow forward through one wave, the consumers are a whole ticket period behind.
 // Residency: the grid is exactly the resident blocks (as for every kernel of this library), so the resolver and every wave
@@ -31,10 +31,23 @@ namespace kg {
 using u32 = uint32_t;
 using u64 = unsigned long long;
 
-constexpr u32 kUpt = 4;                       // units (32 KiB each) per ticket: 128 KiB
-constexpr u32 kRing = 4096;                   // 16-bit entries per wave (8 KiB): the ticket being scanned + the one waiting
+// Ticket size and number of ticket counters (A/B builds: python -m krep_amd.build --variant x -DKG_S1_UPT=4 -DKG_S1_NC=1).
+// Measured in one process per box (tools/ab_bench.py, 32 GiB): 128-KiB tickets from one counter 6.60 ms on a fast placement
+// draw and 7.38 on a slow one (four boxes of five); 64-KiB tickets from eight interleaved counters 6.64 and 6.89 — the same
+// best case, a worst case 7 % better (8 GiB: 1.88 -> 1.76 ms); 32-KiB tickets outrun the resolver (10.4 ms).  The read side
+// alone prefers LARGER tickets (tools/ubench/window_probe.hip); it is the record writes next to it that prefer smaller ones.
+#ifndef KG_S1_UPT
+#define KG_S1_UPT 2
+#endif
+#ifndef KG_S1_NC
+#define KG_S1_NC 8
+#endif
+constexpr u32 kUpt = KG_S1_UPT;               // units (32 KiB each) per ticket: 64 KiB (at most 4: the flush tells units apart by three bounds)
+constexpr u32 kNc = KG_S1_NC;                 // ticket counters (own cache lines); counter c hands out the tickets congruent to c mod kNc
+static_assert(kUpt >= 1 && kUpt <= 4, "flush() derives a record's unit from three boundaries");
+constexpr u32 kRing = 1024u * kUpt;           // 16-bit entries per wave: the ticket being scanned + the one waiting
 constexpr u64 kReady = 1ull << 63;
-constexpr u32 kResolveChunk = 4;              // tickets per resolver lane and step (256 per wave step)
+constexpr u32 kResolveChunk = 16u / kUpt;     // tickets per resolver lane and step (256 per wave step at 128-KiB tickets)
 constexpr u64 kUnitBytes1 = (u64)kRoundsBig * kSegBytes;
 
 __device__ __forceinline__ u32 s_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
@@ -264,13 +277,16 @@ __global__ __launch_bounds__(kBlock, 4) void single_fused(const LitArgs a, u64 *
         }
     };
 
+    // the wave's ticket counter: a.ctr->ticket, or (kNc > 1) one of kNc counters on their own cache lines behind the prefix array
+    const u32 my_c = kNc > 1 ? (blockIdx.x * kWavesPerBlk + wave) % kNc : 0u;
+    u64 *my_ctr = kNc > 1 ? pref + n_tickets + (size_t)my_c * 16u : &a.ctr->ticket;
     uint4 A[kCells];
     u64 t;
     {
         u64 tk = 0;
         if (lane == 0)
-            tk = __hip_atomic_fetch_add(&a.ctr->ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        t = s_rfl64(tk);
+            tk = __hip_atomic_fetch_add(my_ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t = s_rfl64(tk) * kNc + my_c;
     }
     bool haveA = t < n_tickets && a.anchor + t * kTicketBytes + kSegBytes <= a.text_len;
     issue(A, haveA ? a.anchor + t * kTicketBytes : fb);
@@ -314,8 +330,8 @@ __global__ __launch_bounds__(kBlock, 4) void single_fused(const LitArgs a, u64 *
         // the next ticket, and its first round on the way, before the previous ticket's records are written
         u64 tk = 0;
         if (lane == 0)
-            tk = __hip_atomic_fetch_add(&a.ctr->ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const u64 tn = s_rfl64(tk);
+            tk = __hip_atomic_fetch_add(my_ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const u64 tn = s_rfl64(tk) * kNc + my_c;
         haveA = tn < n_tickets && a.anchor + tn * kTicketBytes + kSegBytes <= a.text_len;
         issue(A, haveA ? a.anchor + tn * kTicketBytes : fb);
         if (pend)
@@ -362,6 +378,7 @@ static hipError_t launch_fused(const LitArgs &a, u64 *agg, u64 *pref, u64 n_tick
 }
 
 uint64_t single_fused_tickets(uint64_t n_units) { return (n_units + kUpt - 1) / kUpt; }
+uint64_t single_fused_scratch_words(uint64_t n_tickets) { return 2 * n_tickets + (kNc > 1 ? 16ull * kNc : 0ull); } // counts | prefixes | counters
 
 hipError_t launch_single_fused(const LitArgs &a, unsigned long long *d_agg, unsigned long long *d_pref, uint64_t n_tickets,
                                uint32_t num_cu, hipStream_t st)
