@@ -47,6 +47,7 @@ constexpr u32 kNc = KG_S1_NC;                 // ticket counters (own cache line
 static_assert(kUpt >= 1 && kUpt <= 4, "flush() derives a record's unit from three boundaries");
 constexpr u32 kRing = 1024u * kUpt;           // 16-bit entries per wave: the ticket being scanned + the one waiting
 constexpr u64 kReady = 1ull << 63;
+constexpr u32 kSpinLimit = 1u << 24;          // ~0.25 us per spin: seconds — only a logic error gets there (see the safety nets)
 constexpr u32 kResolveChunk = 16u / kUpt;     // tickets per resolver lane and step (256 per wave step at 128-KiB tickets)
 constexpr u64 kUnitBytes1 = (u64)kRoundsBig * kSegBytes;
 
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(kBlock, 4) void single_fused(const LitArgs a, u64 *
         {
             const u64 mine = t0 + (u64)lane * kResolveChunk;
             u64 v[kResolveChunk];
-            for (;;)
+            for (u32 spins = 0;; ++spins)
             {
                 bool ok = true;
 #pragma unroll
@@ -102,6 +103,16 @@ __global__ __launch_bounds__(kBlock, 4) void single_fused(const LitArgs a, u64 *
                 }
                 if (__ballot(!ok) == 0ull)
                     break;
+                if (spins > kSpinLimit)
+                {
+                    // safety net (never expected): a count that does not arrive within seconds must not hang the device.  Flag the
+                    // scan as failed-over (the host re-runs the two-pass kernels) and release every waiter with a made-up prefix.
+                    if (lane == 0)
+                        atomicAdd(&a.ctr->overflow_units, 1ull);
+                    for (u64 t = t0 + lane; t < n_tickets; t += 64)
+                        __hip_atomic_store(&pref[t], kReady, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return;
+                }
                 __builtin_amdgcn_s_sleep(8);
             }
             u64 s = 0;
@@ -149,11 +160,17 @@ __global__ __launch_bounds__(kBlock, 4) void single_fused(const LitArgs a, u64 *
 #else
         if (lane == 0)
         {
-            for (;;)
+            for (u32 spins = 0;; ++spins)
             {
                 p = __hip_atomic_load(&pref[pend_t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (p & kReady)
                     break;
+                if (spins > 2u * kSpinLimit) // safety net, as in the resolver: flag the scan, go on with a made-up prefix
+                {
+                    atomicAdd(&a.ctr->overflow_units, 1ull);
+                    p = kReady;
+                    break;
+                }
                 __builtin_amdgcn_s_sleep(4);
             }
         }
@@ -280,14 +297,27 @@ __global__ __launch_bounds__(kBlock, 4) void single_fused(const LitArgs a, u64 *
     // the wave's ticket counter: a.ctr->ticket, or (kNc > 1) one of kNc counters on their own cache lines behind the prefix array
     const u32 my_c = kNc > 1 ? (blockIdx.x * kWavesPerBlk + wave) % kNc : 0u;
     u64 *my_ctr = kNc > 1 ? pref + n_tickets + (size_t)my_c * 16u : &a.ctr->ticket;
+    // EVERY ticket must be drawn by somebody — the resolver waits for all of them in order — so a wave whose counter has run
+    // dry moves on to the next one (a counter only grows: dry stays dry).  With fewer scanning waves than counters (a small
+    // text) this is what serves the counters no wave started on; on a large text it is the tail's load balancing.
+    u32 cur_c = my_c, dry = 0;
+    auto draw = [&]() __attribute__((always_inline)) -> u64 {
+        while (dry < kNc)
+        {
+            u64 tk = 0;
+            if (lane == 0)
+                tk = __hip_atomic_fetch_add(kNc > 1 ? pref + n_tickets + (size_t)cur_c * 16u : my_ctr, 1ull, __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_AGENT);
+            const u64 tt = s_rfl64(tk) * kNc + cur_c;
+            if (tt < n_tickets)
+                return tt;
+            cur_c = cur_c + 1u < kNc ? cur_c + 1u : 0u;
+            ++dry;
+        }
+        return ~0ull;
+    };
     uint4 A[kCells];
-    u64 t;
-    {
-        u64 tk = 0;
-        if (lane == 0)
-            tk = __hip_atomic_fetch_add(my_ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        t = s_rfl64(tk) * kNc + my_c;
-    }
+    u64 t = draw();
     bool haveA = t < n_tickets && a.anchor + t * kTicketBytes + kSegBytes <= a.text_len;
     issue(A, haveA ? a.anchor + t * kTicketBytes : fb);
     while (t < n_tickets)
@@ -328,10 +358,7 @@ __global__ __launch_bounds__(kBlock, 4) void single_fused(const LitArgs a, u64 *
         if (lane == 0)
             __hip_atomic_store(&agg[t], (u64)cnt | kReady, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // the next ticket, and its first round on the way, before the previous ticket's records are written
-        u64 tk = 0;
-        if (lane == 0)
-            tk = __hip_atomic_fetch_add(my_ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const u64 tn = s_rfl64(tk) * kNc + my_c;
+        const u64 tn = draw();
         haveA = tn < n_tickets && a.anchor + tn * kTicketBytes + kSegBytes <= a.text_len;
         issue(A, haveA ? a.anchor + tn * kTicketBytes : fb);
         if (pend)
