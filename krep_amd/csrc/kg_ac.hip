@@ -160,7 +160,6 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
         // have_c: the caller already holds the classes of W[0] and W[4] (fast path: it shuffles the 20-bit class word
         // of the neighbour lane instead of its raw bytes, which saves one compress per cell)
         auto cell_body = [&](const int j, u32 (&W)[5], const bool have_c, const u32 pc0, const u32 pc4) __attribute__((always_inline)) {
-            const u64 lbase = seg + (u64)j * kCellBytes + (u64)lane * 16u;
             u32 NL = 0;
             if (LINES)
             {
