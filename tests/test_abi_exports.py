@@ -104,3 +104,68 @@ def test_header_is_plain_c_and_python_mirrors_its_structs(tmp_path):
     sizes = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
     assert sizes == [C.sizeof(abi.SearchParams), C.sizeof(abi.MatchResult), C.sizeof(abi.Config), C.sizeof(abi.SeqCarry),
                      C.sizeof(abi.ScanOut), abi.Config.min_text_bytes.offset, abi.SeqCarry.local_g0_kind.offset], sizes
+
+
+def test_split_mode_table():
+    """Host logic, no GPU: which families may be cut how (krep_gpu_split_mode).  Independent pieces for the
+    all-occurrence functions, chained pieces (one boundary record) for the sequential ones, one window for the three classes
+    DESIGN.md §7 names."""
+    import krep_amd
+    e = krep_amd.load()
+    n = 10_000_000
+    W, P, CH = abi.SPLIT_WHOLE, abi.SPLIT_PIECES, abi.SPLIT_CHAIN
+    table = [
+        # (reference build, only_matching, patterns, params kwargs, expected)
+        (abi.REF_AVX2, False, [b"Sherlock"], {}, P),                                   # border-free: greedy == all occurrences
+        (abi.REF_AVX2, False, [b"Sherlock"], dict(count_lines=True), P),
+        (abi.REF_AVX2, False, [b"abab"], {}, CH),                                      # simd_sse42_search, bordered: greedy walk
+        (abi.REF_AVX2, False, [b"abab"], dict(count_lines=True), P),                   # plain -c needs no selection
+        (abi.REF_AVX2, False, [b"abab"], dict(count_lines=True, whole_word=True), CH),
+        (abi.REF_SCALAR, False, [b"abab"], {}, CH),                                    # kmp_search
+        (abi.REF_SCALAR, False, [b"aXbY"], {}, P),                                     # boyer_moore_search
+        (abi.REF_AVX2, True, [b"ab"], dict(case_sensitive=False), CH),                 # memchr_short_search under -o
+        (abi.REF_AVX2, True, [b"abab"], dict(case_sensitive=False), CH),               # boyer_moore_search under -o
+        (abi.REF_AVX2, True, [b"abba"], {}, P),                                        # SSE4.2 under -o: all occurrences
+        (abi.REF_AVX2, False, [b"x" * 20], dict(count_lines=True), P),                 # AVX2 body without -w: canonical
+        (abi.REF_AVX2, False, [b"x" * 20], dict(count_lines=True, whole_word=True), CH),  # ... with -w: end-of-text replay
+        (abi.REF_AVX512, False, [b"x" * 40], dict(count_lines=True), CH),
+        (abi.REF_AVX512, False, [b"x" * 40], {}, P),
+        (abi.REF_NEON, False, [b"xyz"], dict(count_lines=True), CH),
+        (abi.REF_NEON, False, [b"xyz"], dict(max_count=0, track_positions=False), W),  # neon_search's max_count == 0 corner
+        (abi.REF_AVX2, False, [b"a\nb"], dict(count_lines=True), W),                   # the newline-pattern -c walk
+        (abi.REF_AVX2, False, [b"a\nb"], {}, P),
+        (abi.REF_AVX2, False, [b"ab", b"cd"], {}, P),
+        (abi.REF_AVX2, False, [b"ab", b"cd"], dict(count_lines=True), P),
+        (abi.REF_AVX2, False, [b"a\nb", b"cd"], dict(count_lines=True), W),            # multi-pattern -c, newline inside a pattern
+        (abi.REF_AVX2, False, [b"e"], {}, P),
+    ]
+    try:
+        for level, om, pats, kw, want in table:
+            cfg = e.default_config()
+            cfg.reference_simd, cfg.only_matching = level, int(om)
+            e.set_thread_config(cfg)
+            got = e.split_mode(abi.Params(pats, **kw), n)
+            assert got == want, (level, om, pats, kw, got, want)
+    finally:
+        e.set_thread_config(None)
+
+
+def test_size_policy_of_worthwhile(monkeypatch):
+    """krep_gpu_worthwhile(): size first (no device is touched for a small text), then the input class, then the device."""
+    import krep_amd
+    e = krep_amd.load()
+    p = abi.Params([b"Sherlock"])
+    monkeypatch.setenv("KREP_GPU_ASSUME_AVAILABLE", "1")
+    monkeypatch.delenv("KREP_GPU_DISABLE", raising=False)
+    assert e.default_config().min_text_bytes == 1 << 20
+    assert e.worthwhile(p, 1 << 20) and not e.worthwhile(p, (1 << 20) - 1)
+    e.lib.krep_gpu_set_min_text_bytes(4096)
+    try:
+        assert e.worthwhile(p, 4096) and not e.worthwhile(p, 4095)
+        r = abi.Params([b"a.*b"])
+        r.s.use_regex = True
+        assert not e.worthwhile(r, 1 << 30)
+    finally:
+        e.lib.krep_gpu_set_min_text_bytes((1 << 64) - 1)  # back to "not set": $KREP_GPU_MIN_BYTES, else 1 MiB
+    monkeypatch.setenv("KREP_GPU_DISABLE", "1")
+    assert not e.worthwhile(p, 1 << 30)
