@@ -361,6 +361,20 @@ int krep_gpu_comm_allreduce_device_u64(void *d_values, int n, void *stream);    
 void krep_gpu_comm_destroy(void);
 uint64_t krep_gpu_rccl_calls(void); /* collectives this process has issued through RCCL (diagnostic / self-test) */
 int krep_gpu_rccl_version(void);    /* ncclGetVersion(), 0 when librccl cannot be loaded */
+/* Where the calling thread's LAST sharded host search (search_buffer(num_gpus > 1), the operators with num_gpus > 1) ran:
+ * logical shards, the distinct physical devices they were placed on, the ranks of the communicator the counters met in
+ * (0: a single device, nothing to reduce) and how they met (1 = the RCCL all-reduce, 2 = RCCL could not be used and the
+ * host summed the slots it already held — the search result is the same, krep_gpu_last_error() names the reason).
+ * The multi-GPU self-test (tests/test_gpu_multi.py) asserts on it; a search that did not shard leaves shards = 1. */
+typedef struct krep_gpu_shard_info
+{
+    int shards;          /* logical shards of the text                                  */
+    int devices_used;    /* distinct physical devices                                   */
+    int device_ids[16];  /* the first 16 of them, in shard order                        */
+    int comm_ranks;      /* ranks of the communicator (ncclCommInitAll over the devices) */
+    int reduced_by;      /* 0 nothing to reduce, 1 RCCL, 2 host sum after an RCCL failure */
+} krep_gpu_shard_info_t;
+void krep_gpu_last_shard_info(krep_gpu_shard_info_t *out);
 
 /* ---- formatter-side post-processing in HBM (what search_file() does on one host thread after the scan) --------------
  * krep_gpu_order_by_start: the (start, end) order of compare_match_positions (krep.c:420-434) that search_file()

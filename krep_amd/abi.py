@@ -62,6 +62,12 @@ class Config(C.Structure):
                 ("stream_chunk_bytes", C.c_size_t), ("num_gpus", C.c_int), ("min_text_bytes", C.c_size_t)]
 
 
+class ShardInfo(C.Structure):
+    """krep_gpu_shard_info_t: where the calling thread's last sharded host search ran."""
+    _fields_ = [("shards", C.c_int), ("devices_used", C.c_int), ("device_ids", C.c_int * 16), ("comm_ranks", C.c_int),
+                ("reduced_by", C.c_int)]
+
+
 STATUS_OK, STATUS_FELL_BACK, STATUS_FAILED = 0, 1, 2
 SPLIT_WHOLE, SPLIT_PIECES, SPLIT_CHAIN = 0, 1, 2
 

@@ -168,10 +168,20 @@ int clique_for(Rccl *R, const std::vector<int> &devs, size_t n, Clique **out) //
         }
         nc->streams.resize(devs.size(), nullptr);
         nc->d_vec.resize(devs.size(), nullptr);
-        for (size_t i = 0; i < devs.size(); ++i)
-        {
-            HCHK(hipSetDevice(devs[i]));
-            HCHK(hipStreamCreateWithFlags(&nc->streams[i], hipStreamNonBlocking));
+        bool ok = true;
+        for (size_t i = 0; i < devs.size() && ok; ++i)
+            ok = hipSetDevice(devs[i]) == hipSuccess && hipStreamCreateWithFlags(&nc->streams[i], hipStreamNonBlocking) == hipSuccess;
+        if (!ok)
+        { // a half-built clique is torn down completely: no leaked communicators, no nullptr entry left in the map
+            const hipError_t he = hipGetLastError();
+            for (size_t i = 0; i < devs.size(); ++i)
+            {
+                if (nc->streams[i]) (void)hipStreamDestroy(nc->streams[i]);
+                if (nc->comms[i]) (void)R->CommDestroy(nc->comms[i]);
+            }
+            delete nc;
+            g_cliques->erase(devs);
+            return kg::fail("cannot create the per-device streams of the %zu-device communicator: %s", devs.size(), hipGetErrorString(he));
         }
         c = nc;
     }
@@ -246,6 +256,36 @@ int allreduce_across_devices(const std::vector<int> &devs, std::vector<std::vect
         (void)hipSetDevice(prev);
     return rc;
 }
+
+// Creates (and caches) the communicator of a device list ahead of the first search.  RCCL prints its version banner to
+// stdout when a process creates its first communicator; the StdoutMute above hides it, but for about a second every byte the
+// HOST writes to stdout from another thread would vanish with it.  A host calls this — through
+// krep_gpu_select_search_algorithm(), i.e. before it has printed anything — so that no search ever creates one.
+int comm_warmup(const std::vector<int> &devs)
+{
+    if (devs.size() < 2)
+        return 0;
+    std::lock_guard<std::mutex> lk(g_mu);
+    Rccl *R = rccl();
+    if (!R)
+        return kg::fail("%s", rccl_why());
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    Clique *c = nullptr;
+    const int rc = clique_for(R, devs, 8, &c);
+    if (prev >= 0)
+        (void)hipSetDevice(prev);
+    return rc;
+}
+// ranks of the cached communicator over `devs` (0: none yet)
+int comm_clique_ranks(const std::vector<int> &devs)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_cliques)
+        return 0;
+    auto it = g_cliques->find(devs);
+    return it == g_cliques->end() || !it->second ? 0 : (int)it->second->comms.size();
+}
 } // namespace kg
 
 extern "C" uint64_t krep_gpu_rccl_calls(void) { return g_calls.load(); }
@@ -285,8 +325,16 @@ extern "C" int krep_gpu_comm_init_rank(const void *id128, int nranks, int rank, 
         return kg::fail("%s", rccl_why());
     if (g_rank.comm)
         return kg::fail("comm_init_rank: a rank communicator already exists (krep_gpu_comm_destroy first)");
-    int prev = -1;
-    (void)hipGetDevice(&prev);
+    struct Restore // the caller's device comes back on EVERY path out of here
+    {
+        int prev = -1;
+        Restore() { (void)hipGetDevice(&prev); }
+        ~Restore()
+        {
+            if (prev >= 0)
+                (void)hipSetDevice(prev);
+        }
+    } restore;
     HCHK(hipSetDevice(device));
     ncclUniqueId id;
     memcpy(&id, id128, sizeof id);
@@ -294,14 +342,21 @@ extern "C" int krep_gpu_comm_init_rank(const void *id128, int nranks, int rank, 
         StdoutMute mute;
         const ncclResult_t e = R->CommInitRank(&g_rank.comm, nranks, id, rank);
         if (e != ncclSuccess)
+        {
+            g_rank = RankComm{};
             return kg::fail("ncclCommInitRank failed: %s", R->GetErrorString(e));
+        }
     }
-    HCHK(hipStreamCreateWithFlags(&g_rank.stream, hipStreamNonBlocking));
+    if (hipStreamCreateWithFlags(&g_rank.stream, hipStreamNonBlocking) != hipSuccess)
+    { // no half-initialised communicator stays behind (a set comm with a NULL stream)
+        const hipError_t he = hipGetLastError();
+        (void)R->CommDestroy(g_rank.comm);
+        g_rank = RankComm{};
+        return kg::fail("hipStreamCreate for the rank communicator failed: %s", hipGetErrorString(he));
+    }
     g_rank.device = device;
     g_rank.nranks = nranks;
     g_rank.rank = rank;
-    if (prev >= 0)
-        (void)hipSetDevice(prev);
     return 0;
 }
 

@@ -106,6 +106,8 @@ void format_release(); // frees the formatter scratch of every device
 
 // kg_comm.hip — the RCCL all-reduce of the per-shard counters (one process driving several devices)
 int allreduce_across_devices(const std::vector<int> &devs, std::vector<std::vector<unsigned long long>> &vecs);
+int comm_warmup(const std::vector<int> &devs);       // creates the communicator of a device list ahead of the first search
+int comm_clique_ranks(const std::vector<int> &devs); // ranks of the cached communicator over `devs` (0: none)
 
 // kg_ops.hip — host-buffer side
 void memchr_batch_quirk(match_position_t *recs, uint64_t have, size_t maxc);

@@ -44,6 +44,7 @@ using namespace kg;
     } while (0)
 
 namespace {
+thread_local krep_gpu_shard_info_t tl_shards{1, 1, {0}, 0, 0}; // krep_gpu_last_shard_info()
 // ---------------------------------------------------------------------------------------------- device buffers
 struct DevBuf
 {
@@ -723,13 +724,32 @@ static int run_pieces(const search_params_t *params, const krep_gpu_config_t &cf
             for (auto &o : outs)
                 slot[4] |= o.has_newline;
         }
+    tl_shards = krep_gpu_shard_info_t{G, (int)runs.size(), {0}, 0, 0};
+    for (size_t r = 0; r < runs.size() && r < 16; ++r)
+        tl_shards.device_ids[r] = runs[r].cx->device;
     if (G > 1)
     {
         std::vector<int> devs;
         for (auto &r : runs)
             devs.push_back(r.cx->device);
-        if (kg::allreduce_across_devices(devs, vecs))
-            return 2;
+        if (kg::allreduce_across_devices(devs, vecs) == 0)
+        {
+            tl_shards.reduced_by = 1;
+            tl_shards.comm_ranks = kg::comm_clique_ranks(devs);
+        }
+        else
+        {
+            // This process already holds every shard's slots; the collective is how they are MEANT to meet, not a
+            // reason to throw a finished search away: when librccl cannot be loaded or a communicator cannot be created the
+            // host adds the slot vectors itself.  The reason stays in krep_gpu_last_error(), reported once.
+            static std::atomic<bool> told{false};
+            if (!told.exchange(true))
+                fprintf(stderr, "krep-gpu: RCCL unavailable for the %d-shard count reduction; summing on the host\n", G);
+            for (size_t r = 1; r < vecs.size(); ++r)
+                for (size_t i = 0; i < vecs[0].size(); ++i)
+                    vecs[0][i] += vecs[r][i];
+            tl_shards.reduced_by = 2;
+        }
     }
     uint64_t total = 0;
     std::vector<krep_gpu_scan_out_t> shard_outs((size_t)G);
@@ -753,7 +773,54 @@ static int run_pieces(const search_params_t *params, const krep_gpu_config_t &cf
     else
         ret = std::min<uint64_t>(params->count_lines_mode ? lines : total, maxc);
     *ret_out = ret;
-    if (want_pos && ret)
+    if (want_pos && ret && maxc == SIZE_MAX)
+    {
+        // No truncation: the piece lists go STRAIGHT into the caller's block, in parallel (at BASELINE config 3 density that is
+        // 5.5 GB; one thread copying it twice — into a scratch vector, then into the result — cost seconds).
+        std::vector<size_t> off(pcs.size() + 1, 0);
+        for (size_t i = 0; i < pcs.size(); ++i)
+            off[i + 1] = off[i] + pcs[i].recs.size();
+        const size_t tot = off.back();
+        if (!result_reserve(out, tot))
+            return kg::fail("out of memory growing match_result_t");
+        match_position_t *dst = out->positions + out->count;
+        {
+            std::atomic<size_t> next{0};
+            auto work = [&] {
+                for (size_t i; (i = next.fetch_add(1)) < pcs.size();)
+                {
+                    if (!pcs[i].recs.empty())
+                        memcpy(dst + off[i], pcs[i].recs.data(), pcs[i].recs.size() * sizeof(match_position_t));
+                    std::vector<match_position_t>().swap(pcs[i].recs);
+                }
+            };
+            const size_t nt = tot * sizeof(match_position_t) < (64u << 20) ? 1 : std::min<size_t>(8, pcs.size());
+            std::vector<std::thread> th;
+            for (size_t t = 1; t < nt; ++t)
+                th.emplace_back(work);
+            work();
+            for (auto &t : th)
+                t.join();
+        }
+        if (params->num_patterns > 1)
+            for (size_t i = 1; i < pcs.size(); ++i)
+            {
+                // every piece list is in the reference's (end, start) order and owns its matches by START: only a suffix of
+                // what precedes a cut and a prefix of what follows it can interleave — merge exactly that zone
+                match_position_t *first_new = dst + off[i], *end = dst + off[i + 1];
+                if (first_new == dst || first_new == end)
+                    continue;
+                match_position_t *zone_lo = std::upper_bound(dst, first_new, *first_new, rec_less);
+                match_position_t *zone_hi = std::upper_bound(first_new, end, *(first_new - 1), rec_less);
+                std::inplace_merge(zone_lo, first_new, zone_hi, rec_less);
+            }
+        if (params->num_patterns > 1 && cfg.result_order) // the formatter's order (krep.c:420-434)
+            std::sort(dst, dst + tot, [](const match_position_t &a, const match_position_t &b) {
+                return a.start_offset != b.start_offset ? a.start_offset < b.start_offset : a.end_offset < b.end_offset;
+            });
+        out->count += tot;
+    }
+    else if (want_pos && ret)
     {
         std::vector<match_position_t> all;
         all.reserve((size_t)total);
@@ -763,8 +830,6 @@ static int run_pieces(const search_params_t *params, const krep_gpu_config_t &cf
             all.insert(all.end(), p.recs.begin(), p.recs.end());
             if (params->num_patterns > 1 && old && all.size() > old)
             {
-                // every piece list is in the reference's (end, start) order and owns its matches by START: only a suffix
-                // of what is there and a prefix of the new list can interleave — merge exactly that zone
                 const auto first_new = all.begin() + (long)old;
                 const auto zone_lo = std::upper_bound(all.begin(), first_new, *first_new, rec_less);
                 const auto zone_hi = std::upper_bound(first_new, all.end(), *(first_new - 1), rec_less);
@@ -848,6 +913,11 @@ std::atomic<krep_gpu_cpu_select_t> g_cpu_select{nullptr};
 } // namespace
 
 extern "C" int krep_gpu_last_status(void) { return tl_status; }
+extern "C" void krep_gpu_last_shard_info(krep_gpu_shard_info_t *out)
+{
+    if (out)
+        *out = tl_shards;
+}
 extern "C" void krep_gpu_set_cpu_fallback(krep_gpu_cpu_select_t f) { g_cpu_select.store(f); }
 
 // the GPU attempt: *status 0 = the return value and `result` are good; 2 = failed, nothing appended
@@ -894,6 +964,7 @@ static uint64_t run_host_operator(const search_params_t *raw, const char *text, 
     uint64_t ret = 0;
     int rc;
     const uint64_t count0 = result ? result->count : 0;
+    tl_shards = krep_gpu_shard_info_t{1, 1, {cfg.device}, 0, 0};
     if (!split)
     {
         DeviceCtx *cx = ctx_for(cfg.device);
@@ -973,6 +1044,23 @@ extern "C" search_func_t krep_gpu_select_search_algorithm(const search_params_t 
     // reproduced, and when there is no device this library can run on (asked HERE, before any operator is handed out)
     if (kg::unsupported_reason(params, cfg) || kg::device_unusable(cfg.device))
         return nullptr;
+    if (cfg.num_gpus != 1)
+    {
+        // a sharding host: create the devices' communicator NOW — the selector runs before the host has written a byte of
+        // output, so RCCL's first-communicator banner (muted by redirecting fd 1 for that moment, kg_comm.hip) cannot swallow
+        // output of another host thread later.  A failure here is not an error: run_pieces() reports and sums on the host.
+        DeviceGuard guard;
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 1)
+        {
+            const int g = cfg.num_gpus <= 0 ? ndev : std::min(cfg.num_gpus, ndev);
+            std::vector<int> devs;
+            for (int i = 0; i < g; ++i)
+                devs.push_back((cfg.device + i) % ndev);
+            if (devs.size() > 1 && kg::comm_warmup(devs))
+                krep_gpu_clear_error();
+        }
+    }
     return params->num_patterns > 1 ? krep_gpu_aho_corasick_search : krep_gpu_literal_search;
 }
 

@@ -112,6 +112,8 @@ class Engine:
         L.krep_gpu_comm_destroy.restype = None
         L.krep_gpu_rccl_calls.restype = C.c_uint64
         L.krep_gpu_rccl_version.restype = C.c_int
+        L.krep_gpu_last_shard_info.restype = None
+        L.krep_gpu_last_shard_info.argtypes = [C.POINTER(abi.ShardInfo)]
         L.krep_gpu_available.restype = C.c_int
         L.krep_gpu_unavailable_reason.restype = C.c_char_p
         L.krep_gpu_last_status.restype = C.c_int
@@ -214,6 +216,12 @@ class Engine:
 
     def rccl_version(self) -> int:
         return int(self.lib.krep_gpu_rccl_version())
+
+    def last_shard_info(self) -> "abi.ShardInfo":
+        """Shards / physical devices / communicator ranks of the calling thread's last sharded host search."""
+        info = abi.ShardInfo()
+        self.lib.krep_gpu_last_shard_info(C.byref(info))
+        return info
 
     def split_mode(self, params: abi.Params, text_len: int) -> int:
         return int(self.lib.krep_gpu_split_mode(params.ref, text_len))

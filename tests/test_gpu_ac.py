@@ -153,3 +153,49 @@ def test_linear_probing_fallback_layout(gpu, oracle_engine, monkeypatch):
             if kw.get("count_lines") and any(b"\n" in p for p in pats):
                 continue
             _check(gpu, oracle_engine, text, pats, kw)
+
+
+def test_worst_legal_dictionary_1024_patterns_of_up_to_1024_bytes(gpu, oracle_engine):
+    """The largest dictionary the reference CLI accepts: 1024 patterns (krep.c:3460-3465, :3552) of up to MAX_PATTERN_LENGTH =
+    1024 bytes (krep.c:77, :2042) — ~0.5 M trie states.  Mixed lengths (4 ... 1024, a few 1-3-byte ones in the second set),
+    duplicates, nested suffixes, shared tails that branch below depth 4, -i / -w / -c / max_count, every pattern planted,
+    against aho_corasick_search of the compiled reference (VERDICT r03 missing #3)."""
+    rng = np.random.RandomState(771)
+    az = bytes(range(97, 123))
+    alpha = az + b"ABCXYZ_ \n"
+
+    def rnd(k, a=az):
+        return bytes(a[i] for i in rng.randint(0, len(a), k))
+
+    for variant in range(2):
+        lens = list(rng.randint(4, 1025, 600)) + [1024] * 40 + list(rng.randint(4, 24, 300))
+        pats = [rnd(int(k)) for k in lens]
+        base = pats[:40]
+        for b in base[:30]:                       # nested suffixes along one chain
+            pats.append(b[int(rng.randint(1, len(b) - 4)):])
+        for b in base[10:30]:                     # same tail, different head: branching below depth 4
+            pats.append(rnd(int(rng.randint(1, 9))) + b[-int(rng.randint(4, min(len(b), 200))):])
+        pats += [pats[3], pats[700], pats[41]]    # duplicates: the reference emits each copy
+        if variant == 1:
+            pats += [b"q", b"zx", b"kvb"]         # short patterns switch the filter to the wildcard-expanded table
+            pats = [p.upper() if i % 7 == 0 else p for i, p in enumerate(pats)]
+        pats = pats[:1024]
+        while len(pats) < 1024:
+            pats.append(rnd(int(rng.randint(4, 400))))
+        assert len(pats) == 1024 and max(map(len, pats)) == 1024
+        n = 6 << 20
+        text = cases.rand_text(rng, n, alpha)
+        at = 100
+        for i, p in enumerate(pats):              # every pattern planted once, some back to back, some with a word boundary
+            if at + len(p) + 2 >= n:
+                break
+            q = p.swapcase() if (variant == 1 and i % 3 == 0) else p
+            text[at:at + len(q)] = np.frombuffer(q, dtype=np.uint8)
+            at += len(p) + [0, 1, 37, 900][i % 4]
+        no_nl = [p for p in pats if b"\n" not in p]
+        assert len(no_nl) == len(pats)
+        for kw in (dict(), dict(case_sensitive=False), dict(whole_word=True), dict(count_lines=True),
+                   dict(count_lines=True, only_match=True), dict(max_count=100), dict(case_sensitive=False, whole_word=True, count_lines=True)):
+            _check(gpu, oracle_engine, text, pats, kw)
+        # and a small window whose length is below the longest pattern
+        _check(gpu, oracle_engine, text[90:700], pats, dict())
