@@ -153,6 +153,11 @@ uint64_t krep_gpu_debug_replay_host(int krep_ref_algo, const void *text, size_t 
 void krep_gpu_debug_force_rounds(int rounds);
 /* test hook: staging records per scan unit (0 = auto); small values exercise the emit-mode re-scan */
 void krep_gpu_debug_force_stage_cap(int records);
+/* test hooks of the one-pass single-byte kernel (kg_single.hip): at most `blocks` workgroups (0 = auto) — a starved grid, as
+ * on a shared or partitioned device; and how many of its scans handed over to the two-pass kernels (ring overflow on a
+ * dense text, or the spin-limit safety net) since the process started */
+void krep_gpu_debug_force_single_grid(int blocks);
+uint64_t krep_gpu_debug_single_failovers(void);
 /* Twin of select_search_algorithm() (krep.c:1771): the algorithm the reference build would END UP
  * executing for `params` on a text of `text_len` bytes (text_len matters: the SIMD functions fall back
  * to BMH when text_len < pattern_len, and so on). */

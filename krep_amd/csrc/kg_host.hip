@@ -246,6 +246,10 @@ static std::atomic<int> g_force_stage_cap{0}; // test hook: staging records per 
 namespace kg { extern int g_ac_force_stage_cap; }
 extern "C" void krep_gpu_debug_force_stage_cap(int c) { g_force_stage_cap.store(c); kg::g_ac_force_stage_cap = c; }
 extern "C" void krep_gpu_debug_force_rounds(int r) { g_force_rounds.store(r); }
+namespace kg { extern int g_s1_force_grid; }
+static std::atomic<uint64_t> g_fused1_failovers{0}; // one-pass single-byte scans that handed over to the two-pass kernels
+extern "C" void krep_gpu_debug_force_single_grid(int blocks) { kg::g_s1_force_grid = blocks < 0 ? 0 : blocks; }
+extern "C" uint64_t krep_gpu_debug_single_failovers(void) { return g_fused1_failovers.load(); }
 
 static inline uint8_t lo8(uint8_t c) { return (c >= 'A' && c <= 'Z') ? (uint8_t)(c + 32) : c; }
 
@@ -841,6 +845,7 @@ static int lit_pass(krep_gpu_plan *pl, const Window &w, const LitPass &ps, hipSt
             return 0;
         }
         pl->fused1_ok = false;
+        g_fused1_failovers.fetch_add(1);
     }
     if (chain)
     {

@@ -16,8 +16,20 @@
 //     10 KiB per ticket, ascending with the ticket number.
 // This is the chained scan that round 1 measured at 2.9 TB/s (every tile waited for its predecessor's status) with the wait
 // taken out of it: counts flow forward through one wave, the consumers are a whole ticket period behind.
-// Residency: the grid is exactly the resident blocks (as for every kernel of this library), so the resolver and every wave
-// that holds a ticket are running; a wave publishes its count BEFORE it waits for anything, so no wait can be circular.
+// Progress without assumptions about residency (round 4, ADVICE r03 — the round-3 build could wait circularly when fewer
+// waves than expected were really running: a GPU shared with another process, a partitioned device, a grid that is not
+// fully resident):
+//   * tickets come from ONE counter, kSuper consecutive tickets per draw (64-KiB tickets would otherwise put ~80 fetch-adds/us
+//     on the word), so the set of drawn tickets is always a PREFIX of the ticket space and whoever drew a ticket is a wave that
+//     is running;
+//   * the resolver is whichever wave-0-of-a-block arrives first (an atomic claim) — a running wave by construction — and it
+//     publishes prefixes AS FAR AS THE READY RUN EXTENDS, ticket by ticket, not in steps of 512;
+//   * a wave waits for the prefix of ticket p only while holding tickets it drew AFTER p.
+//   Let m be the smallest ticket whose count is not published.  Everything below m is ready, so every prefix up to m is
+//   published.  If m is drawn, its holder is scanning it or waits for the prefix of an EARLIER ticket, which is published: it
+//   goes on.  If m is not drawn, every wave that waits does so for a ticket below m: published.  No wait is circular, whatever
+//   subset of the grid runs.  (tests/test_gpu_literal.py::test_single_byte_one_pass_with_a_starved_grid forces 1- and 2-block
+//   grids over 16 384 tickets.)
 // A ticket with more hits than the ring holds (denser than ~1.5 %) raises ctr->overflow_units: the host falls back to the
 // two-pass kernels for that scan and for the plan's later ones.
 #include <hip/hip_runtime.h>
@@ -31,20 +43,21 @@ namespace kg {
 using u32 = uint32_t;
 using u64 = unsigned long long;
 
-// Ticket size and number of ticket counters (A/B builds: python -m krep_amd.build --variant x -DKG_S1_UPT=4 -DKG_S1_NC=1).
-// Measured in one process per box (tools/ab_bench.py, 32 GiB): 128-KiB tickets from one counter 6.60 ms on a fast placement
-// draw and 7.38 on a slow one (four boxes of five); 64-KiB tickets from eight interleaved counters 6.64 and 6.89 — the same
-// best case, a worst case 7 % better (8 GiB: 1.88 -> 1.76 ms); 32-KiB tickets outrun the resolver (10.4 ms).  The read side
-// alone prefers LARGER tickets (tools/ubench/window_probe.hip); it is the record writes next to it that prefer smaller ones.
+// Ticket size and tickets per draw (A/B builds: python -m krep_amd.build --variant x -DKG_S1_UPT=4 -DKG_S1_SUPER=1).
+// Measured in one process per box (tools/ab_bench.py, 32 GiB), round 3: 128-KiB tickets 6.60 ms on a fast placement draw and
+// 7.38 on a slow one; 64-KiB tickets 6.64 and 6.89 — the same best case, a worst case 7 % better (8 GiB: 1.88 -> 1.76 ms);
+// 32-KiB tickets outrun the resolver (10.4 ms).  The read side alone prefers LARGER tickets (tools/ubench/window_probe.hip);
+// it is the record writes next to it that prefer smaller ones.
 #ifndef KG_S1_UPT
 #define KG_S1_UPT 2
 #endif
-#ifndef KG_S1_NC
-#define KG_S1_NC 8
+#ifndef KG_S1_SUPER
+#define KG_S1_SUPER 2
 #endif
 constexpr u32 kUpt = KG_S1_UPT;               // units (32 KiB each) per ticket: 64 KiB (at most 4: the flush tells units apart by three bounds)
-constexpr u32 kNc = KG_S1_NC;                 // ticket counters (own cache lines); counter c hands out the tickets congruent to c mod kNc
+constexpr u32 kSuper = KG_S1_SUPER;           // consecutive tickets per draw from the one ticket counter
 static_assert(kUpt >= 1 && kUpt <= 4, "flush() derives a record's unit from three boundaries");
+static_assert(kSuper >= 1 && kSuper <= 8, "tickets per draw");
 constexpr u32 kRing = 1024u * kUpt;           // 16-bit entries per wave: the ticket being scanned + the one waiting
 constexpr u64 kReady = 1ull << 63;
 constexpr u32 kSpinLimit = 1u << 24;          // ~0.25 us per spin: seconds — only a logic error gets there (see the safety nets)
@@ -84,58 +97,85 @@ __global__ __launch_bounds__(kBlock, 4) void single_fused(const LitArgs a, u64 *
     const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const u64 n_units = a.num_tiles * kWavesPerBlk;
 
-    // ---- the resolver: counts -> exclusive prefixes, in ticket order ----------------------------------------------------
-    if (blockIdx.x == 0 && wave == 0)
+    // ---- the resolver: counts -> exclusive prefixes, in ticket order.  Claimed by the first wave 0 of any block that gets
+    // here (a.ctr->pad[0], zeroed with the counters before the launch): a wave that RUNS, whatever part of the grid is resident.
+    bool resolver = false;
+    if (wave == 0)
     {
-        u64 running = 0;
-        for (u64 t0 = 0; t0 < n_tickets; t0 += 64u * kResolveChunk)
+        u64 r = 1;
+        if (lane == 0)
+            r = __hip_atomic_fetch_add(&a.ctr->pad[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        resolver = s_rfl64(r) == 0ull;
+    }
+    if (resolver)
+    {
+        // Window of 64 x kResolveChunk tickets from `base`; every pass publishes the prefixes of the leading run of ready
+        // tickets and moves the window behind it.  In the steady state the scanners are far ahead and a pass takes the whole
+        // window; what matters is that the prefix of ticket p never waits for a ticket BEHIND p.
+        u64 running = 0, base = 0;
+        u32 spins = 0;
+        while (base < n_tickets)
         {
-            const u64 mine = t0 + (u64)lane * kResolveChunk;
+            const u64 mine = base + (u64)lane * kResolveChunk;
             u64 v[kResolveChunk];
-            for (u32 spins = 0;; ++spins)
-            {
-                bool ok = true;
+            u32 lead = 0, nvalid = 0;
+            bool run = true;
 #pragma unroll
-                for (u32 k = 0; k < kResolveChunk; ++k)
-                {
-                    v[k] = mine + k < n_tickets ? __hip_atomic_load(&agg[mine + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kReady;
-                    ok = ok && (v[k] & kReady);
-                }
-                if (__ballot(!ok) == 0ull)
-                    break;
-                if (spins > kSpinLimit)
-                {
-                    // safety net (never expected): a count that does not arrive within seconds must not hang the device.  Flag the
-                    // scan as failed-over (the host re-runs the two-pass kernels) and release every waiter with a made-up prefix.
-                    if (lane == 0)
-                        atomicAdd(&a.ctr->overflow_units, 1ull);
-                    for (u64 t = t0 + lane; t < n_tickets; t += 64)
-                        __hip_atomic_store(&pref[t], kReady, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    return;
-                }
-                __builtin_amdgcn_s_sleep(8);
+            for (u32 k = 0; k < kResolveChunk; ++k)
+            {
+                const bool valid = mine + k < n_tickets;
+                v[k] = valid ? __hip_atomic_load(&agg[mine + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                nvalid += valid ? 1u : 0u;
+                run = run && valid && (v[k] & kReady);
+                lead += run ? 1u : 0u;
             }
+            const u64 open = __ballot(lead != nvalid);                 // lanes whose chunk holds a count that has not arrived
+            const u32 f = open ? (u32)__builtin_ctzll(open) : 64u;     // the first of them: the ready run ends inside its chunk
+            const u32 take = lane < f ? nvalid : (lane == f ? lead : 0u);
             u64 s = 0;
 #pragma unroll
             for (u32 k = 0; k < kResolveChunk; ++k)
-                s += v[k] & ~kReady;
+                s += k < take ? (v[k] & ~kReady) : 0ull;
             u64 incl = s;
+            u32 tincl = take;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1)
             {
                 const u64 up = __shfl_up(incl, o);
+                const u32 tup = __shfl_up(tincl, o);
                 if (lane >= (u32)o)
+                {
                     incl += up;
+                    tincl += tup;
+                }
             }
             u64 e = running + incl - s;
 #pragma unroll
             for (u32 k = 0; k < kResolveChunk; ++k)
             {
-                if (mine + k < n_tickets)
+                if (k < take)
                     __hip_atomic_store(&pref[mine + k], e | kReady, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                e += v[k] & ~kReady;
+                e += k < take ? (v[k] & ~kReady) : 0ull;
             }
+            const u32 published = __shfl(tincl, 63);
             running += __shfl(incl, 63);
+            base += published;
+            if (published)
+                spins = 0;
+            else
+            {
+                if (++spins > kSpinLimit)
+                {
+                    // safety net (never expected): a count that does not arrive within seconds must not hang the device.  Flag the
+                    // scan as failed-over (the host re-runs the two-pass kernels) and release every waiter with a made-up prefix.
+                    if (lane == 0)
+                        atomicAdd(&a.ctr->overflow_units, 1ull);
+                    for (u64 t = base + lane; t < n_tickets; t += 64)
+                        __hip_atomic_store(&pref[t], kReady, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
         }
         if (lane == 0)
             a.ctr->total = running;
@@ -294,27 +334,21 @@ __global__ __launch_bounds__(kBlock, 4) void single_fused(const LitArgs a, u64 *
         }
     };
 
-    // the wave's ticket counter: a.ctr->ticket, or (kNc > 1) one of kNc counters on their own cache lines behind the prefix array
-    const u32 my_c = kNc > 1 ? (blockIdx.x * kWavesPerBlk + wave) % kNc : 0u;
-    u64 *my_ctr = kNc > 1 ? pref + n_tickets + (size_t)my_c * 16u : &a.ctr->ticket;
-    // EVERY ticket must be drawn by somebody — the resolver waits for all of them in order — so a wave whose counter has run
-    // dry moves on to the next one (a counter only grows: dry stays dry).  With fewer scanning waves than counters (a small
-    // text) this is what serves the counters no wave started on; on a large text it is the tail's load balancing.
-    u32 cur_c = my_c, dry = 0;
+    // ONE ticket counter (a.ctr->ticket), kSuper consecutive tickets per draw: what has been drawn is always a prefix of the
+    // ticket space, and a wave's tickets ascend — the two facts the progress argument in the header rests on.
+    u64 sup_next = 0, sup_end = 0; // tickets of the current draw not handed out yet
     auto draw = [&]() __attribute__((always_inline)) -> u64 {
-        while (dry < kNc)
-        {
-            u64 tk = 0;
-            if (lane == 0)
-                tk = __hip_atomic_fetch_add(kNc > 1 ? pref + n_tickets + (size_t)cur_c * 16u : my_ctr, 1ull, __ATOMIC_RELAXED,
-                                            __HIP_MEMORY_SCOPE_AGENT);
-            const u64 tt = s_rfl64(tk) * kNc + cur_c;
-            if (tt < n_tickets)
-                return tt;
-            cur_c = cur_c + 1u < kNc ? cur_c + 1u : 0u;
-            ++dry;
-        }
-        return ~0ull;
+        if (sup_next < sup_end)
+            return sup_next++;
+        u64 tk = 0;
+        if (lane == 0)
+            tk = __hip_atomic_fetch_add(&a.ctr->ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const u64 s0 = s_rfl64(tk) * kSuper;
+        if (s0 >= n_tickets)
+            return ~0ull;
+        sup_end = s0 + kSuper < n_tickets ? s0 + kSuper : n_tickets;
+        sup_next = s0 + 1;
+        return s0;
     };
     uint4 A[kCells];
     u64 t = draw();
@@ -354,7 +388,7 @@ __global__ __launch_bounds__(kBlock, 4) void single_fused(const LitArgs a, u64 *
         }
         if (cnt > room)
             overflowed = true; // too dense for the ring: counted, not recorded — the host re-runs the two-pass kernels
-        // publish the count BEFORE waiting for anything (see the header: no wait can be circular)
+        // publish the count BEFORE waiting for anything; the ticket drawn next is behind every ticket this wave has parked
         if (lane == 0)
             __hip_atomic_store(&agg[t], (u64)cnt | kReady, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // the next ticket, and its first round on the way, before the previous ticket's records are written
@@ -384,7 +418,8 @@ __global__ __launch_bounds__(kBlock, 4) void single_fused(const LitArgs a, u64 *
         atomicAdd(&a.ctr->overflow_units, 1ull);
 }
 
-// grid = the resident blocks of the instantiation x CUs (never more: see the header on residency)
+int g_s1_force_grid = 0; // test hook: at most this many blocks (0 = auto)
+// grid = the resident blocks of the instantiation x CUs
 template <bool CI>
 static hipError_t launch_fused(const LitArgs &a, u64 *agg, u64 *pref, u64 n_tickets, u32 num_cu, hipStream_t st)
 {
@@ -399,13 +434,15 @@ static hipError_t launch_fused(const LitArgs &a, u64 *agg, u64 *pref, u64 n_tick
     }();
     // one block more than the tickets need is never useful; at least 1 scanning wave next to the resolver
     const u64 want = (n_tickets + kWavesPerBlk - 1) / kWavesPerBlk + 1;
-    const u32 grid = (u32)std::max<u64>(1, std::min<u64>(want, (u64)num_cu * bpc));
+    u32 grid = (u32)std::max<u64>(1, std::min<u64>(want, (u64)num_cu * bpc));
+    if (g_s1_force_grid > 0) // test hook: a starved grid (krep_gpu_debug_force_single_grid)
+        grid = std::min<u32>(grid, (u32)g_s1_force_grid);
     hipLaunchKernelGGL((single_fused<CI>), dim3(grid), dim3(kBlock), 0, st, a, agg, pref, n_tickets);
     return hipGetLastError();
 }
 
 uint64_t single_fused_tickets(uint64_t n_units) { return (n_units + kUpt - 1) / kUpt; }
-uint64_t single_fused_scratch_words(uint64_t n_tickets) { return 2 * n_tickets + (kNc > 1 ? 16ull * kNc : 0ull); } // counts | prefixes | counters
+uint64_t single_fused_scratch_words(uint64_t n_tickets) { return 2 * n_tickets; } // counts | prefixes
 
 hipError_t launch_single_fused(const LitArgs &a, unsigned long long *d_agg, unsigned long long *d_pref, uint64_t n_tickets,
                                uint32_t num_cu, hipStream_t st)

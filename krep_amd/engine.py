@@ -112,6 +112,9 @@ class Engine:
         L.krep_gpu_comm_destroy.restype = None
         L.krep_gpu_rccl_calls.restype = C.c_uint64
         L.krep_gpu_rccl_version.restype = C.c_int
+        L.krep_gpu_debug_force_single_grid.restype = None
+        L.krep_gpu_debug_force_single_grid.argtypes = [C.c_int]
+        L.krep_gpu_debug_single_failovers.restype = C.c_uint64
         L.krep_gpu_last_shard_info.restype = None
         L.krep_gpu_last_shard_info.argtypes = [C.POINTER(abi.ShardInfo)]
         L.krep_gpu_available.restype = C.c_int
@@ -143,6 +146,12 @@ class Engine:
 
     def force_rounds(self, r: int):
         self.lib.krep_gpu_debug_force_rounds(r)
+
+    def force_single_grid(self, blocks: int):
+        self.lib.krep_gpu_debug_force_single_grid(blocks)
+
+    def single_failovers(self) -> int:
+        return int(self.lib.krep_gpu_debug_single_failovers())
 
     def force_stage_cap(self, c: int):
         self.lib.krep_gpu_debug_force_stage_cap(c)

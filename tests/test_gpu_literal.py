@@ -211,3 +211,35 @@ def test_the_parity_checker_is_the_compiled_reference(gpu, oracle_engine):
     want = {f"ref:{ol._REF_FILES[lv]}" for lv in ol._REF_FILES if ol.ref_available(lv)}
     assert oracle_engine.direct_calls - before >= len([lv for lv, _, _ in jobs if ol.ref_available(lv)])
     assert want <= oracle_engine.used, (want, oracle_engine.used)
+
+
+@pytest.mark.timeout(240)
+def test_single_byte_one_pass_with_a_starved_grid(gpu):
+    """the one-pass single-byte kernel must make progress when only a few of its waves really run (a
+    shared or partitioned device).  Grids of 1, 2 and 3 workgroups over a 1 GiB text (16 384 tickets of 64 KiB; the round-3
+    kernel waited circularly here until its multi-second safety net fired and the plan fell back to the two-pass kernels):
+    the exact record list, no hand-over to the two-pass kernels, and in seconds."""
+    import time
+    import torch
+    n = 1 << 30
+    buf = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+    gpu.generate(buf.data_ptr(), n, 0, 3, 20260925, b"#", 0)
+    want = torch.nonzero(buf[:n] == ord("#")).flatten()
+    cap = int(want.numel()) + 4096
+    pos = torch.empty(2 * cap, dtype=torch.int64, device="cuda")
+    before = gpu.single_failovers()
+    try:
+        for blocks in (1, 2, 3, 0):
+            gpu.force_single_grid(blocks)
+            pos.zero_()
+            plan = gpu.plan(abi.Params([b"#"]))
+            t0 = time.time()
+            out = plan.scan(buf.data_ptr(), n, 0, n, 0, pos.data_ptr(), cap)
+            dt = time.time() - t0
+            assert out.count == out.stored == int(want.numel()) and not out.overflow, blocks
+            assert torch.equal(pos[: 2 * out.stored].view(-1, 2)[:, 0], want), blocks
+            assert gpu.single_failovers() == before, f"grid of {blocks} blocks handed over to the two-pass kernels"
+            assert dt < 30, (blocks, dt)
+            plan.close()
+    finally:
+        gpu.force_single_grid(0)
