@@ -31,6 +31,7 @@ struct AcArgs
     const u32 *copies;           // per node: number of patterns equal to the node's string
     u32 stride;                  // 1 or 2: text positions per filter lookup (2 = even positions only, see ac_scan_kernel)
     u32 upt;                     // units per wave ticket of the fused kernel (1..kAcUnitsPerTicketMax, by text size)
+    u32 nv;                      // SPEC kernel: verifier waves per workgroup (the last nv of the 16), 0 = every wave verifies its own units
     const uint2 *gram4;          // exact last-4-bytes -> {key, depth-4 node | has_out << 31} (val 0 = empty)
     u32 g4mask;
     const uint4 *g4x;            // entries of 2 x uint4: {key, child, info, endmask} {chain bytes x3, -}; layout by g4x_mode:
@@ -63,6 +64,12 @@ __device__ __forceinline__ u32 ac_eq_bytes(u32 x, u32 c4)
 }
 __device__ __forceinline__ u32 ac_movemask4(u32 t) { return (((t >> 7) * 0x00204081u) >> 21) & 0xfu; }
 __device__ __forceinline__ bool ac_wordc(u32 c) { return (c - '0' < 10u) || ((c | 0x20u) - 'a' < 26u) || c == '_'; }
+
+// workgroup-local flags in LDS (SPEC kernel): plain ds_read / ds_write that the compiler neither caches nor elides
+__device__ __forceinline__ u32 ac_lds_ld(const u32 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void ac_lds_st(u32 *p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// every LDS access issued so far has been performed, and the compiler moves no memory access across this point
+__device__ __forceinline__ void ac_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 struct LS2 { u32 cnt; bool nl, head, tail; };
 __device__ __forceinline__ LS2 ls2_combine(const LS2 &a, const LS2 &b)
@@ -468,6 +475,7 @@ __device__ __forceinline__ void ac_walk_probe2(const AcArgs &a, u64 i, bool live
 }
 
 constexpr u32 kAcUnitsPerTicketMax = 8; // fused kernel: up to 128 KiB per wave ticket (one cold round in 16), fewer on small texts
+constexpr u32 kAcVerifierWaves = 3;     // SPEC kernel: default split of the 16 waves (13 filter + 3 verify)
 constexpr int kAcRounds = 2;            // load rounds per unit: one candidate drain per 16 KiB (53 of 64 lanes busy)
 constexpr u32 kAcUnitBytes = kAcRounds * kSegBytes;
 constexpr u32 kAcBitmapWords = kAcUnitBytes / 32; // one bit per end position of a unit (LINES)
