@@ -5,7 +5,7 @@
 // kernel turns the staging into 5.5 GB of records — 5.8-6.9 ms of scan (depending on where the driver places the staging
 // stores) plus 1.4 ms of gather for a workload whose bytes (34.4 GB read + 5.5 GB written) fit into ~6 ms.
 // Here the records are written by the wave that found the hits, at their FINAL index, and nothing else is stored:
-//   * a wave draws a ticket of kUpt units (64 KiB; eight interleaved counters), scans it exactly as lit_scan<1> does (SWAR byte equality, 16 start
+//   * a wave draws a ticket of kUpt units (128 KiB; one counter), scans it exactly as lit_scan<1> does (SWAR byte equality, 16 start
 //     positions per lane in registers) and puts every hit, already ranked inside the ticket (ballot bit-planes + v_mbcnt),
 //     as a 16-bit unit-relative offset into its LDS ring — nothing goes to memory while it streams;
 //   * it publishes the ticket's hit count (one 8-byte store) and goes on to the NEXT ticket;
@@ -19,17 +19,16 @@
 // Progress without assumptions about residency (round 4, ADVICE r03 — the round-3 build could wait circularly when fewer
 // waves than expected were really running: a GPU shared with another process, a partitioned device, a grid that is not
 // fully resident):
-//   * tickets come from ONE counter, kSuper consecutive tickets per draw (64-KiB tickets would otherwise put ~80 fetch-adds/us
-//     on the word), so the set of drawn tickets is always a PREFIX of the ticket space and whoever drew a ticket is a wave that
-//     is running;
+//   * tickets (128 KiB) come from ONE counter, so the set of drawn tickets is always a PREFIX of the ticket space, and
+//     whoever drew a ticket is a wave that is running;
 //   * the resolver is whichever wave-0-of-a-block arrives first (an atomic claim) — a running wave by construction — and it
 //     publishes prefixes AS FAR AS THE READY RUN EXTENDS, ticket by ticket, not in steps of 512;
 //   * a wave waits for the prefix of ticket p only while holding tickets it drew AFTER p.
 //   Let m be the smallest ticket whose count is not published.  Everything below m is ready, so every prefix up to m is
 //   published.  If m is drawn, its holder is scanning it or waits for the prefix of an EARLIER ticket, which is published: it
 //   goes on.  If m is not drawn, every wave that waits does so for a ticket below m: published.  No wait is circular, whatever
-//   subset of the grid runs.  (tests/test_gpu_literal.py::test_single_byte_one_pass_with_a_starved_grid forces 1- and 2-block
-//   grids over 16 384 tickets.)
+//   subset of the grid runs.  (tests/test_gpu_literal.py::test_single_byte_one_pass_with_a_starved_grid forces 1-, 2- and 3-block
+//   grids over 8 192 tickets.)
 // A ticket with more hits than the ring holds (denser than ~1.5 %) raises ctr->overflow_units: the host falls back to the
 // two-pass kernels for that scan and for the plan's later ones.
 #include <hip/hip_runtime.h>
@@ -43,25 +42,22 @@ namespace kg {
 using u32 = uint32_t;
 using u64 = unsigned long long;
 
-// Ticket size and tickets per draw (A/B builds: python -m krep_amd.build --variant x -DKG_S1_UPT=4 -DKG_S1_SUPER=1).
-// Measured in one process per box (tools/ab_bench.py, 32 GiB), round 3: 128-KiB tickets 6.60 ms on a fast placement draw and
-// 7.38 on a slow one; 64-KiB tickets 6.64 and 6.89 — the same best case, a worst case 7 % better (8 GiB: 1.88 -> 1.76 ms);
-// 32-KiB tickets outrun the resolver (10.4 ms).  The read side alone prefers LARGER tickets (tools/ubench/window_probe.hip);
-// it is the record writes next to it that prefer smaller ones.
+// Ticket size (A/B builds: python -m krep_amd.build --variant x -DKG_S1_UPT=2).  ONE ticket counter: the drawn tickets are
+// always a prefix of the ticket space, which is what the progress argument above needs.  Measured in one process (32 GiB,
+// tools/ab_bench.py, profiles/r04_single_byte_tickets.txt): 128-KiB tickets from the one counter 6.58 ms against 6.55 for
+// round 3's 64-KiB tickets from eight interleaved counters (which could wait circularly on a starved grid); 64-KiB tickets from
+// one counter 8.06 (80 fetch-adds/us on one word: the dequeue limit of the part); TWO consecutive 64-KiB tickets per draw
+// 11.6 ms and four 7 s — a ticket that is drawn long before it is scanned holds back the prefix of everything behind it, and
+// the waves end up scanning in lock step.  A resolver window of 1024 or 2048 tickets instead of 512 gained nothing.
 #ifndef KG_S1_UPT
-#define KG_S1_UPT 2
+#define KG_S1_UPT 4
 #endif
-#ifndef KG_S1_SUPER
-#define KG_S1_SUPER 2
-#endif
-constexpr u32 kUpt = KG_S1_UPT;               // units (32 KiB each) per ticket: 64 KiB (at most 4: the flush tells units apart by three bounds)
-constexpr u32 kSuper = KG_S1_SUPER;           // consecutive tickets per draw from the one ticket counter
+constexpr u32 kUpt = KG_S1_UPT;               // units (32 KiB each) per ticket: 128 KiB (at most 4: the flush tells units apart by three bounds)
 static_assert(kUpt >= 1 && kUpt <= 4, "flush() derives a record's unit from three boundaries");
-static_assert(kSuper >= 1 && kSuper <= 8, "tickets per draw");
 constexpr u32 kRing = 1024u * kUpt;           // 16-bit entries per wave: the ticket being scanned + the one waiting
 constexpr u64 kReady = 1ull << 63;
 constexpr u32 kSpinLimit = 1u << 24;          // ~0.25 us per spin: seconds — only a logic error gets there (see the safety nets)
-constexpr u32 kResolveChunk = 16u / kUpt;     // tickets per resolver lane and step (256 per wave step at 128-KiB tickets)
+constexpr u32 kResolveChunk = 8;              // tickets per resolver lane and pass (512 per pass)
 constexpr u64 kUnitBytes1 = (u64)kRoundsBig * kSegBytes;
 
 __device__ __forceinline__ u32 s_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
@@ -334,21 +330,14 @@ __global__ __launch_bounds__(kBlock, 4) void single_fused(const LitArgs a, u64 *
         }
     };
 
-    // ONE ticket counter (a.ctr->ticket), kSuper consecutive tickets per draw: what has been drawn is always a prefix of the
-    // ticket space, and a wave's tickets ascend — the two facts the progress argument in the header rests on.
-    u64 sup_next = 0, sup_end = 0; // tickets of the current draw not handed out yet
+    // ONE ticket counter (a.ctr->ticket): what has been drawn is always a prefix of the ticket space, and a wave's tickets
+    // ascend — the two facts the progress argument in the header rests on.
     auto draw = [&]() __attribute__((always_inline)) -> u64 {
-        if (sup_next < sup_end)
-            return sup_next++;
         u64 tk = 0;
         if (lane == 0)
             tk = __hip_atomic_fetch_add(&a.ctr->ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const u64 s0 = s_rfl64(tk) * kSuper;
-        if (s0 >= n_tickets)
-            return ~0ull;
-        sup_end = s0 + kSuper < n_tickets ? s0 + kSuper : n_tickets;
-        sup_next = s0 + 1;
-        return s0;
+        tk = s_rfl64(tk);
+        return tk < n_tickets ? tk : ~0ull;
     };
     uint4 A[kCells];
     u64 t = draw();

@@ -216,7 +216,7 @@ def test_the_parity_checker_is_the_compiled_reference(gpu, oracle_engine):
 @pytest.mark.timeout(240)
 def test_single_byte_one_pass_with_a_starved_grid(gpu):
     """the one-pass single-byte kernel must make progress when only a few of its waves really run (a
-    shared or partitioned device).  Grids of 1, 2 and 3 workgroups over a 1 GiB text (16 384 tickets of 64 KiB; the round-3
+    shared or partitioned device).  Grids of 1, 2 and 3 workgroups over a 1 GiB text (8 192 tickets of 128 KiB; the round-3
     kernel waited circularly here until its multi-second safety net fired and the plan fell back to the two-pass kernels):
     the exact record list, no hand-over to the two-pass kernels, and in seconds."""
     import time
