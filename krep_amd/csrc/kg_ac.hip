@@ -1124,6 +1124,8 @@ static hipError_t ac_launch2(const AcArgs &a, u32 grid, u32 lds, hipStream_t st)
 }
 static hipError_t ac_launch(const AcArgs &a, u32 grid, u32 lds, hipStream_t st)
 {
+    if (a.cap)
+        return ac_cap_launch(a, grid, lds, st);
     const bool ci = a.flags & F_CI, ln = a.flags & F_LINES;
     if (ci && ln) return ac_launch2<true, true>(a, grid, lds, st);
     if (ci) return ac_launch2<true, false>(a, grid, lds, st);
@@ -1221,21 +1223,25 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
         a.offsets = (const u64 *)post.d_offsets;
     }
     SCHK(hipSetDevice(t->device));
-    const u32 lds = ac_lds_bytes(a.filter_words, lines);
+    // every pattern >= 4 bytes and no -c: the kernel whose verify stage reads no text (kg_ac_cap.hip; KREP_GPU_AC_CAP=0: A/B hook)
+    const char *cap_env = getenv("KREP_GPU_AC_CAP");
+    a.cap = a.stride == 2 && !lines && !(cap_env && cap_env[0] == '0') ? 1u : 0u;
+    const u32 lds = a.cap ? ac_cap_lds_bytes(a.filter_words) : ac_lds_bytes(a.filter_words, lines);
+    const u32 waves = a.cap ? ac_cap_waves() : (u32)kAcWaves;
     const u32 per_cu = lds <= 80 * 1024 ? 2u : 1u;
     // ticket size by text size: >= ~4 tickets per resident wave before tickets grow (small host buffers keep every
     // CU busy), 8 units (128 KiB) on large texts
     a.upt = (u32)std::min<u64>(kAcUnitsPerTicketMax, std::max<u64>(1, a.num_tiles / ((u64)num_cu * kAcWaves * 4)));
     // verifier waves per workgroup (SPEC kernel, see ac_scan_kernel): only where there is enough text for the split to pay
     a.nv = 0;
-    if (a.stride == 2 && !lines)
+    if (a.stride == 2 && !lines && !a.cap)
     {
         a.nv = kAcVerifierWaves;
         if (const char *e = getenv("KREP_GPU_AC_NV")) // A/B hook: 0 = every wave verifies its own units (the round-3 kernel)
             a.nv = (u32)std::min(8, std::max(0, atoi(e)));
     }
     const u64 n_tickets = (a.num_tiles + a.upt - 1) / a.upt;
-    const u32 grid = (u32)std::min<u64>((n_tickets + kAcWaves - 1) / kAcWaves, (u64)num_cu * per_cu);
+    const u32 grid = (u32)std::min<u64>((n_tickets + waves - 1) / waves, (u64)num_cu * per_cu);
     if (time_it) SCHK(hipEventRecord(ev0, st));
     SCHK(hipMemsetAsync(d_ctr, 0, sizeof(Counters), st));
     SCHK(ac_launch(a, grid, lds, st));
