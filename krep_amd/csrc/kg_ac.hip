@@ -42,18 +42,9 @@ namespace kg {
 // pattern's final 4-gram (a match ends at the tested position t), the 4-gram one byte earlier (the match ends at t + 1;
 // for a 4-byte pattern that gram has an unknown first byte: all 32 classes are set).  Half the LDS lookups — the
 // bank-conflict wall of 4.2 — and half the lookup VALU; a candidate verifies both ends, with both probes in flight.
-// SPEC (round 4; STRIDE == 2 without -c): the 16 waves of the workgroup split into a.nv VERIFIER waves (the last ones: one
-// per SIMD) and 16 - a.nv FILTER waves.  A filter wave only streams and filters; it leaves each unit's candidate bitmap in
-// one of its two LDS buffers and goes straight on to the next unit.  A verifier wave serves the filter waves w with
-// w % nv == its index: enumerates a published bitmap, probes, stages, writes the info word, hands the buffer back.  Why: the
-// probes are two DEPENDENT gathers (text window, table bucket), and vmcnt retires in order — a wave that waits for its probes
-// first waits for the 8 KiB of stream prefetch it issued before them, then for two more memory round trips during which it
-// has nothing in flight; ~2 us per 16 KiB unit, 1.04 of the kernel's 6.7 ms at 32 GiB.  The probes of a
-// verifier wave queue behind nothing but each other, and a filter wave never waits for anything but its own stream.
-template <bool CI, bool LINES, bool SHORT, int STRIDE, bool SPEC = false>
+template <bool CI, bool LINES, bool SHORT, int STRIDE>
 __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
 {
-    static_assert(!SPEC || (STRIDE == 2 && !LINES), "the verifier waves exist for the pair-layout kernel without -c");
     extern __shared__ __attribute__((aligned(16))) u32 s_mem[]; // filter table | per wave: candidate bitmap (+ hit and newline bitmaps for -c)
     const u32 lane = ac_lane();
     const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -72,7 +63,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
     constexpr bool XCAND = PAIR && LINES;
     // candidate bitmap of the unit: one bit per end position, written as the lane's 16-bit filter result per cell —
     // entry (r * 8 + j) * 64 + lane, so that index order is position order
-    u32 *cbits = s_mem + fw + wave * kPerWave; // (SPEC: one of the wave's two 1-KiB buffers, chosen per unit)
+    u32 *cbits = s_mem + fw + wave * kPerWave;
     unsigned short *cbits16 = reinterpret_cast<unsigned short *>(cbits);
     // PIPE: the pair filter only ever sets the even bits of a lane's 16-bit result, so it stores EIGHT bits per lane and cell
     // (bit q <-> tested position 2q + 1): the bitmap is 1 KiB, lane L owns 4 dwords, and the other KiB of the wave's bitmap
@@ -91,230 +82,8 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
     const bool chain = want_pos || LINES;
     const bool emit_final = a.emit_mode != 0;
 
-    // ---- the verify stage of ONE unit (candidate bitmap cb, unit starting at text offset useg): returns the unit's matches.
-    //      Called by the scanning wave itself, or (SPEC) by a verifier wave on a bitmap another wave published.
-    auto verify_unit = [&](const u32 *cb, const u64 useg, u32 *slot, const bool do_stage, const bool do_final, const u64 fbase)
-                           __attribute__((always_inline)) -> u32 {
-        // ---- verify (and stage/emit) the candidates, 64 at a time, one per lane.  Lane L owns the 256 positions
-        //      [256 L, 256 L + 256) of the bitmap (8 dwords); a wave scan of the popcounts gives every lane its rank
-        //      range, and the lane verifying rank q finds its candidate by a binary search over those sums and a
-        //      select of the t-th set bit in the owner's block ------------------------------------------------
-        u32 wcnt = 0; // matches of the unit so far == rank of the next one (uniform)
-        {
-            u32 mycnt = 0;
-            {
-                const uint4 lo = *reinterpret_cast<const uint4 *>(cb + lane * kWPL);
-                mycnt = (u32)(__popc(lo.x) + __popc(lo.y) + __popc(lo.z) + __popc(lo.w));
-                if (!PIPE)
-                {
-                    const uint4 hi = *reinterpret_cast<const uint4 *>(cb + lane * kWPL + 4u);
-                    mycnt += (u32)(__popc(hi.x) + __popc(hi.y) + __popc(hi.z) + __popc(hi.w));
-                }
-            }
-            u32 incl = mycnt; // inclusive prefix of the candidate counts over lanes
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1)
-            {
-                const u32 t = __shfl_up(incl, o);
-                if (lane >= (u32)o)
-                    incl += t;
-            }
-            const u32 n = (a.flags & (1u << 31)) ? 0u : __shfl(incl, 63); // (ablation hook KREP_GPU_AC_NOVERIFY: filter cost only)
-            constexpr bool pair = STRIDE == 2; // a candidate stands for the ends t and t + 1
-            const u32 n_tot = n + ((XCAND && !(a.flags & (1u << 31)) && useg >= 1u) ? 1u : 0u); // rank n: the extra candidate
-            for (u32 b0 = 0; b0 < n_tot; b0 += 64)
-            {
-                const u32 qi = b0 + lane;
-                const bool live = qi < n;
-                const bool isx = XCAND && qi == n && qi < n_tot;
-                u32 rel = 0;
-                {
-                    // owner = first lane whose inclusive sum exceeds my rank
-                    u32 own = 0;
-#pragma unroll
-                    for (u32 step = 32; step; step >>= 1)
-                    {
-                        const u32 t = __shfl(incl, (own + step - 1u) & 63u);
-                        if (t <= qi)
-                            own += step;
-                    }
-                    own &= 63u;
-                    const u32 oincl = __shfl(incl, own), ocnt = __shfl(mycnt, own);
-                    if (live)
-                    {
-                        u32 t = qi - (oincl - ocnt); // my candidate is the t-th set bit of the owner's block
-                        const u32 *blk = cb + own * kWPL;
-                        u32 w = 0, word = blk[0];
-                        for (;;)
-                        {
-                            const u32 c = (u32)__popc(word);
-                            if (t < c)
-                                break;
-                            t -= c;
-                            word = blk[++w];
-                        }
-                        for (; t; --t)
-                            word &= word - 1u;
-                        rel = PIPE ? 2u * (own * 128u + w * 32u + (u32)__builtin_ctz(word)) // (bit b <-> tested position 2b + 1)
-                                   : own * 256u + w * 32u + (u32)__builtin_ctz(word);
-                    }
-                }
-                // pair layout: bit j of the bitmap is tested position j + 1
-                const u64 pos = isx ? useg - 1u : useg + rel + (PAIR ? 1u : 0u);
-                bool liveA = live, liveB = false;
-                if (STRIDE == 2)
-                    liveA = live && pos >= a.end_lo && pos < a.end_hi;
-                if (pair)
-                    liveB = (live || isx) && pos + 1 >= a.end_lo && pos + 1 < a.end_hi &&
-                            (!XCAND || pos + 1 < useg + kAcUnitBytes); // (-c: that end belongs to the next unit's extra candidate)
-                u32 cA = 0, cB = 0;
-                u64 dmA = 0, dmB = 0;
-                bool simA = false, simB = false;
-                if (STRIDE == 2)
-                {
-                    bool slA = false, slB = false;
-                    u32 mA = 0, mB = 0;
-                    if (!(a.flags & (1u << 30))) // (ablation hook KREP_GPU_AC_NOPROBE: candidate enumeration without the probes)
-                        ac_walk_probe2<CI, SHORT>(a, pos, liveA, liveB, LINES, mA, slA, mB, slB);
-                    dmA = mA; dmB = mB;
-                    cA = (u32)__popc(mA); cB = (u32)__popc(mB);
-                    simA = simB = true;
-#pragma unroll 1
-                    for (int e = 0; e < 2; ++e) // the one call site of the level walk
-                        if (e ? slB : slA)
-                        {
-                            u64 dm;
-                            bool sim;
-                            const u32 c = ac_walk_slow<CI, SHORT>(a, pos + (u64)e, LINES, dm, sim);
-                            if (e) { cB = c; dmB = dm; simB = sim; }
-                            else { cA = c; dmA = dm; simA = sim; }
-                        }
-                }
-                else if (liveA)
-                    cA = ac_walk_fast<CI, SHORT>(a, pos, LINES, dmA, simA);
-                const u32 c = cA + cB;
-                u32 incl = c;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1)
-                {
-                    const u32 t = __shfl_up(incl, o);
-                    if (lane >= (u32)o)
-                        incl += t;
-                }
-                const u32 rank0 = wcnt + incl - c;
-                wcnt += __shfl(incl, 63);
-#pragma unroll 1
-                for (int e = 0; e < (pair ? 2 : 1); ++e)
-                {
-                    const u32 ce = e ? cB : cA;
-                    if (!ce)
-                        continue;
-                    const u64 pe = pos + (u64)e, dme = e ? dmB : dmA;
-                    const u32 re = rank0 + (e ? cA : 0u), rele = (u32)(pe - useg); // the END's bit in the unit's hit bitmap
-                    const bool sime = e ? simB : simA;
-                    if (LINES)
-                        atomicOr(&bitmap[rele >> 5], 1u << (rele & 31u));
-                    if (do_stage || do_final)
-                    {
-                        auto write = [&](u32 at, u64 s0, u32 len) {
-                            if (do_stage)
-                            {
-                                if (at < a.stage_cap)
-                                    slot[at] = ((u32)(s0 + 1024u - useg) << 11) | len; // start relative to the unit (>= -1023), length <= 1024
-                            }
-                            else
-                            {
-                                const u64 g = fbase + at;
-                                if (g < a.pos_cap)
-                                {
-                                    const u64 st = s0 + a.global_base, en = st + len;
-                                    *reinterpret_cast<uint4 *>(a.positions + 2 * g) =
-                                        make_uint4((u32)st, (u32)(st >> 32), (u32)en, (u32)(en >> 32));
-                                }
-                            }
-                        };
-                        if (sime)
-                        {
-                            u32 at = re;
-                            for (u64 rest = dme; rest;) // longest first
-                            {
-                                const u32 d = 63u - (u32)__builtin_clzll(rest);
-                                rest &= ~(1ull << d);
-                                write(at++, pe + 1 - (u64)d, d);
-                            }
-                        }
-                        else
-                            ac_walk<CI, true, !SHORT>(a, pe, ce, [&](u32 r, u64 s2, u32 len) { write(re + r, s2, len); });
-                    }
-                }
-            }
-        }
-
-        return wcnt;
-    };
-
     u64 acc_total = 0;
-    // SPEC: the hand-over block lives in the LAST wave's LDS area (always a verifier, which parks nothing): 8 words per filter
-    // wave — [0] units published, [1] units consumed, [2] finished, [4..7] the unit index (u64) behind each of its two buffers
-    u32 *const ctl = s_mem + fw + (kAcWaves - 1) * kPerWave;
-    const u32 NV = SPEC ? a.nv : 0u, NF = kAcWaves - NV;
-    if (SPEC && threadIdx.x < kAcWaves * 8u)
-        ctl[threadIdx.x] = 0u;
     __syncthreads(); // filter tables are in LDS from here on; the waves never synchronise again
-
-    if (SPEC && wave >= NF)
-    {
-        // ---- a verifier wave: serves the filter waves w = vi, vi + NV, ... round robin until all of them have finished ----
-        const u32 vi = wave - NF;
-        for (;;)
-        {
-            bool any = false, live = false;
-            for (u32 w = vi; w < NF; w += NV)
-            {
-                u32 *c = ctl + w * 8u;
-                const u32 fin = __builtin_amdgcn_readfirstlane(ac_lds_ld(c + 2)); // BEFORE the count: a set flag means the count is final
-                ac_lds_fence();
-                const u32 prod = __builtin_amdgcn_readfirstlane(ac_lds_ld(c + 0));
-                const u32 cons = __builtin_amdgcn_readfirstlane(ac_lds_ld(c + 1));
-                if (prod == cons)
-                {
-                    live = live || !fin;
-                    continue;
-                }
-                ac_lds_fence(); // the bitmap and the unit index were written before the count
-                const u32 buf = cons & 1u;
-                const u64 unit = (u64)__builtin_amdgcn_readfirstlane(ac_lds_ld(c + 4 + 2 * buf)) |
-                                 ((u64)__builtin_amdgcn_readfirstlane(ac_lds_ld(c + 5 + 2 * buf)) << 32);
-                const u32 *cb = s_mem + fw + w * kPerWave + buf * 256u;
-                const u64 useg = a.anchor + unit * (u64)kAcUnitBytes;
-                u32 *slot = reinterpret_cast<u32 *>(a.stage) + unit * (u64)a.stage_cap;
-                const u32 wcnt = verify_unit(cb, useg, slot, want_pos, false, 0ull);
-                ac_lds_fence(); // every read of the bitmap is done: the buffer goes back
-                if (lane == 0)
-                    ac_lds_st(c + 1, cons + 1u);
-                acc_total += wcnt;
-                if (chain && lane == 0)
-                {
-                    a.unitinfo[unit] = (u64)wcnt | (wcnt ? (kLnHead | kLnTail) : 0ull);
-                    if (want_pos && wcnt > a.stage_cap)
-                    {
-                        atomicAdd(&a.ctr->overflow_units, 1ull);
-                        atomicMax(&a.ctr->max_unit_count, (u64)wcnt);
-                    }
-                }
-                any = live = true;
-            }
-            if (!live)
-                break;
-            if (!any)
-                __builtin_amdgcn_s_sleep(2);
-        }
-        if (lane == 0 && acc_total)
-            atomicAdd(&a.ctr->total, acc_total);
-        return;
-    }
-    u32 *const myctl = ctl + wave * 8u;
-    u32 nprod = 0; // SPEC: units this filter wave has published
 
     // Waves are autonomous: each draws its own ticket for a.upt consecutive 16-KiB units (128 KiB on large texts:
     // ~25 fetch-adds/us on the single ticket word at 3 TB/s).  A per-tile workgroup barrier (one block per CU
@@ -341,21 +110,13 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
         if (emit_final && (u32)(a.unitinfo[unit] & kUiCountMask) <= a.stage_cap)
             continue;
 
-        if (SPEC)
-        {
-            // this unit's bitmap goes into buffer nprod & 1: wait until the verifier has handed it back (two units of slack)
-            while ((u32)(nprod - __builtin_amdgcn_readfirstlane(ac_lds_ld(myctl + 1))) >= 2u)
-                __builtin_amdgcn_s_sleep(1);
-            cbits = s_mem + fw + wave * kPerWave + (nprod & 1u) * 256u;
-            cbits8 = reinterpret_cast<uint8_t *>(cbits);
-        }
-        const bool parked = !SPEC && PIPE && !emit_final && chain && a.stage_cap == 16u && a.upt <= kAcUnitsPerTicketMax;
+        const bool parked = PIPE && !emit_final && chain && a.stage_cap == 16u && a.upt <= kAcUnitsPerTicketMax;
         u32 *slot = parked ? park_slots + (u32)(unit - u_begin) * 16u
                            : reinterpret_cast<u32 *>(a.stage) + unit * (u64)a.stage_cap; // 32-bit staged words, see write() below
         const bool do_final = emit_final && want_pos;
         const bool do_stage = !emit_final && want_pos;
         const u64 fbase = do_final ? a.offsets[unit] : 0ull;
-        u32 wcnt = 0; // matches of the unit (uniform)
+        u32 wcnt = 0; // matches of the unit so far == rank of the next one (uniform)
 
 #pragma unroll
         for (int r = 0; r < kAcRounds; ++r)
@@ -603,21 +364,159 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
         carry = before;
         } // rounds
 
-        if (SPEC)
+        // ---- verify (and stage/emit) the candidates, 64 at a time, one per lane.  Lane L owns the 256 positions
+        //      [256 L, 256 L + 256) of the bitmap (8 dwords); a wave scan of the popcounts gives every lane its rank
+        //      range, and the lane verifying rank q finds its candidate by a binary search over those sums and a
+        //      select of the t-th set bit in the owner's block ------------------------------------------------
         {
-            // publish: unit index, then (everything above performed) the count — the verifier reads them in the opposite order
-            if (lane == 0)
+            u32 mycnt = 0;
             {
-                ac_lds_st(myctl + 4 + 2 * (nprod & 1u), (u32)unit);
-                ac_lds_st(myctl + 5 + 2 * (nprod & 1u), (u32)(unit >> 32));
+                const uint4 lo = *reinterpret_cast<const uint4 *>(cbits + lane * kWPL);
+                mycnt = (u32)(__popc(lo.x) + __popc(lo.y) + __popc(lo.z) + __popc(lo.w));
+                if (!PIPE)
+                {
+                    const uint4 hi = *reinterpret_cast<const uint4 *>(cbits + lane * kWPL + 4u);
+                    mycnt += (u32)(__popc(hi.x) + __popc(hi.y) + __popc(hi.z) + __popc(hi.w));
+                }
             }
-            ac_lds_fence();
-            ++nprod;
-            if (lane == 0)
-                ac_lds_st(myctl + 0, nprod);
-            continue;
+            u32 incl = mycnt; // inclusive prefix of the candidate counts over lanes
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1)
+            {
+                const u32 t = __shfl_up(incl, o);
+                if (lane >= (u32)o)
+                    incl += t;
+            }
+            const u32 n = (a.flags & (1u << 31)) ? 0u : __shfl(incl, 63); // (ablation hook KREP_GPU_AC_NOVERIFY: filter cost only)
+            constexpr bool pair = STRIDE == 2; // a candidate stands for the ends t and t + 1
+            const u32 n_tot = n + ((XCAND && !(a.flags & (1u << 31)) && useg >= 1u) ? 1u : 0u); // rank n: the extra candidate
+            for (u32 b0 = 0; b0 < n_tot; b0 += 64)
+            {
+                const u32 qi = b0 + lane;
+                const bool live = qi < n;
+                const bool isx = XCAND && qi == n && qi < n_tot;
+                u32 rel = 0;
+                {
+                    // owner = first lane whose inclusive sum exceeds my rank
+                    u32 own = 0;
+#pragma unroll
+                    for (u32 step = 32; step; step >>= 1)
+                    {
+                        const u32 t = __shfl(incl, (own + step - 1u) & 63u);
+                        if (t <= qi)
+                            own += step;
+                    }
+                    own &= 63u;
+                    const u32 oincl = __shfl(incl, own), ocnt = __shfl(mycnt, own);
+                    if (live)
+                    {
+                        u32 t = qi - (oincl - ocnt); // my candidate is the t-th set bit of the owner's block
+                        const u32 *blk = cbits + own * kWPL;
+                        u32 w = 0, word = blk[0];
+                        for (;;)
+                        {
+                            const u32 c = (u32)__popc(word);
+                            if (t < c)
+                                break;
+                            t -= c;
+                            word = blk[++w];
+                        }
+                        for (; t; --t)
+                            word &= word - 1u;
+                        rel = PIPE ? 2u * (own * 128u + w * 32u + (u32)__builtin_ctz(word)) // (bit b <-> tested position 2b + 1)
+                                   : own * 256u + w * 32u + (u32)__builtin_ctz(word);
+                    }
+                }
+                // pair layout: bit j of the bitmap is tested position j + 1
+                const u64 pos = isx ? useg - 1u : useg + rel + (PAIR ? 1u : 0u);
+                bool liveA = live, liveB = false;
+                if (STRIDE == 2)
+                    liveA = live && pos >= a.end_lo && pos < a.end_hi;
+                if (pair)
+                    liveB = (live || isx) && pos + 1 >= a.end_lo && pos + 1 < a.end_hi &&
+                            (!XCAND || pos + 1 < useg + kAcUnitBytes); // (-c: that end belongs to the next unit's extra candidate)
+                u32 cA = 0, cB = 0;
+                u64 dmA = 0, dmB = 0;
+                bool simA = false, simB = false;
+                if (STRIDE == 2)
+                {
+                    bool slA = false, slB = false;
+                    u32 mA = 0, mB = 0;
+                    if (!(a.flags & (1u << 30))) // (ablation hook KREP_GPU_AC_NOPROBE: candidate enumeration without the probes)
+                        ac_walk_probe2<CI, SHORT>(a, pos, liveA, liveB, LINES, mA, slA, mB, slB);
+                    dmA = mA; dmB = mB;
+                    cA = (u32)__popc(mA); cB = (u32)__popc(mB);
+                    simA = simB = true;
+#pragma unroll 1
+                    for (int e = 0; e < 2; ++e) // the one call site of the level walk
+                        if (e ? slB : slA)
+                        {
+                            u64 dm;
+                            bool sim;
+                            const u32 c = ac_walk_slow<CI, SHORT>(a, pos + (u64)e, LINES, dm, sim);
+                            if (e) { cB = c; dmB = dm; simB = sim; }
+                            else { cA = c; dmA = dm; simA = sim; }
+                        }
+                }
+                else if (liveA)
+                    cA = ac_walk_fast<CI, SHORT>(a, pos, LINES, dmA, simA);
+                const u32 c = cA + cB;
+                u32 incl = c;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1)
+                {
+                    const u32 t = __shfl_up(incl, o);
+                    if (lane >= (u32)o)
+                        incl += t;
+                }
+                const u32 rank0 = wcnt + incl - c;
+                wcnt += __shfl(incl, 63);
+#pragma unroll 1
+                for (int e = 0; e < (pair ? 2 : 1); ++e)
+                {
+                    const u32 ce = e ? cB : cA;
+                    if (!ce)
+                        continue;
+                    const u64 pe = pos + (u64)e, dme = e ? dmB : dmA;
+                    const u32 re = rank0 + (e ? cA : 0u), rele = (u32)(pe - useg); // the END's bit in the unit's hit bitmap
+                    const bool sime = e ? simB : simA;
+                    if (LINES)
+                        atomicOr(&bitmap[rele >> 5], 1u << (rele & 31u));
+                    if (do_stage || do_final)
+                    {
+                        auto write = [&](u32 at, u64 s0, u32 len) {
+                            if (do_stage)
+                            {
+                                if (at < a.stage_cap)
+                                    slot[at] = ((u32)(s0 + 1024u - useg) << 11) | len; // start relative to the unit (>= -1023), length <= 1024
+                            }
+                            else
+                            {
+                                const u64 g = fbase + at;
+                                if (g < a.pos_cap)
+                                {
+                                    const u64 st = s0 + a.global_base, en = st + len;
+                                    *reinterpret_cast<uint4 *>(a.positions + 2 * g) =
+                                        make_uint4((u32)st, (u32)(st >> 32), (u32)en, (u32)(en >> 32));
+                                }
+                            }
+                        };
+                        if (sime)
+                        {
+                            u32 at = re;
+                            for (u64 rest = dme; rest;) // longest first
+                            {
+                                const u32 d = 63u - (u32)__builtin_clzll(rest);
+                                rest &= ~(1ull << d);
+                                write(at++, pe + 1 - (u64)d, d);
+                            }
+                        }
+                        else
+                            ac_walk<CI, true, !SHORT>(a, pe, ce, [&](u32 r, u64 s2, u32 len) { write(re + r, s2, len); });
+                    }
+                }
+            }
         }
-        wcnt = verify_unit(cbits, useg, slot, do_stage, do_final, fbase);
 
         LS2 wls{0, false, false, false};
         if (LINES)
@@ -695,7 +594,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
             }
         }
       }
-      if (!SPEC && PIPE && !emit_final && chain && a.stage_cap == 16u && a.upt <= kAcUnitsPerTicketMax)
+      if (PIPE && !emit_final && chain && a.stage_cap == 16u && a.upt <= kAcUnitsPerTicketMax)
       {
         // the ticket's parked info words and slots (consecutive units: one contiguous 64-byte-per-unit region), two stores
         const u32 nun = (u32)(u_end - u_begin);
@@ -704,13 +603,6 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
         if (want_pos && lane < nun * 4u)
             reinterpret_cast<uint4 *>(reinterpret_cast<u32 *>(a.stage) + u_begin * 16u)[lane] = reinterpret_cast<const uint4 *>(park_slots)[lane];
       }
-    }
-    if (SPEC)
-    { // nothing more comes from this wave (set after its last count: a verifier that sees the flag sees the final count)
-        ac_lds_fence();
-        if (lane == 0)
-            ac_lds_st(myctl + 2, 1u);
-        return;
     }
     if (lane == 0 && acc_total && !a.emit_mode)
         atomicAdd(&a.ctr->total, acc_total);
@@ -1088,7 +980,7 @@ static u32 ac_lds_bytes(u32 filter_words, bool lines)
 }
 
 constexpr u32 kAcMaxLds = 160u * 1024u; // LDS of a gfx950 CU: the most a launch of the scan kernel can ask for
-template <bool CI, bool LN, bool SHORT, int STRIDE, bool SPEC = false>
+template <bool CI, bool LN, bool SHORT, int STRIDE>
 static hipError_t ac_launch3(const AcArgs &a, u32 grid, u32 lds, hipStream_t st)
 {
     // more than 64 KiB of dynamic LDS has to be requested explicitly — once per instantiation and device, not on every launch
@@ -1101,31 +993,26 @@ static hipError_t ac_launch3(const AcArgs &a, u32 grid, u32 lds, hipStream_t st)
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= kMaxDev || !granted[dev].load(std::memory_order_acquire))
     {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ac_scan_kernel<CI, LN, SHORT, STRIDE, SPEC>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ac_scan_kernel<CI, LN, SHORT, STRIDE>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAcMaxLds);
         if (e != hipSuccess)
             return e;
         if (dev >= 0 && dev < kMaxDev)
             granted[dev].store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((ac_scan_kernel<CI, LN, SHORT, STRIDE, SPEC>), dim3(grid), dim3(kAcBlock), lds, st, a);
+    hipLaunchKernelGGL((ac_scan_kernel<CI, LN, SHORT, STRIDE>), dim3(grid), dim3(kAcBlock), lds, st, a);
     return hipGetLastError();
 }
 template <bool CI, bool LN>
 static hipError_t ac_launch2(const AcArgs &a, u32 grid, u32 lds, hipStream_t st)
 {
     const bool shorts = a.has1 || a.has2 || a.has3;
-    if constexpr (!LN)
-        if (a.stride == 2 && a.nv && !a.emit_mode) // verifier waves (SPEC): the main pass of the pair-layout kernel without -c
-            return shorts ? ac_launch3<CI, false, true, 2, true>(a, grid, lds, st) : ac_launch3<CI, false, false, 2, true>(a, grid, lds, st);
     if (a.stride == 2)
         return shorts ? ac_launch3<CI, LN, true, 2>(a, grid, lds, st) : ac_launch3<CI, LN, false, 2>(a, grid, lds, st);
     return shorts ? ac_launch3<CI, LN, true, 1>(a, grid, lds, st) : ac_launch3<CI, LN, false, 1>(a, grid, lds, st);
 }
 static hipError_t ac_launch(const AcArgs &a, u32 grid, u32 lds, hipStream_t st)
 {
-    if (a.cap)
-        return ac_cap_launch(a, grid, lds, st);
     const bool ci = a.flags & F_CI, ln = a.flags & F_LINES;
     if (ci && ln) return ac_launch2<true, true>(a, grid, lds, st);
     if (ci) return ac_launch2<true, false>(a, grid, lds, st);
@@ -1223,25 +1110,13 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
         a.offsets = (const u64 *)post.d_offsets;
     }
     SCHK(hipSetDevice(t->device));
-    // every pattern >= 4 bytes and no -c: the kernel whose verify stage reads no text (kg_ac_cap.hip; KREP_GPU_AC_CAP=0: A/B hook)
-    const char *cap_env = getenv("KREP_GPU_AC_CAP");
-    a.cap = a.stride == 2 && !lines && !(cap_env && cap_env[0] == '0') ? 1u : 0u;
-    const u32 lds = a.cap ? ac_cap_lds_bytes(a.filter_words) : ac_lds_bytes(a.filter_words, lines);
-    const u32 waves = a.cap ? ac_cap_waves() : (u32)kAcWaves;
+    const u32 lds = ac_lds_bytes(a.filter_words, lines);
     const u32 per_cu = lds <= 80 * 1024 ? 2u : 1u;
     // ticket size by text size: >= ~4 tickets per resident wave before tickets grow (small host buffers keep every
     // CU busy), 8 units (128 KiB) on large texts
     a.upt = (u32)std::min<u64>(kAcUnitsPerTicketMax, std::max<u64>(1, a.num_tiles / ((u64)num_cu * kAcWaves * 4)));
-    // verifier waves per workgroup (SPEC kernel, see ac_scan_kernel): only where there is enough text for the split to pay
-    a.nv = 0;
-    if (a.stride == 2 && !lines && !a.cap)
-    {
-        a.nv = kAcVerifierWaves;
-        if (const char *e = getenv("KREP_GPU_AC_NV")) // A/B hook: 0 = every wave verifies its own units (the round-3 kernel)
-            a.nv = (u32)std::min(8, std::max(0, atoi(e)));
-    }
     const u64 n_tickets = (a.num_tiles + a.upt - 1) / a.upt;
-    const u32 grid = (u32)std::min<u64>((n_tickets + waves - 1) / waves, (u64)num_cu * per_cu);
+    const u32 grid = (u32)std::min<u64>((n_tickets + kAcWaves - 1) / kAcWaves, (u64)num_cu * per_cu);
     if (time_it) SCHK(hipEventRecord(ev0, st));
     SCHK(hipMemsetAsync(d_ctr, 0, sizeof(Counters), st));
     SCHK(ac_launch(a, grid, lds, st));

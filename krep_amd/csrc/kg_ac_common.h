@@ -31,8 +31,6 @@ struct AcArgs
     const u32 *copies;           // per node: number of patterns equal to the node's string
     u32 stride;                  // 1 or 2: text positions per filter lookup (2 = even positions only, see ac_scan_kernel)
     u32 upt;                     // units per wave ticket of the fused kernel (1..kAcUnitsPerTicketMax, by text size)
-    u32 cap;                     // 1: the record-capturing kernel of kg_ac_cap.hip runs this scan (patterns >= 4 bytes, no -c)
-    u32 nv;                      // SPEC kernel: verifier waves per workgroup (the last nv of the 16), 0 = every wave verifies its own units
     const uint2 *gram4;          // exact last-4-bytes -> {key, depth-4 node | has_out << 31} (val 0 = empty)
     u32 g4mask;
     const uint4 *g4x;            // entries of 2 x uint4: {key, child, info, endmask} {chain bytes x3, -}; layout by g4x_mode:
@@ -65,12 +63,6 @@ __device__ __forceinline__ u32 ac_eq_bytes(u32 x, u32 c4)
 }
 __device__ __forceinline__ u32 ac_movemask4(u32 t) { return (((t >> 7) * 0x00204081u) >> 21) & 0xfu; }
 __device__ __forceinline__ bool ac_wordc(u32 c) { return (c - '0' < 10u) || ((c | 0x20u) - 'a' < 26u) || c == '_'; }
-
-// workgroup-local flags in LDS (SPEC kernel): plain ds_read / ds_write that the compiler neither caches nor elides
-__device__ __forceinline__ u32 ac_lds_ld(const u32 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ void ac_lds_st(u32 *p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-// every LDS access issued so far has been performed, and the compiler moves no memory access across this point
-__device__ __forceinline__ void ac_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 struct LS2 { u32 cnt; bool nl, head, tail; };
 __device__ __forceinline__ LS2 ls2_combine(const LS2 &a, const LS2 &b)
@@ -294,15 +286,11 @@ __device__ __forceinline__ u32 ac_short_bits(const AcArgs &a, u32 E)
     return sb;
 }
 
-// depth mask of the matches ending at `end` from a probed entry (found) and the short-pattern bits sb.
-// avail: how many of the window's 12 chain bytes (those in front of the last 4) are real text — a window cut from a record of
-// kg_ac_cap.hip may start inside the text the lane never held.  When the chain agrees with everything that is there and goes on
-// beyond it, the verdict needs the full window: undecided = true (dm then holds only the ends inside the real bytes).
+// depth mask of the matches ending at `end` from a probed entry (found) and the short-pattern bits sb
 __device__ __forceinline__ void ac_eval_entry(const AcArgs &a, bool found, const u32 (&T)[4], const uint4 &e0, const uint4 &e1,
-                                              u32 sb, u64 end, bool own_by_end, u32 &dm, bool &slow, u32 avail, bool &undecided)
+                                              u32 sb, u64 end, bool own_by_end, u32 &dm, bool &slow)
 {
     u32 m = sb;
-    undecided = false;
     if (found)
     {
         const u32 info = e0.z, clen = info & 15u;
@@ -314,8 +302,6 @@ __device__ __forceinline__ void ac_eval_entry(const AcArgs &a, bool found, const
             if (L == 8u)
                 L += same(T[0] ^ e1.x);
         }
-        L = L < avail ? L : avail;
-        undecided = L == avail && clen > avail;
         L = L < clen ? L : clen;
         slow = !(info & kG4Simple) || (L == clen && (info & kG4Cont));
         m |= ((e0.y >> 31) << 4) | ((e0.w & ((1u << L) - 1u)) << 5); // bit d: a pattern of length d ends here
@@ -334,12 +320,6 @@ __device__ __forceinline__ void ac_eval_entry(const AcArgs &a, bool found, const
         }
     }
     dm = m;
-}
-__device__ __forceinline__ void ac_eval_entry(const AcArgs &a, bool found, const u32 (&T)[4], const uint4 &e0, const uint4 &e1,
-                                              u32 sb, u64 end, bool own_by_end, u32 &dm, bool &slow)
-{
-    bool und;
-    ac_eval_entry(a, found, T, e0, e1, sb, end, own_by_end, dm, slow, 12u, und);
 }
 
 // the level-by-level walk behind the fast verifiers: count, and (dictionaries without short patterns) the depth mask
@@ -406,87 +386,9 @@ __device__ __forceinline__ u32 ac_walk_fast(const AcArgs &a, u64 i, bool own_by_
     return (u32)__popc(dm);
 }
 
-// The table entries of the two end positions i and i + 1 of a stride-2 candidate, by the last four bytes TA3 / TB3 of their
-// text windows (case-folded by the caller): both probes are in flight together (one latency for the pair).
-struct AcPairEntries
-{
-    uint4 a0, a1, b0, b1;
-    bool foundA, foundB;
-};
-__device__ __forceinline__ void ac_fetch_pair(const AcArgs &a, u32 TA3, u32 TB3, bool liveA, bool liveB, AcPairEntries &r)
-{
-    u32 hA = (TA3 * kHashMul) >> 9, hB = (TB3 * kHashMul) >> 9;
-    r.a0 = make_uint4(0, 0, 0, 0);
-    r.a1 = r.b0 = r.b1 = r.a0;
-    bool doneA = !liveA || !a.has4, doneB = !liveB || !a.has4;
-    r.foundA = r.foundB = false;
-    if (a.g4x_mode)
-    {
-        const uint4 *ba = a.g4x + 4 * (size_t)(((TA3 * a.g4x_mul) >> 9) & a.g4x_mask);
-        const uint4 *bb = a.g4x + 4 * (size_t)(((TB3 * a.g4x_mul) >> 9) & a.g4x_mask);
-        const uint4 x0 = ba[0], x1 = ba[1], x2 = ba[2], x3 = ba[3], y0 = bb[0], y1 = bb[1], y2 = bb[2], y3 = bb[3];
-        const bool ha0 = x0.y != 0u && x0.x == TA3, ha1 = x2.y != 0u && x2.x == TA3;
-        const bool hb0 = y0.y != 0u && y0.x == TB3, hb1 = y2.y != 0u && y2.x == TB3;
-        r.a0 = ha0 ? x0 : x2; r.a1 = ha0 ? x1 : x3;
-        r.b0 = hb0 ? y0 : y2; r.b1 = hb0 ? y1 : y3;
-        r.foundA = !doneA && (ha0 || ha1);
-        r.foundB = !doneB && (hb0 || hb1);
-        doneA = doneB = true;
-    }
-    while (!(doneA && doneB))
-    {
-        const uint4 *ea = a.g4x + 2 * (size_t)(hA & a.g4mask), *eb = a.g4x + 2 * (size_t)(hB & a.g4mask);
-        const uint4 x0 = ea[0], x1 = ea[1], y0 = eb[0], y1 = eb[1];
-        if (!doneA)
-        {
-            r.a0 = x0; r.a1 = x1;
-            if (x0.y == 0u) doneA = true;
-            else if (x0.x == TA3) doneA = r.foundA = true;
-            else ++hA;
-        }
-        if (!doneB)
-        {
-            r.b0 = y0; r.b1 = y1;
-            if (y0.y == 0u) doneB = true;
-            else if (y0.x == TB3) doneB = r.foundB = true;
-            else ++hB;
-        }
-    }
-}
-template <bool CI>
-__device__ __forceinline__ void ac_fold_windows(u32 (&TA)[4], u32 (&TB)[4])
-{
-    if (CI)
-    {
-#pragma unroll
-        for (int w = 0; w < 4; ++w)
-        {
-            TA[w] = ac_fold4(TA[w]);
-            TB[w] = ac_fold4(TB[w]);
-        }
-    }
-}
-// ... and their verdicts.  No level walk in here: an end that needs it comes back with slow = true and the caller runs
-// ac_walk_slow from its single call site.
-template <bool CI, bool SHORT>
-__device__ __forceinline__ void ac_probe_pair(const AcArgs &a, u64 i, u32 (&TA)[4], u32 (&TB)[4], bool liveA, bool liveB,
-                                              bool own_by_end, u32 &dmA, bool &slowA, u32 &dmB, bool &slowB)
-{
-    ac_fold_windows<CI>(TA, TB);
-    const u32 sbA = SHORT ? ac_short_bits(a, TA[3]) : 0u, sbB = SHORT ? ac_short_bits(a, TB[3]) : 0u;
-    AcPairEntries e;
-    ac_fetch_pair(a, TA[3], TB[3], liveA, liveB, e);
-    dmA = dmB = 0;
-    slowA = slowB = false;
-    if (liveA)
-        ac_eval_entry(a, e.foundA, TA, e.a0, e.a1, sbA, i, own_by_end, dmA, slowA);
-    if (liveB)
-        ac_eval_entry(a, e.foundB, TB, e.b0, e.b1, sbB, i + 1, own_by_end, dmB, slowB);
-}
-
-// ... with the windows fetched from the text: ONE 20-byte window serves both ends (A = its first 16 bytes, B = the same one byte
-// further by funnel shifts).  Only the byte text[i + 1] is read behind A, and only when it exists (liveB): nothing is touched
-// past the end of the buffer.
+// The same for the two end positions i and i + 1 of a stride-2 candidate: both text windows and both table probes
+// are in flight together (one latency for the pair).  No level walk in here: an end that needs it comes back with
+// slow = true and the caller runs ac_walk_slow from its single call site.
 template <bool CI, bool SHORT>
 __device__ __forceinline__ void ac_walk_probe2(const AcArgs &a, u64 i, bool liveA, bool liveB, bool own_by_end,
                                                u32 &dmA, bool &slowA, u32 &dmB, bool &slowB)
@@ -499,6 +401,9 @@ __device__ __forceinline__ void ac_walk_probe2(const AcArgs &a, u64 i, bool live
         slowB = liveB;
         return;
     }
+    // ONE 20-byte window serves both ends: A = its first 16 bytes (the text up to i), B = the same one byte further (up to
+    // i + 1) by funnel shifts — five loads where two windows took eight.  Only the byte text[i + 1] is read behind A, and
+    // only when it exists (liveB): nothing is touched past the end of the buffer.
     struct __attribute__((packed)) U32p { u32 v; };
     const U32p *qa = reinterpret_cast<const U32p *>(a.text + (i - 15));
     const u32 w0 = qa[0].v, w1 = qa[1].v, w2 = qa[2].v, w3 = qa[3].v, w4 = liveB ? (u32)a.text[i + 1] : 0u;
@@ -511,11 +416,58 @@ __device__ __forceinline__ void ac_walk_probe2(const AcArgs &a, u64 i, bool live
         TB[2] = __builtin_amdgcn_alignbyte(w3, w2, 1);
         TB[3] = __builtin_amdgcn_alignbyte(w4, w3, 1);
     }
-    ac_probe_pair<CI, SHORT>(a, i, TA, TB, liveA, liveB, own_by_end, dmA, slowA, dmB, slowB);
+    if (CI)
+    {
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+        {
+            TA[w] = ac_fold4(TA[w]);
+            TB[w] = ac_fold4(TB[w]);
+        }
+    }
+    const u32 sbA = SHORT ? ac_short_bits(a, TA[3]) : 0u, sbB = SHORT ? ac_short_bits(a, TB[3]) : 0u;
+    u32 hA = (TA[3] * kHashMul) >> 9, hB = (TB[3] * kHashMul) >> 9;
+    uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0, b0 = a0, b1 = a0;
+    bool doneA = !liveA || !a.has4, doneB = !liveB || !a.has4, foundA = false, foundB = false;
+    if (a.g4x_mode)
+    {
+        const uint4 *ba = a.g4x + 4 * (size_t)(((TA[3] * a.g4x_mul) >> 9) & a.g4x_mask);
+        const uint4 *bb = a.g4x + 4 * (size_t)(((TB[3] * a.g4x_mul) >> 9) & a.g4x_mask);
+        const uint4 x0 = ba[0], x1 = ba[1], x2 = ba[2], x3 = ba[3], y0 = bb[0], y1 = bb[1], y2 = bb[2], y3 = bb[3];
+        const bool ha0 = x0.y != 0u && x0.x == TA[3], ha1 = x2.y != 0u && x2.x == TA[3];
+        const bool hb0 = y0.y != 0u && y0.x == TB[3], hb1 = y2.y != 0u && y2.x == TB[3];
+        a0 = ha0 ? x0 : x2; a1 = ha0 ? x1 : x3;
+        b0 = hb0 ? y0 : y2; b1 = hb0 ? y1 : y3;
+        foundA = !doneA && (ha0 || ha1);
+        foundB = !doneB && (hb0 || hb1);
+        doneA = doneB = true;
+    }
+    while (!(doneA && doneB))
+    {
+        const uint4 *ea = a.g4x + 2 * (size_t)(hA & a.g4mask), *eb = a.g4x + 2 * (size_t)(hB & a.g4mask);
+        const uint4 x0 = ea[0], x1 = ea[1], y0 = eb[0], y1 = eb[1];
+        if (!doneA)
+        {
+            a0 = x0; a1 = x1;
+            if (x0.y == 0u) doneA = true;
+            else if (x0.x == TA[3]) doneA = foundA = true;
+            else ++hA;
+        }
+        if (!doneB)
+        {
+            b0 = y0; b1 = y1;
+            if (y0.y == 0u) doneB = true;
+            else if (y0.x == TB[3]) doneB = foundB = true;
+            else ++hB;
+        }
+    }
+    if (liveA)
+        ac_eval_entry(a, foundA, TA, a0, a1, sbA, i, own_by_end, dmA, slowA);
+    if (liveB)
+        ac_eval_entry(a, foundB, TB, b0, b1, sbB, i + 1, own_by_end, dmB, slowB);
 }
 
 constexpr u32 kAcUnitsPerTicketMax = 8; // fused kernel: up to 128 KiB per wave ticket (one cold round in 16), fewer on small texts
-constexpr u32 kAcVerifierWaves = 0;     // SPEC kernel (an experiment kept for A/B runs, KREP_GPU_AC_NV=n): verifier waves per workgroup; 0 = off
 constexpr int kAcRounds = 2;            // load rounds per unit: one candidate drain per 16 KiB (53 of 64 lanes busy)
 constexpr u32 kAcUnitBytes = kAcRounds * kSegBytes;
 constexpr u32 kAcBitmapWords = kAcUnitBytes / 32; // one bit per end position of a unit (LINES)
@@ -547,10 +499,5 @@ __host__ __device__ __forceinline__ void ac_pair_slot(u32 x, u32 &dword, u32 &bi
     bit = x & 31u;
     dword = (c1 ^ ((c2 & 15u) << 1)) | ((c2 >> 4) << 5) | (c3 << 6) | ((c2 & 15u) << 11);
 }
-
-// kg_ac_cap.hip — the kernel for dictionaries whose patterns all have >= 4 bytes, without -c: records captured by the filter
-hipError_t ac_cap_launch(const AcArgs &a, u32 grid, u32 lds, hipStream_t st);
-u32 ac_cap_lds_bytes(u32 filter_words);
-u32 ac_cap_waves();
 
 } // namespace kg
