@@ -1022,7 +1022,8 @@ static hipError_t ac_launch(const AcArgs &a, u32 grid, u32 lds, hipStream_t st)
 
 int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, int num_cu, const uint8_t *d_text, size_t text_len,
             size_t own_lo, size_t own_hi, size_t global_base, match_position_t *d_pos, uint64_t cap, bool ww, bool lines,
-            bool track, size_t max_count, hipStream_t st, int time_it, hipEvent_t ev0, hipEvent_t ev1, krep_gpu_scan_out_t *out)
+            bool track, size_t max_count, hipStream_t st, int time_it, hipEvent_t ev0, hipEvent_t ev1, krep_gpu_scan_out_t *out,
+            bool lines_on_list)
 {
     memset(out, 0, sizeof *out);
     if (max_count == 0) // aho_corasick.c:316
@@ -1122,11 +1123,18 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
     SCHK(ac_launch(a, grid, lds, st));
     if (chain && post_order(post, n_units, a.stage_cap, 0, a.anchor + global_base, unit_bytes, lines, (uint64_t *)d_pos, want, d_ctr, num_cu, st))
         return 2;
+    // lines_on_list (kg_host.hip scan_ac_lines_on_list): the distinct lines of the record list just gathered, counted by the
+    // newline gaps between neighbours, behind the post-pass on the same stream — valid when no unit overflowed its staging
+    // slot and the list fitted (the caller checks both and repeats otherwise)
+    if (lines_on_list && want && tail_launch_line_gaps(d_text, global_base, (const uint64_t *)d_pos, &d_ctr->total, want, &d_ctr->lines, st))
+        return 2;
     if (time_it) SCHK(hipEventRecord(ev1, st));
     SCHK(hipMemcpyAsync(h_ctr, d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, st));
     SCHK(hipStreamSynchronize(st));
     if (want && !g_ac_force_stage_cap && h_ctr->overflow_units * 64 > n_units)
         t->stage_cap = 64; // a dense dictionary / text: the next scans stage 64 matches per unit
+    const bool list_lines_valid = lines_on_list && want && !h_ctr->overflow_units && h_ctr->total <= want;
+    const u64 list_lines = h_ctr->lines;
     if (want && h_ctr->overflow_units)
     {
         AcArgs e = a;
@@ -1149,6 +1157,8 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
     out->has_newline = (summary & kLnNl) != 0;
     out->head_line_hit = (summary & kLnHead) != 0;
     out->tail_line_hit = (summary & kLnTail) != 0;
+    if (lines_on_list)
+        out->line_count = list_lines_valid ? list_lines : ~0ull; // ~0: the list was not complete when the gaps were counted
     out->count = std::min<u64>(lines ? nl : total, (u64)max_count);
     if (want && track)
     {

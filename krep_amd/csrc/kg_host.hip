@@ -1560,6 +1560,93 @@ static int scan_ac_newline_lines(krep_gpu_plan *pl, const Window &w, hipStream_t
     return 0;
 }
 
+// aho_corasick_search with count_lines_mode, no newline inside any pattern, on a large sparse text: the matches are scanned as
+// RECORDS by the fast kernel (staging + post-pass into the plan's grow-only list) and the lines are counted ON THE LIST — two
+// neighbours of the end-ordered list lie on different lines iff the gap between them holds a '\n' (kg_tail.hip,
+// tail_line_gaps).  The in-kernel line bookkeeping of kg_ac.hip (exact newline mask of every 1-KiB cell, hit and newline
+// bitmaps per unit, a line pass over all 16 cells of every unit) runs at 0.43 of the HBM roofline on BASELINE config 4; this
+// road costs the records scan (0.61) plus ~2 cache lines per match.  The line summary of the window (has_newline / head / tail,
+// krep_gpu_combine_line_counts) comes from two early-exit newline sweeps and the first and last record.  Matches are owned by
+// START here, by END in the in-kernel road: the same lines either way (a match without '\n' starts and ends on one line).
+// Returns 1 when the text turns out to be too dense for the list (the caller takes the in-kernel road), 2 on error.
+constexpr size_t kAcLinesOnListMin = (size_t)32 << 20;
+static int scan_ac_lines_on_list(krep_gpu_plan *pl, const Window &w, hipStream_t st, int time_it, krep_gpu_scan_out_t *out)
+{
+    memset(out, 0, sizeof *out);
+    if (pl->max_count == 0) // aho_corasick.c:316
+        return 0;
+    const size_t own_hi = std::min(w.own_hi, w.text_len);
+    if (w.own_lo >= own_hi)
+        return 0;
+    if (time_it) HIPCHK(hipEventRecord(pl->ev0, st));
+    const uint64_t dense = w.text_len / 16 + 4096; // more matches than this: 16 B of record per 16 B of text is no shortcut
+    if (pl->nl_cap == 0)
+    {
+        const uint64_t want = std::max<uint64_t>(w.text_len / 1024, 1u << 16);
+        HIPCHK(hipMalloc(&pl->d_nl_rec, want * sizeof(match_position_t)));
+        pl->nl_cap = want;
+    }
+    krep_gpu_scan_out_t o1;
+    for (int attempt = 0;; ++attempt)
+    {
+        const int rc = ac_scan(pl->ac, pl->d_ctr, pl->h_ctr, pl->post, pl->num_cu, w.d_text, w.text_len, w.own_lo, own_hi, w.global_base,
+                               pl->d_nl_rec, pl->nl_cap, pl->ww, false, true, SIZE_MAX, st, 0, pl->ev0, pl->ev1, &o1, true);
+        if (rc)
+            return rc;
+        if (o1.total_matches > dense)
+            return 1;
+        if (!o1.overflow || attempt == 1)
+            break;
+        if (pl->d_nl_rec) (void)hipFree(pl->d_nl_rec);
+        if (pl->d_nl_ln) (void)hipFree(pl->d_nl_ln); // (the other user of the list sizes both)
+        pl->d_nl_rec = nullptr;
+        pl->d_nl_ln = nullptr;
+        pl->nl_cap = 0;
+        const uint64_t want = o1.total_matches + o1.total_matches / 8 + 1024;
+        HIPCHK(hipMalloc(&pl->d_nl_rec, want * sizeof(match_position_t)));
+        pl->nl_cap = want;
+    }
+    const uint64_t total = o1.total_matches;
+    uint64_t lines = o1.line_count; // counted behind the post-pass on the stream, unless some unit overflowed its staging slot
+    if (total && lines == ~0ull && tail_count_line_gaps(w.d_text, w.global_base, (const uint64_t *)pl->d_nl_rec, total, &pl->d_ctr->pad[0], &pl->h_ctr->pad[0],
+                                      st, &lines))
+        return 2;
+    if (time_it) HIPCHK(hipEventRecord(pl->ev1, st));
+    // the window's line summary: first and last '\n' of the owned bytes, first and last record
+    uint64_t first_nl = own_hi, last_nl1 = 0;
+    if (tail_find_next_newline(w.d_text, w.own_lo, own_hi, &pl->d_ctr->pad[0], &pl->h_ctr->pad[0], st, &first_nl))
+        return 2;
+    const bool has_nl = first_nl < own_hi;
+    if (has_nl && tail_find_prev_newline(w.d_text, own_hi, &pl->d_ctr->pad[0], &pl->h_ctr->pad[0], st, &last_nl1))
+        return 2;
+    bool head = total != 0, tail = total != 0;
+    if (total && has_nl)
+    {
+        match_position_t ends[2];
+        HIPCHK(hipMemcpyAsync(&ends[0], pl->d_nl_rec, sizeof(match_position_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(&ends[1], pl->d_nl_rec + (total - 1), sizeof(match_position_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        // a match before the first / behind the last newline exists iff the first / last record of the end-ordered list is one
+        // (no match holds a newline, so none can reach across it)
+        head = ends[0].start_offset - w.global_base < first_nl;
+        tail = ends[1].start_offset - w.global_base >= last_nl1;
+    }
+    if (time_it)
+    {
+        HIPCHK(hipStreamSynchronize(st));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, pl->ev0, pl->ev1));
+        out->kernel_ms = ms;
+    }
+    out->total_matches = total;
+    out->line_count = lines;
+    out->has_newline = has_nl;
+    out->head_line_hit = head;
+    out->tail_line_hit = tail;
+    out->count = std::min<uint64_t>(lines, pl->max_count);
+    return 0;
+}
+
 static int scan_device_impl(krep_gpu_plan_t *pl, const void *d_text, size_t text_len, size_t own_lo, size_t own_hi,
                             size_t global_base, size_t global_len, match_position_t *d_positions, uint64_t position_capacity,
                             void *stream, int time_it, const krep_gpu_seq_carry_t *carry_in, krep_gpu_seq_carry_t *carry_out,
@@ -1593,6 +1680,14 @@ static int scan_device_impl(krep_gpu_plan_t *pl, const void *d_text, size_t text
     {
         Window w{(const uint8_t *)d_text, text_len, own_lo, own_hi, global_base, global_len};
         return scan_ac_newline_lines(pl, w, st, time_it, out);
+    }
+    if (pl->ref_algo == KREP_RA_AHO_CORASICK && pl->lines && text_len >= kAcLinesOnListMin && !getenv("KREP_GPU_AC_LINES_INKERNEL"))
+    {
+        // (small texts keep the in-kernel road: the list road ends with a few host round trips, ~0.1 ms)
+        Window w{(const uint8_t *)d_text, text_len, own_lo, own_hi, global_base, global_len};
+        const int rc = scan_ac_lines_on_list(pl, w, st, time_it, out);
+        if (rc != 1)
+            return rc;
     }
     if (pl->ref_algo == KREP_RA_AHO_CORASICK)
         return ac_scan(pl->ac, pl->d_ctr, pl->h_ctr, pl->post, pl->num_cu, (const uint8_t *)d_text,

@@ -77,6 +77,10 @@ int tail_find_prev_newline(const uint8_t *d_text, uint64_t before, unsigned long
                            hipStream_t st, uint64_t *pos_plus1);
 int tail_count_changes(const uint64_t *d_v, uint64_t n, unsigned long long *d_slot, unsigned long long *h_slot, hipStream_t st,
                        uint64_t *changes);
+int tail_count_line_gaps(const uint8_t *d_text, uint64_t global_base, const uint64_t *d_rec, uint64_t n, unsigned long long *d_slot,
+                         unsigned long long *h_slot, hipStream_t st, uint64_t *lines);
+int tail_launch_line_gaps(const uint8_t *d_text, uint64_t global_base, const uint64_t *d_rec, const unsigned long long *d_n, uint64_t cap,
+                          unsigned long long *d_out, hipStream_t st);
 int tail_run_replay(const ReplayIn &r, unsigned long long *d_slot, unsigned long long *h_slot, hipStream_t st, uint64_t *lines);
 
 // kg_ac.hip — multi-pattern scan
@@ -86,7 +90,7 @@ void ac_free(AcTables *t);
 int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, int num_cu,
             const uint8_t *d_text, size_t text_len, size_t own_lo, size_t own_hi, size_t global_base,
             match_position_t *d_pos, uint64_t cap, bool ww, bool lines, bool track, size_t max_count, hipStream_t st,
-            int time_it, hipEvent_t ev0, hipEvent_t ev1, krep_gpu_scan_out_t *out);
+            int time_it, hipEvent_t ev0, hipEvent_t ev1, krep_gpu_scan_out_t *out, bool lines_on_list = false);
 
 // kg_host.hip — configuration (explicit; see krep_gpu_config_t), selector mirror, result container
 krep_gpu_config_t current_config(); // the calling thread's override, else the process-wide defaults

@@ -116,6 +116,76 @@ __global__ __launch_bounds__(256) void tail_changes(const u64 *__restrict__ v, u
         atomicAdd(out, (u64)c);
 }
 
+// out[0] += number of records i whose match lies on another line than record i - 1's (i == 0 counts): aho_corasick_search -c
+// for patterns WITHOUT a newline (aho_corasick.c:383-396) on the ordered record list.  Records ascend in `end`, and a match
+// holds no newline, so two neighbours share a line iff they overlap or the gap [end of the earlier, start of the later) holds
+// no '\n'.  The gap is read with an early exit: ~80 bytes on text with lines, the whole gap (each text byte at most once
+// over all threads) on text without.  rec offsets are global: base = global offset of text[0].
+__device__ __forceinline__ bool tail_gap_has_newline(const uint8_t *__restrict__ t, u64 lo, u64 hi)
+{
+    // aligned 16-byte vectors only, four in flight per step (a 64-byte line: with 80-byte lines the first step decides more than
+    // half of the gaps, and a step is one memory round trip however wide it is); the bytes in front of lo / behind hi are masked
+    // out of the test (reading them is safe: they share an aligned 16-byte granule with a byte of the gap)
+    auto z = [](u32 x) -> u32 { const u32 y = x ^ 0x0a0a0a0au; return (y - 0x01010101u) & ~y & 0x80808080u; }; // 0x80 per '\n' byte
+    const size_t mis = ((size_t)(t + lo)) & 15u;
+    const uint8_t *p = t + lo - mis; // aligned
+    const u64 total = hi - lo + mis; // bytes from p to hi
+    for (u64 off = 0; off < total; off += 64)
+    {
+        uint4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            v[q] = off + 16u * q < total ? *reinterpret_cast<const uint4 *>(p + off + 16u * q) : make_uint4(0, 0, 0, 0);
+        // byte index (relative to p + off) window that counts: [first, last)
+        const u64 first = off == 0 ? (u64)mis : 0ull, last = total - off < 64 ? total - off : 64ull;
+        u32 any = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w)
+        {
+            const uint4 &vv = v[w >> 2];
+            const u32 m = z((w & 3) == 0 ? vv.x : (w & 3) == 1 ? vv.y : (w & 3) == 2 ? vv.z : vv.w);
+            const u64 b0 = 4ull * w; // bytes [b0, b0 + 4) of the 64
+            u32 keep = 0xffffffffu;
+            if (first > b0)
+                keep = first - b0 >= 4 ? 0u : keep << (8 * (u32)(first - b0));
+            if (last < b0 + 4)
+                keep = last <= b0 ? 0u : keep & (0xffffffffu >> (8 * (u32)(b0 + 4 - last)));
+            any |= m & keep;
+        }
+        if (any)
+            return true;
+    }
+    return false;
+}
+// n_dev != NULL: the number of records is read on the device (min(*n_dev, n)): the launch needs no host round trip behind
+// the scan that produced the list
+__global__ __launch_bounds__(256) void tail_line_gaps(const uint8_t *__restrict__ text, const u64 *__restrict__ rec, u64 n, const u64 *n_dev,
+                                                      u64 base, u64 *out)
+{
+    if (n_dev)
+    {
+        const u64 nd = *n_dev;
+        n = nd < n ? nd : n;
+    }
+    u32 c = 0;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x)
+    {
+        if (i == 0)
+        {
+            ++c;
+            continue;
+        }
+        const u64 pe = rec[2 * i - 1] - base, cs = rec[2 * i] - base; // end of the previous match (exclusive), start of this one
+        if (cs > pe && tail_gap_has_newline(text, pe, cs))
+            ++c;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1)
+        c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0 && c)
+        atomicAdd(out, (u64)c);
+}
+
 __global__ void tail_replay(ReplayIn r, u64 *out)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0)
@@ -185,6 +255,36 @@ int tail_count_changes(const uint64_t *d_v, uint64_t n, unsigned long long *d_sl
     TCHK(hipMemcpyAsync(h_slot, d_slot, sizeof(u64), hipMemcpyDeviceToHost, st));
     TCHK(hipStreamSynchronize(st));
     *changes = *h_slot;
+    return 0;
+}
+
+int tail_count_line_gaps(const uint8_t *d_text, uint64_t global_base, const uint64_t *d_rec, uint64_t n, unsigned long long *d_slot,
+                         unsigned long long *h_slot, hipStream_t st, uint64_t *lines)
+{
+    TCHK(hipMemsetAsync(d_slot, 0, sizeof(u64), st));
+    if (n)
+    {
+        const u32 grid = (u32)std::min<u64>((n + 255) / 256, 8192);
+        hipLaunchKernelGGL(tail_line_gaps, dim3(grid), dim3(256), 0, st, d_text, (const u64 *)d_rec, (u64)n, (const u64 *)nullptr, (u64)global_base,
+                           (u64 *)d_slot);
+        TCHK(hipGetLastError());
+    }
+    TCHK(hipMemcpyAsync(h_slot, d_slot, sizeof(u64), hipMemcpyDeviceToHost, st));
+    TCHK(hipStreamSynchronize(st));
+    *lines = *h_slot;
+    return 0;
+}
+
+// the same without a host round trip: at most `cap` records, their number read from *d_n on the device, the count ADDED to *d_out
+int tail_launch_line_gaps(const uint8_t *d_text, uint64_t global_base, const uint64_t *d_rec, const unsigned long long *d_n, uint64_t cap,
+                          unsigned long long *d_out, hipStream_t st)
+{
+    if (!cap)
+        return 0;
+    const u32 grid = (u32)std::min<u64>((cap + 255) / 256, 8192);
+    hipLaunchKernelGGL(tail_line_gaps, dim3(grid), dim3(256), 0, st, d_text, (const u64 *)d_rec, (u64)cap, (const u64 *)d_n, (u64)global_base,
+                       (u64 *)d_out);
+    TCHK(hipGetLastError());
     return 0;
 }
 

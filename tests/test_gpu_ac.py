@@ -199,3 +199,47 @@ def test_worst_legal_dictionary_1024_patterns_of_up_to_1024_bytes(gpu, oracle_en
             _check(gpu, oracle_engine, text, pats, kw)
         # and a small window whose length is below the longest pattern
         _check(gpu, oracle_engine, text[90:700], pats, dict())
+
+
+def test_count_lines_on_the_record_list(gpu, oracle_engine, monkeypatch):
+    """Multi-pattern -c on a text large enough for the list road (kg_host.hip scan_ac_lines_on_list: records by the fast
+    kernel, lines counted on the end-ordered list by their newline gaps): whole text and ownership windows (the line summary
+    of each window folds with krep_gpu_combine_line_counts), -w, -i, max_count, a text without any newline, a newline-free
+    half, and the in-kernel road on the same input — all against aho_corasick_search of the compiled reference."""
+    import torch
+    rng = np.random.RandomState(4711)
+    n = 40 << 20
+    az = bytes(range(97, 123))
+    for variant in ("lines", "few_newlines", "no_newline"):
+        alpha = az + (b" \n" if variant == "lines" else b" ")
+        text = cases.rand_text(rng, n, alpha)
+        if variant == "few_newlines":  # newlines only in the first half: long gaps behind them
+            nl = rng.randint(0, n // 2, 3000)
+            text[nl] = 10
+        pats = []
+        while len(pats) < 60:  # (no newline inside a pattern: that class counts emission-order line changes, one window only)
+            q = cases.pick_pattern(rng, text[: 1 << 20], int(rng.randint(4, 14)), az)
+            if b"\n" not in q:
+                pats.append(q)
+        pats += [pats[0][1:] + b"q", b"zq" + pats[1]]  # neighbours that overlap / nest their ends
+        d = torch.from_numpy(text).cuda()
+        for kw in (dict(), dict(whole_word=True), dict(case_sensitive=False), dict(max_count=1000)):
+            kwc = dict(count_lines=True, **kw)
+            want = oracle_engine.call(abi.RA_AHO_CORASICK, abi.Params(pats, **kwc), text)[0]
+            plan = gpu.plan(abi.Params(pats, **kwc))
+            whole = plan.scan(d.data_ptr(), n)
+            assert whole.count == want, (variant, kw, whole.count, want)
+            monkeypatch.setenv("KREP_GPU_AC_LINES_INKERNEL", "1")
+            inker = plan.scan(d.data_ptr(), n)
+            monkeypatch.delenv("KREP_GPU_AC_LINES_INKERNEL")
+            assert (inker.count, inker.line_count, inker.total_matches) == (whole.count, whole.line_count, whole.total_matches)
+            if "max_count" in kw:
+                plan.close()
+                continue
+            cuts = [0, 5, (1 << 20) + 3, 17 << 20, (17 << 20) + 1, 33 << 20, n]
+            outs = [plan.scan(d.data_ptr(), n, lo, hi) for lo, hi in zip(cuts[:-1], cuts[1:])]
+            arr = (abi.ScanOut * len(outs))(*outs)
+            assert gpu.lib.krep_gpu_combine_line_counts(arr, len(outs)) == want, (variant, kw)
+            assert sum(o.total_matches for o in outs) == whole.total_matches
+            plan.close()
+        del d

@@ -273,6 +273,14 @@ def test_thousand_patterns_32gib_full_size(gpu):
     finally:
         gpu.set_algo_override(abi.ALGO_AUTO)
     assert total == out.count
+    # -c at full size (the list road: records + newline gaps) against an independent path: the 1-based line number of every
+    # record's start (kg_format.hip, krep_gpu_line_numbers) -> the number of distinct lines
+    lines_dev = torch.empty(out.stored, dtype=torch.int64, device="cuda")
+    gpu.line_numbers(buf.data_ptr(), n, pos.data_ptr(), out.stored, lines_dev.data_ptr())
+    distinct = int(torch.unique(lines_dev).numel())
+    got_c = gpu.plan(abi.Params(pats, count_lines=True)).scan(buf.data_ptr(), n)
+    assert got_c.count == distinct == got_c.line_count and got_c.total_matches == out.count
+    del lines_dev
     o = ol.checker()  # aho_corasick_search of the compiled reference
     order = torch.argsort(st, stable=True)  # by start, ties keep the (end) order
     st_sorted = st[order]
