@@ -161,29 +161,65 @@ def cpu_baseline(wl, sample_bytes, d_buf):
                sample=f"{n / 2**30:.1f} GiB slice of the same haystack, {threads} threads x {name}, chunk+overlap as "
                       f"krep.c:2851-2905, best of {len(times)} (median {n / statistics.median(times) / 1e9:.1f} GB/s), "
                       f"count={sum(counts)}")
-    # the reference CLI itself (its own thread pool and mmap path) on a /dev/shm copy of the sample
-    if kind == "reference" and not multi and cli and os.path.exists(cli):
+    # The CLIs end to end on a /dev/shm copy of the sample, wall clock of the whole process (mmap + MAP_POPULATE, thread pool,
+    # HIP runtime start, PCIe): the reference's own binary, and the SAME source with the backend wired in
+    # (oracle/_ref/krep_gpu_cli, integration/make_krep_gpu_cli.py) — once forced onto the GPU (KREP_GPU_COST_MODEL=0: size alone
+    # decides) and once with krep_gpu_worthwhile()'s cost model choosing (what a user of the drop-in gets).
+    if kind == "reference" and cli and os.path.exists(cli):
         tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
         path = f"{tmpdir}/krep_bench_{os.getpid()}.bin"
+        ppath = f"{tmpdir}/krep_bench_{os.getpid()}.pat"
+        gcli = os.path.join(ol.REF_DIR, "krep_gpu_cli")
         try:
             nb = min(n, 2 << 30)
             text[:nb].tofile(path)
-            pat = wl["patterns"][0].decode("latin-1")
-            tt = []
-            for _ in range(3):
-                t0 = time.time()
-                r = subprocess.run([cli, "-c", "-o", "--color=never", pat, path], capture_output=True, timeout=120)
-                tt.append(time.time() - t0)
-            res["cli"] = dict(value=round(nb / min(tt) / 1e9, 3), unit="GB/s",
-                              cmd=f"oracle/_ref/{os.path.basename(cli)} (reference Makefile flags, {simd}) -c -o {pat} {tmpdir}/<{nb / 2**30:.0f} GiB sample>, "
-                                  f"default threads, wall clock incl. mmap, best of 3, stdout={r.stdout.strip()[-40:].decode('latin-1')}")
+            if multi:
+                with open(ppath, "wb") as f:
+                    f.write(b"\n".join(wl["patterns"]) + b"\n")
+                pat_args, pat_desc = ["-f", ppath], f"-f <{len(wl['patterns'])} patterns>"
+            else:
+                pat_args = [wl["patterns"][0].decode("latin-1")]
+                pat_desc = pat_args[0]
+
+            def wall(binary, extra_env, reps=3):
+                env = {k: v for k, v in os.environ.items() if not k.startswith("KREP_GPU")}
+                env.update(extra_env)
+                tt, out = [], b""
+                for _ in range(reps):
+                    t0 = time.time()
+                    r = subprocess.run([binary, "-c", "-o", "--color=never"] + pat_args + [path], capture_output=True, timeout=300, env=env)
+                    tt.append(time.time() - t0)
+                    out = r.stdout.strip()[-40:]
+                return min(tt), out.decode("latin-1")
+
+            t_cpu, o_cpu = wall(cli, {})
+            res["cli"] = dict(value=round(nb / t_cpu / 1e9, 3), unit="GB/s", seconds=round(t_cpu, 4),
+                              cmd=f"oracle/_ref/{os.path.basename(cli)} (reference Makefile flags, {simd}) -c -o {pat_desc} {tmpdir}/<{nb / 2**30:.0f} GiB sample>, "
+                                  f"default threads, wall clock incl. mmap, best of 3, stdout={o_cpu}")
+            if os.path.exists(gcli):
+                t_gpu, o_gpu = wall(gcli, {"KREP_GPU": "1", "KREP_GPU_COST_MODEL": "0"})
+                t_auto, o_auto = wall(gcli, {"KREP_GPU": "1"})
+                from krep_amd import load
+                est = load().cost_estimate(p, nb, 0)
+                res["gpu_cli"] = dict(
+                    value=round(nb / t_gpu / 1e9, 3), unit="GB/s", seconds=round(t_gpu, 4),
+                    cmd=f"KREP_GPU=1 KREP_GPU_COST_MODEL=0 oracle/_ref/krep_gpu_cli -c -o {pat_desc} <same file>: the reference CLI with the "
+                        f"backend wired in, forced onto the GPU; wall clock of the whole process incl. HIP runtime start, mmap, PCIe; "
+                        f"best of 3, stdout={o_gpu}",
+                    same_output_as_cpu_cli=(o_gpu == o_cpu),
+                    with_cost_model=dict(value=round(nb / t_auto / 1e9, 3), seconds=round(t_auto, 4), stdout_same=(o_auto == o_cpu),
+                                         cmd="KREP_GPU=1 (krep_gpu_worthwhile()'s cost model decides per file)"),
+                    cost_model_estimate=dict(gpu_seconds=round(est.gpu_seconds, 4), cpu_seconds=round(est.cpu_seconds, 4),
+                                             cpu_threads=est.cpu_threads, picks="gpu" if est.gpu_seconds < est.cpu_seconds else "cpu",
+                                             note="fresh process: t_gpu includes the device start"))
         except Exception as e:  # reported, never required
-            res["cli"] = dict(value=None, unit="GB/s", cmd=f"failed: {e}")
+            res.setdefault("cli", dict(value=None, unit="GB/s", cmd=f"failed: {e}"))
         finally:
-            try:
-                os.remove(path)
-            except OSError:
-                pass
+            for q in (path, ppath):
+                try:
+                    os.remove(q)
+                except OSError:
+                    pass
     return res
 
 

@@ -187,10 +187,40 @@ enum krep_gpu_status
                                "could not look", NOT "no match" — nothing was appended to `result`                 */
 };
 int krep_gpu_last_status(void);
-/* Should a caller hand THIS text to the backend?  1 iff krep_gpu_available() && krep_gpu_can_accelerate(params) &&
- * text_len >= min_text_bytes.  search_file() asks this once per file (krep.c:2404-2420 already special-cases small
- * files): `krep -r` over many small files must not pay one device round trip per file. */
+/* Should a caller hand THIS text to the backend?  search_file() asks this once per file (krep.c:2404-2420 already special-cases
+ * small files; krep.c:2729-2770 scales its thread count with the size).  1 iff
+ *   text_len >= min_text_bytes  &&  krep_gpu_can_accelerate(params)  &&  the cost model expects the GPU to be faster  &&
+ *   krep_gpu_available()   (asked last: a text that stays on the CPU never starts the HIP runtime).
+ * The cost model (krep_amd/csrc/kg_cost.hip):
+ *   t_gpu = (device not yet initialised in this process ? gpu_init_ms : 0) + gpu_launch_us + text_len / host-path rate
+ *   t_cpu = text_len / min(cpu_threads x per-thread rate of the function select_search_algorithm() would run, its cap)
+ * cpu_threads <= 0: what search_file() itself would use, min(cores, text_len / 4 MiB), at least 1 (krep.c:2748-2759).
+ * The host-path rate and the device-start time are calibrated once per process by the library itself (the first large
+ * operator call, the availability probe); everything is overridable: krep_gpu_set_cost_rates(), $KREP_GPU_COST
+ * ("host=50,launch=100,init=450,memchr=12:180,simd=6:150,scalar=1.5:100,ac=0.4:100": GB/s per thread : cap).
+ * rates.enabled = 0 or $KREP_GPU_COST_MODEL=0: size and input class alone decide (the round-3 rule). */
+typedef struct krep_gpu_cost_rates
+{
+    int enabled;
+    double gpu_host_path_gbps, gpu_launch_us, gpu_init_ms;
+    double cpu_memchr_gbps, cpu_memchr_cap_gbps;  /* memchr_search                                                  */
+    double cpu_simd_gbps, cpu_simd_cap_gbps;      /* simd_sse42 / avx2 / avx512 / neon_search, memchr_short_search  */
+    double cpu_scalar_gbps, cpu_scalar_cap_gbps;  /* boyer_moore_search, kmp_search                                 */
+    double cpu_ac_gbps, cpu_ac_cap_gbps;          /* aho_corasick_search while its automaton fits the caches ...    */
+    double cpu_ac_cache_bytes, cpu_ac_exponent;   /* ... and x (cache / automaton bytes)^exponent beyond (2 KiB per state) */
+} krep_gpu_cost_rates_t;
+typedef struct krep_gpu_cost
+{
+    double gpu_seconds, cpu_seconds;  /* the two estimates                                                  */
+    double gpu_host_path_gbps;        /* the host-path rate used (calibrated when this process has measured one) */
+    int cpu_threads, cpu_algo;        /* threads assumed; enum krep_ref_algo of the CPU function             */
+    int device_ready;                 /* 1: this process has already started its device (no init in t_gpu)  */
+} krep_gpu_cost_t;
 int krep_gpu_worthwhile(const search_params_t *params, size_t text_len);
+int krep_gpu_worthwhile_ex(const search_params_t *params, size_t text_len, int cpu_threads);
+int krep_gpu_cost_estimate(const search_params_t *params, size_t text_len, int cpu_threads, krep_gpu_cost_t *out); /* 0 ok */
+void krep_gpu_get_cost_rates(krep_gpu_cost_rates_t *out);
+void krep_gpu_set_cost_rates(const krep_gpu_cost_rates_t *rates); /* NULL: back to the defaults + $KREP_GPU_COST */
 /* test hook: make the next operator calls fail at a chosen point — 0 off, 1 device allocation, 2 host->device copy,
  * 3 kernel launch, 4 device->host copy of the records.  Also read from $KREP_GPU_INJECT_FAILURE. */
 void krep_gpu_debug_inject_failure(int kind);

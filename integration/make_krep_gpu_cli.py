@@ -52,9 +52,12 @@ static search_func_t krep_cpu_select(const search_params_t *p)
     gpu_bypass = saved;
     return f;
 }
+static __thread int krep_cpu_threads_hint = 0; /* threads the CPU path would use for this text (0: search_file()'s own policy) */
 static search_func_t krep_select_for(const search_params_t *p, size_t text_len)
 {
-    if (!use_gpu || p->use_regex || !krep_gpu_worthwhile(p, text_len))
+    /* size, input class, the backend's cost model (GPU iff init + launch + bytes / PCIe rate beats bytes / the CPU function's
+       rate on `threads` threads) and the device, in that order */
+    if (!use_gpu || p->use_regex || !krep_gpu_worthwhile_ex(p, text_len, krep_cpu_threads_hint))
         return krep_cpu_select(p);
     return select_search_algorithm(p);
 }
@@ -88,6 +91,7 @@ static bool krep_is_gpu_fn(search_func_t f) { return f == krep_gpu_literal_searc
     #    (krep.c:2404-2420 special-cases small files too: `krep -r` must not pay a device round trip per small file)
     one_chunk = r"""
 #ifdef KREP_WITH_GPU
+    krep_cpu_threads_hint = actual_thread_count; /* what the CPU path would run this file on (krep.c:2729-2744) */
     if (krep_is_gpu_fn(krep_select_for(&current_params, file_size)))
         actual_thread_count = 1;
 #endif
@@ -102,7 +106,7 @@ static bool krep_is_gpu_fn(search_func_t f) { return f == krep_gpu_literal_searc
     pat = r'search_func_t search_algo = select_search_algorithm\(&current_params\);'
     if not re.search(pat, src):
         raise SystemExit("anchor not found: search_string's selection")
-    src = re.sub(pat, '\n#ifdef KREP_WITH_GPU\n    search_func_t search_algo = krep_select_for(&current_params, text_len);\n#else\n'
+    src = re.sub(pat, '\n#ifdef KREP_WITH_GPU\n    krep_cpu_threads_hint = 1; /* search_string() is single-threaded */\n    search_func_t search_algo = krep_select_for(&current_params, text_len);\n#else\n'
                       '    search_func_t search_algo = select_search_algorithm(&current_params);\n#endif\n', src, count=1)
     # 5. the CLI switch: environment variable, read at the top of main() (krep.c:3451).  No device is touched here — a run
     #    over small files never initialises the HIP runtime: krep_gpu_worthwhile() looks at the size first, and without a

@@ -62,6 +62,21 @@ class Config(C.Structure):
                 ("stream_chunk_bytes", C.c_size_t), ("num_gpus", C.c_int), ("min_text_bytes", C.c_size_t)]
 
 
+class CostRates(C.Structure):
+    """krep_gpu_cost_rates_t"""
+    _fields_ = [("enabled", C.c_int), ("gpu_host_path_gbps", C.c_double), ("gpu_launch_us", C.c_double), ("gpu_init_ms", C.c_double),
+                ("cpu_memchr_gbps", C.c_double), ("cpu_memchr_cap_gbps", C.c_double), ("cpu_simd_gbps", C.c_double),
+                ("cpu_simd_cap_gbps", C.c_double), ("cpu_scalar_gbps", C.c_double), ("cpu_scalar_cap_gbps", C.c_double),
+                ("cpu_ac_gbps", C.c_double), ("cpu_ac_cap_gbps", C.c_double), ("cpu_ac_cache_bytes", C.c_double),
+                ("cpu_ac_exponent", C.c_double)]
+
+
+class Cost(C.Structure):
+    """krep_gpu_cost_t"""
+    _fields_ = [("gpu_seconds", C.c_double), ("cpu_seconds", C.c_double), ("gpu_host_path_gbps", C.c_double),
+                ("cpu_threads", C.c_int), ("cpu_algo", C.c_int), ("device_ready", C.c_int)]
+
+
 class ShardInfo(C.Structure):
     """krep_gpu_shard_info_t: where the calling thread's last sharded host search ran."""
     _fields_ = [("shards", C.c_int), ("devices_used", C.c_int), ("device_ids", C.c_int * 16), ("comm_ranks", C.c_int),

@@ -10,7 +10,10 @@ namespace kg {
 using u32 = uint32_t;
 using u64 = unsigned long long;
 
-constexpr int kAcBlock = 1024;             // 16 waves share one copy of the filter tables in LDS
+#ifndef KG_AC_BLOCK
+#define KG_AC_BLOCK 1024
+#endif
+constexpr int kAcBlock = KG_AC_BLOCK;      // 16 waves share one copy of the filter tables in LDS (A/B builds: -DKG_AC_BLOCK=512)
 constexpr int kAcWaves = kAcBlock / 64;
 constexpr u32 kS1Words = 256 / 32, kS2Words = 65536 / 32, kS3Words = (1u << 24) / 32; // exact bitmaps of 1-/2-/3-byte patterns
 constexpr u32 kHashMul = 0x9E3779B1u;

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -195,6 +196,7 @@ const char *device_unusable(int device)
         if (*e && *e != '0')                                  // reaches the operators and exercises their run-time failure paths
             return nullptr;
     int ndev = 0;
+    const auto t_first = std::chrono::steady_clock::now(); // (the process's first HIP call starts the runtime: kg_cost.hip wants to know)
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     {
         (void)hipGetLastError();
@@ -213,7 +215,11 @@ const char *device_unusable(int device)
         a.reason.resize((size_t)ndev);
     }
     if (a.state[device] == 0)
+    {
         a.state[device] = probe_device(device, a.reason[device]) ? 1 : 2;
+        if (a.state[device] == 1)
+            cost_note_device_init(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_first).count());
+    }
     if (a.state[device] == 1)
         return nullptr;
     tl_unavail = a.reason[device];
@@ -419,11 +425,7 @@ extern "C" int krep_gpu_can_accelerate(const search_params_t *p)
     const krep_gpu_config_t c = kg::current_config();
     return kg::unsupported_reason(p, c) == nullptr && kg::device_unusable(c.device) == nullptr ? 1 : 0;
 }
-extern "C" int krep_gpu_worthwhile(const search_params_t *p, size_t text_len)
-{
-    const krep_gpu_config_t c = kg::current_config();
-    return text_len >= c.min_text_bytes && kg::unsupported_reason(p, c) == nullptr && kg::device_unusable(c.device) == nullptr ? 1 : 0;
-}
+// (krep_gpu_worthwhile: kg_cost.hip)
 
 // ------------------------------------------------------------------------------------ result container (krep.c:139-251 contract)
 extern "C" match_result_t *krep_gpu_match_result_init(uint64_t cap)

@@ -113,6 +113,10 @@ int allreduce_across_devices(const std::vector<int> &devs, std::vector<std::vect
 int comm_warmup(const std::vector<int> &devs);       // creates the communicator of a device list ahead of the first search
 int comm_clique_ranks(const std::vector<int> &devs); // ranks of the cached communicator over `devs` (0: none)
 
+// kg_cost.hip — krep_gpu_worthwhile()'s cost model: what this process has measured about its own GPU side
+void cost_note_device_init(double ms);                  // the first device call of the process (availability probe)
+void cost_note_host_path(size_t bytes, double seconds); // a host-buffer operator call that went through the staging ring
+
 // kg_ops.hip — host-buffer side
 void memchr_batch_quirk(match_position_t *recs, uint64_t have, size_t maxc);
 

@@ -18,6 +18,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cmath>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -80,6 +82,85 @@ struct DevBuf
         p = nullptr;
         cap = 0;
         dev = -1;
+    }
+};
+
+// ONE allocation per device for the host path: the text buffer(s) and, right behind them, the record buffer.  Where the driver
+// places a buffer physically moves the offsets-producing scans by several per cent, and freeing / re-allocating buffers between
+// calls is what churns that placement (profiles/r03_box_to_box.txt: the record buffer re-allocated inside one
+// process draws 6.58 ... 7.42 ms for the single-byte workload).  Round 3 kept that discipline in bench.py only; here the CLI
+// and every host-buffer caller get it: the arena grows (rarely: 1.5x steps), it is never freed and re-made per call, and the
+// record area always sits behind the text.  A list that outgrows its area (a second, exact-size pass) takes a buffer of its
+// own for that call: the staged text must not move.
+struct Arena
+{
+    uint8_t *base = nullptr;
+    size_t cap = 0, text_each = 0, pos_bytes = 0;
+    int ntext = 0, dev = -1;
+    DevBuf pos_extra; // only while a record list does not fit pos_bytes
+    static size_t pos_for(size_t text_bytes) { return std::max<size_t>((size_t)1 << 20, text_bytes / 4 + 4096); } // 16 B per 64 B of text
+    // `count` text buffers of `each` bytes (64-byte multiples) + the record area: keeps what is there when it is large enough
+    int ensure(size_t each, int count, int device)
+    {
+        each = (each + 255) & ~(size_t)255;
+        if (base && dev == device && ntext >= count && text_each >= each)
+            return 0;
+        const int n = std::max(count, ntext);
+        size_t want_each = std::max(each, text_each);
+        if (base && dev == device)
+            want_each = std::max(want_each, text_each + text_each / 2); // grow in steps: a run of growing files re-allocates log times
+        const size_t want_pos = pos_for(want_each), total = (size_t)n * want_each + want_pos;
+        release();
+        HIPCHK(hipSetDevice(device));
+        if (kg::inject(1))
+            return kg::fail("injected failure: device allocation of %zu bytes", total);
+        if (hipMalloc(&base, total) != hipSuccess)
+        {
+            base = nullptr;
+            (void)hipGetLastError();
+            // not enough room for the growth step: exactly what was asked for
+            want_each = each;
+            const size_t exact = (size_t)count * each + pos_for(each);
+            if (hipMalloc(&base, exact) != hipSuccess)
+            {
+                base = nullptr;
+                (void)hipGetLastError();
+                return kg::fail("hipMalloc of %zu bytes failed on device %d", exact, device);
+            }
+            cap = exact;
+            ntext = count;
+            text_each = each;
+            pos_bytes = pos_for(each);
+            dev = device;
+            return 0;
+        }
+        cap = total;
+        ntext = n;
+        text_each = want_each;
+        pos_bytes = want_pos;
+        dev = device;
+        return 0;
+    }
+    uint8_t *text(int i) const { return base + (size_t)i * text_each; }
+    // the record area for `bytes` of records: behind the text when it fits, a buffer of its own otherwise
+    uint8_t *pos(size_t bytes, int device)
+    {
+        if (base && bytes <= pos_bytes)
+            return base + (size_t)ntext * text_each;
+        return pos_extra.ensure(bytes, device) ? nullptr : pos_extra.p;
+    }
+    void release()
+    {
+        if (base)
+        {
+            (void)hipSetDevice(dev);
+            (void)hipFree(base);
+        }
+        base = nullptr;
+        cap = text_each = pos_bytes = 0;
+        ntext = 0;
+        dev = -1;
+        pos_extra.release();
     }
 };
 
@@ -154,10 +235,33 @@ struct Stager
             if (seq >= 2)
                 HIPCHK(hipEventSynchronize(done[b])); // the DMA that last used this staging buffer
             {
-                // the staging copy is the bottleneck of the host path (one core ~12 GB/s): split it over 4 threads
-                constexpr int kT = 4;
-                std::thread th[kT - 1];
-                const size_t part = (n + kT - 1) / kT;
+                // The staging copy feeds a DMA engine that takes 57.6 GB/s from pinned memory on this part
+                // (tools/ubench/host_register.hip, profiles/r04_ingest.txt); one host thread copies 12-30 GB/s depending on the
+                // host, so the copy is split over just enough helper threads to stay ahead of the DMA — measured once per
+                // process on the first full chunk (round 3 always used 4).  Zero-copy ingest (hipHostRegister of the caller's
+                // mapping, krep.c:2630-2726) was measured and is NOT used: pinning 2 GiB costs 90-106 ms, the ring moves them
+                // in 39 ms.  $KREP_GPU_COPY_THREADS overrides.
+                static std::atomic<int> threads{0};
+                int kT = threads.load(std::memory_order_relaxed);
+                if (kT == 0)
+                {
+                    const char *e = getenv("KREP_GPU_COPY_THREADS");
+                    kT = e && *e ? std::min(8, std::max(1, atoi(e))) : 0;
+                    if (kT == 0 && n >= ((size_t)8 << 20))
+                    {
+                        const size_t probe = (size_t)4 << 20; // (this part of the chunk is copied again below: a one-off 4 MiB)
+                        const auto t0 = std::chrono::steady_clock::now();
+                        memcpy(pin[b], src + off, probe);
+                        const double gbps = probe / std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / 1e9;
+                        kT = std::min(4, std::max(2, (int)std::ceil(64.0 / std::max(1.0, gbps))));
+                    }
+                    if (kT)
+                        threads.store(kT, std::memory_order_relaxed);
+                    else
+                        kT = 2; // a small first chunk: decide later
+                }
+                std::thread th[8];
+                const size_t part = (n + (size_t)kT - 1) / (size_t)kT;
                 for (int q = 1; q < kT; ++q)
                 {
                     const size_t o = (size_t)q * part;
@@ -240,7 +344,7 @@ struct DeviceCtx
     };
     std::vector<Entry> plans; // small LRU
     uint64_t tick = 0;
-    DevBuf text[2], pos;
+    Arena mem; // text buffer(s) + record area, one allocation
     Stager stager;
 
     krep_gpu_plan_t *plan_for(const search_params_t *p, const krep_gpu_config_t &c)
@@ -275,9 +379,7 @@ struct DeviceCtx
         for (auto &e : plans)
             krep_gpu_plan_destroy(e.plan);
         plans.clear();
-        text[0].release();
-        text[1].release();
-        pos.release();
+        mem.release();
         stager.release();
     }
 };
@@ -344,9 +446,10 @@ static int run_whole(DeviceCtx &cx, const search_params_t *params, const krep_gp
         return 2;
     if (pl->ref_algo == KREP_RA_AHO_CORASICK && !params->ac_trie)
         return 0; // aho_corasick.c:306: no trie, no matches
-    if (cx.text[0].ensure(text_len + 64, cx.device))
+    if (cx.mem.ensure(text_len + 64, 1, cx.device))
         return 2;
-    if (text_len && (cx.stager.init(cx.device) || cx.stager.copy(cx.text[0].p, text, text_len)))
+    uint8_t *const d_text = cx.mem.text(0);
+    if (text_len && (cx.stager.init(cx.device) || cx.stager.copy(d_text, text, text_len)))
     {
         if (!kg::have_error())
             kg::fail("H2D copy failed");
@@ -362,12 +465,13 @@ static int run_whole(DeviceCtx &cx, const search_params_t *params, const krep_gp
         cap = std::max<uint64_t>(cap, 1);
     }
     krep_gpu_scan_out_t so;
+    match_position_t *d_pos = nullptr;
     for (int attempt = 0;; ++attempt)
     {
-        if (cap && cx.pos.ensure(cap * sizeof(match_position_t), cx.device))
+        d_pos = cap ? (match_position_t *)cx.mem.pos(cap * sizeof(match_position_t), cx.device) : nullptr;
+        if (cap && !d_pos)
             return 2;
-        if (krep_gpu_scan_device_ex(pl, cx.text[0].p, text_len, 0, text_len, 0, text_len, cap ? (match_position_t *)cx.pos.p : nullptr,
-                                    cap, nullptr, 0, &so))
+        if (krep_gpu_scan_device_ex(pl, d_text, text_len, 0, text_len, 0, text_len, d_pos, cap, nullptr, 0, &so))
             return 2;
         if (!so.overflow || attempt == 1)
             break;
@@ -377,10 +481,10 @@ static int run_whole(DeviceCtx &cx, const search_params_t *params, const krep_gp
     if (want_pos && so.stored)
     {
         if (cfg.result_order && pl->ref_algo == KREP_RA_AHO_CORASICK &&
-            krep_gpu_order_by_start((match_position_t *)cx.pos.p, so.stored, text_len, nullptr))
+            krep_gpu_order_by_start(d_pos, so.stored, text_len, nullptr))
             return 2;
         std::vector<match_position_t> tmp(so.stored);
-        if (kg::inject(4) || hipMemcpy(tmp.data(), cx.pos.p, so.stored * sizeof(match_position_t), hipMemcpyDeviceToHost) != hipSuccess)
+        if (kg::inject(4) || hipMemcpy(tmp.data(), d_pos, so.stored * sizeof(match_position_t), hipMemcpyDeviceToHost) != hipSuccess)
             return kg::fail("D2H copy of the records failed");
         uint64_t n = so.stored;
         const int algo = pl->ref_algo == KREP_RA_AHO_CORASICK ? KREP_RA_AHO_CORASICK : mirror_effective(pl->ref_algo, &pl->sp, text_len);
@@ -443,12 +547,14 @@ int scan_one_piece(DeviceCtx &cx, krep_gpu_plan_t *pl, const uint8_t *d_text, Pi
     uint64_t cap = want_pos ? std::max<uint64_t>(1u << 16, nb / 64) : 0;
     p->carry_used = carry_in ? *carry_in : krep_gpu_seq_carry_t{};
     p->recs.clear();
+    match_position_t *d_pos = nullptr;
     for (int attempt = 0;; ++attempt)
     {
-        if (cap && cx.pos.ensure(cap * sizeof(match_position_t), cx.device))
+        d_pos = cap ? (match_position_t *)cx.mem.pos(cap * sizeof(match_position_t), cx.device) : nullptr;
+        if (cap && !d_pos)
             return 2;
-        if (krep_gpu_scan_device_seq(pl, d_text, nb, p->lo - p->b0, p->hi - p->b0, p->b0, global_len,
-                                     cap ? (match_position_t *)cx.pos.p : nullptr, cap, nullptr, 0, carry_in, &p->carry_out, &p->out))
+        if (krep_gpu_scan_device_seq(pl, d_text, nb, p->lo - p->b0, p->hi - p->b0, p->b0, global_len, d_pos, cap, nullptr, 0, carry_in,
+                                     &p->carry_out, &p->out))
             return 2;
         if (!p->out.overflow || attempt == 1)
             break;
@@ -458,7 +564,7 @@ int scan_one_piece(DeviceCtx &cx, krep_gpu_plan_t *pl, const uint8_t *d_text, Pi
     {
         p->recs.resize(p->out.stored);
         if (kg::inject(4) ||
-            hipMemcpy(p->recs.data(), cx.pos.p, p->out.stored * sizeof(match_position_t), hipMemcpyDeviceToHost) != hipSuccess)
+            hipMemcpy(p->recs.data(), d_pos, p->out.stored * sizeof(match_position_t), hipMemcpyDeviceToHost) != hipSuccess)
             return kg::fail("D2H copy of the records failed");
     }
     return 0;
@@ -481,12 +587,11 @@ void run_device(DeviceRun *dr)
     size_t maxb = 0;
     for (Piece *p : dr->pieces)
         maxb = std::max(maxb, p->b1 - p->b0);
-    for (int i = 0; i < (np > 1 ? 2 : 1); ++i)
-        if (cx.text[i].ensure(maxb + 64, cx.device))
-        {
-            dr->err = krep_gpu_last_error();
-            return;
-        }
+    if (cx.mem.ensure(maxb + 64, np > 1 ? 2 : 1, cx.device))
+    {
+        dr->err = krep_gpu_last_error();
+        return;
+    }
     // producer: queues the staging of piece k into buffer k & 1 once piece k-2 has been consumed; ready[k & 1] fires when
     // its last DMA is done.  The staging ring never drains between pieces.
     hipEvent_t ready[2] = {nullptr, nullptr};
@@ -511,7 +616,7 @@ void run_device(DeviceRun *dr)
                     return;
             }
             Piece *p = dr->pieces[k];
-            const int rc = cx.stager.copy_async(cx.text[k & 1].p, dr->buf + p->b0, p->b1 - p->b0, ready[k & 1]);
+            const int rc = cx.stager.copy_async(cx.mem.text((int)(k & 1)), dr->buf + p->b0, p->b1 - p->b0, ready[k & 1]);
             std::lock_guard<std::mutex> l(m);
             if (rc)
             {
@@ -563,7 +668,7 @@ void run_device(DeviceRun *dr)
         const krep_gpu_seq_carry_t *cin = nullptr;
         if (dr->chain && k > 0 && dr->pieces[k - 1]->shard == p->shard)
             cin = &dr->pieces[k - 1]->carry_out;
-        if (scan_one_piece(cx, pl, cx.text[k & 1].p, p, dr->len, dr->want_pos, cin))
+        if (scan_one_piece(cx, pl, cx.mem.text((int)(k & 1)), p, dr->len, dr->want_pos, cin))
         {
             dr->err = krep_gpu_last_error();
             finish(false);
@@ -681,8 +786,8 @@ static int run_pieces(const search_params_t *params, const krep_gpu_config_t &cf
                 search_params_t local = *params;
                 local.max_count = SIZE_MAX;
                 krep_gpu_plan_t *pl = cx.plan_for(&local, cfg);
-                if (!pl || cx.text[0].ensure(p.b1 - p.b0 + 64, cx.device) || cx.stager.init(cx.device) ||
-                    cx.stager.copy(cx.text[0].p, buf + p.b0, p.b1 - p.b0) || scan_one_piece(cx, pl, cx.text[0].p, &p, len, want_pos, &tc))
+                if (!pl || cx.mem.ensure(p.b1 - p.b0 + 64, 1, cx.device) || cx.stager.init(cx.device) ||
+                    cx.stager.copy(cx.mem.text(0), buf + p.b0, p.b1 - p.b0) || scan_one_piece(cx, pl, cx.mem.text(0), &p, len, want_pos, &tc))
                     return 2;
             }
             // fold this piece's own contribution onto the true record (for a piece scanned with the true record this
@@ -991,9 +1096,11 @@ static uint64_t run_with_fallback(const search_params_t *params, const char *tex
 {
     int st = 2;
     krep_gpu_clear_error();
+    const auto t0 = std::chrono::steady_clock::now();
     const uint64_t n = run_host_operator(params, text, text_len, result, cfg, num_gpus, &st);
     if (st == 0)
     {
+        kg::cost_note_host_path(text_len, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
         tl_status = KREP_GPU_OK;
         if (status_out) *status_out = 0;
         return n;

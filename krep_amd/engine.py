@@ -124,6 +124,14 @@ class Engine:
         L.krep_gpu_set_cpu_fallback.argtypes = [C.c_void_p]
         L.krep_gpu_worthwhile.restype = C.c_int
         L.krep_gpu_worthwhile.argtypes = [C.POINTER(abi.SearchParams), C.c_size_t]
+        L.krep_gpu_worthwhile_ex.restype = C.c_int
+        L.krep_gpu_worthwhile_ex.argtypes = [C.POINTER(abi.SearchParams), C.c_size_t, C.c_int]
+        L.krep_gpu_cost_estimate.restype = C.c_int
+        L.krep_gpu_cost_estimate.argtypes = [C.POINTER(abi.SearchParams), C.c_size_t, C.c_int, C.POINTER(abi.Cost)]
+        L.krep_gpu_get_cost_rates.restype = None
+        L.krep_gpu_get_cost_rates.argtypes = [C.POINTER(abi.CostRates)]
+        L.krep_gpu_set_cost_rates.restype = None
+        L.krep_gpu_set_cost_rates.argtypes = [C.POINTER(abi.CostRates)]
         L.krep_gpu_set_min_text_bytes.restype = None
         L.krep_gpu_set_min_text_bytes.argtypes = [C.c_size_t]
         L.krep_gpu_device_count.restype = C.c_int
@@ -190,6 +198,23 @@ class Engine:
 
     def worthwhile(self, params: abi.Params, text_len: int) -> bool:
         return bool(self.lib.krep_gpu_worthwhile(params.ref, text_len))
+
+    def worthwhile_ex(self, params: abi.Params, text_len: int, cpu_threads: int) -> bool:
+        return bool(self.lib.krep_gpu_worthwhile_ex(params.ref, text_len, cpu_threads))
+
+    def cost_estimate(self, params: abi.Params, text_len: int, cpu_threads: int = 0) -> "abi.Cost":
+        c = abi.Cost()
+        if self.lib.krep_gpu_cost_estimate(params.ref, text_len, cpu_threads, C.byref(c)):
+            raise KrepGpuError("krep_gpu_cost_estimate failed")
+        return c
+
+    def cost_rates(self) -> "abi.CostRates":
+        r = abi.CostRates()
+        self.lib.krep_gpu_get_cost_rates(C.byref(r))
+        return r
+
+    def set_cost_rates(self, rates: "abi.CostRates | None"):
+        self.lib.krep_gpu_set_cost_rates(C.byref(rates) if rates is not None else None)
 
     def inject_failure(self, kind: int):
         self.lib.krep_gpu_debug_inject_failure(kind)

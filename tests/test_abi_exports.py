@@ -151,21 +151,74 @@ def test_split_mode_table():
 
 
 def test_size_policy_of_worthwhile(monkeypatch):
-    """krep_gpu_worthwhile(): size first (no device is touched for a small text), then the input class, then the device."""
+    """krep_gpu_worthwhile(): size first (no device is touched for a small text), then the input class, then the COST MODEL
+    (kg_cost.hip: t_gpu = init + launch + bytes / host-path rate against t_cpu = bytes / min(threads x rate, cap) of the function
+    the reference would run), then the device.  VERDICT r03 item 4: for a host-resident single literal on a many-core box the
+    CPU pointer is the right answer, for a 1000-pattern dictionary the GPU."""
     import krep_amd
     e = krep_amd.load()
     p = abi.Params([b"Sherlock"])
     monkeypatch.setenv("KREP_GPU_ASSUME_AVAILABLE", "1")
     monkeypatch.delenv("KREP_GPU_DISABLE", raising=False)
+    monkeypatch.delenv("KREP_GPU_COST", raising=False)
+    monkeypatch.delenv("KREP_GPU_COST_MODEL", raising=False)
+    e.set_cost_rates(None)
     assert e.default_config().min_text_bytes == 1 << 20
-    assert e.worthwhile(p, 1 << 20) and not e.worthwhile(p, (1 << 20) - 1)
-    e.lib.krep_gpu_set_min_text_bytes(4096)
+    rates = e.cost_rates()
+    assert rates.enabled == 1 and rates.gpu_host_path_gbps > 0 and rates.cpu_simd_cap_gbps > rates.gpu_host_path_gbps
     try:
+        # ---- the size rule alone (cost model off): exactly the threshold
+        off = e.cost_rates()
+        off.enabled = 0
+        e.set_cost_rates(off)
+        assert e.worthwhile(p, 1 << 20) and not e.worthwhile(p, (1 << 20) - 1)
+        e.lib.krep_gpu_set_min_text_bytes(4096)
         assert e.worthwhile(p, 4096) and not e.worthwhile(p, 4095)
         r = abi.Params([b"a.*b"])
         r.s.use_regex = True
         assert not e.worthwhile(r, 1 << 30)
-    finally:
         e.lib.krep_gpu_set_min_text_bytes((1 << 64) - 1)  # back to "not set": $KREP_GPU_MIN_BYTES, else 1 MiB
+        # ---- the cost model with its default rates
+        e.set_cost_rates(None)
+        dic = abi.Params([bytes([97 + (i * 7 + j) % 26 for j in range(4 + i % 13)]) for i in range(1000)])
+        one_thread, many = 1, 256
+        # a single SIMD literal: 256 threads read host memory faster than PCIe delivers it -> the CPU function, at any size
+        for n in (8 << 20, 1 << 30, 32 << 30):
+            c = e.cost_estimate(p, n, many)
+            assert c.cpu_algo in (abi.RA_SSE42, abi.RA_AVX2) and c.cpu_threads == many and c.cpu_seconds < c.gpu_seconds
+            assert not e.worthwhile_ex(p, n, many)
+        # ... on ONE thread (krep -t 1) the GPU wins once the device start is paid for (6 GB/s against 50)
+        assert not e.worthwhile_ex(p, 64 << 20, one_thread)      # 0.01 s of CPU work < 0.45 s of device start
+        assert e.worthwhile_ex(p, 8 << 30, one_thread)           # 1.4 s against 0.6 s
+        # 1000 patterns (aho_corasick_search: 8 605 states x 2 KiB do not fit any cache): the GPU, from tens of MiB on
+        c = e.cost_estimate(dic, 1 << 30, many)
+        assert c.cpu_algo == abi.RA_AHO_CORASICK and c.gpu_seconds < c.cpu_seconds
+        assert e.worthwhile_ex(dic, 1 << 30, many) and e.worthwhile(dic, 32 << 30)
+        assert not e.worthwhile_ex(dic, 2 << 20, many)           # 2 MiB: the device start alone costs more
+        # the default thread count is search_file()'s: min(cores, size / 4 MiB), at least 1 (krep.c:2748-2759)
+        assert e.cost_estimate(p, 3 << 20).cpu_threads == 1
+        assert e.cost_estimate(p, 64 << 20).cpu_threads == min(os.cpu_count() or 1, 16)
+        # overriding a rate moves the verdict: a host whose memchr path is slow
+        slow = e.cost_rates()
+        slow.cpu_simd_gbps, slow.cpu_simd_cap_gbps, slow.gpu_init_ms = 0.1, 1.0, 0.0
+        e.set_cost_rates(slow)
+        assert e.worthwhile_ex(p, 64 << 20, many)
+        e.set_cost_rates(None)
+        monkeypatch.setenv("KREP_GPU_COST", "simd=0.1:1,init=0")
+        assert e.worthwhile_ex(p, 64 << 20, many)
+        monkeypatch.delenv("KREP_GPU_COST")
+        e.set_cost_rates(None)
+        monkeypatch.setenv("KREP_GPU_COST_MODEL", "0")
+        assert e.worthwhile_ex(p, 64 << 20, many)                # the size rule again
+        monkeypatch.delenv("KREP_GPU_COST_MODEL")
+    finally:
+        e.lib.krep_gpu_set_min_text_bytes((1 << 64) - 1)
+        e.set_cost_rates(None)
     monkeypatch.setenv("KREP_GPU_DISABLE", "1")
-    assert not e.worthwhile(p, 1 << 30)
+    off = e.cost_rates()
+    off.enabled = 0
+    e.set_cost_rates(off)
+    try:
+        assert not e.worthwhile(p, 1 << 30)
+    finally:
+        e.set_cost_rates(None)

@@ -22,7 +22,7 @@ CLI = os.path.join(ROOT, "oracle", "_ref", "krep_gpu_cli")
 needs_cli = pytest.mark.skipif(not os.path.exists(CLI), reason="oracle/_ref/krep_gpu_cli not built (needs /root/reference)")
 
 _CLEAN = ("KREP_GPU", "KREP_GPU_DISABLE", "KREP_GPU_ASSUME_AVAILABLE", "KREP_GPU_INJECT_FAILURE", "KREP_GPU_NO_FALLBACK_HOOK",
-          "KREP_GPU_MIN_BYTES", "KREP_GPU_DEVICE", "KREP_GPU_NUM")
+          "KREP_GPU_MIN_BYTES", "KREP_GPU_DEVICE", "KREP_GPU_NUM", "KREP_GPU_COST_MODEL", "KREP_GPU_COST")
 
 
 def run(args, **env):
@@ -75,7 +75,7 @@ def test_cli_operator_failure_falls_back_to_the_cpu_function(files, hook):
     box injected).  hook=True: the backend calls the CLI's registered CPU selector itself (krep_gpu_set_cpu_fallback);
     hook=False: it returns status KREP_GPU_FAILED and the patched search_chunk_thread()/search_string() re-run the chunk
     with the CPU pointer (krep.c:1944-1948).  Either way: the CPU CLI's bytes and exit code."""
-    env = dict(KREP_GPU=1, KREP_GPU_ASSUME_AVAILABLE=1, KREP_GPU_INJECT_FAILURE=1, KREP_GPU_MIN_BYTES=0)
+    env = dict(KREP_GPU=1, KREP_GPU_ASSUME_AVAILABLE=1, KREP_GPU_INJECT_FAILURE=1, KREP_GPU_MIN_BYTES=0, KREP_GPU_COST_MODEL=0)
     if not hook:
         env["KREP_GPU_NO_FALLBACK_HOOK"] = 1
     for args, path in invocations(*files):

@@ -15,11 +15,12 @@ CLI = os.path.join(ROOT, "oracle", "_ref", "krep_gpu_cli")
 
 def run(args, gpu, **extra):
     env = dict(os.environ)
-    for k in ("KREP_GPU", "KREP_GPU_NUM", "KREP_GPU_MIN_BYTES", "KREP_GPU_DISABLE", "KREP_GPU_INJECT_FAILURE"):
+    for k in ("KREP_GPU", "KREP_GPU_NUM", "KREP_GPU_MIN_BYTES", "KREP_GPU_COST_MODEL", "KREP_GPU_COST", "KREP_GPU_DISABLE", "KREP_GPU_INJECT_FAILURE"):
         env.pop(k, None)
     if gpu:
         env["KREP_GPU"] = "1"
-        env["KREP_GPU_MIN_BYTES"] = "0"  # the small fixtures go through the backend too (the size policy has its own test)
+        env["KREP_GPU_MIN_BYTES"] = "0"   # the small fixtures go through the backend too: neither the size threshold nor the
+        env["KREP_GPU_COST_MODEL"] = "0"  # cost model keeps them on the CPU (krep_gpu_worthwhile has its own test)
     env.update({k: str(v) for k, v in extra.items()})
     r = subprocess.run([CLI] + args, env=env, capture_output=True, timeout=300)
     return r.returncode, r.stdout, r.stderr

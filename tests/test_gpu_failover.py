@@ -118,11 +118,11 @@ def test_cli_with_an_unusable_device_or_failing_operator(tmp_path):
     for args, path in invocations(f_big, f_small):
         a = ["-t", "1", "--color=never"] + args + [str(path)]
         cpu = run(a)
-        ok = run(a, KREP_GPU=1, KREP_GPU_MIN_BYTES=0)
+        ok = run(a, KREP_GPU=1, KREP_GPU_MIN_BYTES=0, KREP_GPU_COST_MODEL=0)
         assert ok[:2] == cpu[:2] and b"krep-gpu" not in ok[2], (args, ok)
-        bad_dev = run(a, KREP_GPU=1, KREP_GPU_DEVICE=99, KREP_GPU_MIN_BYTES=0)
+        bad_dev = run(a, KREP_GPU=1, KREP_GPU_DEVICE=99, KREP_GPU_MIN_BYTES=0, KREP_GPU_COST_MODEL=0)
         assert bad_dev[:2] == cpu[:2] and b"krep-gpu" not in bad_dev[2], (args, bad_dev)
         for kind in KINDS:
             for extra in ({}, {"KREP_GPU_NO_FALLBACK_HOOK": 1}):
-                got = run(a, KREP_GPU=1, KREP_GPU_INJECT_FAILURE=kind, KREP_GPU_MIN_BYTES=0, **extra)
+                got = run(a, KREP_GPU=1, KREP_GPU_INJECT_FAILURE=kind, KREP_GPU_MIN_BYTES=0, KREP_GPU_COST_MODEL=0, **extra)
                 assert got[:2] == cpu[:2], (args, KINDS[kind], extra, cpu[:2], got)
