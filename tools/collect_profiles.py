@@ -17,6 +17,17 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT, PROF = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 DOMINANT = {"literal8": "kg::lit_scan", "memchr1": "kg::single_fused", "ac1000": "kg::ac_scan_kernel"}
+# the sources whose change makes a workload's traffic figure stale (bench.py checks the hash before it quotes the figure)
+KERNEL_SOURCES = {"literal8": ["kg_literal.hip", "kg_post.hip", "kg_common.h"], "memchr1": ["kg_single.hip", "kg_common.h"],
+                  "ac1000": ["kg_ac.hip", "kg_ac_common.h", "kg_post.hip", "kg_common.h"]}
+
+
+def sources_sha(workload):
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES[workload]:
+        h.update(open(os.path.join(ROOT, "krep_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 WARMUP_DROPPED = 3  # launches of every kernel left out of the steady-state statistics (tools/profile_round.sh runs --warmup 3)
 
 
@@ -99,6 +110,7 @@ def main():
             traffic[w] = {
                 "hbm_bytes_per_launch": hbm, "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write,
                 "algorithmic_bytes": alg, "ratio": round(hbm / alg, 4), "kernel": dom, "measured_by": tag,
+                "kernel_sources": KERNEL_SOURCES[w], "kernel_sources_sha": sources_sha(w),
                 "method": f"tools/profile_round.sh {tag}: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate "
                           f"passes of `python bench.py --workload {w} --steps 2 --warmup 1 --no-cpu-baseline`; "
                           "FETCH_SIZE doubled (16 B/lane streams on gfx950, MI355X_MICROARCH.md HBM section); counters "
