@@ -121,8 +121,14 @@ __device__ __noinline__ W6 load_window_guarded(const uint8_t *text, u64 text_len
 // R: load rounds per UNIT.  A wave scans one contiguous R x 8 KiB unit at a time (statically dealt, see below), keeps the
 // R x 8 per-lane hit masks in registers and publishes the unit's aggregate + staged hits; no wave waits for another.
 template <int KIND, bool MASKED, bool CI, bool LINES, int R>
-// >= 4 waves per SIMD (<= 128 VGPRs) for the plain variants: the allocator otherwise drifts to 137 and loses a wave
-__global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
+// >= 4 waves per SIMD (<= 128 VGPRs) for the plain variants: the allocator otherwise drifts to 137 and loses a wave.  The
+// single byte with -c on 32-KiB units (32 deferred mask registers + the line bookkeeping) does not fit 128 without 16 bytes of
+// scratch per lane; 3 blocks per CU on 168 registers without the spill were measured and are SLOWER (32 GiB, 1 % hits: 11.39
+// against 9.81 ms, profiles/r04_literal_sweep_32gib.txt) — the fourth wave per SIMD is worth more than the 16 bytes.
+#ifndef KG_LIT1_LINES_WAVES
+#define KG_LIT1_LINES_WAVES 4
+#endif
+__global__ __launch_bounds__(kBlock, (KIND == 1 && LINES && R == 4) ? KG_LIT1_LINES_WAVES : 4) void lit_scan(const LitArgs a)
 {
     const u32 lane = lane_id();
     const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -328,13 +334,18 @@ __global__ __launch_bounds__(kBlock, 4) void lit_scan(const LitArgs a)
                         c[k] = (KIND == 4 && MASKED) ? (((A0[k] ^ p0q) & a.k0) == 0u) : (A0[k] == p0q);
                         any |= __ballot(c[k]);
                     }
+                    // The superset IS the exact test when every compared byte of the pattern's first word is a letter
+                    // ((x | 0x20) == (p | 0x20) <=> x is one of p's two cases): `-i th`, `-i the`, `-i sherlock` ... — the common
+                    // case, and for 2-3-byte patterns (a candidate in nearly every 1-KiB cell) the difference between re-doing
+                    // all 16 compares and not: m = 2 -i ran at 0.42 of the roofline (r03), the case-sensitive m = 2 at 0.73.
+                    const bool cix0 = !CI || (a.l0 & a.k0 & 0x20202020u) == (a.k0 & 0x20202020u); // (uniform)
                     if (any) // wave-uniform: almost never taken for a selective 4-byte prefix
                     {
 #pragma unroll
                         for (int k = 0; k < 16; ++k)
                         {
                             bool h = c[k];
-                            if (CI)
+                            if (CI && !cix0)
                             {
                                 const u32 e0 = A(k) | a.l0; // exact: (x | 0x20 in the pattern's letter lanes) == folded pattern
                                 h = h && ((KIND == 4 && MASKED) ? (((e0 ^ a.p0) & a.k0) == 0u) : (e0 == a.p0));
