@@ -1100,7 +1100,7 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
     const u64 n_units = a.num_tiles;
     // 16 staged matches (32-bit words: unit-relative start + length) = one 64-byte slot per 16 KiB unit; BASELINE config 4 puts 5.3
     // matches in a unit.  Units that hold more are re-scanned in emit mode, and a scan in which more than 1 in 64 units did
-    // raises the dictionary's slot to 64 for its next scans.  (Small slots keep the store stream dense: kg_host.hip, lit_pass.)
+    // raises the dictionary's slot to 64 for its next scans.  (Small slots keep the store stream dense: kg_scan.hip, lit_pass.)
     a.stage_cap = want ? (g_ac_force_stage_cap ? (u32)g_ac_force_stage_cap : t->stage_cap) : 0u;
     if (chain)
     {
@@ -1123,7 +1123,7 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
     SCHK(ac_launch(a, grid, lds, st));
     if (chain && post_order(post, n_units, a.stage_cap, 0, a.anchor + global_base, unit_bytes, lines, (uint64_t *)d_pos, want, d_ctr, num_cu, st))
         return 2;
-    // lines_on_list (kg_host.hip scan_ac_lines_on_list): the distinct lines of the record list just gathered, counted by the
+    // lines_on_list (kg_scan.hip scan_ac_lines_on_list): the distinct lines of the record list just gathered, counted by the
     // newline gaps between neighbours, behind the post-pass on the same stream — valid when no unit overflowed its staging
     // slot and the list fitted (the caller checks both and repeats otherwise)
     if (lines_on_list && want && tail_launch_line_gaps(d_text, global_base, (const uint64_t *)d_pos, &d_ctr->total, want, &d_ctr->lines, st))

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <cstring>
 #include <vector>
 
 #include "../../include/krep_gpu.h"
@@ -92,7 +94,19 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
             match_position_t *d_pos, uint64_t cap, bool ww, bool lines, bool track, size_t max_count, hipStream_t st,
             int time_it, hipEvent_t ev0, hipEvent_t ev1, krep_gpu_scan_out_t *out, bool lines_on_list = false);
 
-// kg_host.hip — configuration (explicit; see krep_gpu_config_t), selector mirror, result container
+// kg_config.hip — test hooks shared with the scan drivers
+extern std::atomic<int> g_force_rounds, g_force_stage_cap;   // krep_gpu_debug_force_rounds / _stage_cap
+extern std::atomic<uint64_t> g_fused1_failovers;             // one-pass single-byte scans that handed over to the two-pass kernels
+inline uint8_t lo8(uint8_t c) { return (c >= 'A' && c <= 'Z') ? (uint8_t)(c + 32) : c; } // lower_table, krep.c:125-134
+inline bool pattern_has_border(const uint8_t *p, size_t m)   // a proper prefix is also a suffix: all occurrences != greedy
+{
+    for (size_t k = 1; k < m; ++k)
+        if (memcmp(p, p + k, m - k) == 0)
+            return true;
+    return false;
+}
+
+// kg_config.hip / kg_mirror.hip — configuration (explicit; see krep_gpu_config_t), selector mirror, result container
 krep_gpu_config_t current_config(); // the calling thread's override, else the process-wide defaults
 int mirror_top(const search_params_t *p, const krep_gpu_config_t &c);
 int mirror_effective(int top, const search_params_t *p, size_t text_len);

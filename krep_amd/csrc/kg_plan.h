@@ -1,4 +1,4 @@
-// kg_plan.h — the plan object behind krep_gpu_plan_t (shared by kg_host.hip, kg_ops.hip and kg_multi.hip).
+// kg_plan.h — the plan object behind krep_gpu_plan_t (shared by kg_plan.hip, kg_scan.hip and kg_ops.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 

@@ -1,8 +1,8 @@
-// kg_host.hip — core of the C-ABI of the krep-gpu backend (include/krep_gpu.h): configuration (the mirrored
-// reference globals), the select_search_algorithm() mirror, the result container, plans, and the device-resident
-// scan krep_gpu_scan_device[_ex]() with every reference return-value convention.
-// Host logic only; kernels live in kg_literal.hip / kg_ac.hip / kg_post.hip / kg_greedy.hip / kg_tail.hip.
-// The host-buffer operators (search_func_t entry points, search_buffer, streaming ingest) are in kg_ops.hip.
+// kg_scan.hip — krep_gpu_scan_device[_ex|_seq](): the device-resident scan with every reference return-value convention
+// (verdict_for), the single-literal pass and its post-passes (lit_pass), the match-set families (greedy walks, end-of-text
+// replay of the block-structured -c bodies, kg_greedy.hip / kg_tail.hip), how a text may be split (kg::split_mode, the boundary
+// record kg::fold_carry) and the multi-pattern drivers around kg_ac.hip.  Host logic only; kernels live in kg_literal.hip /
+// kg_single.hip / kg_ac.hip / kg_post.hip / kg_greedy.hip / kg_tail.hip / kg_format.hip.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -24,22 +24,6 @@
 
 using namespace kg;
 
-// ------------------------------------------------------------------------------------ errors
-static thread_local std::string g_err;
-namespace kg {
-int fail(const char *fmt, ...)
-{
-    char buf[512];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
-    va_end(ap);
-    g_err = buf;
-    fprintf(stderr, "krep-gpu: %s\n", buf);
-    return 2;
-}
-bool have_error() { return !g_err.empty(); }
-} // namespace kg
 #define HIPCHK(x)                                                                             \
     do                                                                                        \
     {                                                                                         \
@@ -47,612 +31,6 @@ bool have_error() { return !g_err.empty(); }
         if (e_ != hipSuccess)                                                                 \
             return kg::fail("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
-
-extern "C" const char *krep_gpu_last_error(void) { return g_err.c_str(); }
-extern "C" void krep_gpu_clear_error(void) { g_err.clear(); }
-extern "C" const char *krep_gpu_version(void) { return "krep-gpu 0.3 (gfx950)"; }
-extern "C" int krep_gpu_device_count(void)
-{
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess)
-        return 0;
-    return n;
-}
-
-// ------------------------------------------------------------------------------------ configuration
-// The reference decides its algorithm — hence the match-set family — from compile-time SIMD macros and three
-// file-static globals (krep.c:47-74, :117-120).  Here they are one explicit krep_gpu_config_t.  The setters below write
-// PROCESS-WIDE defaults (relaxed atomics: the reference's globals are process-wide too, set once by main() before the
-// pool threads start); krep_gpu_set_thread_config() overrides them for the calling thread; plans and search_buffer_ex()
-// carry their configuration explicitly.  Nothing on a scan path writes any of this.
-static std::atomic<int> g_simd{KREP_REF_AVX2}, g_only_matching{0}, g_no_simd{0}, g_algo_override{KREP_ALGO_AUTO},
-    g_result_order{0}, g_device{-1};
-static std::atomic<size_t> g_stream_chunk{0};
-static std::atomic<int> g_num_gpus{INT32_MIN};            // INT32_MIN: not set -> $KREP_GPU_NUM, else 1
-static std::atomic<size_t> g_min_bytes{SIZE_MAX};         // SIZE_MAX: not set -> $KREP_GPU_MIN_BYTES, else 1 MiB
-static thread_local bool tl_cfg_set = false;
-static thread_local krep_gpu_config_t tl_cfg;
-
-static int env_device()
-{
-    const char *e = getenv("KREP_GPU_DEVICE");
-    return e && *e ? atoi(e) : 0;
-}
-static int env_num_gpus()
-{
-    const char *e = getenv("KREP_GPU_NUM");
-    return e && *e ? atoi(e) : 1;
-}
-static size_t env_min_bytes()
-{
-    const char *e = getenv("KREP_GPU_MIN_BYTES");
-    return e && *e ? (size_t)strtoull(e, nullptr, 0) : ((size_t)1 << 20);
-}
-extern "C" void krep_gpu_config_default(krep_gpu_config_t *c)
-{
-    if (!c)
-        return;
-    c->reference_simd = g_simd.load(std::memory_order_relaxed);
-    c->only_matching = g_only_matching.load(std::memory_order_relaxed);
-    c->force_no_simd = g_no_simd.load(std::memory_order_relaxed);
-    c->algo_override = g_algo_override.load(std::memory_order_relaxed);
-    c->result_order = g_result_order.load(std::memory_order_relaxed);
-    const int d = g_device.load(std::memory_order_relaxed);
-    c->device = d >= 0 ? d : env_device();
-    c->stream_chunk_bytes = g_stream_chunk.load(std::memory_order_relaxed);
-    const int ng = g_num_gpus.load(std::memory_order_relaxed);
-    c->num_gpus = ng != INT32_MIN ? ng : env_num_gpus();
-    const size_t mb = g_min_bytes.load(std::memory_order_relaxed);
-    c->min_text_bytes = mb != SIZE_MAX ? mb : env_min_bytes();
-}
-extern "C" void krep_gpu_set_thread_config(const krep_gpu_config_t *c)
-{
-    tl_cfg_set = c != nullptr;
-    if (c)
-        tl_cfg = *c;
-}
-namespace kg {
-krep_gpu_config_t current_config()
-{
-    if (tl_cfg_set)
-        return tl_cfg;
-    krep_gpu_config_t c;
-    krep_gpu_config_default(&c);
-    return c;
-}
-} // namespace kg
-extern "C" void krep_gpu_set_reference_simd(int l) { g_simd.store(l, std::memory_order_relaxed); }
-extern "C" int krep_gpu_get_reference_simd(void) { return kg::current_config().reference_simd; }
-extern "C" void krep_gpu_set_only_matching(int on) { g_only_matching.store(on != 0, std::memory_order_relaxed); }
-extern "C" void krep_gpu_set_result_order(int by_start) { g_result_order.store(by_start != 0, std::memory_order_relaxed); }
-extern "C" void krep_gpu_set_force_no_simd(int on) { g_no_simd.store(on != 0, std::memory_order_relaxed); }
-extern "C" void krep_gpu_set_algo_override(int a) { g_algo_override.store(a, std::memory_order_relaxed); }
-extern "C" void krep_gpu_set_device(int d) { g_device.store(d, std::memory_order_relaxed); }
-extern "C" void krep_gpu_set_stream_chunk(size_t bytes) { g_stream_chunk.store(bytes, std::memory_order_relaxed); }
-extern "C" void krep_gpu_set_num_gpus(int n) { g_num_gpus.store(n, std::memory_order_relaxed); }
-extern "C" void krep_gpu_set_min_text_bytes(size_t b) { g_min_bytes.store(b, std::memory_order_relaxed); }
-
-// ------------------------------------------------------------------------------------ availability
-// "Is there a device this library can run on" is asked by the SELECTOR, before any operator is handed out (SURVEY §8b:
-// a backend must be able to fail BEFORE producing output): device count, range of the configured device, gfx950, and one
-// probe kernel of this code object launched and read back.  Once per device and process.
-__global__ void kg_probe_kernel(unsigned *out) { *out = 0x950u; }
-namespace {
-struct Avail
-{
-    std::mutex mu;
-    std::vector<int> state;           // per device: 0 unknown, 1 usable, 2 not usable
-    std::vector<std::string> reason;  // why not
-};
-Avail &avail()
-{
-    static Avail *a = new Avail(); // leaked: may be consulted from atexit paths
-    return *a;
-}
-thread_local std::string tl_unavail;
-bool probe_device(int device, std::string &why)
-{
-    int prev = -1;
-    (void)hipGetDevice(&prev);
-    auto done = [&](bool ok) {
-        if (prev >= 0)
-            (void)hipSetDevice(prev);
-        (void)hipGetLastError();
-        return ok;
-    };
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) != hipSuccess)
-    {
-        why = "hipGetDeviceProperties failed";
-        return done(false);
-    }
-    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-    {
-        why = std::string("device is ") + prop.gcnArchName + ", this library holds gfx950 code only";
-        return done(false);
-    }
-    unsigned *d = nullptr, h = 0;
-    if (hipSetDevice(device) != hipSuccess || hipMalloc(&d, sizeof(unsigned)) != hipSuccess)
-    {
-        why = "cannot allocate on the device";
-        return done(false);
-    }
-    hipLaunchKernelGGL(kg_probe_kernel, dim3(1), dim3(1), 0, nullptr, d);
-    const bool ok = hipGetLastError() == hipSuccess && hipMemcpy(&h, d, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h == 0x950u;
-    (void)hipFree(d);
-    if (!ok)
-        why = "the gfx950 code object of this library does not run on the device";
-    return done(ok);
-}
-} // namespace
-namespace kg {
-// NULL = usable; otherwise the reason (valid until the calling thread asks again)
-const char *device_unusable(int device)
-{
-    if (const char *e = getenv("KREP_GPU_DISABLE"))
-        if (*e && *e != '0')
-            return "disabled by KREP_GPU_DISABLE";
-    if (const char *e = getenv("KREP_GPU_ASSUME_AVAILABLE")) // test hook: skip the probe, so that a box WITHOUT a device
-        if (*e && *e != '0')                                  // reaches the operators and exercises their run-time failure paths
-            return nullptr;
-    int ndev = 0;
-    const auto t_first = std::chrono::steady_clock::now(); // (the process's first HIP call starts the runtime: kg_cost.hip wants to know)
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-    {
-        (void)hipGetLastError();
-        return "no HIP device available";
-    }
-    if (device < 0 || device >= ndev)
-    {
-        tl_unavail = "device " + std::to_string(device) + " out of range (have " + std::to_string(ndev) + ")";
-        return tl_unavail.c_str();
-    }
-    Avail &a = avail();
-    std::lock_guard<std::mutex> lk(a.mu);
-    if ((size_t)ndev > a.state.size())
-    {
-        a.state.resize((size_t)ndev, 0);
-        a.reason.resize((size_t)ndev);
-    }
-    if (a.state[device] == 0)
-    {
-        a.state[device] = probe_device(device, a.reason[device]) ? 1 : 2;
-        if (a.state[device] == 1)
-            cost_note_device_init(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_first).count());
-    }
-    if (a.state[device] == 1)
-        return nullptr;
-    tl_unavail = a.reason[device];
-    return tl_unavail.c_str();
-}
-// ---- failure injection (test hook): the failure paths of the operators must be reachable on a healthy box
-static std::atomic<int> g_inject{-1};
-bool inject(int kind)
-{
-    int v = g_inject.load(std::memory_order_relaxed);
-    if (v < 0)
-    {
-        const char *e = getenv("KREP_GPU_INJECT_FAILURE");
-        v = e && *e ? atoi(e) : 0;
-        g_inject.store(v, std::memory_order_relaxed);
-    }
-    return v == kind;
-}
-} // namespace kg
-extern "C" void krep_gpu_debug_inject_failure(int kind) { kg::g_inject.store(kind < 0 ? 0 : kind, std::memory_order_relaxed); }
-extern "C" int krep_gpu_available(void) { return kg::device_unusable(kg::current_config().device) == nullptr ? 1 : 0; }
-extern "C" const char *krep_gpu_unavailable_reason(void)
-{
-    const char *r = kg::device_unusable(kg::current_config().device);
-    return r ? r : "";
-}
-
-static std::atomic<int> g_force_rounds{0};    // test hook: 0 = auto, 1 / 4 = force the tile shape
-static std::atomic<int> g_force_stage_cap{0}; // test hook: staging records per unit (0 = auto)
-namespace kg { extern int g_ac_force_stage_cap; }
-extern "C" void krep_gpu_debug_force_stage_cap(int c) { g_force_stage_cap.store(c); kg::g_ac_force_stage_cap = c; }
-extern "C" void krep_gpu_debug_force_rounds(int r) { g_force_rounds.store(r); }
-namespace kg { extern int g_s1_force_grid; }
-static std::atomic<uint64_t> g_fused1_failovers{0}; // one-pass single-byte scans that handed over to the two-pass kernels
-extern "C" void krep_gpu_debug_force_single_grid(int blocks) { kg::g_s1_force_grid = blocks < 0 ? 0 : blocks; }
-extern "C" uint64_t krep_gpu_debug_single_failovers(void) { return g_fused1_failovers.load(); }
-
-static inline uint8_t lo8(uint8_t c) { return (c >= 'A' && c <= 'Z') ? (uint8_t)(c + 32) : c; }
-
-// is_repetitive_pattern(), krep.c:1873-1914 (decides KMP vs BMH on builds without SIMD)
-static bool repetitive_pattern(const char *s, size_t m)
-{
-    if (m < 3)
-        return false;
-    size_t run = 0;
-    char prev = s[0];
-    for (size_t i = 1; i < m; ++i)
-    {
-        if (s[i] == prev)
-        {
-            if (++run >= m / 2)
-                return true;
-        }
-        else
-        {
-            run = 0;
-            prev = s[i];
-        }
-    }
-    for (size_t per = 2; per <= m / 2; ++per)
-    {
-        bool ok = true;
-        for (size_t i = per; i < m && ok; ++i)
-            ok = s[i] == s[i % per];
-        if (ok)
-            return true;
-    }
-    return false;
-}
-
-namespace kg {
-// The function pointer select_search_algorithm() would return (krep.c:1771-1870) ...
-int mirror_top(const search_params_t *p, const krep_gpu_config_t &c)
-{
-    if (p->use_regex)
-        return KREP_RA_REGEX;
-    if (p->num_patterns > 1)
-        return KREP_RA_AHO_CORASICK;
-    if (c.algo_override == KREP_ALGO_BM)
-        return KREP_RA_BMH;
-    if (c.algo_override == KREP_ALGO_KMP)
-        return KREP_RA_KMP;
-    const int simd = c.reference_simd;
-    const size_t simd_max = simd == KREP_REF_AVX512 ? 64 : simd == KREP_REF_AVX2 ? 32
-                          : (simd == KREP_REF_SSE42 || simd == KREP_REF_NEON)    ? 16 : 0; // krep.c:101-113
-    const int top = simd == KREP_REF_AVX512 ? KREP_RA_AVX512 : simd == KREP_REF_AVX2 ? KREP_RA_AVX2
-                  : simd == KREP_REF_SSE42 ? KREP_RA_SSE42 : simd == KREP_REF_NEON ? KREP_RA_NEON : KREP_RA_NONE;
-    const size_t m = p->pattern_len;
-    const bool can = !c.force_no_simd && simd_max > 0 && m <= simd_max;
-    if (m == 1)
-        return KREP_RA_MEMCHR;
-    if (m < 4)
-        return (can && p->case_sensitive && top != KREP_RA_NONE) ? top : KREP_RA_MEMCHR_SHORT;
-    if (can)
-    {
-        if (simd == KREP_REF_AVX512 && m <= 64 && p->case_sensitive)
-            return KREP_RA_AVX512;
-        if ((simd == KREP_REF_AVX512 || simd == KREP_REF_AVX2) && m <= 32)
-            return KREP_RA_AVX2;
-        if (simd == KREP_REF_SSE42 && m <= 16 && p->case_sensitive)
-            return KREP_RA_SSE42;
-        if (simd == KREP_REF_NEON && p->case_sensitive)
-            return KREP_RA_NEON;
-    }
-    if (m < 8 && repetitive_pattern(p->pattern, m))
-        return KREP_RA_KMP;
-    return KREP_RA_BMH;
-}
-// ... and the function that ends up doing the work after the internal delegation chain
-// (krep.c:4512-4515, :4708-4712, :4883-4896, :5114-5126).
-int mirror_effective(int top, const search_params_t *p, size_t text_len)
-{
-    const size_t m = p->pattern_len;
-    int a = top;
-    if (a == KREP_RA_AVX512)
-    {
-        if (m == 0 || m > 64 || !p->case_sensitive || text_len < m || m <= 32)
-            a = KREP_RA_AVX2;
-    }
-    if (a == KREP_RA_AVX2)
-    {
-        if (m == 0 || m > 32 || !p->case_sensitive || text_len < m)
-            a = KREP_RA_BMH;
-        else if (m <= 16)
-            a = KREP_RA_SSE42;
-    }
-    if (a == KREP_RA_SSE42)
-    {
-        if (m == 0 || m > 16 || !p->case_sensitive || text_len < m)
-            a = KREP_RA_BMH;
-    }
-    if (a == KREP_RA_NEON && (!p->case_sensitive || m == 0 || text_len < m))
-        a = KREP_RA_BMH;
-    return a;
-}
-} // namespace kg
-extern "C" int krep_gpu_mirror_select(const search_params_t *p, size_t text_len)
-{
-    if (!p)
-        return KREP_RA_NONE;
-    return mirror_effective(mirror_top(p, kg::current_config()), p, text_len);
-}
-extern "C" const char *krep_gpu_algorithm_name(int a)
-{
-    switch (a) // get_algorithm_name(), krep.c:1964-1996
-    {
-    case KREP_RA_BMH: return "Boyer-Moore-Horspool";
-    case KREP_RA_KMP: return "Knuth-Morris-Pratt";
-    case KREP_RA_REGEX: return "Regex";
-    case KREP_RA_AHO_CORASICK: return "Aho-Corasick";
-    case KREP_RA_MEMCHR: return "memchr";
-    case KREP_RA_MEMCHR_SHORT: return "memchr-short";
-    case KREP_RA_SSE42: return "SSE4.2";
-    case KREP_RA_AVX2: return "AVX2";
-    case KREP_RA_AVX512: return "AVX-512";
-    case KREP_RA_NEON: return "NEON";
-    default: return "Unknown";
-    }
-}
-
-// ------------------------------------------------------------------------------------ what is accelerated
-// ONE input class is not taken; for it krep_gpu_can_accelerate() says 0, krep_gpu_select_search_algorithm() returns NULL (the
-// caller keeps its CPU function pointer, exactly like the regex case) and an operator called with it anyway takes the failure road:
-//  * memchr_short_search in -c mode while the file-static only_matching is set: main() never produces that
-//    combination (krep.c:3811-3814 clears count_lines_mode under -o), so it has no reference behaviour to pin.
-// (Round 3: -c through simd_sse42_search / kmp_search with a '\n' inside the pattern — refused until then — is reproduced by a
-//  walk over the ordered occurrence list, kg_greedy.hip (3).)
-static bool pattern_has_border(const uint8_t *p, size_t m)
-{
-    for (size_t k = 1; k < m; ++k)
-        if (memcmp(p, p + k, m - k) == 0)
-            return true;
-    return false;
-}
-namespace kg {
-const char *unsupported_reason(const search_params_t *p, const krep_gpu_config_t &c)
-{
-    if (!p)
-        return "NULL params";
-    if (p->use_regex)
-        return "regex search is not part of the accelerated path (keep krep's regex_search)";
-    if (p->num_patterns > 1)
-        return (p->patterns && p->pattern_lens) ? nullptr : "several patterns announced but patterns / pattern_lens are NULL";
-    if (!p->pattern && !(p->num_patterns == 1 && p->patterns && p->pattern_lens && p->patterns[0]))
-        return "no pattern";
-    search_params_t q = *p; // legacy callers fill only pattern / pattern_len (test/test_krep.c:233-235); others only the arrays
-    if (p->num_patterns == 1 && p->patterns && p->pattern_lens && p->patterns[0])
-    {
-        q.pattern = p->patterns[0];
-        q.pattern_len = p->pattern_lens[0];
-    }
-    p = &q;
-    const int top = mirror_top(p, c);
-    const int eff = mirror_effective(top, p, SIZE_MAX / 2);
-    if (p->count_lines_mode && c.only_matching && eff == KREP_RA_MEMCHR_SHORT)
-        return "memchr_short_search with count_lines_mode AND only_matching is not accelerated (unreachable from the "
-               "reference CLI, krep.c:3811-3814)";
-    return nullptr;
-}
-} // namespace kg
-extern "C" int krep_gpu_can_accelerate(const search_params_t *p)
-{
-    const krep_gpu_config_t c = kg::current_config();
-    return kg::unsupported_reason(p, c) == nullptr && kg::device_unusable(c.device) == nullptr ? 1 : 0;
-}
-// (krep_gpu_worthwhile: kg_cost.hip)
-
-// ------------------------------------------------------------------------------------ result container (krep.c:139-251 contract)
-extern "C" match_result_t *krep_gpu_match_result_init(uint64_t cap)
-{
-    match_result_t *r = (match_result_t *)malloc(sizeof *r);
-    if (!r)
-        return nullptr;
-    if (cap == 0)
-        cap = 16;
-    if (cap > SIZE_MAX / sizeof(match_position_t))
-    {
-        free(r);
-        return nullptr;
-    }
-    r->positions = (match_position_t *)malloc(cap * sizeof(match_position_t));
-    if (!r->positions)
-    {
-        free(r);
-        return nullptr;
-    }
-    r->count = 0;
-    r->capacity = cap;
-    return r;
-}
-extern "C" void krep_gpu_match_result_free(match_result_t *r)
-{
-    if (!r)
-        return;
-    free(r->positions);
-    free(r);
-}
-namespace kg {
-// make room for `extra` more records (malloc family, so the reference's match_result_free works)
-bool result_reserve(match_result_t *r, uint64_t extra)
-{
-    const uint64_t need = r->count + extra;
-    if (need <= r->capacity && r->positions)
-        return true;
-    uint64_t cap = r->capacity ? r->capacity : 16;
-    while (cap < need)
-        cap *= 2; // same doubling policy as match_result_add (krep.c:217)
-    match_position_t *np = (match_position_t *)realloc(r->positions, cap * sizeof(match_position_t));
-    if (!np)
-        return false;
-    r->positions = np;
-    r->capacity = cap;
-    return true;
-}
-} // namespace kg
-
-// ------------------------------------------------------------------------------------ plans
-extern "C" krep_gpu_plan_t *krep_gpu_plan_create_ex(const search_params_t *p, const krep_gpu_config_t *cfg_in)
-{
-    if (!p)
-    {
-        kg::fail("plan_create: NULL params");
-        return nullptr;
-    }
-    const krep_gpu_config_t cfg = cfg_in ? *cfg_in : kg::current_config();
-    const int device = cfg.device;
-    if (const char *why = kg::device_unusable(device))
-    {
-        kg::fail("%s", why);
-        return nullptr;
-    }
-    if (kg::inject(1))
-    {
-        kg::fail("injected failure: device allocation (plan)");
-        return nullptr;
-    }
-    if (hipSetDevice(device) != hipSuccess)
-    {
-        kg::fail("hipSetDevice(%d) failed", device);
-        return nullptr;
-    }
-    auto *pl = new krep_gpu_plan();
-    pl->cfg = cfg;
-    pl->device = device;
-    pl->only_matching = cfg.only_matching != 0;
-    pl->cs = p->case_sensitive;
-    pl->ww = p->whole_word;
-    pl->lines = p->count_lines_mode;
-    pl->track = p->track_positions;
-    pl->max_count = p->max_count;
-    if (p->num_patterns >= 1 && p->patterns && p->pattern_lens)
-        for (size_t i = 0; i < p->num_patterns; ++i)
-            pl->pats.emplace_back((const uint8_t *)p->patterns[i], (const uint8_t *)p->patterns[i] + p->pattern_lens[i]);
-    else if (p->pattern)
-        pl->pats.emplace_back((const uint8_t *)p->pattern, (const uint8_t *)p->pattern + p->pattern_len);
-    for (auto &v : pl->pats)
-    {
-        pl->pat_ptrs.push_back((const char *)v.data());
-        pl->pat_lens.push_back(v.size());
-    }
-    pl->sp = *p;
-    pl->sp.patterns = pl->pat_ptrs.data();
-    pl->sp.pattern_lens = pl->pat_lens.data();
-    pl->sp.num_patterns = pl->pats.size();
-    if (!pl->pats.empty())
-    {
-        pl->sp.pattern = pl->pat_ptrs[0];
-        pl->sp.pattern_len = pl->pat_lens[0];
-    }
-    pl->ref_algo = mirror_top(&pl->sp, cfg);
-    if (const char *why = kg::unsupported_reason(&pl->sp, cfg))
-        pl->unsupported = why;
-
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess)
-        pl->num_cu = prop.multiProcessorCount;
-    bool ok = hipMalloc(&pl->d_ctr, sizeof(Counters)) == hipSuccess &&
-              hipHostMalloc(&pl->h_ctr, sizeof(Counters)) == hipSuccess &&
-              hipEventCreate(&pl->ev0) == hipSuccess && hipEventCreate(&pl->ev1) == hipSuccess;
-    if (ok && pl->sp.num_patterns == 1 && pl->pats[0].size() >= 1)
-    {
-        const auto &raw = pl->pats[0];
-        pl->m = (uint32_t)raw.size();
-        pl->pat_folded = raw;
-        if (!pl->cs)
-            for (auto &c : pl->pat_folded)
-                c = lo8(c);
-        pl->has_border = pattern_has_border(pl->pat_folded.data(), pl->pat_folded.size());
-        pl->has_newline = memchr(raw.data(), '\n', raw.size()) != nullptr;
-        uint8_t w[8] = {0}, k[8] = {0};
-        for (uint32_t i = 0; i < 8 && i < pl->m; ++i)
-        {
-            w[i] = pl->pat_folded[i];
-            k[i] = 0xff;
-        }
-        memcpy(&pl->p0, w, 4);
-        memcpy(&pl->p1, w + 4, 4);
-        memcpy(&pl->k0, k, 4);
-        memcpy(&pl->k1, k + 4, 4);
-        if (pl->m == 1)
-            pl->p0 = 0x01010101u * w[0];
-        {
-            uint8_t w2[8] = {0}, kk[8] = {0}, ll[8] = {0};
-            for (uint32_t i = 8; i < 16 && i < pl->m; ++i)
-            {
-                w2[i - 8] = pl->pat_folded[i];
-                kk[i - 8] = 0xff;
-                ll[i - 8] = (!pl->cs && w2[i - 8] >= 'a' && w2[i - 8] <= 'z') ? 0x20 : 0;
-            }
-            memcpy(&pl->p2, w2, 4); memcpy(&pl->p3, w2 + 4, 4);
-            memcpy(&pl->k2, kk, 4); memcpy(&pl->k3, kk + 4, 4);
-            memcpy(&pl->l2, ll, 4); memcpy(&pl->l3, ll + 4, 4);
-        }
-        if (!pl->cs)
-        { // letter lanes of the first 8 (folded) pattern bytes
-            uint8_t l[8] = {0};
-            for (uint32_t i = 0; i < 8 && i < pl->m; ++i)
-                l[i] = (w[i] >= 'a' && w[i] <= 'z') ? 0x20 : 0;
-            memcpy(&pl->l0, l, 4);
-            memcpy(&pl->l1, l + 4, 4);
-            if (pl->m == 1)
-                pl->l0 = 0x01010101u * l[0];
-        }
-        ok = hipMalloc(&pl->d_pat, pl->m) == hipSuccess &&
-             hipMemcpy(pl->d_pat, pl->pat_folded.data(), pl->m, hipMemcpyHostToDevice) == hipSuccess;
-        if (ok && pl->m > 8)
-        {
-            pl->n_chunks = (pl->m - 8 + 7) / 8;
-            std::vector<unsigned long long> ch(2 * pl->n_chunks, 0ull); // pattern words, then their letter masks (-i)
-            for (uint32_t k = 0; k < pl->n_chunks; ++k)
-            {
-                const uint8_t *src = pl->pat_folded.data() + std::min<uint32_t>(8 + 8 * k, pl->m - 8);
-                memcpy(&ch[k], src, 8);
-                uint8_t l[8];
-                for (int b = 0; b < 8; ++b)
-                    l[b] = (!pl->cs && src[b] >= 'a' && src[b] <= 'z') ? 0x20 : 0;
-                memcpy(&ch[pl->n_chunks + k], l, 8);
-            }
-            ok = hipMalloc(&pl->d_pat_chunks, ch.size() * 8) == hipSuccess &&
-                 hipMemcpy(pl->d_pat_chunks, ch.data(), ch.size() * 8, hipMemcpyHostToDevice) == hipSuccess;
-        }
-    }
-    if (ok && pl->ref_algo == KREP_RA_AHO_CORASICK)
-    {
-        for (auto &v : pl->pats)
-            if (!v.empty() && memchr(v.data(), '\n', v.size()))
-                pl->ac_has_newline = true;
-        pl->ac = ac_build(pl->sp, device);
-        ok = pl->ac != nullptr;
-    }
-    if (!ok)
-    {
-        if (g_err.empty())
-            kg::fail("plan_create: device allocation failed");
-        krep_gpu_plan_destroy(pl);
-        return nullptr;
-    }
-    return pl;
-}
-extern "C" krep_gpu_plan_t *krep_gpu_plan_create(const search_params_t *p, int only_matching, int device)
-{
-    krep_gpu_config_t c = kg::current_config();
-    c.only_matching = only_matching != 0;
-    c.device = device;
-    return krep_gpu_plan_create_ex(p, &c);
-}
-
-#define DBGFREE(x)                                                                      \
-    do                                                                                  \
-    {                                                                                   \
-        hipError_t e_ = (x);                                                            \
-        if (e_ != hipSuccess && getenv("KREP_GPU_DEBUG"))                               \
-            fprintf(stderr, "krep-gpu: (debug) %s -> %s\n", #x, hipGetErrorString(e_)); \
-    } while (0)
-extern "C" void krep_gpu_plan_destroy(krep_gpu_plan_t *pl)
-{
-    if (!pl)
-        return;
-    (void)hipSetDevice(pl->device);
-    if (pl->d_pat) DBGFREE(hipFree(pl->d_pat));
-    if (pl->d_pat_chunks) DBGFREE(hipFree(pl->d_pat_chunks));
-    if (pl->d_ctr) DBGFREE(hipFree(pl->d_ctr));
-    if (pl->h_ctr) DBGFREE(hipHostFree(pl->h_ctr));
-    if (pl->ev0) DBGFREE(hipEventDestroy(pl->ev0));
-    if (pl->ev1) DBGFREE(hipEventDestroy(pl->ev1));
-    if (pl->ac) ac_free(pl->ac);
-    if (pl->d_nl_rec) DBGFREE(hipFree(pl->d_nl_rec));
-    if (pl->d_nl_ln) DBGFREE(hipFree(pl->d_nl_ln));
-    post_free(pl->post);
-    post_free(pl->aux);
-    delete pl;
-}
-extern "C" int krep_gpu_plan_ref_algo(const krep_gpu_plan_t *pl) { return pl ? pl->ref_algo : KREP_RA_NONE; }
 
 // ------------------------------------------------------------------------------------ reference return-value conventions
 // What the reference function returns / stores given the number of emitted matches (`total`, after
@@ -1741,3 +1119,4 @@ extern "C" uint64_t krep_gpu_combine_line_counts(const krep_gpu_scan_out_t *s, i
     }
     return total;
 }
+

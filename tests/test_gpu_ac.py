@@ -202,7 +202,7 @@ def test_worst_legal_dictionary_1024_patterns_of_up_to_1024_bytes(gpu, oracle_en
 
 
 def test_count_lines_on_the_record_list(gpu, oracle_engine, monkeypatch):
-    """Multi-pattern -c on a text large enough for the list road (kg_host.hip scan_ac_lines_on_list: records by the fast
+    """Multi-pattern -c on a text large enough for the list road (kg_scan.hip scan_ac_lines_on_list: records by the fast
     kernel, lines counted on the end-ordered list by their newline gaps): whole text and ownership windows (the line summary
     of each window folds with krep_gpu_combine_line_counts), -w, -i, max_count, a text without any newline, a newline-free
     half, and the in-kernel road on the same input — all against aho_corasick_search of the compiled reference."""

@@ -50,7 +50,7 @@ def accepted(text, pat, ww):
 
 
 def decompose(text, pat, ww, algo):
-    """(K, cur, open): what the device side hands to the replay (kg_host.hip: replay_entry)."""
+    """(K, cur, open): what the device side hands to the replay (kg_scan.hip: replay_entry)."""
     n, B = len(text), BLOCK[algo]
     X = n - W if n > W else 0
     if X == 0:
@@ -119,7 +119,7 @@ def test_replay_plus_canonical_prefix_equals_reference_function(lib, algo, seed)
 # ---- the same in PIECES (round 3): every piece contributes its own part of the line-skip history, the product's fold
 # (kg::fold_carry, exported as krep_gpu_debug_fold_carry) combines them in text order — whatever order they were scanned in —
 # and only the piece that ends the text replays.  The per-piece quantities below restate what the device side derives
-# (kg_host.hip, the replay branch of scan_literal for a window inside the text).
+# (kg_scan.hip, the replay branch of scan_literal for a window inside the text).
 def piece_record(text, acc, lo, hi, X, final, algo):
     n = len(text)
     lim, nl_end = (X, n) if final else (hi, hi)
