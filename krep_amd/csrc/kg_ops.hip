@@ -15,6 +15,8 @@
 // travels explicitly (krep_gpu_config_t); nothing here writes a global.
 #include <hip/hip_runtime.h>
 #include <pthread.h>
+#include <sched.h>
+#include <cctype>
 
 #include <algorithm>
 #include <atomic>
@@ -570,6 +572,58 @@ int scan_one_piece(DeviceCtx &cx, krep_gpu_plan_t *pl, const uint8_t *d_text, Pi
     return 0;
 }
 
+// A worker thread of a multi-device run goes to the CPUs of its device's NUMA node before it touches anything: the pinned
+// staging ring it allocates, the staging copies (its helper threads inherit the mask) and the record lists it fills then live
+// next to the PCIe root the DMA goes through — on a two-socket node half the devices are a socket away from a thread the OS
+// placed at random, and a copy across the socket link feeds the DMA engine at a fraction of the local rate.  Only OUR threads
+// are moved (the single-device paths run on the caller's thread and leave its affinity alone); every step is optional: no
+// sysfs entry, one node, or a failing call leave the thread where it is.
+static void bind_thread_near_device(int device)
+{
+    char bdf[32] = {0};
+    if (hipDeviceGetPCIBusId(bdf, sizeof bdf, device) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        return;
+    }
+    for (char *c = bdf; *c; ++c)
+        *c = (char)tolower(*c);
+    char path[160];
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bdf);
+    FILE *f = fopen(path, "r");
+    if (!f)
+        return;
+    int node = -1;
+    const int got = fscanf(f, "%d", &node);
+    fclose(f);
+    if (got != 1 || node < 0)
+        return;
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    f = fopen(path, "r");
+    if (!f)
+        return;
+    char list[4096] = {0};
+    const bool ok = fgets(list, sizeof list, f) != nullptr;
+    fclose(f);
+    if (!ok)
+        return;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    int n = 0;
+    for (char *tok = strtok(list, ",\n"); tok; tok = strtok(nullptr, ",\n"))
+    {
+        int a = 0, b = 0;
+        const int k = sscanf(tok, "%d-%d", &a, &b);
+        if (k == 1)
+            b = a;
+        if (k >= 1)
+            for (int c = a; c <= b && c < CPU_SETSIZE; ++c, ++n)
+                CPU_SET(c, &set);
+    }
+    if (n)
+        (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);
+}
+
 void run_device(DeviceRun *dr)
 {
     DeviceCtx &cx = *dr->cx;
@@ -758,7 +812,11 @@ static int run_pieces(const search_params_t *params, const krep_gpu_config_t &cf
     {
         std::vector<std::thread> th;
         for (auto &r : runs)
-            th.emplace_back(run_device, &r);
+            th.emplace_back([](DeviceRun *d) {
+                if (!getenv("KREP_GPU_NO_NUMA_BIND"))
+                    bind_thread_near_device(d->cx->device);
+                run_device(d);
+            }, &r);
         for (auto &t : th)
             t.join();
     }
