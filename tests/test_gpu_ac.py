@@ -236,6 +236,15 @@ def test_count_lines_on_the_record_list(gpu, oracle_engine, monkeypatch):
             if "max_count" in kw:
                 plan.close()
                 continue
+            # the host-buffer operator on the same text, streamed in 33 MiB pieces (each piece takes the list road, the line
+            # summaries of the pieces fold on the host) and sharded over three logical devices
+            gpu.set_stream_chunk(33 << 20)
+            try:
+                got_stream = gpu.search(abi.Params(pats, **kwc), text, want_result=False)[0]
+                rc, got_shard, _ = gpu.search_buffer(abi.Params(pats, **kwc), text, num_gpus=3, want_result=False)
+            finally:
+                gpu.set_stream_chunk(0)
+            assert got_stream == want and got_shard == want and rc == (0 if want else 1), (variant, kw, got_stream, got_shard, want)
             cuts = [0, 5, (1 << 20) + 3, 17 << 20, (17 << 20) + 1, 33 << 20, n]
             outs = [plan.scan(d.data_ptr(), n, lo, hi) for lo, hi in zip(cuts[:-1], cuts[1:])]
             arr = (abi.ScanOut * len(outs))(*outs)
