@@ -28,7 +28,12 @@ if os.environ.get("AB_PATTERN"):
 kw = dict(count_lines=True, only_match=True) if mode == "count" else dict(count_lines=True) if mode == "lines" else {}
 cap = (n // 50 if kind == 3 else n // 1500) + 4096 if mode == "pos" else 0
 pos = torch.empty(2 * cap, dtype=torch.int64, device="cuda") if cap else None
-plans = [(name, e.plan(abi.Params(wl["patterns"], **kw))) for name, e in engs]
+plans = []
+for name, e in engs:  # the environment of a variant also holds while its plan (and tables) are built
+    os.environ.update(envs[name])
+    plans.append((name, e.plan(abi.Params(wl["patterns"], **kw))))
+    for k in envs[name]:
+        os.environ.pop(k, None)
 times = {name: [] for name, _ in plans}
 for rep in range(int(os.environ.get("AB_REPS", "9"))):
     for name, pl in plans:
