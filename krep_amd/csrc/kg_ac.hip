@@ -42,11 +42,9 @@ namespace kg {
 // pattern's final 4-gram (a match ends at the tested position t), the 4-gram one byte earlier (the match ends at t + 1;
 // for a 4-byte pattern that gram has an unknown first byte: all 32 classes are set).  Half the LDS lookups — the
 // bank-conflict wall of 4.2 — and half the lookup VALU; a candidate verifies both ends, with both probes in flight.
-// P2: two-plane slots (kg_ac_common.h, ac_pair_slot64) — stride 2, no -c, every pattern >= 4 bytes.
-template <bool CI, bool LINES, bool SHORT, int STRIDE, bool P2 = false>
+template <bool CI, bool LINES, bool SHORT, int STRIDE>
 __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
 {
-    static_assert(!P2 || (STRIDE == 2 && !LINES && !SHORT), "two-plane slots: the pair-layout kernel without -c, patterns >= 4 bytes");
     extern __shared__ __attribute__((aligned(16))) u32 s_mem[]; // filter table | per wave: candidate bitmap (+ hit and newline bitmaps for -c)
     const u32 lane = ac_lane();
     const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -161,8 +159,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
         // W[0] = the 4 bytes before the lane, W[1..4] = the lane's 16 bytes of cell j
         // have_c: the caller already holds the classes of W[0] and W[4] (fast path: it shuffles the 20-bit class word
         // of the neighbour lane instead of its raw bytes, which saves one compress per cell)
-        // nxt (P2, have_nxt): a word whose bits 16-20 hold the class of the NEXT lane's first byte
-        auto cell_body = [&](const int j, u32 (&W)[5], const bool have_c, const u32 pc0, const u32 pc4, const u32 nxt, const bool have_nxt) __attribute__((always_inline)) {
+        auto cell_body = [&](const int j, u32 (&W)[5], const bool have_c, const u32 pc0, const u32 pc4) __attribute__((always_inline)) {
             u32 NL = 0;
             if (LINES)
             {
@@ -191,46 +188,19 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 t[4] = have_c ? pc4 : ac_pair(W[4]);
                 u32 xs[8], dws[8];
                 typedef __attribute__((address_space(3))) const u32 lds_u32;
-                typedef __attribute__((address_space(3))) const u64 lds_u64;
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                {
+                    const int w = q / 2 + 1;
+                    xs[q] = (q & 1) ? t[w] : __builtin_amdgcn_alignbit(t[w], t[w - 1], 16u);
+                    // (-c: a 2^19-bit table, address bit 16 = bit 3 of the class c2 dropped)
+                    dws[q] = *(lds_u32 *)(size_t)(((xs[q] >> 3) ^ (xs[q] >> 13)) & (XB == 20 ? 0x1fffcu : 0xfffcu));
+                }
+                __builtin_amdgcn_sched_barrier(0);
                 u32 acc = 0;
-                if constexpr (P2)
-                {
-                    // two-plane slots: plane 1 is tested with the class of the byte behind the tested position = bits 16-20 of the
-                    // NEXT position's register — for the lane's last position the next LANE's first byte (nxt; lane 63 and the
-                    // ragged rounds have none in registers: that one position passes — a superset, as everywhere)
-                    u64 d2[8];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q)
-                    {
-                        const int w = q / 2 + 1;
-                        xs[q] = (q & 1) ? t[w] : __builtin_amdgcn_alignbit(t[w], t[w - 1], 16u);
-                        d2[q] = *(lds_u64 *)(size_t)ac_pair_slot64(xs[q]);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int q = 0; q < 8; ++q)
-                    {
-                        u32 b1 = (u32)(d2[q] >> 32) >> (((q < 7 ? xs[q < 7 ? q + 1 : q] : nxt) >> 16) & 31u);
-                        if (q == 7)
-                            b1 |= (!have_nxt || lane == 63u) ? 1u : 0u;
-                        acc = __builtin_amdgcn_alignbit(((u32)d2[q] >> (xs[q] & 31u)) & b1, acc, 2u);
-                    }
-                }
-                else
-                {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q)
-                    {
-                        const int w = q / 2 + 1;
-                        xs[q] = (q & 1) ? t[w] : __builtin_amdgcn_alignbit(t[w], t[w - 1], 16u);
-                        // (-c: a 2^19-bit table, address bit 16 = bit 3 of the class c2 dropped)
-                        dws[q] = *(lds_u32 *)(size_t)(((xs[q] >> 3) ^ (xs[q] >> 13)) & (XB == 20 ? 0x1fffcu : 0xfffcu));
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int q = 0; q < 8; ++q)
-                        acc = __builtin_amdgcn_alignbit(dws[q] >> (xs[q] & 31u), acc, 2u);
-                }
+                for (int q = 0; q < 8; ++q)
+                    acc = __builtin_amdgcn_alignbit(dws[q] >> (xs[q] & 31u), acc, 2u);
                 cand = (acc >> 16) & 0x5555u; // bit 2q <-> tested position 2q + 1 (the verify stage adds the 1)
             }
             else
@@ -307,11 +277,9 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
             else
                 cbits16[(u32)r * (kSegBytes / 16) + (u32)j * kWave + lane] = (unsigned short)cand;
         };
-        if (PIPE && fast_now && !P2)
+        if (PIPE && fast_now)
         {
-            // Pair layout, software-pipelined over the cells of the round (two-plane slots take the straight-line road below:
-            // a second set of table words for the cell in flight does not fit the 128 registers of a 1024-thread workgroup, and the
-            // pipelining itself measured no effect — docs/history.md 4.2): the table reads of cell j + 1 are issued before the
+            // Pair layout, software-pipelined over the cells of the round: the table reads of cell j + 1 are issued before the
             // results of cell j are consumed, so a wave waits for LDS once per round instead of once per cell (the LDS pipe
             // is ~50 % busy with 4 waves per SIMD: the exposed read latency, not its throughput, was the limit).
             u32 xs[2][8], dw[2][8];
@@ -365,10 +333,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                     const u32 c0 = (u32)__builtin_amdgcn_update_dpp((int)cb, (int)c4, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
                     W[0] = 0;
                     before = __builtin_amdgcn_readlane(W[4], 63); // the next cell's (and round's) left neighbour
-                    u32 nxt = 0;
-                    if constexpr (P2) // the next lane's first byte: its first pair register, moved so that the class sits at bits 16-20
-                        nxt = (u32)__builtin_amdgcn_update_dpp(0, (int)(ac_pair(W[1]) << 16), 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-                    cell_body(j, W, true, c0, c4, nxt, true);
+                    cell_body(j, W, true, c0, c4);
                 }
             }
         }
@@ -391,7 +356,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                     }
                     W[w] = v;
                 }
-                cell_body(j, W, false, 0u, 0u, 0u, false);
+                cell_body(j, W, false, 0u, 0u);
             }
         }
 
@@ -479,6 +444,8 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                     u32 mA = 0, mB = 0;
                     if (!(a.flags & (1u << 30))) // (ablation hook KREP_GPU_AC_NOPROBE: candidate enumeration without the probes)
                         ac_walk_probe2<CI, SHORT>(a, pos, liveA, liveB, LINES, mA, slA, mB, slB);
+                    else
+                        mA = liveA ? 1u : 0u; // ... and the count that comes back is the number of candidates
                     dmA = mA; dmB = mB;
                     cA = (u32)__popc(mA); cB = (u32)__popc(mB);
                     simA = simB = true;
@@ -653,7 +620,6 @@ struct AcTables
     bool short_dup = false;     // a 1-3-byte pattern occurs more than once (the bitmaps cannot count copies)
     u32 *d_filterx20 = nullptr, *d_filterx19 = nullptr; // exact-class filter tables (2^20 bits; 2^19 for -c)
     u32 *d_filters20 = nullptr, *d_filters19 = nullptr; // the same for the stride-2 filter (nullptr: stride 2 not worth it)
-    u32 *d_filters64 = nullptr; // ... as two-plane slots (ac_pair_slot64): every pattern >= 4 bytes, no -c
     u32 *d_s1 = nullptr, *d_s2 = nullptr, *d_s3 = nullptr; // exact bitmaps of the 1-/2-/3-byte patterns
     uint2 *d_edges = nullptr;
     u32 emask = 0;
@@ -952,40 +918,6 @@ AcTables *ac_build(const search_params_t &sp, int device)
                 ACHK(hipMemcpy(t->d_filters20, S20.data(), S20.size() * sizeof(u32), hipMemcpyHostToDevice));
                 ACHK(hipMalloc(&t->d_filters19, S19.size() * sizeof(u32)));
                 ACHK(hipMemcpy(t->d_filters19, S19.data(), S19.size() * sizeof(u32), hipMemcpyHostToDevice));
-                if (t->lmin >= 4 && !getenv("KREP_GPU_AC_ONE_PLANE"))
-                {
-                    // two-plane slots (kg_ac_common.h): plane 0 = the class 4-gram as above, plane 1 = the class of the byte
-                    // behind the tested position — all ones for a pattern that ends AT it, the pattern's last byte for one that
-                    // ends one byte behind it (whose gram in front has an unknown first class only when the pattern has 4 bytes)
-                    std::vector<u32> S64((1u << kXBitsBig) / 32, 0);
-                    auto cls = [](uint8_t b) -> u32 { return (u32)b & 31u; };
-                    auto pairreg = [&](const uint8_t *g) -> u32 { return cls(g[0]) | (cls(g[1]) << 5) | (cls(g[2]) << 16) | (cls(g[3]) << 21); };
-                    for (auto &p : pats)
-                    {
-                        const size_t n = p.size();
-                        {   // ends at the tested position
-                            const u32 u = pairreg(p.data() + (n - 4)), at = ac_pair_slot64(u) >> 2;
-                            S64[at] |= 1u << (u & 31u);
-                            S64[at + 1] = 0xffffffffu;
-                        }
-                        if (n >= 5)
-                        {   // ends one byte behind it: the gram is the four bytes in front of the last one
-                            const u32 u = pairreg(p.data() + (n - 5)), at = ac_pair_slot64(u) >> 2;
-                            S64[at] |= 1u << (u & 31u);
-                            S64[at + 1] |= 1u << cls(p[n - 1]);
-                        }
-                        else
-                        {   // 4 bytes: the first class of that gram is unknown — every bit of plane 0, in the slot of each of its 32 values?
-                            // no: the SLOT is made of the last three classes only, which ARE known (p[0..2]); the unknown class is the bit
-                            uint8_t g[4] = {0, p[0], p[1], p[2]};
-                            const u32 at = ac_pair_slot64(pairreg(g)) >> 2;
-                            S64[at] = 0xffffffffu;
-                            S64[at + 1] |= 1u << cls(p[3]);
-                        }
-                    }
-                    ACHK(hipMalloc(&t->d_filters64, S64.size() * sizeof(u32)));
-                    ACHK(hipMemcpy(t->d_filters64, S64.data(), S64.size() * sizeof(u32), hipMemcpyHostToDevice));
-                }
             }
         }
         if (!S1.empty())
@@ -1026,7 +958,6 @@ void ac_free(AcTables *t)
     if (t->d_filterx19) (void)hipFree(t->d_filterx19);
     if (t->d_filters20) (void)hipFree(t->d_filters20);
     if (t->d_filters19) (void)hipFree(t->d_filters19);
-    if (t->d_filters64) (void)hipFree(t->d_filters64);
     if (t->d_edges) (void)hipFree(t->d_edges);
     if (t->d_copies) (void)hipFree(t->d_copies);
     if (t->d_gram4) (void)hipFree(t->d_gram4);
@@ -1051,7 +982,7 @@ static u32 ac_lds_bytes(u32 filter_words, bool lines)
 }
 
 constexpr u32 kAcMaxLds = 160u * 1024u; // LDS of a gfx950 CU: the most a launch of the scan kernel can ask for
-template <bool CI, bool LN, bool SHORT, int STRIDE, bool P2 = false>
+template <bool CI, bool LN, bool SHORT, int STRIDE>
 static hipError_t ac_launch3(const AcArgs &a, u32 grid, u32 lds, hipStream_t st)
 {
     // more than 64 KiB of dynamic LDS has to be requested explicitly — once per instantiation and device, not on every launch
@@ -1064,23 +995,20 @@ static hipError_t ac_launch3(const AcArgs &a, u32 grid, u32 lds, hipStream_t st)
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= kMaxDev || !granted[dev].load(std::memory_order_acquire))
     {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ac_scan_kernel<CI, LN, SHORT, STRIDE, P2>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ac_scan_kernel<CI, LN, SHORT, STRIDE>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAcMaxLds);
         if (e != hipSuccess)
             return e;
         if (dev >= 0 && dev < kMaxDev)
             granted[dev].store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((ac_scan_kernel<CI, LN, SHORT, STRIDE, P2>), dim3(grid), dim3(kAcBlock), lds, st, a);
+    hipLaunchKernelGGL((ac_scan_kernel<CI, LN, SHORT, STRIDE>), dim3(grid), dim3(kAcBlock), lds, st, a);
     return hipGetLastError();
 }
 template <bool CI, bool LN>
 static hipError_t ac_launch2(const AcArgs &a, u32 grid, u32 lds, hipStream_t st)
 {
     const bool shorts = a.has1 || a.has2 || a.has3;
-    if constexpr (!LN)
-        if (a.stride == 2 && a.planes == 2 && !shorts)
-            return ac_launch3<CI, false, false, 2, true>(a, grid, lds, st);
     if (a.stride == 2)
         return shorts ? ac_launch3<CI, LN, true, 2>(a, grid, lds, st) : ac_launch3<CI, LN, false, 2>(a, grid, lds, st);
     return shorts ? ac_launch3<CI, LN, true, 1>(a, grid, lds, st) : ac_launch3<CI, LN, false, 1>(a, grid, lds, st);
@@ -1142,23 +1070,17 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
     a.flags = (t->ci ? F_CI : 0) | (ww ? F_WW : 0) | (lines ? F_LINES : 0);
     if (getenv("KREP_GPU_AC_NOVERIFY")) // measurement hook: filter cost only (wrong results by design)
         a.flags |= 1u << 31;
-    if (getenv("KREP_GPU_AC_NOPROBE")) // measurement hook: filter + candidate enumeration, no probes (wrong results by design)
+    if (getenv("KREP_GPU_AC_NOPROBE")) // measurement hook: filter + candidate enumeration, no probes: a count-only scan returns the number of candidates
         a.flags |= 1u << 30;
     a.lmax = t->lmax;
     a.has1 = t->has1; a.has2 = t->has2; a.has3 = t->has3; a.has4 = t->has4;
     a.stride = 1;
     a.filter = lines ? t->d_filterx19 : t->d_filterx20;
     a.filter_words = (1u << (lines ? kXBitsLines : kXBitsBig)) / 32;
-    a.planes = 1;
     if (t->d_filters20)
     {
         a.filter = lines ? t->d_filters19 : t->d_filters20;
         a.stride = 2;
-        if (!lines && t->d_filters64)
-        {
-            a.filter = t->d_filters64;
-            a.planes = 2;
-        }
     }
     a.s1 = t->d_s1; a.s2 = t->d_s2; a.s3 = t->d_s3;
     if (t->short_dup)

@@ -33,7 +33,6 @@ struct AcArgs
     u32 emask;
     const u32 *copies;           // per node: number of patterns equal to the node's string
     u32 stride;                  // 1 or 2: text positions per filter lookup (2 = even positions only, see ac_scan_kernel)
-    u32 planes;                  // 2: the stride-2 table holds two-plane slots (ac_pair_slot64); else one bit per class 4-gram
     u32 upt;                     // units per wave ticket of the fused kernel (1..kAcUnitsPerTicketMax, by text size)
     const uint2 *gram4;          // exact last-4-bytes -> {key, depth-4 node | has_out << 31} (val 0 = empty)
     u32 g4mask;
@@ -503,17 +502,5 @@ __host__ __device__ __forceinline__ void ac_pair_slot(u32 x, u32 &dword, u32 &bi
     bit = x & 31u;
     dword = (c1 ^ ((c2 & 15u) << 1)) | ((c2 >> 4) << 5) | (c3 << 6) | ((c2 & 15u) << 11);
 }
-
-// Two-plane slot of the stride-2 filter for dictionaries whose patterns all have >= 4 bytes (round 4).  One ds_read_b64 per
-// tested position p returns, for the slot of the classes (c(p-2), c(p-1), c(p)):
-//   plane 0, bit c(p-3): some pattern's gram ends with these four classes     (as the one-plane table: the exact class 4-gram)
-//   plane 1, bit c(p+1): ... and the byte BEHIND the tested position fits      (all ones for a pattern that ENDS at p)
-// A pattern that ends one byte behind p (the other end a stride-2 candidate stands for) knows that byte: it is its last one.
-// For a 4-byte pattern it replaces the unknown byte in FRONT of the gram — 32 wildcard entries in the one-plane table, half of
-// all candidates of BASELINE config 4 — by a known one.  2^14 slots x 8 bytes = the same 128 KiB: the 15 class bits of the
-// slot lose one (c1's top bit meets c2's bit 3), which doubles the chance hits of plane 0; in total 4080 -> ~2220 live
-// (slot, bit, bit) triples for config 4.  Byte address from the pair register u = {c0, c1 | c2, c3}: two shifts and one v_bitop3
-// like before, LDS bank = c1 mixed with c2.
-__host__ __device__ __forceinline__ u32 ac_pair_slot64(u32 u) { return ((u >> 2) ^ (u >> 12)) & 0x1fff8u; } // byte address of the slot
 
 } // namespace kg

@@ -35,14 +35,16 @@ for name, e in engs:  # the environment of a variant also holds while its plan (
     for k in envs[name]:
         os.environ.pop(k, None)
 times = {name: [] for name, _ in plans}
+counts = {}
 for rep in range(int(os.environ.get("AB_REPS", "9"))):
     for name, pl in plans:
         os.environ.update(envs[name])
         out = pl.scan(buf.data_ptr(), n, 0, n, 0, pos.data_ptr() if cap else 0, cap, time_it=True)
         for k in envs[name]:
             os.environ.pop(k, None)
+        counts[name] = out.count
         if rep:
             times[name].append(out.kernel_ms)
 for name, _ in plans:
     t = times[name]
-    print(f"{name:40s} {mode:5s} kind={kind} median {statistics.median(t):7.3f} ms  min {min(t):7.3f}  {n / statistics.median(t) / 1e6:7.1f} GB/s   count={out.count}")
+    print(f"{name:40s} {mode:5s} kind={kind} median {statistics.median(t):7.3f} ms  min {min(t):7.3f}  {n / statistics.median(t) / 1e6:7.1f} GB/s   count={counts[name]}")
