@@ -630,6 +630,7 @@ struct AcTables
     u32 g4mask = 0;
     u32 g4x_mode = 0, g4x_mask = 0, g4x_mul = 0;
     u32 stage_cap = 16; // staged matches per unit (16, raised to 64 by a scan whose units overflowed; see ac_scan)
+    AcTiny tiny{};      // ok: the dictionary runs in kg_ac_tiny.hip (every pattern <= 4 bytes, few of them)
 };
 
 #define ACHK(x)                                                                                \
@@ -697,6 +698,37 @@ AcTables *ac_build(const search_params_t &sp, int device)
         else if (n == 2) { t->has2 = 1; setbit(S2, kS2Words, (u32)p[0] | ((u32)p[1] << 8)); }
         else if (n == 3) { t->has3 = 1; setbit(S3, kS3Words, (u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16)); }
         else t->has4 = 1;
+    }
+    // ---- tiny dictionary?  (kg_ac_tiny.hip: compared in registers, no tables)
+    {
+        AcTiny &td = t->tiny;
+        // ... and worth it: with a 1- or 2-byte pattern the general kernel reads two or three LDS tables per position (3.3 TB/s
+        // on `he she hers`, 1.4 on `e t`); a dictionary of 3- and 4-byte patterns only runs there at 5.2-5.9 TB/s, faster than
+        // the register compare (profiles/r04_dictionaries.txt)
+        bool ok = !pats.empty() && !t->has_empty && t->lmax <= 4 && t->lmin <= 2 && !getenv("KREP_GPU_AC_NO_TINY");
+        for (size_t i = 0; ok && i < pats.size(); ++i)
+        {
+            for (size_t k = 0; k < i; ++k)
+                if (pats[k] == pats[i])
+                    ok = false; // a duplicate reports twice (aho_corasick.c:383-437): the masks cannot count copies
+            const size_t L = pats[i].size();
+            if (!ok || td.n[L - 1] >= kTinyPer)
+            {
+                ok = false;
+                break;
+            }
+            const u32 p = td.n[L - 1]++;
+            for (size_t s = 0; s < L; ++s)
+            {
+                const uint8_t c = pats[i][L - 1 - s];
+                td.pk[L - 1][p] |= (u32)c << (8 * s);
+                td.lf[L - 1][p] |= (t->ci && c >= 'a' && c <= 'z') ? 1u << s : 0u;
+            }
+        }
+        td.lmax = t->lmax;
+        for (int L = 0; L < 4; ++L)
+            td.ncls += td.n[L] ? 1u : 0u;
+        td.ok = ok ? 1u : 0u;
     }
     // ---- reversed trie ----
     std::unordered_map<u32, u32> edge; // key = node << 8 | byte
@@ -1113,16 +1145,20 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
         a.offsets = (const u64 *)post.d_offsets;
     }
     SCHK(hipSetDevice(t->device));
+    // tiny dictionaries run in kg_ac_tiny.hip (same units, staging, info words and post-pass); -w takes the general kernel
+    const bool tiny = t->tiny.ok && !ww;
+    const u32 waves = tiny ? (u32)kTinyWaves : (u32)kAcWaves;
     const u32 lds = ac_lds_bytes(a.filter_words, lines);
     const u32 per_cu = lds <= 80 * 1024 ? 2u : 1u;
     // ticket size by text size: >= ~4 tickets per resident wave before tickets grow (small host buffers keep every
     // CU busy), 8 units (128 KiB) on large texts
-    a.upt = (u32)std::min<u64>(kAcUnitsPerTicketMax, std::max<u64>(1, a.num_tiles / ((u64)num_cu * kAcWaves * 4)));
+    a.upt = (u32)std::min<u64>(kAcUnitsPerTicketMax, std::max<u64>(1, a.num_tiles / ((u64)num_cu * waves * 4)));
     const u64 n_tickets = (a.num_tiles + a.upt - 1) / a.upt;
-    const u32 grid = (u32)std::min<u64>((n_tickets + kAcWaves - 1) / kAcWaves, (u64)num_cu * per_cu);
+    const u32 grid = (u32)std::min<u64>((n_tickets + waves - 1) / waves, (u64)num_cu * per_cu);
+    auto launch = [&](const AcArgs &args) { return tiny ? ac_tiny_launch(args, t->tiny, n_tickets, (u32)num_cu, st) : ac_launch(args, grid, lds, st); };
     if (time_it) SCHK(hipEventRecord(ev0, st));
     SCHK(hipMemsetAsync(d_ctr, 0, sizeof(Counters), st));
-    SCHK(ac_launch(a, grid, lds, st));
+    SCHK(launch(a));
     if (chain && post_order(post, n_units, a.stage_cap, 0, a.anchor + global_base, unit_bytes, lines, (uint64_t *)d_pos, want, d_ctr, num_cu, st))
         return 2;
     // lines_on_list (kg_scan.hip scan_ac_lines_on_list): the distinct lines of the record list just gathered, counted by the
@@ -1133,8 +1169,16 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
     if (time_it) SCHK(hipEventRecord(ev1, st));
     SCHK(hipMemcpyAsync(h_ctr, d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, st));
     SCHK(hipStreamSynchronize(st));
-    if (want && !g_ac_force_stage_cap && h_ctr->overflow_units * 64 > n_units)
-        t->stage_cap = 64; // a dense dictionary / text: the next scans stage 64 matches per unit
+    if (want && !g_ac_force_stage_cap)
+    {
+        // a dense dictionary / text: the next scans stage 64 matches per unit — or, when most units of a tiny dictionary hold more
+        // than that and the average is beyond 256 (`-e e -e t`: a thousand per unit), none at all: the first launch only counts (no masks kept, nothing staged)
+        // and the emit-mode launch writes every record
+        if (tiny && h_ctr->overflow_units * 2 > n_units && h_ctr->total > n_units * 256)
+            t->stage_cap = 0;
+        else if (t->stage_cap && h_ctr->overflow_units * 64 > n_units)
+            t->stage_cap = 64;
+    }
     const bool list_lines_valid = lines_on_list && want && !h_ctr->overflow_units && h_ctr->total <= want;
     const u64 list_lines = h_ctr->lines;
     if (want && h_ctr->overflow_units)
@@ -1142,7 +1186,7 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
         AcArgs e = a;
         e.emit_mode = 1;
         SCHK(hipMemsetAsync(&d_ctr->ticket, 0, sizeof(unsigned long long), st));
-        SCHK(ac_launch(e, grid, lds, st));
+        SCHK(launch(e));
         if (time_it) SCHK(hipEventRecord(ev1, st));
         SCHK(hipStreamSynchronize(st));
     }

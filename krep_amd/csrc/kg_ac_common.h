@@ -49,6 +49,22 @@ struct AcArgs
     u64 pos_cap;
 };
 
+// Tiny dictionaries (kg_ac_tiny.hip): every pattern 1..4 bytes, at most kTinyPer of each length, no duplicates.  The patterns
+// travel as kernel arguments, one dword each: byte s = the pattern byte s places before its END (folded under -i), and a
+// second dword of flags: bit s = that byte is a letter (-i compares it as (x | 0x20) == c).
+constexpr u32 kTinyPer = 4;
+constexpr int kTinyWaves = 4;  // small workgroups: 8 KiB of LDS per wave when records are wanted (the length words of a
+                               // 16-KiB unit), 4 KiB under -c, none for a count
+struct AcTiny
+{
+    u32 ok;           // the dictionary qualifies
+    u32 lmax, ncls;   // longest pattern; number of distinct lengths
+    u32 n[4];         // patterns of length 1, 2, 3, 4
+    u32 pk[4][kTinyPer];
+    u32 lf[4][kTinyPer];
+};
+hipError_t ac_tiny_launch(const AcArgs &a, const AcTiny &td, u64 n_tickets, u32 num_cu, hipStream_t st); // sizes its own grid
+
 __device__ __forceinline__ u32 ac_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 __device__ __forceinline__ u64 ac_rfl64(u64 v)
 {

@@ -1,0 +1,622 @@
+// kg_ac_tiny.hip — the multi-pattern scan (aho_corasick_search, /root/reference/aho_corasick.c:303-463) for TINY dictionaries:
+// every pattern 1..4 bytes long, at most kTinyPer patterns of each length, no duplicates (`-e he -e she -e hers`, `-e e -e t`).
+//
+// The general kernel (kg_ac.hip) looks every text position up in LDS tables and verifies candidates through hash probes: with
+// 1-3-byte patterns that is 2-3 table reads per position at stride 1 (the LDS pipe saturates near 3 TB/s) and, for a dense
+// dictionary, a memory round trip per hit.  Here the dictionary lives in SCALAR registers and the text is compared in vector
+// registers, four positions per dword:
+//   X_j = the lane's 16 bytes shifted by j bytes (byte e of X_j is text[e - j]; 3 x 4 v_alignbyte per 1-KiB cell),
+//   a pattern c_0 .. c_{L-1} ends at byte e  <=>  byte e of  V = (X_{L-1} ^ c_0c_0c_0c_0) | ... | (X_0 ^ c_{L-1}...)  is zero,
+//   one exact zero-byte test per pattern and dword (ac_eq_bytes), OR-ed into one flag word per LENGTH and dword.
+// Per cell and lane that leaves (a) a 16-bit mask of the END positions that hold a match, in position order, and (b) per
+// length a 16-bit mask in a scrambled order that costs 4 shifts instead of 4 multiplies (bit 8 b + w <-> position 4 w + b);
+// both go to LDS (10 KiB per wave: 12 waves per workgroup), and once per 16-KiB unit every lane walks the 256 positions it
+// owns and writes their matches — longest first, as the automaton's output chain reports them (aho_corasick.c:383-437) —
+// at the rank a wave prefix of the per-lane counts gives it.  No candidates, no probes, no text gathers: a dense dictionary
+// costs its record stores and nothing else.  Units, staging slots, info words, emit-mode re-scan and the post-pass are
+// those of the general kernel (ac_scan drives both).
+#include <algorithm>
+#include <atomic>
+#include <type_traits>
+
+#include "kg_ac_common.h"
+#include "kg_internal.h"
+
+namespace kg {
+
+bool ac_tiny_keeps(const AcArgs &a);
+constexpr int kTinyBlock = kTinyWaves * 64;
+constexpr u32 kTinyEntries = kAcUnitBytes / 16; // lane-cells of a unit (1024)
+
+__device__ __forceinline__ u32 tiny_scramble16(u32 m) // position-ordered 16 bits -> bit 8 b + w for position 4 w + b
+{
+    u32 f = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+        f |= ((((m >> (4 * w)) & 0xfu) * 0x00204081u) & 0x01010101u) << w;
+    return f;
+}
+
+// KEEP: the masks of a unit go to LDS (records are wanted, or -c counts lines); without it only their popcounts matter
+// EMIT: the emit-mode launch (final records of the units whose matches did not fit their staging slot; its own instantiation
+// because its record walk holds a unit's 32 length words in registers — in the streaming launch those registers spilled, and a
+// scratch reload waits in the same in-order vmcnt queue as the prefetched text: the pipeline drained once per unit)
+template <bool CI, bool LINES, bool KEEP, bool EMIT>
+__global__ __launch_bounds__(kTinyBlock, (KEEP && !EMIT) ? 2 : 3) void ac_tiny_kernel(const AcArgs a, const AcTiny td)
+{
+    extern __shared__ __attribute__((aligned(16))) u32 s_tiny[];
+    const u32 lane = ac_lane(), wave = threadIdx.x >> 6;
+    // per wave, -c: END mask + newline mask per lane-cell, position order (2 + 2 KiB); records: the length words per lane-cell (8 KiB)
+    //           + the staging slots (<= 64 words) and info words of a ticket's <= 8 units, parked until the ticket ends: a wave
+    //           stores nothing while it streams (on gfx9 a store waits in the same in-order vmcnt queue as the prefetched loads)
+    constexpr u32 kPark = kAcUnitsPerTicketMax * 64 + kAcUnitsPerTicketMax * 2;
+    constexpr u32 kPerWave = LINES ? kTinyEntries : kTinyEntries * 2 + kPark;
+    u32 *base = s_tiny + wave * kPerWave;
+    u32 *park_slots = base + kTinyEntries * 2;                                                     // [unit of the ticket][64]
+    u64 *park_info = reinterpret_cast<u64 *>(base + kTinyEntries * 2 + kAcUnitsPerTicketMax * 64); // [unit of the ticket]
+    unsigned short *h16 = reinterpret_cast<unsigned short *>(base);
+    unsigned short *n16 = reinterpret_cast<unsigned short *>(base + kTinyEntries / 2);
+    uint2 *cw = reinterpret_cast<uint2 *>(base);
+
+    const bool want_pos = (a.flags & F_POS) != 0;
+    const bool chain = want_pos || LINES;
+    constexpr bool emit_final = EMIT; // (== a.emit_mode != 0: ac_tiny_launch)
+    u64 acc_total = 0; // chain: wave total (uniform); else this LANE's hits (reduced once, at the end)
+    u64 ovf_units = 0; // units of this wave whose matches exceeded the staging slot, and the largest such count (lane 0's copy counts)
+    u32 ovf_max = 0;
+    static_assert(KEEP || !LINES, "-c keeps the masks");
+    static_assert(!EMIT || (KEEP && !LINES), "emit mode writes records");
+    u32 k7f;
+    asm volatile("v_mov_b32 %0, 0x7f7f7f7f" : "=v"(k7f)); // (a vector register on purpose: see the splats in the cell)
+    const u32 lmax = __builtin_amdgcn_readfirstlane(td.lmax);
+    const u32 n1 = __builtin_amdgcn_readfirstlane(td.n[0]), n2 = __builtin_amdgcn_readfirstlane(td.n[1]),
+              n3 = __builtin_amdgcn_readfirstlane(td.n[2]), n4 = __builtin_amdgcn_readfirstlane(td.n[3]);
+
+    for (;;)
+    {
+        u64 tk = 0;
+        if (lane == 0)
+            tk = __hip_atomic_fetch_add(&a.ctr->ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tk = ac_rfl64(tk);
+        const u64 u_begin = tk * (u64)a.upt;
+        if (u_begin >= a.num_tiles)
+            break;
+        const u64 u_end = (u_begin + a.upt < a.num_tiles) ? u_begin + a.upt : a.num_tiles;
+        uint4 d[kCells]; // the round about to be filtered (or on its way)
+        bool have = false;
+        u32 carry = 0;
+        for (u64 unit = u_begin; unit < u_end; ++unit)
+        {
+            const u64 useg = a.anchor + unit * (u64)kAcUnitBytes;
+            if (emit_final && (u32)(a.unitinfo[unit] & kUiCountMask) <= a.stage_cap)
+                continue;
+            const bool do_final = emit_final && want_pos, do_stage = !emit_final && want_pos;
+            u32 *slot = reinterpret_cast<u32 *>(a.stage) + unit * (u64)a.stage_cap;
+            // parked: staged matches and info words wait in LDS for the ticket's end (slots beyond 64 entries — a test hook — and
+            // tickets beyond 8 units do not fit: they store as they go)
+            const bool parked = KEEP && !LINES && do_stage && a.stage_cap <= 64u && a.upt <= kAcUnitsPerTicketMax;
+            const u64 fbase = do_final ? a.offsets[unit] : 0ull;
+            u32 mycnt = 0; // hits in the lane-cells this lane FILTERED (count-only modes)
+
+#pragma unroll 1
+            for (int r = 0; r < kAcRounds; ++r)
+            {
+                const u64 seg = useg + (u64)r * kSegBytes;
+                const bool fast_now = seg + kSegBytes <= a.text_len;
+                // interior: every END of the round lies in the launch's window, and so does the START of a 4-byte match at its
+                // first byte (starts own a match outside -c) — nothing to clip
+                const bool interior = seg >= a.own_lo + 3 && seg + kSegBytes <= a.own_hi && seg + kSegBytes <= a.end_hi;
+                const uint4 *src = reinterpret_cast<const uint4 *>(a.text + seg) + lane;
+                auto cell = [&](auto interC, const int j, const u32 (&D)[4], const u32 P) __attribute__((always_inline)) {
+                    constexpr bool inter = decltype(interC)::value, kp = KEEP;
+                    // The dictionary's shape, re-read through an empty asm in every cell: as loop-invariant booleans the ~20
+                    // conditions below were hoisted into 40 scalar registers, spilled to vector lanes and read back with
+                    // v_readlane before every branch; as fresh scalars each is one s_cmp in front of its branch.
+                    u32 c1 = n1, c2 = n2, c3 = n3, c4 = n4, lmx = lmax;
+                    asm volatile("" : "+s"(c1), "+s"(c2), "+s"(c3), "+s"(c4), "+s"(lmx));
+                    u32 NL = 0;
+                    if (LINES)
+                    {
+#pragma unroll
+                        for (int w = 0; w < 4; ++w)
+                            NL |= ac_movemask4(ac_eq_bytes(D[w], 0x0a0a0a0au)) << (4 * w);
+                    }
+                    // ---- the shifted copies of the lane's bytes: byte e of X[s][w] is text[lane base + 4 w + e - s], as far back
+                    //      as the longest pattern reaches (a class that uses X[s] exists only when lmax > s: never read undefined)
+                    u32 X[4][4];
+#pragma unroll
+                    for (int w = 0; w < 4; ++w)
+                        X[0][w] = D[w];
+                    if (lmx > 1u)
+                    {
+#pragma unroll
+                        for (int w = 0; w < 4; ++w)
+                            X[1][w] = __builtin_amdgcn_alignbyte(D[w], w ? D[w - 1] : P, 3u);
+                        if (lmx > 2u)
+                        {
+#pragma unroll
+                            for (int w = 0; w < 4; ++w)
+                                X[2][w] = __builtin_amdgcn_alignbyte(D[w], w ? D[w - 1] : P, 2u);
+                            if (lmx > 3u)
+                            {
+#pragma unroll
+                                for (int w = 0; w < 4; ++w)
+                                    X[3][w] = __builtin_amdgcn_alignbyte(D[w], w ? D[w - 1] : P, 1u);
+                            }
+                        }
+                    }
+                    // window of the launch (boundary rounds only), per length: the END in [end_lo, end_hi), never before byte L - 1
+                    // of the text, and (outside -c, where a match is owned by its start) the START in [own_lo, own_hi)
+                    const u32 lrel = (u32)j * kCellBytes + lane * 16u;
+                    auto clip = [&](u64 lo, u64 hi) -> u32 {
+                        const u32 rlo = lo > seg ? (u32)((lo - seg) < kSegBytes ? (lo - seg) : kSegBytes) : 0u;
+                        const u32 rhi = hi > seg ? (u32)((hi - seg) < kSegBytes ? (hi - seg) : kSegBytes) : 0u;
+                        const u32 klo = rlo > lrel ? ((rlo - lrel) < 16u ? (rlo - lrel) : 16u) : 0u;
+                        const u32 khi = rhi > lrel ? ((rhi - lrel) < 16u ? (rhi - lrel) : 16u) : 0u;
+                        return khi > klo ? (((1u << khi) - 1u) & ~((1u << klo) - 1u)) : 0u;
+                    };
+                    // ---- per length: 0x80 in every byte at which a pattern of that length ENDS.  One pattern = one scalar
+                    //      register (its bytes, last one lowest) + under -i one of letter flags; splats on the scalar unit.
+                    u32 HA[4] = {0u, 0u, 0u, 0u}, F[4] = {0u, 0u, 0u, 0u}; // any length, per dword | scrambled mask per length
+                    u32 m16 = 0;                                           // END mask in position order
+                    auto one = [&](auto Lc, u32 (&Z)[4], const bool first, const u32 pk, const u32 lf) __attribute__((always_inline)) {
+                        constexpr int L = decltype(Lc)::value;
+                        // the splats are made on the scalar unit and MOVED to vector registers: v_bitop3_b32 / v_and / v_xor with
+                        // vector operands only issue every ~2.2 cycles, with a scalar operand every ~3.7 (profiles/r04_valu_issue_rates.txt)
+                        u32 c[L], m[L];
+#pragma unroll
+                        for (int s = 0; s < L; ++s)
+                        {
+                            const u32 cs = ((pk >> (8 * s)) & 0xffu) * 0x01010101u;
+                            const u32 ms = ((lf >> s) & 1u) * 0x20202020u; // -i: a letter matches both of its cases, (x | 0x20) == c
+                            asm volatile("v_mov_b32 %0, %1" : "=v"(c[s]) : "s"(cs));
+                            if (CI)
+                                asm volatile("v_mov_b32 %0, %1" : "=v"(m[s]) : "s"(ms));
+                        }
+#pragma unroll
+                        for (int w = 0; w < 4; ++w)
+                        {
+                            u32 V = 0;
+#pragma unroll
+                            for (int s = 0; s < L; ++s) // s bytes before the end: pattern byte L - 1 - s
+                                V |= (CI ? (X[s][w] | m[s]) : X[s][w]) ^ c[s];
+                            const u32 z = ~(((V & k7f) + k7f) | V | k7f); // 0x80 in every zero byte, exact (ac_eq_bytes)
+                            Z[w] = first ? z : (Z[w] | z);
+                        }
+                    };
+                    auto cls = [&](auto Lc, const u32 n) __attribute__((always_inline)) {
+                        constexpr int L = decltype(Lc)::value;
+                        if (n) // (uniform, like the three below)
+                        {
+                            u32 Z[4];
+                            one(Lc, Z, true, td.pk[L - 1][0], td.lf[L - 1][0]);
+                            if (n > 1)
+                            {
+                                one(Lc, Z, false, td.pk[L - 1][1], td.lf[L - 1][1]);
+                                if (n > 2)
+                                {
+                                    one(Lc, Z, false, td.pk[L - 1][2], td.lf[L - 1][2]);
+                                    if (n > 3)
+                                        one(Lc, Z, false, td.pk[L - 1][3], td.lf[L - 1][3]);
+                                }
+                            }
+                            if (inter)
+                            {
+                                if (!kp)
+                                { // a count: the flags are all that is needed
+#pragma unroll
+                                    for (int w = 0; w < 4; ++w)
+                                        mycnt = __builtin_popcount(Z[w]) + mycnt; // (v_bcnt_u32_b32 adds its second operand)
+                                }
+                                else
+                                { // the length's mask in the scrambled order: 4 shifts instead of 4 multiplies
+                                    F[L - 1] = (Z[0] >> 7) | (Z[1] >> 6) | (Z[2] >> 5) | (Z[3] >> 4);
+                                    if (LINES) // (the line pass wants the ENDs in position order)
+                                    {
+#pragma unroll
+                                        for (int w = 0; w < 4; ++w)
+                                            HA[w] |= Z[w];
+                                    }
+                                }
+                            }
+                            else
+                            {
+                                u32 pm = 0;
+#pragma unroll
+                                for (int w = 0; w < 4; ++w)
+                                    pm |= ac_movemask4(Z[w]) << (4 * w);
+                                pm &= clip(a.end_lo, a.end_hi) & clip((u64)(L - 1), ~0ull);
+                                if (!LINES)
+                                    pm &= clip(a.own_lo + (u64)(L - 1), a.own_hi + (u64)(L - 1));
+                                m16 |= pm;
+                                F[L - 1] = tiny_scramble16(pm);
+                                mycnt += kp ? 0u : (u32)__popc(pm);
+                            }
+                        }
+                    };
+                    cls(std::integral_constant<int, 1>{}, c1);
+                    cls(std::integral_constant<int, 2>{}, c2);
+                    cls(std::integral_constant<int, 3>{}, c3);
+                    cls(std::integral_constant<int, 4>{}, c4);
+                    if (kp)
+                    {
+                        if (inter && LINES)
+                        { // END mask in position order: one multiply per dword
+#pragma unroll
+                            for (int w = 0; w < 4; ++w)
+                                m16 |= ac_movemask4(HA[w]) << (4 * w);
+                        }
+                        u32 nlm = NL;
+                        if (LINES && !inter)
+                            nlm &= clip(a.own_lo, a.own_hi);
+                        const u32 idx = (u32)r * (kSegBytes / 16) + (u32)j * kWave + lane;
+                        const u32 cwx = F[0] | (F[1] << 4), cwy = F[2] | (F[3] << 4);
+                        mycnt += (u32)(__popc(cwx) + __popc(cwy));
+                        if (LINES)
+                        {
+                            h16[idx] = (unsigned short)m16;
+                            n16[idx] = (unsigned short)nlm;
+                        }
+                        else
+                            cw[idx] = make_uint2(cwx, cwy);
+                    }
+                };
+                if (fast_now)
+                {
+                    // Rolling prefetch as in ac_scan_kernel: cell j of the NEXT round replaces cell j as soon as it has been copied
+                    // out, so a wave always has 8 KiB in flight.  The per-pattern code of a cell sits behind uniform branches,
+                    // but no path through it issues a load: the s_waitcnt counts stay static (the ragged round is a separate loop).
+                    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+                    auto ntload = [](const uint4 *p) -> uint4 { // nothing re-reads the text here: stream it past the caches
+                        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+                        return make_uint4(v.x, v.y, v.z, v.w);
+                    };
+                    u32 before = 0; // the 4 bytes in front of the round (uniform)
+                    if (have)
+                        before = carry;
+                    else
+                    {
+                        if (seg >= 4)
+                            before = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const u32 *>(a.text + seg - 4));
+#pragma unroll
+                        for (int j = 0; j < kCells; ++j)
+                            d[j] = ntload(src + j * kWave);
+                    }
+                    const bool pf_next = !emit_final && seg + 2 * (u64)kSegBytes <= a.text_len && (r + 1 < kAcRounds || unit + 1 < u_end);
+                    const uint4 *nsrc = pf_next ? src + kSegBytes / 16 : reinterpret_cast<const uint4 *>(a.text + seg); // (none: one cached line)
+                    auto cells = [&](auto interC) __attribute__((always_inline)) {
+#pragma unroll
+                        for (int j = 0; j < kCells; ++j)
+                        {
+                            const u32 D[4] = {d[j].x, d[j].y, d[j].z, d[j].w};
+                            d[j] = ntload(nsrc + j * kWave);
+                            const u32 P = (u32)__builtin_amdgcn_update_dpp((int)before, (int)D[3], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+                            before = __builtin_amdgcn_readlane(D[3], 63);
+                            cell(interC, j, D, P);
+                        }
+                    };
+                    if (interior) // two copies of the round: the window clipping of a boundary round costs the interior ones nothing
+                        cells(std::true_type{});
+                    else
+                        cells(std::false_type{});
+                    have = pf_next;
+                    carry = before;
+                }
+                else
+                {
+                    have = false;
+#pragma unroll 1
+                    for (int j = 0; j < kCells; ++j)
+                    { // the ragged end of the text: bytewise, bounds-checked (bytes outside read as 0 and are clipped in the cell)
+                        const u64 lbase = seg + (u64)j * kCellBytes + (u64)lane * 16u;
+                        u32 W[5];
+#pragma unroll
+                        for (int w = 0; w < 5; ++w)
+                        {
+                            u32 v = 0;
+                            for (int b = 0; b < 4; ++b)
+                            {
+                                const u64 o = lbase + (u64)(w * 4 + b);
+                                if (o >= 4 && o - 4 < a.text_len)
+                                    v |= (u32)a.text[o - 4] << (8 * b);
+                            }
+                            W[w] = v;
+                        }
+                        const u32 D[4] = {W[1], W[2], W[3], W[4]};
+                        cell(std::false_type{}, j, D, W[0]); // (a ragged round is a boundary round)
+                    }
+                }
+            } // rounds
+
+            u32 wcnt = 0; // matches of the unit (uniform)
+            if (KEEP && !LINES && want_pos) // (-c never asks for records: ac_scan)
+            {
+                // ---- records: lane L owns the lane-cells [16 L, 16 L + 16) = the unit's positions [256 L, 256 L + 256); their
+                //      length words come into registers, a wave prefix of the per-lane counts ranks them
+                uint4 q[EMIT ? 8 : 1];
+                u32 oc = 0, nz = 0; // nz: bit i = the lane's i-th lane-cell holds a match
+                {
+                    const uint4 *mine = reinterpret_cast<const uint4 *>(cw + 16u * lane);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                    {
+                        const uint4 v = mine[k];
+                        if (EMIT)
+                            q[k] = v;
+                        oc += (u32)(__popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w));
+                        nz |= ((v.x | v.y) ? 1u << (2 * k) : 0u) | ((v.z | v.w) ? 2u << (2 * k) : 0u);
+                    }
+                }
+                u32 incl = oc;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1)
+                {
+                    const u32 t = __shfl_up(incl, o);
+                    if (lane >= (u32)o)
+                        incl += t;
+                }
+                wcnt = __shfl(incl, 63);
+                const u32 at0 = incl - oc; // rank of this lane's first match in the unit
+                // the matches of one lane-cell in the reference's order — END ascending, longest first (aho_corasick.c:383-437):
+                // put(rank, start relative to the unit (>= -3), length)
+                auto cellwalk = [&](const u32 i, const u32 cx, const u32 cy, u32 &at, auto put) __attribute__((always_inline)) {
+                    // ENDs of the lane-cell in position order: bit 8 b + w of the any-length word is position 4 w + b
+                    const u32 hs = (cx | (cx >> 4) | cy | (cy >> 4)) & 0x0f0f0f0fu;
+                    u32 h = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                    { // bit w of the byte's nibble -> bit 4 w + b (shifts and ORs: a multiply would carry where two bits meet)
+                        const u32 x = (hs >> (8 * b)) & 0xfu;
+                        h |= ((x | (x << 3) | (x << 6) | (x << 9)) & 0x1111u) << b;
+                    }
+                    const int r0 = (int)((16u * lane + i) * 16u) + 1; // (one past the END of position 0 of the cell)
+                    while (h)
+                    {
+                        const u32 e = (u32)__builtin_ctz(h);
+                        h &= h - 1u;
+                        const u32 bit = 8u * (e & 3u) + (e >> 2);
+                        const int end1 = r0 + (int)e;
+                        if ((cy >> (bit + 4u)) & 1u) put(at++, end1 - 4, 4u);
+                        if ((cy >> bit) & 1u) put(at++, end1 - 3, 3u);
+                        if ((cx >> (bit + 4u)) & 1u) put(at++, end1 - 2, 2u);
+                        if ((cx >> bit) & 1u) put(at++, end1 - 1, 1u);
+                    }
+                };
+                if constexpr (!EMIT)
+                {
+                    // staging (a sparse dictionary: a few matches per unit): only the lane-cells that hold one, re-read from LDS
+                    // (through 64 words of LDS and out with ONE store of consecutive lanes: twenty scattered 4-byte stores per unit
+                    //  were a third of this kernel's time; slots beyond 64 entries — a test hook — take them directly)
+                    const bool via_lds = parked;
+                    u32 *sitems = park_slots + (u32)(unit - u_begin) * 64u;
+                    if (oc && at0 < a.stage_cap)
+                    {
+                        u32 at = at0;
+                        while (nz)
+                        {
+                            const u32 i = (u32)__builtin_ctz(nz);
+                            nz &= nz - 1u;
+                            const uint2 c2 = cw[16u * lane + i];
+                            cellwalk(i, c2.x, c2.y, at, [&](const u32 rk, const int srel, const u32 len) {
+                                if (rk < a.stage_cap)
+                                {
+                                    const u32 word = ((u32)(srel + 1024) << 11) | len; // as ac_scan_kernel stages them
+                                    if (via_lds)
+                                        sitems[rk] = word;
+                                    else
+                                        slot[rk] = word;
+                                }
+                            });
+                        }
+                    }
+                    // (parked: the slot leaves with the ticket, below)
+                }
+                if constexpr (EMIT)
+                {
+                    // final records (an overflowed unit, or every unit of a dense dictionary): 2048 at a time through LDS — the
+                    // length words are in registers now, their 8 KiB take the compact items — and out with consecutive lanes on
+                    // consecutive records (a lane storing its own run of records touches 64 different lines per instruction)
+                    u32 *items = reinterpret_cast<u32 *>(cw);
+                    for (u32 cb = 0; cb < wcnt; cb += 2048u)
+                    {
+                        if (oc && at0 < cb + 2048u && at0 + oc > cb)
+                        {
+                            u32 at = at0;
+#pragma unroll
+                            for (int i = 0; i < 16; ++i)
+                            {
+                                const u32 cx = (i & 1) ? q[i >> 1].z : q[i >> 1].x, cy = (i & 1) ? q[i >> 1].w : q[i >> 1].y;
+                                if (cx | cy)
+                                    cellwalk((u32)i, cx, cy, at, [&](const u32 rk, const int srel, const u32 len) {
+                                        if (rk - cb < 2048u)
+                                            items[rk - cb] = ((u32)(srel + 4) << 2) | (len - 1u);
+                                    });
+                            }
+                        }
+                        const u32 nitem = wcnt - cb < 2048u ? wcnt - cb : 2048u;
+                        for (u32 k = lane; k < nitem; k += 64u)
+                        {
+                            const u32 it = items[k];
+                            const u64 g = fbase + cb + k;
+                            if (g < a.pos_cap)
+                            {
+                                const u64 st = useg + (u64)(it >> 2) - 4u + a.global_base, en = st + (it & 3u) + 1u;
+                                *reinterpret_cast<uint4 *>(a.positions + 2 * g) = make_uint4((u32)st, (u32)(st >> 32), (u32)en, (u32)(en >> 32));
+                            }
+                        }
+                    }
+                }
+            }
+            else
+            {
+                if (chain) // -c: the unit's match count goes into its info word
+                {
+                    u32 c = mycnt;
+#pragma unroll
+                    for (int o = 32; o >= 1; o >>= 1)
+                        c += __shfl_xor(c, o);
+                    wcnt = c;
+                }
+                else
+                    acc_total += mycnt;
+            }
+
+            LS2 wls{0, false, false, false};
+            if (LINES)
+            {
+                // the distinct lines of the unit that hold a match END: ac_scan_kernel's line pass, on this lane's own masks
+#pragma unroll 1
+                for (int rj = 0; rj < kAcRounds * kCells; ++rj)
+                {
+                    const u32 H = h16[(u32)rj * kWave + lane], N = n16[(u32)rj * kWave + lane];
+                    const u64 anyhit = __ballot(H != 0u);
+                    const bool l_nl = N != 0u;
+                    const u64 B_nl = __ballot(l_nl);
+                    LS2 cell{0, B_nl != 0, false, false};
+                    if (anyhit)
+                    {
+                        const u32 S = ((N << 1) | 1u) & 0xffffu, Hs = H | N;
+                        const u32 firsts = H & Hs & ~(Hs - S);
+                        bool l_head, l_tail;
+                        if (l_nl)
+                        {
+                            const u32 lo_nl = N & (0u - N);
+                            l_head = (H & (lo_nl | (lo_nl - 1u))) != 0u;
+                            l_tail = (H >> (32 - __builtin_clz(N))) != 0u;
+                        }
+                        else
+                            l_head = l_tail = H != 0u;
+                        const u64 B_any = anyhit, B_tail = __ballot(l_tail), B_head = __ballot(l_head);
+                        const u64 lt = (1ull << lane) - 1ull;
+                        const u64 nl_below = B_nl & lt;
+                        bool open;
+                        if (nl_below)
+                        {
+                            const int q = 63 - __builtin_clzll(nl_below);
+                            open = ((B_tail >> q) & 1ull) || (B_any & lt & ~((2ull << q) - 1ull)) != 0;
+                        }
+                        else
+                            open = (B_any & lt) != 0;
+                        u32 lc = __popc(firsts) - ((open && l_head) ? 1u : 0u);
+#pragma unroll
+                        for (int o = 32; o >= 1; o >>= 1)
+                            lc += __shfl_xor(lc, o);
+                        cell.cnt = lc;
+                        if (cell.nl)
+                        {
+                            const int f = __builtin_ctzll(B_nl), l = 63 - __builtin_clzll(B_nl);
+                            cell.head = (B_any & ((1ull << f) - 1ull)) != 0 || ((B_head >> f) & 1ull);
+                            cell.tail = (l < 63 && (B_any >> (l + 1)) != 0) || ((B_tail >> l) & 1ull);
+                        }
+                        else
+                            cell.head = cell.tail = true;
+                    }
+                    wls = ls2_combine(wls, cell);
+                }
+            }
+
+            if (chain)
+                acc_total += wcnt;
+            if (chain && !emit_final && lane == 0)
+            {
+                u64 info = (u64)wcnt;
+                if (LINES)
+                    info |= (wls.nl ? kLnNl : 0) | (wls.head ? kLnHead : 0) | (wls.tail ? kLnTail : 0) |
+                            ((u64)(wls.cnt & kUiLineMask) << kUiLineShift);
+                else if (wcnt)
+                    info |= kLnHead | kLnTail;
+                if (parked)
+                    park_info[(u32)(unit - u_begin)] = info;
+                else
+                    a.unitinfo[unit] = info;
+                if (want_pos && wcnt > a.stage_cap)
+                { // (kept per wave: with a dense dictionary EVERY unit overflows, and two atomics per unit on one address serialise)
+                    ++ovf_units;
+                    ovf_max = wcnt > ovf_max ? wcnt : ovf_max;
+                }
+            }
+        }
+        if (KEEP && !LINES && want_pos && !emit_final && a.stage_cap <= 64u && a.upt <= kAcUnitsPerTicketMax)
+        { // the ticket's parked info words and staging slots, in a few stores of consecutive lanes
+            const u32 nun = (u32)(u_end - u_begin);
+            if (lane < nun)
+                a.unitinfo[u_begin + lane] = park_info[lane];
+            u32 *dst = reinterpret_cast<u32 *>(a.stage) + u_begin * (u64)a.stage_cap;
+            for (u32 k = lane; k < nun * a.stage_cap; k += 64u)
+                dst[k] = park_slots[(k / a.stage_cap) * 64u + k % a.stage_cap];
+        }
+    }
+    if (!chain)
+    { // count only: the lanes' own totals, reduced once
+        u64 c = acc_total;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1)
+            c += (u64)__shfl_xor((unsigned long long)c, o);
+        acc_total = c;
+    }
+    if (lane == 0 && acc_total && !a.emit_mode)
+        atomicAdd(&a.ctr->total, acc_total);
+    if (lane == 0 && ovf_units)
+    {
+        atomicAdd(&a.ctr->overflow_units, (unsigned long long)ovf_units);
+        atomicMax(&a.ctr->max_unit_count, (unsigned long long)ovf_max);
+    }
+}
+
+u32 ac_tiny_lds_bytes(bool lines, bool records)
+{
+    if (!lines && !records)
+        return 0; // a count: nothing is kept
+    return kTinyWaves * (lines ? kTinyEntries : kTinyEntries * 2 + kAcUnitsPerTicketMax * 66) * (u32)sizeof(u32);
+}
+// resident workgroups per CU: 12 waves by registers for the counting and the emit-mode instantiations, 8 for the ones that keep
+// a unit's masks AND stream (their record / line pass runs with the next round's prefetch in registers: under the 168-register
+// cap of 3 waves per SIMD it spilled, and a scratch access drains the in-order vmcnt queue of the prefetch — 2 waves per SIMD,
+// no scratch)
+u32 ac_tiny_blocks_per_cu(const AcArgs &a)
+{
+    const bool keep = ac_tiny_keeps(a), lines = (a.flags & F_LINES) != 0;
+    const u32 lds = keep ? ac_tiny_lds_bytes(lines, !lines) : 0u, by_regs = (keep && !a.emit_mode) ? 2u : 3u;
+    return lds ? std::min<u32>(by_regs, 160u * 1024u / lds) : by_regs;
+}
+
+template <bool CI, bool LN, bool KEEP, bool EMIT>
+static hipError_t tiny_launch3(const AcArgs &a, const AcTiny &td, u32 grid, hipStream_t st)
+{
+    constexpr int kMaxDev = 64; // (dynamic LDS beyond 64 KiB is granted once per instantiation and device: see ac_launch3)
+    static std::atomic<bool> granted[kMaxDev];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= kMaxDev || !granted[dev].load(std::memory_order_acquire))
+    {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ac_tiny_kernel<CI, LN, KEEP, EMIT>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess)
+            return e;
+        if (dev >= 0 && dev < kMaxDev)
+            granted[dev].store(true, std::memory_order_release);
+    }
+    hipLaunchKernelGGL((ac_tiny_kernel<CI, LN, KEEP, EMIT>), dim3(grid), dim3(kTinyBlock), KEEP ? ac_tiny_lds_bytes(LN, !LN) : 0u, st, a, td);
+    return hipGetLastError();
+}
+
+// records == false: a count — or the COUNT PASS of a dense dictionary (F_POS with stage_cap 0: every unit "overflows" an empty
+// staging slot and gets its records from the emit-mode launch; see ac_scan)
+bool ac_tiny_keeps(const AcArgs &a)
+{
+    return (a.flags & F_LINES) || ((a.flags & F_POS) && (a.emit_mode || a.stage_cap));
+}
+
+hipError_t ac_tiny_launch(const AcArgs &a, const AcTiny &td, u64 n_tickets, u32 num_cu, hipStream_t st)
+{
+    const u32 grid = (u32)std::min<u64>((n_tickets + kTinyWaves - 1) / kTinyWaves, (u64)num_cu * ac_tiny_blocks_per_cu(a));
+    const bool ci = a.flags & F_CI, ln = a.flags & F_LINES, keep = ac_tiny_keeps(a);
+    g_tiny_launches.fetch_add(1, std::memory_order_relaxed);
+    const bool emit = a.emit_mode != 0;
+    if (ln) return ci ? tiny_launch3<true, true, true, false>(a, td, grid, st) : tiny_launch3<false, true, true, false>(a, td, grid, st);
+    if (emit) return ci ? tiny_launch3<true, false, true, true>(a, td, grid, st) : tiny_launch3<false, false, true, true>(a, td, grid, st);
+    if (keep) return ci ? tiny_launch3<true, false, true, false>(a, td, grid, st) : tiny_launch3<false, false, true, false>(a, td, grid, st);
+    return ci ? tiny_launch3<true, false, false, false>(a, td, grid, st) : tiny_launch3<false, false, false, false>(a, td, grid, st);
+}
+
+} // namespace kg

@@ -437,6 +437,8 @@ int post_order(PostScratch &s, uint64_t n_units, uint32_t stage_cap, uint32_t fi
 {
     if (post_offsets_pass(s, n_units, want_lines, d_ctr, st))
         return 2;
+    if (stage_cap == 0 && pos_cap) // nothing was staged (kg_ac.hip: a dense tiny dictionary): every record comes from the emit-mode launch
+        return 0;
     return post_gather_pass(s, n_units, stage_cap, fixed_len, origin, unit_bytes, d_pos, pos_cap, num_cu, st);
 }
 

@@ -1,0 +1,160 @@
+"""GPU parity for TINY dictionaries (every pattern 1..4 bytes: krep_amd/csrc/kg_ac_tiny.hip) against the reference's
+aho_corasick_search: count, every (start, end) record and the emission order (end ascending, longest first —
+/root/reference/aho_corasick.c:383-437), -i, -c lines, -c -o, max_count, windows, staging overflow, dense hits."""
+import numpy as np
+import pytest
+
+import cases
+from krep_amd import abi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import krep_amd
+    e = krep_amd.load()
+    assert e.device_count() >= 1
+    return e
+
+
+def _check(gpu, o, text, pats, kw, tiny=True):
+    before = gpu.tiny_launches()
+    want = o.call(abi.RA_AHO_CORASICK, abi.Params(pats, **kw), text)
+    got = gpu.search(abi.Params(pats, **kw), text)
+    assert got[0] == want[0], (pats, kw, len(text), got[0], want[0])
+    assert np.array_equal(got[1], want[1]), (pats, kw, got[1][:8], want[1][:8])
+    if tiny is not None and len(text) and kw.get("max_count", 1) != 0:
+        assert (gpu.tiny_launches() > before) == tiny, (pats, kw, "tiny kernel expected" if tiny else "general kernel expected")
+
+
+def _distinct(rng, text, alpha, lens, k):
+    pats = []
+    for _ in range(50):
+        if len(pats) == k:
+            break
+        p = cases.pick_pattern(rng, text, lens[rng.randint(0, len(lens))], alpha)
+        if p not in pats and sum(len(q) == len(p) for q in pats) < 4:
+            pats.append(p)
+    return pats
+
+
+def test_the_textbook_dictionary(gpu, oracle_engine):
+    text = np.frombuffer(b"ushers and she said: hers, not his; he hesitated.\nSHE heard HERS\n" * 3000, dtype=np.uint8)
+    pats = [b"he", b"she", b"hers", b"his"]
+    for kw in (dict(), dict(case_sensitive=False), dict(count_lines=True), dict(count_lines=True, only_match=True),
+               dict(max_count=5), dict(case_sensitive=False, count_lines=True)):
+        _check(gpu, oracle_engine, text, pats, kw)
+    _check(gpu, oracle_engine, text, pats, dict(whole_word=True), tiny=False)  # -w stays on the general kernel
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_tiny_dictionaries(gpu, oracle_engine, seed):
+    rng = np.random.RandomState(900 + seed)
+    for it in range(30):
+        alpha = [b"ab", b"abc\n", b"abAB -\n", bytes(range(97, 105)) + b" \n", b"\x00\x01a\n"][it % 5]
+        n = [1, 3, 4, 17, 500, 8191, 8192, 8195, 16384, 16389, 40000, 140000, 300007][rng.randint(0, 13)]
+        text = cases.rand_text(rng, n, alpha)
+        lens = [[1], [2], [1, 2, 3, 4], [2, 3, 4], [2, 4], [1, 4], [1, 3]][rng.randint(0, 7)]
+        pats = _distinct(rng, text, alpha, lens, [2, 2, 3, 5, 8][rng.randint(0, 5)])
+        if len(pats) < 2 or min(len(p) for p in pats) > 2:
+            continue  # (one pattern is the literal scan's business; 3- and 4-byte patterns only: the general kernel's)
+        kw = dict(case_sensitive=bool(rng.rand() < 0.6), max_count=([abi.SIZE_MAX] * 4 + [1, 4, 77])[rng.randint(0, 7)])
+        mode = ["pos", "pos", "lines", "count"][rng.randint(0, 4)]
+        if not kw["case_sensitive"] and len({p.lower() for p in pats}) != len(pats):
+            continue  # duplicates after folding: the general kernel (covered by test_gpu_ac.py)
+        if mode == "lines":
+            if any(b"\n" in p for p in pats):
+                continue
+            kw.update(count_lines=True)
+        elif mode == "count":
+            kw.update(count_lines=True, only_match=True)
+        _check(gpu, oracle_engine, text, pats, kw)
+
+
+def test_dense_hits_overflow_every_staging_slot(gpu, oracle_engine):
+    rng = np.random.RandomState(7)
+    text = cases.rand_text(rng, 1 << 20, b"etaoin shrdlu\n")
+    for pats in ([b"e", b"t"], [b"e", b"th", b"t", b"he"], [b"a", b"ao", b"tao", b"etao"]):  # (0.5 to 0.15 matches per byte)
+        _check(gpu, oracle_engine, text, pats, dict())
+        _check(gpu, oracle_engine, text, pats, dict(count_lines=True))
+        _check(gpu, oracle_engine, text, pats, dict(count_lines=True, only_match=True))
+    try:
+        gpu.force_stage_cap(4)
+        _check(gpu, oracle_engine, text[:200_000], [b"sh", b"rd", b"lu\n"], dict())
+        _check(gpu, oracle_engine, text[:200_000], [b"s", b"rd", b"dlu"], dict(case_sensitive=False))
+    finally:
+        gpu.force_stage_cap(0)
+
+
+def test_windows_and_shards_own_every_match_once(gpu, oracle_engine):
+    """search_buffer over N logical shards (start-offset ownership, /root/reference/krep.c:2729-2770): every match once."""
+    rng = np.random.RandomState(11)
+    text = cases.rand_text(rng, 200_003, b"abc \n")
+    pats = [b"a", b"ab", b"cab", b"abca"]
+    p = abi.Params(pats)
+    want = oracle_engine.call(abi.RA_AHO_CORASICK, p, text)
+    for shards in (2, 3, 7):
+        before = gpu.tiny_launches()
+        rc, n, pos = gpu.search_buffer(p, text, num_gpus=shards)
+        assert rc == 0 and n == want[0], (shards, rc, n, want[0])
+        assert np.array_equal(pos, want[1]), shards
+        assert gpu.tiny_launches() > before
+    pl = abi.Params(pats, count_lines=True)
+    wl = oracle_engine.call(abi.RA_AHO_CORASICK, pl, text)
+    for shards in (2, 5):
+        rc, n, _ = gpu.search_buffer(pl, text, num_gpus=shards)
+        assert rc == 0 and n == wl[0], (shards, n, wl[0])
+
+
+def test_nul_bytes_never_match_in_front_of_the_text(gpu, oracle_engine):
+    text = np.frombuffer(b"\x00\x00a\x00\x00\x00b" + b"\x00" * 40 + b"a\x00", dtype=np.uint8)
+    for pats in ([b"\x00", b"b"], [b"\x00\x00", b"b\x00"], [b"\x00\x00\x00\x00", b"\x00a"], [b"\x00\x00\x00", b"a\x00"], [b"\x00\x00\x00\x00", b"\x00"]):
+        _check(gpu, oracle_engine, text, pats, dict())
+        _check(gpu, oracle_engine, text, pats, dict(count_lines=True, only_match=True))
+
+
+def test_general_kernel_when_the_dictionary_does_not_qualify(gpu, oracle_engine):
+    rng = np.random.RandomState(3)
+    text = cases.rand_text(rng, 50_000, b"abcd \n")
+    _check(gpu, oracle_engine, text, [b"ab", b"abcda"], dict(), tiny=False)                       # a 5-byte pattern
+    _check(gpu, oracle_engine, text, [b"a", b"b", b"c", b"d", b" "], dict(), tiny=False)          # five of one length
+    _check(gpu, oracle_engine, text, [b"ab", b"ab"], dict(), tiny=False)                          # a duplicate
+    _check(gpu, oracle_engine, text, [b"abc", b"bcd", b"cdab"], dict(), tiny=False)               # nothing shorter than 3 bytes
+
+
+def test_a_plan_learns_that_its_dictionary_is_dense(gpu, oracle_engine):
+    """The second and later scans of a plan whose units all overflowed their staging slots run as a count pass plus an
+    emit-mode pass that writes every record (kg_ac.hip, ac_scan): same count, same records, same order, every time — also
+    through ownership windows (/root/reference/krep.c:2729-2770) and with a list capacity below the count."""
+    import torch
+    rng = np.random.RandomState(21)
+    text = cases.rand_text(rng, (1 << 20) + 12345, b"etaoin shrdlu\n")
+    d = torch.from_numpy(text).cuda()
+    n = text.size
+    for pats, kw in (([b"e", b"t"], dict()), ([b"t", b"ao", b"in "], dict(case_sensitive=False))):
+        want = oracle_engine.call(abi.RA_AHO_CORASICK, abi.Params(pats, **kw), text)
+        plan = gpu.plan(abi.Params(pats, **kw))
+        cap = int(want[0]) + 5
+        pos = torch.zeros(2 * cap, dtype=torch.int64, device="cuda")
+        for rep in range(4):
+            pos.zero_()
+            out = plan.scan(d.data_ptr(), n, 0, n, 0, pos.data_ptr(), cap)
+            assert out.count == want[0], (pats, rep, out.count, want[0])
+            got = pos[:2 * out.count].cpu().numpy().astype(np.uint64).reshape(-1, 2)
+            assert np.array_equal(got, want[1]), (pats, rep)
+        # windows: three pieces owned by start offset concatenate to the whole list
+        cuts = [0, 300_001, 700_007, n]
+        acc = []
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            pos.zero_()
+            out = plan.scan(d.data_ptr(), n, lo, hi, 0, pos.data_ptr(), cap)
+            acc.append(pos[:2 * out.count].cpu().numpy().astype(np.uint64).reshape(-1, 2))
+        assert np.array_equal(np.concatenate(acc), want[1]), pats
+        # a list shorter than the count: the first `small` records, the full count
+        small = 1000
+        pos.zero_()
+        out = plan.scan(d.data_ptr(), n, 0, n, 0, pos.data_ptr(), small)
+        assert out.count == want[0] and out.overflow
+        assert np.array_equal(pos[:2 * small].cpu().numpy().astype(np.uint64).reshape(-1, 2), want[1][:small]), pats
+        plan.close()
