@@ -738,6 +738,8 @@ void run_device(DeviceRun *dr)
 }
 } // namespace
 
+constexpr size_t kChainTailPiece = 256u << 10; // the piece that holds the end of the text, chained multi-shard runs (run_pieces)
+
 static int run_pieces(const search_params_t *params, const krep_gpu_config_t &cfg, const char *buf, size_t len, int num_gpus,
                       size_t chunk, match_result_t *out, uint64_t *ret_out)
 {
@@ -784,6 +786,21 @@ static int run_pieces(const search_params_t *params, const krep_gpu_config_t &cf
     }
     const bool want_pos = params->track_positions && out != nullptr && !params->count_lines_mode;
     const bool chain = kg::split_mode(params, cfg, len) == kSplitChain;
+    if (chain && G > 1 && !pcs.empty() && pcs.back().hi == len && pcs.back().hi - pcs.back().lo > 2 * kChainTailPiece)
+    {
+        // Sequential families over several shards: the piece that ENDS the text is the only one whose result depends on the
+        // line-skip history of everything in front of it (the end-of-text replay, kg_replay.h) — and every shard starts from a
+        // zero record, so whenever an earlier shard held an accepted occurrence that piece is staged and scanned again below.
+        // Its last 256 KiB become a piece of their own (same device, scanned behind its neighbour with that neighbour's record):
+        // the repeat then costs 256 KiB, not a shard.
+        Piece t = pcs.back();
+        Piece &big = pcs.back();
+        big.hi = len - kChainTailPiece;
+        big.b1 = std::min(len, big.hi + ctx);
+        t.lo = big.hi;
+        t.b0 = t.lo > ctx ? t.lo - ctx : 0;
+        pcs.push_back(std::move(t));
+    }
     // one worker per PHYSICAL device (several logical shards may share one on a small box)
     std::vector<DeviceRun> runs;
     for (Piece &p : pcs)
