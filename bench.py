@@ -209,6 +209,7 @@ def cpu_baseline(wl, sample_bytes, d_buf):
                         f"backend wired in, forced onto the GPU; wall clock of the whole process incl. HIP runtime start, mmap, PCIe; "
                         f"best of 3, stdout={o_gpu}",
                     same_output_as_cpu_cli=(o_gpu == o_cpu),  # (the reference's own chunked path counts a match in a chunk overlap twice)
+                    **({} if o_gpu == o_cpu else {"output_note": "the CPU CLI ran its threaded path, which counts a match inside a chunk overlap twice (krep.c:2952); the backend reproduces the single-chunk count (tests/ compare against that)"}),
                     with_cost_model=dict(value=round(nb / t_auto / 1e9, 3), seconds=round(t_auto, 4), stdout_same=(o_auto == o_cpu),
                                          cmd="KREP_GPU=1 (krep_gpu_worthwhile()'s cost model decides per file)"),
                     cost_model_estimate=dict(gpu_seconds=round(fresh_gpu, 4), cpu_seconds=round(est.cpu_seconds, 4),

@@ -25,6 +25,10 @@
 namespace kg {
 
 bool ac_tiny_keeps(const AcArgs &a);
+#ifndef KG_TINY_KEEP_WAVES
+#define KG_TINY_KEEP_WAVES 2
+#endif
+#define KG_TINY_KEEP_WAVES_ARG ((KEEP && !EMIT) ? KG_TINY_KEEP_WAVES : 3)
 constexpr int kTinyBlock = kTinyWaves * 64;
 constexpr u32 kTinyEntries = kAcUnitBytes / 16; // lane-cells of a unit (1024)
 
@@ -42,7 +46,7 @@ __device__ __forceinline__ u32 tiny_scramble16(u32 m) // position-ordered 16 bit
 // because its record walk holds a unit's 32 length words in registers — in the streaming launch those registers spilled, and a
 // scratch reload waits in the same in-order vmcnt queue as the prefetched text: the pipeline drained once per unit)
 template <bool CI, bool LINES, bool KEEP, bool EMIT>
-__global__ __launch_bounds__(kTinyBlock, (KEEP && !EMIT) ? 2 : 3) void ac_tiny_kernel(const AcArgs a, const AcTiny td)
+__global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_kernel(const AcArgs a, const AcTiny td)
 {
     extern __shared__ __attribute__((aligned(16))) u32 s_tiny[];
     const u32 lane = ac_lane(), wave = threadIdx.x >> 6;
@@ -337,7 +341,7 @@ __global__ __launch_bounds__(kTinyBlock, (KEEP && !EMIT) ? 2 : 3) void ac_tiny_k
                 u32 oc = 0, nz = 0; // nz: bit i = the lane's i-th lane-cell holds a match
                 {
                     const uint4 *mine = reinterpret_cast<const uint4 *>(cw + 16u * lane);
-#pragma unroll
+#pragma unroll(EMIT ? 8 : 2) // (streaming launch: two reads in flight, not eight — 24 registers less beside the text prefetch)
                     for (int k = 0; k < 8; ++k)
                     {
                         const uint4 v = mine[k];
@@ -576,7 +580,7 @@ u32 ac_tiny_lds_bytes(bool lines, bool records)
 u32 ac_tiny_blocks_per_cu(const AcArgs &a)
 {
     const bool keep = ac_tiny_keeps(a), lines = (a.flags & F_LINES) != 0;
-    const u32 lds = keep ? ac_tiny_lds_bytes(lines, !lines) : 0u, by_regs = (keep && !a.emit_mode) ? 2u : 3u;
+    const u32 lds = keep ? ac_tiny_lds_bytes(lines, !lines) : 0u, by_regs = (keep && !a.emit_mode) ? (u32)KG_TINY_KEEP_WAVES : 3u;
     return lds ? std::min<u32>(by_regs, 160u * 1024u / lds) : by_regs;
 }
 
