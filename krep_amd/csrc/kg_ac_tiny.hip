@@ -82,17 +82,23 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
         if (lane == 0)
             tk = __hip_atomic_fetch_add(&a.ctr->ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         tk = ac_rfl64(tk);
-        const u64 u_begin = tk * (u64)a.upt;
+        // (emit mode draws groups of 64 units and looks at all their info words at once: one load per lane and a ballot instead
+        //  of a dependent load per unit)
+        const u64 upt = EMIT ? 64ull : (u64)a.upt;
+        const u64 u_begin = tk * upt;
         if (u_begin >= a.num_tiles)
             break;
-        const u64 u_end = (u_begin + a.upt < a.num_tiles) ? u_begin + a.upt : a.num_tiles;
+        const u64 u_end = (u_begin + upt < a.num_tiles) ? u_begin + upt : a.num_tiles;
+        u64 em_mask = 0;
+        if (EMIT)
+            em_mask = __ballot(u_begin + lane < u_end && (u32)(a.unitinfo[u_begin + lane] & kUiCountMask) > a.stage_cap);
         uint4 d[kCells]; // the round about to be filtered (or on its way)
         bool have = false;
         u32 carry = 0;
         for (u64 unit = u_begin; unit < u_end; ++unit)
         {
             const u64 useg = a.anchor + unit * (u64)kAcUnitBytes;
-            if (emit_final && (u32)(a.unitinfo[unit] & kUiCountMask) <= a.stage_cap)
+            if (emit_final && !((em_mask >> (u32)(unit - u_begin)) & 1ull))
                 continue;
             const bool do_final = emit_final && want_pos, do_stage = !emit_final && want_pos;
             u32 *slot = reinterpret_cast<u32 *>(a.stage) + unit * (u64)a.stage_cap;

@@ -177,9 +177,32 @@ __global__ __launch_bounds__(kBlock, (KIND == 1 && LINES && R == 4) ? KG_LIT1_LI
     const u64 n_units = a.num_tiles * kWavesPerBlk;
     // (a.upt == 0, texts below 512 MiB: the static interleaved deal — such a scan lasts < 100 us, the ticket word would be its limit)
     u64 tk_next = (u64)blockIdx.x * kWavesPerBlk + wave, tk_end = a.upt ? tk_next : ~0ull;
+    // Emit mode (re-scan of the units that overflowed their staging slot) draws GROUPS of 64 units: one info word per lane, a
+    // ballot of the overflowed ones.  Walking the units one dependent load at a time cost the launch 1.6 ms per million units
+    // even when three of them had overflowed (`-i sh`, 32 GiB).
+    u64 em_base = 0, em_mask = 0;
     for (;;)
     {
-        if (a.upt && tk_next == tk_end)
+        if (a.emit_mode)
+        {
+            while (!em_mask)
+            {
+                u64 g = 0;
+                if (lane == 0)
+                    g = __hip_atomic_fetch_add(&a.ctr->ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                em_base = rfl64(g) * 64ull;
+                if (em_base >= n_units)
+                    break;
+                const u64 u = em_base + lane;
+                em_mask = __ballot(u < n_units && (u32)(a.unitinfo[u] & kUiCountMask) > a.stage_cap);
+            }
+            if (!em_mask)
+                break;
+            tk_next = em_base + (u64)__builtin_ctzll(em_mask);
+            em_mask &= em_mask - 1ull;
+            tk_end = ~0ull;
+        }
+        else if (a.upt && tk_next == tk_end)
         {
             u64 tk = 0;
             if (lane == 0)
@@ -197,8 +220,6 @@ __global__ __launch_bounds__(kBlock, (KIND == 1 && LINES && R == 4) ? KG_LIT1_LI
         if (unit >= n_units)
             break; // tickets (and the static stride) ascend: nothing is left for this wave
         const u64 ubase = a.anchor + unit * kUnitBytes;
-        if (a.emit_mode && (u32)(a.unitinfo[unit] & kUiCountMask) <= a.stage_cap)
-            continue; // wave-uniform: only overflowed units are re-scanned
 
         // KIND 1 (single byte, ~330 hits per unit at 1 %): every cell holds hits, so the masks are kept and written out in one go
         // at the unit's end (inline stores between the loads cost it 7 %); the sparse kinds write their rare hits where they find them

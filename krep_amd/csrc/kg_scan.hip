@@ -247,8 +247,19 @@ static int lit_pass(krep_gpu_plan *pl, const Window &w, const LitPass &ps, hipSt
         if (ps.ev_end) HIPCHK(hipEventRecord(ps.ev_end, st));
         HIPCHK(hipMemcpyAsync(pl->h_ctr, pl->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        if ((a.flags & F_POS) && m_scan != 1 && a.rounds == kRoundsBig && pl->h_ctr->overflow_units * 64 > n_units)
-            pl->sparse_cap = 64; // a dense input: the next scans of this plan stage 64 hits per unit
+        if ((a.flags & F_POS) && m_scan != 1 && a.rounds == kRoundsBig && pl->h_ctr->overflow_units * 64 > n_units && !fsc)
+        {
+            // a dense input: the next scans of this plan stage 64 hits per unit — and if more than 1 unit in 64 overflows that as
+            // well (`-i sh`: 36 hits per unit on average, clustered), as many as the fullest unit held, up to 256: re-scanning
+            // 5 % of the units cold cost m = 2 -i a fifth of its time
+            uint32_t want = 64;
+            if (pl->sparse_cap >= 64)
+                for (want = 128; want < 256 && want < pl->h_ctr->max_unit_count; want *= 2) {}
+            pl->sparse_cap = std::max(pl->sparse_cap, want);
+        }
+        if (getenv("KREP_GPU_DEBUG") && (a.flags & F_POS))
+            fprintf(stderr, "krep-gpu: literal scan: %llu of %llu units overflowed a %u-entry slot (fullest: %llu)\n", pl->h_ctr->overflow_units,
+                    (unsigned long long)n_units, a.stage_cap, pl->h_ctr->max_unit_count);
         if ((a.flags & F_POS) && pl->h_ctr->overflow_units)
         {
             // some units held more hits than their staging slot: re-scan exactly those, writing in place

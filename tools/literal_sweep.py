@@ -27,7 +27,7 @@ for m in lens:
             row.append(f"{name}: n/a")
             continue
         best = 1e9
-        for _ in range(3):
+        for _ in range(int(os.environ.get("LS_REPS", "3"))):
             out = plan.scan(buf.data_ptr(), n, 0, n, 0, pos.data_ptr() if want_pos else 0, cap if want_pos else 0, time_it=True)
             best = min(best, out.kernel_ms)
         row.append(f"{name}: {n / best / 1e6:5.0f} ({out.count})")
