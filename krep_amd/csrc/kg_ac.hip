@@ -631,6 +631,12 @@ struct AcTables
     u32 g4x_mode = 0, g4x_mask = 0, g4x_mul = 0;
     u32 stage_cap = 16; // staged matches per unit (16, raised to 64 by a scan whose units overflowed; see ac_scan)
     AcTiny tiny{};      // ok: the dictionary runs in kg_ac_tiny.hip (every pattern <= 4 bytes, few of them)
+    // a dictionary of 2..4 distinct single bytes: with records it is the one-pass single-byte scan with a needle SET
+    // (kg_single.hip: records at their final index, nothing staged) — until a scan proves too dense for its largest rings
+    u32 set_n = 0;
+    uint8_t set_b[4] = {0, 0, 0, 0};
+    bool set_ok = true;
+    int set_shape = 0;
 };
 
 #define ACHK(x)                                                                                \
@@ -729,6 +735,12 @@ AcTables *ac_build(const search_params_t &sp, int device)
         for (int L = 0; L < 4; ++L)
             td.ncls += td.n[L] ? 1u : 0u;
         td.ok = ok ? 1u : 0u;
+        if (ok && t->lmax == 1 && pats.size() >= 2 && pats.size() <= 4)
+        {
+            t->set_n = (u32)pats.size();
+            for (size_t i = 0; i < pats.size(); ++i)
+                t->set_b[i] = pats[i][0];
+        }
     }
     // ---- reversed trie ----
     std::unordered_map<u32, u32> edge; // key = node << 8 | byte
@@ -1130,6 +1142,87 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
         a.flags |= F_POS;
     a.positions = (u64 *)d_pos;
     a.pos_cap = want;
+    // ---- a dictionary of single bytes, records wanted: memchr_search's one-pass kernel with a needle set (kg_single.hip).  The
+    // matches of aho_corasick_search for such a dictionary are one (i, i + 1) per matching position in text order
+    // (aho_corasick.c:383-437) — exactly that kernel's records.  Shapes by counted density as in lit_pass (kg_scan.hip).
+    if (t->set_n && want && !ww && !lines_on_list && t->set_ok && text_len >= (size_t)16 * kSegBytes && !g_ac_force_stage_cap &&
+        !getenv("KREP_GPU_NO_FUSED1") && !getenv("KREP_GPU_AC_NO_TINY"))
+    {
+        LitArgs la{};
+        la.text = d_text;
+        la.text_len = text_len;
+        la.own_lo = own_lo;
+        la.own_hi = own_hi;
+        la.anchor = own_lo & ~(u64)15;
+        la.rounds = kRoundsBig;
+        const u64 tile_bytes = (u64)kRoundsBig * kSegBytes * kWavesPerBlk;
+        la.num_tiles = (own_hi - la.anchor + tile_bytes - 1) / tile_bytes;
+        la.global_base = global_base;
+        la.ww_exempt_left = ~0ull;
+        la.m = 1;
+        la.flags = (t->ci ? F_CI : 0) | F_POS;
+        la.ctr = d_ctr;
+        la.positions = (uint64_t *)d_pos;
+        la.pos_cap = want;
+        la.set_n = t->set_n;
+        for (u32 k = 0; k < t->set_n; ++k)
+        {
+            la.set_p[k] = 0x01010101u * t->set_b[k];
+            la.set_l[k] = (t->ci && t->set_b[k] >= 'a' && t->set_b[k] <= 'z') ? 0x20202020u : 0u;
+        }
+        la.p0 = la.set_p[0];
+        la.l0 = la.set_l[0];
+        la.k0 = 0xffu;
+        const u64 units32 = la.num_tiles * kWavesPerBlk;
+        SCHK(hipSetDevice(t->device));
+        if (time_it) SCHK(hipEventRecord(ev0, st));
+        for (;;)
+        {
+            const int shape = t->set_shape;
+            const u64 n_tk = single_fused_tickets(units32, shape);
+            if (n_tk > post.tk_cap)
+            {
+                if (post.d_tk) (void)hipFree(post.d_tk);
+                post.d_tk = nullptr;
+                post.tk_cap = 0;
+                SCHK(hipMalloc(&post.d_tk, single_fused_scratch_words(n_tk) * sizeof(unsigned long long)));
+                post.tk_cap = n_tk;
+            }
+            SCHK(hipMemsetAsync(d_ctr, 0, sizeof(Counters), st));
+            SCHK(hipMemsetAsync(post.d_tk, 0, single_fused_scratch_words(n_tk) * sizeof(unsigned long long), st));
+            SCHK(launch_single_fused(la, post.d_tk, post.d_tk + n_tk, n_tk, (u32)num_cu, shape, st));
+            if (time_it) SCHK(hipEventRecord(ev1, st));
+            SCHK(hipMemcpyAsync(h_ctr, d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, st));
+            SCHK(hipStreamSynchronize(st));
+            if (!h_ctr->overflow_units)
+            {
+                if (time_it)
+                {
+                    float ms = 0;
+                    SCHK(hipEventElapsedTime(&ms, ev0, ev1));
+                    out->kernel_ms = ms;
+                }
+                const u64 total = h_ctr->total;
+                out->total_matches = total;
+                out->head_line_hit = out->tail_line_hit = total != 0;
+                out->count = std::min<u64>(total, (u64)max_count);
+                if (track)
+                {
+                    out->stored = std::min<u64>(out->count, want);
+                    out->overflow = out->count > cap;
+                }
+                return 0;
+            }
+            const double density = (double)h_ctr->total / (double)(own_hi - la.anchor);
+            int next = shape + 1;
+            while (next <= 2 && density > single_fused_max_density(next))
+                ++next;
+            if (next > 2 || h_ctr->total == 0)
+                break;
+            t->set_shape = next;
+        }
+        t->set_ok = false; // denser than the largest rings hold: the register-compare kernel below, for good
+    }
     const bool chain = want || lines;
     const u64 n_units = a.num_tiles;
     // 16 staged matches (32-bit words: unit-relative start + length) = one 64-byte slot per 16 KiB unit; BASELINE config 4 puts 5.3

@@ -68,6 +68,8 @@ struct LitArgs {
     uint32_t p0, p1, k0, k1;      // first <=8 pattern bytes (folded when F_CI) and their byte masks
     uint32_t p2, p3, k2, k3, l2, l3; // pattern bytes 8..15 (m = 9..16 verify in registers), their byte and letter masks
     uint32_t l0, l1;              // F_CI: 0x20 in the byte lanes where the (folded) pattern holds a letter — (x | l) == p
+    uint32_t set_n;               // kg_single.hip: a byte SET of set_n (2..4) needles instead of the one byte p0 (0 = no set)
+    uint32_t set_p[4], set_l[4];  // ... their splats and (F_CI) letter masks
                                   // is the C-locale case-insensitive compare of that byte (one OR instead of folding the text)
     const uint8_t *pat;           // device copy of the (folded) pattern, for m > 8
     const unsigned long long *pat_chunks; // m > 8: (folded) pattern bytes [q_k, q_k + 8), q_k = min(8 + 8k, m - 8), 8-byte aligned

@@ -19,10 +19,11 @@ bool inject(int kind);                   // test hook: is failure `kind` being i
 hipError_t launch_literal(const LitArgs &a, uint32_t num_cu, hipStream_t st); // grid = resident blocks of the variant x CUs
 
 // kg_single.hip — single byte with records in one pass (counts resolved by one wave, records written a ticket later)
-uint64_t single_fused_tickets(uint64_t n_units);
+uint64_t single_fused_tickets(uint64_t n_units, int shape);
 uint64_t single_fused_scratch_words(uint64_t n_tickets);
+double single_fused_max_density(int shape); // hits per byte a shape's rings are sure to hold (shape 0 / 1 / 2: ~1.2 / 5 / 10 %)
 hipError_t launch_single_fused(const LitArgs &a, unsigned long long *d_agg, unsigned long long *d_pref, uint64_t n_tickets,
-                               uint32_t num_cu, hipStream_t st);
+                               uint32_t num_cu, int shape, hipStream_t st);
 
 // kg_post.hip — ordering post-pass shared by the literal and Aho-Corasick scans
 struct PostScratch

@@ -196,33 +196,47 @@ static int lit_pass(krep_gpu_plan *pl, const Window &w, const LitPass &ps, hipSt
     res->unit_bytes = unit_bytes;
     res->anchor = a.anchor;
     // ---- single byte with records (memchr_search, BASELINE config 3): ONE pass, the records written by the scanning waves
-    // at their final index (kg_single.hip) — no staging, no info words, no post-pass.  Too dense for its LDS rings (> ~1.5 %
-    // hits): counted but not recorded; the two-pass kernels below take this scan and the plan's later ones.
+    // at their final index (kg_single.hip) — no staging, no info words, no post-pass.  A scan too dense for the rings of its
+    // shape is counted but not recorded: the count picks the shape that holds it (up to ~10 % hits) and the scan runs again in
+    // that shape — the plan keeps it; beyond that the two-pass kernels below take this scan and the plan's later ones.
     if (m_scan == 1 && ps.sink == LitPass::RECORDS && !ps.ww && !ps.lines && !ps.first_byte && a.rounds == kRoundsBig && fsc == 0 &&
         ps.excl_lo == ps.excl_hi && pl->fused1_ok && w.text_len >= 2 * (size_t)kSegBytes && !getenv("KREP_GPU_NO_FUSED1"))
     {
-        const uint64_t n_tk = single_fused_tickets(n_units);
-        if (n_tk > post.tk_cap)
-        {
-            if (post.d_tk) (void)hipFree(post.d_tk);
-            post.d_tk = nullptr;
-            post.tk_cap = 0;
-            HIPCHK(hipMalloc(&post.d_tk, single_fused_scratch_words(n_tk) * sizeof(unsigned long long)));
-            post.tk_cap = n_tk;
-        }
         a.positions = ps.d_out;
         a.pos_cap = ps.out_cap;
-        HIPCHK(hipMemsetAsync(pl->d_ctr, 0, sizeof(Counters), st));
-        HIPCHK(hipMemsetAsync(post.d_tk, 0, single_fused_scratch_words(n_tk) * sizeof(unsigned long long), st));
-        HIPCHK(launch_single_fused(a, post.d_tk, post.d_tk + n_tk, n_tk, grid, st));
-        if (ps.ev_end) HIPCHK(hipEventRecord(ps.ev_end, st));
-        HIPCHK(hipMemcpyAsync(pl->h_ctr, pl->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        if (!pl->h_ctr->overflow_units)
+        for (;;)
         {
-            res->total = pl->h_ctr->total;
-            res->summary = res->total ? (kLnHead | kLnTail) : 0;
-            return 0;
+            const int shape = pl->fused1_shape;
+            const uint64_t n_tk = single_fused_tickets(n_units, shape);
+            if (n_tk > post.tk_cap)
+            {
+                if (post.d_tk) (void)hipFree(post.d_tk);
+                post.d_tk = nullptr;
+                post.tk_cap = 0;
+                HIPCHK(hipMalloc(&post.d_tk, single_fused_scratch_words(n_tk) * sizeof(unsigned long long)));
+                post.tk_cap = n_tk;
+            }
+            HIPCHK(hipMemsetAsync(pl->d_ctr, 0, sizeof(Counters), st));
+            HIPCHK(hipMemsetAsync(post.d_tk, 0, single_fused_scratch_words(n_tk) * sizeof(unsigned long long), st));
+            HIPCHK(launch_single_fused(a, post.d_tk, post.d_tk + n_tk, n_tk, grid, shape, st));
+            if (ps.ev_end) HIPCHK(hipEventRecord(ps.ev_end, st));
+            HIPCHK(hipMemcpyAsync(pl->h_ctr, pl->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            if (!pl->h_ctr->overflow_units)
+            {
+                res->total = pl->h_ctr->total;
+                res->summary = res->total ? (kLnHead | kLnTail) : 0;
+                return 0;
+            }
+            // the scan counted every ticket (the resolver's running sum): the density chooses the shape — unless the spin-limit
+            // safety net fired (then the total is not to be trusted and the two-pass kernels take over)
+            const double density = (double)pl->h_ctr->total / (double)(hi_match - a.anchor);
+            int next = shape + 1;
+            while (next <= 2 && density > single_fused_max_density(next))
+                ++next;
+            if (next > 2 || pl->h_ctr->total == 0)
+                break;
+            pl->fused1_shape = next;
         }
         pl->fused1_ok = false;
         g_fused1_failovers.fetch_add(1);

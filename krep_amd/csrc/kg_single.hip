@@ -29,8 +29,14 @@
 //   goes on.  If m is not drawn, every wave that waits does so for a ticket below m: published.  No wait is circular, whatever
 //   subset of the grid runs.  (tests/test_gpu_literal.py::test_single_byte_one_pass_with_a_starved_grid forces 1-, 2- and 3-block
 //   grids over 8 192 tickets.)
-// A ticket with more hits than the ring holds (denser than ~1.5 %) raises ctr->overflow_units: the host falls back to the
-// two-pass kernels for that scan and for the plan's later ones.
+// A ticket with more hits than the ring holds raises ctr->overflow_units (the scan still COUNTS: the resolver's running sum is
+// the total).  Three shapes (template parameters UPT = 32-KiB units per ticket, RING = 16-bit entries per wave, WPE = waves per
+// SIMD): 128-KiB tickets / 8 KiB of ring / 16 waves per CU for up to ~1.5 % hits (BASELINE config 3); 64-KiB tickets / 16 KiB /
+// 8 waves for up to ~6 %; 32-KiB tickets / 16 KiB / 8 waves for up to ~12 % (80 tickets per microsecond is what one counter
+// gives: fine while the records, 16 bytes per hit, are most of the traffic).  The host picks the shape from the density the
+// first scan of a plan counted (kg_scan.hip, lit_pass) and falls back to the two-pass kernels beyond that.
+// SET: up to four needle bytes instead of one — a dictionary of single-byte patterns (`-e e -e t`) is this scan with a set
+// (aho_corasick_search reports such matches in text order, one per position: the records are memchr_search's).
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdlib>
@@ -52,9 +58,10 @@ using u64 = unsigned long long;
 #ifndef KG_S1_UPT
 #define KG_S1_UPT 4
 #endif
-constexpr u32 kUpt = KG_S1_UPT;               // units (32 KiB each) per ticket: 128 KiB (at most 4: the flush tells units apart by three bounds)
-static_assert(kUpt >= 1 && kUpt <= 4, "flush() derives a record's unit from three boundaries");
-constexpr u32 kRing = 1024u * kUpt;           // 16-bit entries per wave: the ticket being scanned + the one waiting
+constexpr u32 kUptStd = KG_S1_UPT;            // units (32 KiB each) per ticket: 128 KiB (at most 4: the flush tells units apart by three bounds)
+static_assert(kUptStd >= 1 && kUptStd <= 4, "flush() derives a record's unit from three boundaries");
+constexpr u32 kRingStd = 1024u * kUptStd;     // 16-bit entries per wave: the ticket being scanned + the one waiting
+constexpr u32 kRingDense = 8192u;             // ... of the two dense shapes (16 KiB per wave: 2 workgroups per CU)
 constexpr u64 kReady = 1ull << 63;
 constexpr u32 kSpinLimit = 1u << 24;          // ~0.25 us per spin: seconds — only a logic error gets there (see the safety nets)
 constexpr u32 kResolveChunk = 8;              // tickets per resolver lane and pass (512 per pass)
@@ -85,10 +92,11 @@ __device__ __noinline__ uint4 s_load16_guarded(const uint8_t *text, u64 text_len
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-template <bool CI>
-__global__ __launch_bounds__(kBlock, 4) void single_fused(const LitArgs a, u64 *__restrict__ agg, u64 *__restrict__ pref,
-                                                          const u64 n_tickets)
+template <bool CI, u32 kUpt, u32 kRing, int WPE, bool SET>
+__global__ __launch_bounds__(kBlock, WPE) void single_fused(const LitArgs a, u64 *__restrict__ agg, u64 *__restrict__ pref,
+                                                            const u64 n_tickets)
 {
+    static_assert(kUpt >= 1 && kUpt <= 4 && (kRing & (kRing - 1u)) == 0u, "ticket / ring shape");
     const u32 lane = s_lane();
     const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const u64 n_units = a.num_tiles * kWavesPerBlk;
@@ -287,9 +295,24 @@ __global__ __launch_bounds__(kBlock, 4) void single_fused(const LitArgs a, u64 *
         {
             const u32 D[4] = {X[j].x, X[j].y, X[j].z, X[j].w};
             u32 m16 = 0;
+            if (SET)
+            { // a byte SET: the equality flags of its (<= 4) needles OR-ed before the one movemask per dword
 #pragma unroll
-            for (int w = 0; w < 4; ++w)
-                m16 |= s_movemask4(s_eq_bytes(CI ? (D[w] | a.l0) : D[w], a.p0)) << (4 * w);
+                for (int w = 0; w < 4; ++w)
+                {
+                    u32 f = s_eq_bytes(CI ? (D[w] | a.set_l[0]) : D[w], a.set_p[0]);
+                    if (a.set_n > 1u) f |= s_eq_bytes(CI ? (D[w] | a.set_l[1]) : D[w], a.set_p[1]);
+                    if (a.set_n > 2u) f |= s_eq_bytes(CI ? (D[w] | a.set_l[2]) : D[w], a.set_p[2]);
+                    if (a.set_n > 3u) f |= s_eq_bytes(CI ? (D[w] | a.set_l[3]) : D[w], a.set_p[3]);
+                    m16 |= s_movemask4(f) << (4 * w);
+                }
+            }
+            else
+            {
+#pragma unroll
+                for (int w = 0; w < 4; ++w)
+                    m16 |= s_movemask4(s_eq_bytes(CI ? (D[w] | a.l0) : D[w], a.p0)) << (4 * w);
+            }
             if (!interior)
             {
                 const u64 lbase = seg + (u64)j * kCellBytes + (u64)lane * 16u;
@@ -409,12 +432,12 @@ __global__ __launch_bounds__(kBlock, 4) void single_fused(const LitArgs a, u64 *
 
 int g_s1_force_grid = 0; // test hook: at most this many blocks (0 = auto)
 // grid = the resident blocks of the instantiation x CUs
-template <bool CI>
+template <bool CI, u32 UPT, u32 RING, int WPE, bool SET>
 static hipError_t launch_fused(const LitArgs &a, u64 *agg, u64 *pref, u64 n_tickets, u32 num_cu, hipStream_t st)
 {
     static const u32 bpc = [] {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, single_fused<CI>, kBlock, 0) != hipSuccess || n < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, single_fused<CI, UPT, RING, WPE, SET>, kBlock, 0) != hipSuccess || n < 1)
         {
             (void)hipGetLastError();
             n = 1;
@@ -426,18 +449,38 @@ static hipError_t launch_fused(const LitArgs &a, u64 *agg, u64 *pref, u64 n_tick
     u32 grid = (u32)std::max<u64>(1, std::min<u64>(want, (u64)num_cu * bpc));
     if (g_s1_force_grid > 0) // test hook: a starved grid (krep_gpu_debug_force_single_grid)
         grid = std::min<u32>(grid, (u32)g_s1_force_grid);
-    hipLaunchKernelGGL((single_fused<CI>), dim3(grid), dim3(kBlock), 0, st, a, agg, pref, n_tickets);
+    hipLaunchKernelGGL((single_fused<CI, UPT, RING, WPE, SET>), dim3(grid), dim3(kBlock), 0, st, a, agg, pref, n_tickets);
     return hipGetLastError();
 }
 
-uint64_t single_fused_tickets(uint64_t n_units) { return (n_units + kUpt - 1) / kUpt; }
+// shape 0: 128-KiB tickets (<= ~1.5 % hits); 1: 64-KiB tickets, 16-KiB rings (<= ~6 %); 2: 32-KiB tickets, 16-KiB rings (<= ~12 %)
+static u32 shape_upt(int shape) { return shape == 0 ? kUptStd : (shape == 1 ? 2u : 1u); }
+uint64_t single_fused_tickets(uint64_t n_units, int shape) { return (n_units + shape_upt(shape) - 1) / shape_upt(shape); }
 uint64_t single_fused_scratch_words(uint64_t n_tickets) { return 2 * n_tickets; } // counts | prefixes
+// the densest text (hits per byte) a shape's ring is sure to hold: half a ring per ticket, with a margin for clustering
+double single_fused_max_density(int shape)
+{
+    const double ring = shape == 0 ? kRingStd : kRingDense, bytes = (double)shape_upt(shape) * (double)kUnitBytes1;
+    return 0.4 * ring / bytes;
+}
+
+template <bool CI, bool SET>
+static hipError_t launch_shape(const LitArgs &a, u64 *agg, u64 *pref, u64 n_tickets, u32 num_cu, int shape, hipStream_t st)
+{
+    if (shape == 0) return launch_fused<CI, kUptStd, kRingStd, 4, SET>(a, agg, pref, n_tickets, num_cu, st);
+    if (shape == 1) return launch_fused<CI, 2u, kRingDense, 2, SET>(a, agg, pref, n_tickets, num_cu, st);
+    return launch_fused<CI, 1u, kRingDense, 2, SET>(a, agg, pref, n_tickets, num_cu, st);
+}
 
 hipError_t launch_single_fused(const LitArgs &a, unsigned long long *d_agg, unsigned long long *d_pref, uint64_t n_tickets,
-                               uint32_t num_cu, hipStream_t st)
+                               uint32_t num_cu, int shape, hipStream_t st)
 {
-    return (a.flags & F_CI) ? launch_fused<true>(a, d_agg, d_pref, n_tickets, num_cu, st)
-                            : launch_fused<false>(a, d_agg, d_pref, n_tickets, num_cu, st);
+    const bool ci = (a.flags & F_CI) != 0, set = a.set_n != 0u;
+    if (set)
+        return ci ? launch_shape<true, true>(a, d_agg, d_pref, n_tickets, num_cu, shape, st)
+                  : launch_shape<false, true>(a, d_agg, d_pref, n_tickets, num_cu, shape, st);
+    return ci ? launch_shape<true, false>(a, d_agg, d_pref, n_tickets, num_cu, shape, st)
+              : launch_shape<false, false>(a, d_agg, d_pref, n_tickets, num_cu, shape, st);
 }
 
 } // namespace kg

@@ -158,3 +158,39 @@ def test_a_plan_learns_that_its_dictionary_is_dense(gpu, oracle_engine):
         assert out.count == want[0] and out.overflow
         assert np.array_equal(pos[:2 * small].cpu().numpy().astype(np.uint64).reshape(-1, 2), want[1][:small]), pats
         plan.close()
+
+
+def test_a_dictionary_of_single_bytes_is_the_one_pass_byte_scan_with_a_set(gpu, oracle_engine):
+    """`-e e -e t` with records runs in kg_single.hip (needle set, records at their final index, rings sized by the counted
+    density); without records, under -w, under -c or denser than its rings it stays where it was.  Order and content of the
+    list: aho_corasick_search, /root/reference/aho_corasick.c:383-437."""
+    import torch
+    rng = np.random.RandomState(5)
+    n = 6 * (1 << 20) + 1234
+    # (alphabet, dictionary, one-pass expected): 7 % / 6 % / 10 % of the bytes match; 13 % and 100 % are beyond the largest rings
+    for alpha, pats, one_pass in ((b"etaoin shrdlu\n" * 2 + b"ET", [b"e", b"x"], True), (bytes(range(64, 128)), [b"a", b"B", b"c", b"\x7f"], True),
+                                  (b"abcdefghij" * 6 + b"\n", [b"x", b"a"], True), (b"etaoin shrdlu\n" * 2 + b"ET", [b"e", b"t"], False),
+                                  (b"ab", [b"a", b"b"], False)):
+        text = cases.rand_text(rng, n, alpha)
+        for kw in (dict(), dict(case_sensitive=False), dict(max_count=1000)):
+            before = gpu.tiny_launches()
+            want = oracle_engine.call(abi.RA_AHO_CORASICK, abi.Params(pats, **kw), text)
+            got = gpu.search(abi.Params(pats, **kw), text)
+            assert got[0] == want[0] and np.array_equal(got[1], want[1]), (pats, kw, got[0], want[0])
+            if kw.get("case_sensitive", True):  # (-i doubles the density of the letters: which road it takes is not the point here)
+                assert (gpu.tiny_launches() == before) == one_pass, (pats, kw, "one-pass byte-set scan expected" if one_pass else "register compare expected")
+        # windows owned by start offset concatenate to the whole list; a re-used plan keeps its shape
+        d = torch.from_numpy(text).cuda()
+        want = oracle_engine.call(abi.RA_AHO_CORASICK, abi.Params(pats), text)
+        plan = gpu.plan(abi.Params(pats))
+        cap = int(want[0]) + 3
+        pos = torch.zeros(2 * cap, dtype=torch.int64, device="cuda")
+        acc = []
+        for lo, hi in ((0, 1_000_003), (1_000_003, 4_000_000), (4_000_000, n)):
+            pos.zero_()
+            out = plan.scan(d.data_ptr(), n, lo, hi, 0, pos.data_ptr(), cap)
+            acc.append(pos[:2 * out.count].cpu().numpy().astype(np.uint64).reshape(-1, 2))
+        assert np.array_equal(np.concatenate(acc), want[1]), pats
+        plan.close()
+        _check(gpu, oracle_engine, text[:300_000], pats, dict(count_lines=True, only_match=True), tiny=None)
+        _check(gpu, oracle_engine, text[:300_000], pats, dict(count_lines=True), tiny=None if b"\n" not in alpha else True)

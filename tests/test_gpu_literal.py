@@ -243,3 +243,38 @@ def test_single_byte_one_pass_with_a_starved_grid(gpu):
             plan.close()
     finally:
         gpu.force_single_grid(0)
+
+
+def test_single_byte_one_pass_dense_shapes(gpu, oracle_engine):
+    """The one-pass single-byte kernel beyond ~1.5 % hits (kg_single.hip: 64- and 32-KiB tickets with 16-KiB rings, chosen from
+    the density the first scan counted): 2.5 %, 8 % and — too dense for any ring, the two-pass kernels — 25 % of the bytes;
+    a new plan and a re-used one, case-insensitive too.  memchr_search, /root/reference/krep.c:3891-4041."""
+    import torch
+    rng = np.random.RandomState(77)
+    n = 5 * (1 << 20) + 333
+    gpu.force_rounds(4)  # (the large-text tile shape on a small text)
+    try:
+        for alpha, expect_two_pass in ((b"e" + bytes(range(65, 65 + 39)), False), (b"e" + b"abcdfghijkl", False), (b"eabc", True)):
+            text = cases.rand_text(rng, n, alpha)
+            text[::4001] = ord("E")
+            for kw in (dict(), dict(case_sensitive=False)):
+                p = abi.Params([b"e"], **kw)
+                want = oracle_engine.call(gpu.mirror_select(p, n), abi.Params([b"e"], **kw), text)
+                before = gpu.single_failovers()
+                got = gpu.search(p, text)
+                assert got[0] == want[0] and np.array_equal(got[1], want[1]), (alpha[:4], kw, got[0], want[0])
+                assert (gpu.single_failovers() > before) == expect_two_pass, (alpha[:4], kw)
+            d = torch.from_numpy(text).cuda()
+            pw = abi.Params([b"e"])
+            want = oracle_engine.call(gpu.mirror_select(pw, n), abi.Params([b"e"]), text)
+            plan = gpu.plan(abi.Params([b"e"]))
+            cap = int(want[0]) + 7
+            pos = torch.zeros(2 * cap, dtype=torch.int64, device="cuda")
+            for rep in range(3):  # the second and third scan start in the shape the first one chose
+                pos.zero_()
+                out = plan.scan(d.data_ptr(), n, 0, n, 0, pos.data_ptr(), cap)
+                assert out.count == want[0]
+                assert np.array_equal(pos[:2 * out.count].cpu().numpy().astype(np.uint64).reshape(-1, 2), want[1]), (alpha[:4], rep)
+            plan.close()
+    finally:
+        gpu.force_rounds(0)

@@ -42,7 +42,7 @@ for seed in range(7000, 7000 + nseeds):
         got = gpu.search(abi.Params(pats, **kw), text)
         cases_run += 1
         if got[0] != want[0] or not np.array_equal(got[1], want[1]): fail("search", seed, it, pats, kw, n, got[0], want[0])
-        if kw["max_count"] and gpu.tiny_launches() == before: fail("tiny kernel not used", seed, it, pats, kw)
+        if kw["max_count"] and gpu.tiny_launches() == before and max(len(p) for p in pats) > 1: fail("tiny kernel not used", seed, it, pats, kw)  # (single bytes with records: kg_single.hip)
         # logical shards through the host operator
         if n >= 8192 and rng.rand() < 0.5:
             g = int(rng.randint(2, 6))
