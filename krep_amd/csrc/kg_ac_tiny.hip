@@ -215,8 +215,8 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
                                 if (!kp)
                                 { // a count: the flags are all that is needed
 #pragma unroll
-                                    for (int w = 0; w < 4; ++w)
-                                        mycnt = __builtin_popcount(Z[w]) + mycnt; // (v_bcnt_u32_b32 adds its second operand)
+                                    for (int w = 0; w < 4; ++w) // (v_bcnt_u32_b32 adds its second operand: one instruction per dword)
+                                        asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(mycnt) : "v"(Z[w]));
                                 }
                                 else
                                 { // the length's mask in the scrambled order: 4 shifts instead of 4 multiplies
