@@ -8,13 +8,18 @@
 //   X_j = the lane's 16 bytes shifted by j bytes (byte e of X_j is text[e - j]; 3 x 4 v_alignbyte per 1-KiB cell),
 //   a pattern c_0 .. c_{L-1} ends at byte e  <=>  byte e of  V = (X_{L-1} ^ c_0c_0c_0c_0) | ... | (X_0 ^ c_{L-1}...)  is zero,
 //   one exact zero-byte test per pattern and dword (ac_eq_bytes), OR-ed into one flag word per LENGTH and dword.
-// Per cell and lane that leaves (a) a 16-bit mask of the END positions that hold a match, in position order, and (b) per
-// length a 16-bit mask in a scrambled order that costs 4 shifts instead of 4 multiplies (bit 8 b + w <-> position 4 w + b);
-// both go to LDS (10 KiB per wave: 12 waves per workgroup), and once per 16-KiB unit every lane walks the 256 positions it
-// owns and writes their matches — longest first, as the automaton's output chain reports them (aho_corasick.c:383-437) —
-// at the rank a wave prefix of the per-lane counts gives it.  No candidates, no probes, no text gathers: a dense dictionary
-// costs its record stores and nothing else.  Units, staging slots, info words, emit-mode re-scan and the post-pass are
-// those of the general kernel (ac_scan drives both).
+// What a cell leaves depends on what the scan is for (template parameters):
+//   * a count (`KEEP = false`): the popcounts of the flag words — no LDS at all, 12 waves per CU;
+//   * records (`KEEP`): per lane-cell the four lengths' 16-bit masks in a scrambled order that costs 4 shifts instead of 4
+//     multiplies (bit 8 b + w <-> position 4 w + b), 8 KiB of LDS per wave.  Once per 16-KiB unit a wave prefix of the per-lane
+//     popcounts ranks the matches, and every lane walks the lane-cells it owns — END ascending, longest first, as the automaton's
+//     output chain reports them (aho_corasick.c:383-437) — into the unit's staging slot, parked in LDS until the ticket ends;
+//   * `-c` (`LINES`): the END mask and the newline mask of the cell in position order, and the general kernel's line pass per unit;
+//   * the emit-mode launch (`EMIT`): final records for the units whose matches did not fit their slot — or for every unit of a
+//     plan that turned out dense (ac_scan: count pass, offsets from the post-pass, this launch) — 2048 at a time through LDS so
+//     that consecutive lanes store consecutive records.
+// No candidates, no probes, no text gathers.  Units, staging slots, info words, emit mode and the post-pass are those of the
+// general kernel (ac_scan drives both); workgroups of 4 waves (256 threads), as many per CU as registers and LDS allow.
 #include <algorithm>
 #include <atomic>
 #include <type_traits>
