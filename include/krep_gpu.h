@@ -305,7 +305,10 @@ int krep_gpu_plan_ref_algo(const krep_gpu_plan_t *plan); /* enum krep_ref_algo t
  * (offset within d_text) + global_base.  d_positions may be NULL (count only) and receives at most
  * `position_capacity` records, in the reference's emission order.  `stream` is a hipStream_t (NULL =
  * default stream); with time_it != 0 the kernels are bracketed by hipEvents on that stream and the
- * call synchronises.  Returns 0 on success, non-zero on error (krep_gpu_last_error()). */
+ * call synchronises.  The kernels move 16 bytes per lane from d_text + a multiple of 16: a 16-byte aligned d_text (any
+ * hipMalloc block) is the fast case; a slice at an odd offset is scanned correctly (gfx950 serves unaligned vector loads;
+ * tests/test_gpu_fullsize.py scans such slices), an aligned block plus an ownership window is the better way to say it.
+ * Returns 0 on success, non-zero on error (krep_gpu_last_error()). */
 int krep_gpu_scan_device(krep_gpu_plan_t *plan, const void *d_text, size_t text_len, size_t own_lo,
                          size_t own_hi, size_t global_base, match_position_t *d_positions,
                          uint64_t position_capacity, void *stream, int time_it,
