@@ -711,26 +711,38 @@ AcTables *ac_build(const search_params_t &sp, int device)
         // ... and worth it: with a 1- or 2-byte pattern the general kernel reads two or three LDS tables per position (3.3 TB/s
         // on `he she hers`, 1.4 on `e t`); a dictionary of 3- and 4-byte patterns only runs there at 5.2-5.9 TB/s, faster than
         // the register compare (profiles/r04_dictionaries.txt)
-        bool ok = !pats.empty() && !t->has_empty && t->lmax <= 4 && t->lmin <= 2 && !getenv("KREP_GPU_AC_NO_TINY");
+        // Lengths: 1..4, or 1..3 beside ONE length of 5..8 (`-e a -e Sherlock`), which then takes the place of length 4
+        bool ok = !pats.empty() && !t->has_empty && t->lmax <= 8 && t->lmin <= 2 && !getenv("KREP_GPU_AC_NO_TINY");
+        const u32 llong = t->lmax > 4 ? t->lmax : 0u;
         for (size_t i = 0; ok && i < pats.size(); ++i)
         {
             for (size_t k = 0; k < i; ++k)
                 if (pats[k] == pats[i])
                     ok = false; // a duplicate reports twice (aho_corasick.c:383-437): the masks cannot count copies
             const size_t L = pats[i].size();
-            if (!ok || td.n[L - 1] >= kTinyPer)
+            if (llong && L >= 4 && L != llong)
+                ok = false; // a second length beyond 3 bytes
+            const size_t cls = L > 4 ? 4 : L; // the class a pattern is compared and reported in
+            if (!ok || td.n[cls - 1] >= kTinyPer)
             {
                 ok = false;
                 break;
             }
-            const u32 p = td.n[L - 1]++;
-            for (size_t s = 0; s < L; ++s)
+            const u32 p = td.n[cls - 1]++;
+            for (size_t s = 0; s < cls; ++s) // (a long pattern: its LAST four bytes)
             {
                 const uint8_t c = pats[i][L - 1 - s];
-                td.pk[L - 1][p] |= (u32)c << (8 * s);
-                td.lf[L - 1][p] |= (t->ci && c >= 'a' && c <= 'z') ? 1u << s : 0u;
+                td.pk[cls - 1][p] |= (u32)c << (8 * s);
+                td.lf[cls - 1][p] |= (t->ci && c >= 'a' && c <= 'z') ? 1u << s : 0u;
+            }
+            for (size_t s = 0; L > 4 && s < L - 4; ++s) // ... and its first L - 4, byte s = s places before the end of that part
+            {
+                const uint8_t c = pats[i][L - 5 - s];
+                td.pk2[p] |= (u32)c << (8 * s);
+                td.lf2[p] |= (t->ci && c >= 'a' && c <= 'z') ? 1u << s : 0u;
             }
         }
+        td.llong = ok ? llong : 0u;
         td.lmax = t->lmax;
         for (int L = 0; L < 4; ++L)
             td.ncls += td.n[L] ? 1u : 0u;

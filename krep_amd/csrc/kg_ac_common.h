@@ -49,7 +49,8 @@ struct AcArgs
     u64 pos_cap;
 };
 
-// Tiny dictionaries (kg_ac_tiny.hip): every pattern 1..4 bytes, at most kTinyPer of each length, no duplicates.  The patterns
+// Tiny dictionaries (kg_ac_tiny.hip): every pattern 1..4 bytes (or 1..3 and ONE length of 5..8), at most kTinyPer of each length,
+// no duplicates.  The patterns
 // travel as kernel arguments, one dword each: byte s = the pattern byte s places before its END (folded under -i), and a
 // second dword of flags: bit s = that byte is a letter (-i compares it as (x | 0x20) == c).
 constexpr u32 kTinyPer = 4;
@@ -62,6 +63,10 @@ struct AcTiny
     u32 n[4];         // patterns of length 1, 2, 3, 4
     u32 pk[4][kTinyPer];
     u32 lf[4][kTinyPer];
+    // ONE long length (5..8 bytes, llong; 0 = none) may take the place of length 4: pk[3] / lf[3] then hold the LAST four bytes of
+    // those patterns and pk2 / lf2 their first llong - 4 bytes (byte s = s places before the end of that part)
+    u32 llong;
+    u32 pk2[kTinyPer], lf2[kTinyPer];
 };
 hipError_t ac_tiny_launch(const AcArgs &a, const AcTiny &td, u64 n_tickets, u32 num_cu, hipStream_t st); // sizes its own grid
 

@@ -50,7 +50,8 @@ __device__ __forceinline__ u32 tiny_scramble16(u32 m) // position-ordered 16 bit
 // EMIT: the emit-mode launch (final records of the units whose matches did not fit their staging slot; its own instantiation
 // because its record walk holds a unit's 32 length words in registers — in the streaming launch those registers spilled, and a
 // scratch reload waits in the same in-order vmcnt queue as the prefetched text: the pipeline drained once per unit)
-template <bool CI, bool LINES, bool KEEP, bool EMIT>
+// LONG: the dictionary holds a long length (AcTiny::llong) — its own instantiations, so that the others carry none of its code
+template <bool CI, bool LINES, bool KEEP, bool EMIT, bool LONG>
 __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_kernel(const AcArgs a, const AcTiny td)
 {
     extern __shared__ __attribute__((aligned(16))) u32 s_tiny[];
@@ -77,7 +78,8 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
     static_assert(!EMIT || (KEEP && !LINES), "emit mode writes records");
     u32 k7f;
     asm volatile("v_mov_b32 %0, 0x7f7f7f7f" : "=v"(k7f)); // (a vector register on purpose: see the splats in the cell)
-    const u32 lmax = __builtin_amdgcn_readfirstlane(td.lmax);
+    const u32 lmax = __builtin_amdgcn_readfirstlane(td.lmax), llong = LONG ? __builtin_amdgcn_readfirstlane(td.llong) : 0u;
+    const u32 len4 = llong ? llong : 4u; // the length behind class 4 (a LONG class of 5..8 bytes takes its place: AcTiny)
     const u32 n1 = __builtin_amdgcn_readfirstlane(td.n[0]), n2 = __builtin_amdgcn_readfirstlane(td.n[1]),
               n3 = __builtin_amdgcn_readfirstlane(td.n[2]), n4 = __builtin_amdgcn_readfirstlane(td.n[3]);
 
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
             em_mask = __ballot(u_begin + lane < u_end && (u32)(a.unitinfo[u_begin + lane] & kUiCountMask) > a.stage_cap);
         uint4 d[kCells]; // the round about to be filtered (or on its way)
         bool have = false;
-        u32 carry = 0;
+        u32 carry = 0, carry2 = 0;
         for (u64 unit = u_begin; unit < u_end; ++unit)
         {
             const u64 useg = a.anchor + unit * (u64)kAcUnitBytes;
@@ -120,15 +122,17 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
                 const bool fast_now = seg + kSegBytes <= a.text_len;
                 // interior: every END of the round lies in the launch's window, and so does the START of a 4-byte match at its
                 // first byte (starts own a match outside -c) — nothing to clip
-                const bool interior = seg >= a.own_lo + 3 && seg + kSegBytes <= a.own_hi && seg + kSegBytes <= a.end_hi;
+                const bool interior = seg >= a.own_lo + (lmax - 1u) && seg + kSegBytes <= a.own_hi && seg + kSegBytes <= a.end_hi;
                 const uint4 *src = reinterpret_cast<const uint4 *>(a.text + seg) + lane;
-                auto cell = [&](auto interC, const int j, const u32 (&D)[4], const u32 P) __attribute__((always_inline)) {
+                auto cell = [&](auto interC, const int j, const u32 (&D)[4], const u32 P, const u32 P2) __attribute__((always_inline)) {
                     constexpr bool inter = decltype(interC)::value, kp = KEEP;
                     // The dictionary's shape, re-read through an empty asm in every cell: as loop-invariant booleans the ~20
                     // conditions below were hoisted into 40 scalar registers, spilled to vector lanes and read back with
                     // v_readlane before every branch; as fresh scalars each is one s_cmp in front of its branch.
-                    u32 c1 = n1, c2 = n2, c3 = n3, c4 = n4, lmx = lmax;
+                    u32 c1 = n1, c2 = n2, c3 = n3, c4 = n4, lmx = lmax, ll = llong;
                     asm volatile("" : "+s"(c1), "+s"(c2), "+s"(c3), "+s"(c4), "+s"(lmx));
+                    if (LONG)
+                        asm volatile("" : "+s"(ll));
                     u32 NL = 0;
                     if (LINES)
                     {
@@ -160,6 +164,15 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
                             }
                         }
                     }
+                    // a LONG pattern (5..8 bytes) = its last four bytes ending here AND its first ll - 4 bytes ending one dword
+                    // earlier: the same shifted copies one dword to the left, whose first dword comes from the 8 bytes in front
+                    u32 XP[4] = {P, 0u, 0u, 0u};
+                    if (LONG && ll)
+                    {
+                        XP[1] = __builtin_amdgcn_alignbyte(P, P2, 3u);
+                        XP[2] = __builtin_amdgcn_alignbyte(P, P2, 2u);
+                        XP[3] = __builtin_amdgcn_alignbyte(P, P2, 1u);
+                    }
                     // window of the launch (boundary rounds only), per length: the END in [end_lo, end_hi), never before byte L - 1
                     // of the text, and (outside -c, where a match is owned by its start) the START in [own_lo, own_hi)
                     const u32 lrel = (u32)j * kCellBytes + lane * 16u;
@@ -174,7 +187,7 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
                     //      register (its bytes, last one lowest) + under -i one of letter flags; splats on the scalar unit.
                     u32 HA[4] = {0u, 0u, 0u, 0u}, F[4] = {0u, 0u, 0u, 0u}; // any length, per dword | scrambled mask per length
                     u32 m16 = 0;                                           // END mask in position order
-                    auto one = [&](auto Lc, u32 (&Z)[4], const bool first, const u32 pk, const u32 lf) __attribute__((always_inline)) {
+                    auto one = [&](auto Lc, u32 (&Z)[4], const bool first, const u32 pk, const u32 lf, const u32 pk2, const u32 lf2) __attribute__((always_inline)) {
                         constexpr int L = decltype(Lc)::value;
                         // the splats are made on the scalar unit and MOVED to vector registers: v_bitop3_b32 / v_and / v_xor with
                         // vector operands only issue every ~2.2 cycles, with a scalar operand every ~3.7 (profiles/r04_valu_issue_rates.txt)
@@ -195,6 +208,25 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
 #pragma unroll
                             for (int s = 0; s < L; ++s) // s bytes before the end: pattern byte L - 1 - s
                                 V |= (CI ? (X[s][w] | m[s]) : X[s][w]) ^ c[s];
+                            if (LONG && L == 4 && ll) // (uniform) the long pattern's first ll - 4 bytes, one dword earlier
+                            {
+                                auto xa = [&](const int sa) -> u32 { return w ? X[sa][w ? w - 1 : 0] : XP[sa]; };
+                                auto term = [&](const int sa) -> u32 {
+                                    const u32 ca = ((pk2 >> (8 * sa)) & 0xffu) * 0x01010101u, ma = ((lf2 >> sa) & 1u) * 0x20202020u;
+                                    return (CI ? (xa(sa) | ma) : xa(sa)) ^ ca;
+                                };
+                                V |= term(0);
+                                if (ll > 5u)
+                                {
+                                    V |= term(1);
+                                    if (ll > 6u)
+                                    {
+                                        V |= term(2);
+                                        if (ll > 7u)
+                                            V |= term(3);
+                                    }
+                                }
+                            }
                             const u32 z = ~(((V & k7f) + k7f) | V | k7f); // 0x80 in every zero byte, exact (ac_eq_bytes)
                             Z[w] = first ? z : (Z[w] | z);
                         }
@@ -204,15 +236,15 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
                         if (n) // (uniform, like the three below)
                         {
                             u32 Z[4];
-                            one(Lc, Z, true, td.pk[L - 1][0], td.lf[L - 1][0]);
+                            one(Lc, Z, true, td.pk[L - 1][0], td.lf[L - 1][0], td.pk2[0], td.lf2[0]);
                             if (n > 1)
                             {
-                                one(Lc, Z, false, td.pk[L - 1][1], td.lf[L - 1][1]);
+                                one(Lc, Z, false, td.pk[L - 1][1], td.lf[L - 1][1], td.pk2[1], td.lf2[1]);
                                 if (n > 2)
                                 {
-                                    one(Lc, Z, false, td.pk[L - 1][2], td.lf[L - 1][2]);
+                                    one(Lc, Z, false, td.pk[L - 1][2], td.lf[L - 1][2], td.pk2[2], td.lf2[2]);
                                     if (n > 3)
-                                        one(Lc, Z, false, td.pk[L - 1][3], td.lf[L - 1][3]);
+                                        one(Lc, Z, false, td.pk[L - 1][3], td.lf[L - 1][3], td.pk2[3], td.lf2[3]);
                                 }
                             }
                             if (inter)
@@ -240,9 +272,10 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
 #pragma unroll
                                 for (int w = 0; w < 4; ++w)
                                     pm |= ac_movemask4(Z[w]) << (4 * w);
-                                pm &= clip(a.end_lo, a.end_hi) & clip((u64)(L - 1), ~0ull);
+                                const u64 lm1 = (L == 4 ? (u64)len4 : (u64)L) - 1ull; // (class 4 may stand for a long length)
+                                pm &= clip(a.end_lo, a.end_hi) & clip(lm1, ~0ull);
                                 if (!LINES)
-                                    pm &= clip(a.own_lo + (u64)(L - 1), a.own_hi + (u64)(L - 1));
+                                    pm &= clip(a.own_lo + lm1, a.own_hi + lm1);
                                 m16 |= pm;
                                 F[L - 1] = tiny_scramble16(pm);
                                 mycnt += kp ? 0u : (u32)__popc(pm);
@@ -286,13 +319,18 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
                         const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
                         return make_uint4(v.x, v.y, v.z, v.w);
                     };
-                    u32 before = 0; // the 4 bytes in front of the round (uniform)
+                    u32 before = 0, before2 = 0; // the 4 bytes in front of the round, and the 4 in front of those (uniform)
                     if (have)
+                    {
                         before = carry;
+                        before2 = carry2;
+                    }
                     else
                     {
                         if (seg >= 4)
                             before = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const u32 *>(a.text + seg - 4));
+                        if (LONG && llong && seg >= 8)
+                            before2 = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const u32 *>(a.text + seg - 8));
 #pragma unroll
                         for (int j = 0; j < kCells; ++j)
                             d[j] = ntload(src + j * kWave);
@@ -307,7 +345,13 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
                             d[j] = ntload(nsrc + j * kWave);
                             const u32 P = (u32)__builtin_amdgcn_update_dpp((int)before, (int)D[3], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
                             before = __builtin_amdgcn_readlane(D[3], 63);
-                            cell(interC, j, D, P);
+                            u32 P2 = 0;
+                            if (LONG && llong) // (uniform: only a long pattern looks eight bytes back)
+                            {
+                                P2 = (u32)__builtin_amdgcn_update_dpp((int)before2, (int)D[2], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+                                before2 = __builtin_amdgcn_readlane(D[2], 63);
+                            }
+                            cell(interC, j, D, P, P2);
                         }
                     };
                     if (interior) // two copies of the round: the window clipping of a boundary round costs the interior ones nothing
@@ -316,6 +360,7 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
                         cells(std::false_type{});
                     have = pf_next;
                     carry = before;
+                    carry2 = before2;
                 }
                 else
                 {
@@ -324,21 +369,21 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
                     for (int j = 0; j < kCells; ++j)
                     { // the ragged end of the text: bytewise, bounds-checked (bytes outside read as 0 and are clipped in the cell)
                         const u64 lbase = seg + (u64)j * kCellBytes + (u64)lane * 16u;
-                        u32 W[5];
+                        u32 W[6]; // the 8 bytes in front of the lane's 16, and those
 #pragma unroll
-                        for (int w = 0; w < 5; ++w)
+                        for (int w = 0; w < 6; ++w)
                         {
                             u32 v = 0;
                             for (int b = 0; b < 4; ++b)
                             {
                                 const u64 o = lbase + (u64)(w * 4 + b);
-                                if (o >= 4 && o - 4 < a.text_len)
-                                    v |= (u32)a.text[o - 4] << (8 * b);
+                                if (o >= 8 && o - 8 < a.text_len)
+                                    v |= (u32)a.text[o - 8] << (8 * b);
                             }
                             W[w] = v;
                         }
-                        const u32 D[4] = {W[1], W[2], W[3], W[4]};
-                        cell(std::false_type{}, j, D, W[0]); // (a ragged round is a boundary round)
+                        const u32 D[4] = {W[2], W[3], W[4], W[5]};
+                        cell(std::false_type{}, j, D, W[1], W[0]); // (a ragged round is a boundary round)
                     }
                 }
             } // rounds
@@ -391,7 +436,7 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
                         h &= h - 1u;
                         const u32 bit = 8u * (e & 3u) + (e >> 2);
                         const int end1 = r0 + (int)e;
-                        if ((cy >> (bit + 4u)) & 1u) put(at++, end1 - 4, 4u);
+                        if ((cy >> (bit + 4u)) & 1u) put(at++, end1 - (int)len4, len4);
                         if ((cy >> bit) & 1u) put(at++, end1 - 3, 3u);
                         if ((cx >> (bit + 4u)) & 1u) put(at++, end1 - 2, 2u);
                         if ((cx >> bit) & 1u) put(at++, end1 - 1, 1u);
@@ -444,7 +489,7 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
                                 if (cx | cy)
                                     cellwalk((u32)i, cx, cy, at, [&](const u32 rk, const int srel, const u32 len) {
                                         if (rk - cb < 2048u)
-                                            items[rk - cb] = ((u32)(srel + 4) << 2) | (len - 1u);
+                                            items[rk - cb] = ((u32)(srel + 8) << 3) | (len - 1u);
                                     });
                             }
                         }
@@ -455,7 +500,7 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
                             const u64 g = fbase + cb + k;
                             if (g < a.pos_cap)
                             {
-                                const u64 st = useg + (u64)(it >> 2) - 4u + a.global_base, en = st + (it & 3u) + 1u;
+                                const u64 st = useg + (u64)(it >> 3) - 8u + a.global_base, en = st + (it & 7u) + 1u;
                                 *reinterpret_cast<uint4 *>(a.positions + 2 * g) = make_uint4((u32)st, (u32)(st >> 32), (u32)en, (u32)(en >> 32));
                             }
                         }
@@ -595,8 +640,8 @@ u32 ac_tiny_blocks_per_cu(const AcArgs &a)
     return lds ? std::min<u32>(by_regs, 160u * 1024u / lds) : by_regs;
 }
 
-template <bool CI, bool LN, bool KEEP, bool EMIT>
-static hipError_t tiny_launch3(const AcArgs &a, const AcTiny &td, u32 grid, hipStream_t st)
+template <bool CI, bool LN, bool KEEP, bool EMIT, bool LONG>
+static hipError_t tiny_launch4(const AcArgs &a, const AcTiny &td, u32 grid, hipStream_t st)
 {
     constexpr int kMaxDev = 64; // (dynamic LDS beyond 64 KiB is granted once per instantiation and device: see ac_launch3)
     static std::atomic<bool> granted[kMaxDev];
@@ -604,15 +649,21 @@ static hipError_t tiny_launch3(const AcArgs &a, const AcTiny &td, u32 grid, hipS
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= kMaxDev || !granted[dev].load(std::memory_order_acquire))
     {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ac_tiny_kernel<CI, LN, KEEP, EMIT>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ac_tiny_kernel<CI, LN, KEEP, EMIT, LONG>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess)
             return e;
         if (dev >= 0 && dev < kMaxDev)
             granted[dev].store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((ac_tiny_kernel<CI, LN, KEEP, EMIT>), dim3(grid), dim3(kTinyBlock), KEEP ? ac_tiny_lds_bytes(LN, !LN) : 0u, st, a, td);
+    hipLaunchKernelGGL((ac_tiny_kernel<CI, LN, KEEP, EMIT, LONG>), dim3(grid), dim3(kTinyBlock), KEEP ? ac_tiny_lds_bytes(LN, !LN) : 0u, st, a, td);
     return hipGetLastError();
+}
+
+template <bool CI, bool LN, bool KEEP, bool EMIT>
+static hipError_t tiny_launch3(const AcArgs &a, const AcTiny &td, u32 grid, hipStream_t st)
+{
+    return td.llong ? tiny_launch4<CI, LN, KEEP, EMIT, true>(a, td, grid, st) : tiny_launch4<CI, LN, KEEP, EMIT, false>(a, td, grid, st);
 }
 
 // records == false: a count — or the COUNT PASS of a dense dictionary (F_POS with stage_cap 0: every unit "overflows" an empty

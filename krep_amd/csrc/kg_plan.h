@@ -43,6 +43,7 @@ struct krep_gpu_plan
     match_position_t *d_nl_rec = nullptr; // multi-pattern -c with a newline inside a pattern (scan_ac_newline_lines): the
     uint64_t *d_nl_ln = nullptr;          // ordered record list and the line number of every start; grow-only
     uint64_t nl_cap = 0;
+    bool lines_list_off = false; // multi-pattern -c: a scan found the text too dense for the record-list road (kg_scan.hip)
     kg::PostScratch aux;  // small auxiliary passes that must not disturb `post` (end-of-text replay)
     search_params_t sp{}; // shallow copy with patterns pointing into `pats`
     std::vector<const char *> pat_ptrs;

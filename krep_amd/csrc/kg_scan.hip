@@ -984,7 +984,13 @@ static int scan_ac_lines_on_list(krep_gpu_plan *pl, const Window &w, hipStream_t
     if (w.own_lo >= own_hi)
         return 0;
     if (time_it) HIPCHK(hipEventRecord(pl->ev0, st));
-    const uint64_t dense = w.text_len / 16 + 4096; // more matches than this: 16 B of record per 16 B of text is no shortcut
+    // More matches than this and the list is no shortcut: a record costs its 16 bytes plus ~2 random cache lines of gap test
+    // (~48 ps), the in-kernel line pass 0.1-0.13 ps per byte of text — break-even at one match per ~400 bytes (measured at
+    // 32 GiB, profiles/r04_dictionaries.txt: `xq zj`, one per 500 bytes, 3.1 TB/s on the list against 2.2 in the kernel;
+    // `er th an`, one per 300, 1.8 against 2.0; `a Sherlock`, one per 28, 0.65 against 2.4).  The plan remembers.
+    const uint64_t dense = w.text_len / 400 + 4096;
+    if (pl->lines_list_off)
+        return 1;
     if (pl->nl_cap == 0)
     {
         const uint64_t want = std::max<uint64_t>(w.text_len / 1024, 1u << 16);
@@ -999,7 +1005,10 @@ static int scan_ac_lines_on_list(krep_gpu_plan *pl, const Window &w, hipStream_t
         if (rc)
             return rc;
         if (o1.total_matches > dense)
+        {
+            pl->lines_list_off = true;
             return 1;
+        }
         if (!o1.overflow || attempt == 1)
             break;
         if (pl->d_nl_rec) (void)hipFree(pl->d_nl_rec);

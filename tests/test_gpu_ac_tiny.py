@@ -55,7 +55,7 @@ def test_random_tiny_dictionaries(gpu, oracle_engine, seed):
         alpha = [b"ab", b"abc\n", b"abAB -\n", bytes(range(97, 105)) + b" \n", b"\x00\x01a\n"][it % 5]
         n = [1, 3, 4, 17, 500, 8191, 8192, 8195, 16384, 16389, 40000, 140000, 300007][rng.randint(0, 13)]
         text = cases.rand_text(rng, n, alpha)
-        lens = [[1], [2], [1, 2, 3, 4], [2, 3, 4], [2, 4], [1, 4], [1, 3]][rng.randint(0, 7)]
+        lens = [[1], [2], [1, 2, 3, 4], [2, 3, 4], [2, 4], [1, 4], [1, 3], [1, 5], [2, 3, 8], [1, 2, 6], [2, 7, 7]][rng.randint(0, 11)]
         pats = _distinct(rng, text, alpha, lens, [2, 2, 3, 5, 8][rng.randint(0, 5)])
         if len(pats) < 2 or min(len(p) for p in pats) > 2:
             continue  # (one pattern is the literal scan's business; 3- and 4-byte patterns only: the general kernel's)
@@ -117,7 +117,8 @@ def test_nul_bytes_never_match_in_front_of_the_text(gpu, oracle_engine):
 def test_general_kernel_when_the_dictionary_does_not_qualify(gpu, oracle_engine):
     rng = np.random.RandomState(3)
     text = cases.rand_text(rng, 50_000, b"abcd \n")
-    _check(gpu, oracle_engine, text, [b"ab", b"abcda"], dict(), tiny=False)                       # a 5-byte pattern
+    _check(gpu, oracle_engine, text, [b"ab", b"abcd", b"abcda"], dict(), tiny=False)              # two lengths beyond 3 bytes
+    _check(gpu, oracle_engine, text, [b"ab", b"abcdabcda"], dict(), tiny=False)                   # a 9-byte pattern
     _check(gpu, oracle_engine, text, [b"a", b"b", b"c", b"d", b" "], dict(), tiny=False)          # five of one length
     _check(gpu, oracle_engine, text, [b"ab", b"ab"], dict(), tiny=False)                          # a duplicate
     _check(gpu, oracle_engine, text, [b"abc", b"bcd", b"cdab"], dict(), tiny=False)               # nothing shorter than 3 bytes
@@ -194,3 +195,37 @@ def test_a_dictionary_of_single_bytes_is_the_one_pass_byte_scan_with_a_set(gpu, 
         plan.close()
         _check(gpu, oracle_engine, text[:300_000], pats, dict(count_lines=True, only_match=True), tiny=None)
         _check(gpu, oracle_engine, text[:300_000], pats, dict(count_lines=True), tiny=None if b"\n" not in alpha else True)
+
+
+def test_one_long_length_beside_short_patterns(gpu, oracle_engine):
+    """`-e a -e Sherlock`: ONE length of 5..8 bytes may stand beside 1..3-byte patterns — its last four bytes are compared at the
+    END, its first ones a dword earlier (kg_ac_tiny.hip).  All modes, -i, matches across cell / round / unit boundaries and at the
+    very start of the text, windows."""
+    import torch
+    rng = np.random.RandomState(31)
+    n = 3 * (1 << 20) + 4321
+    text = cases.rand_text(rng, n, b"abcdefghij klmnop\n")
+    for pat, spots in ((b"Sherlock", (0, 3, 13, 1017, 1020, 8185, 8190, 16379, 16383, 131070, n - 8)), (b"HoLmes", (40, 1022, 16381, n - 6)),
+                       (b"Watso", (77, 8189, n - 5)), (b"Baskerv", (200, 16380, 999_999))):
+        for sp in spots:
+            text[sp:sp + len(pat)] = np.frombuffer(pat, dtype=np.uint8)
+    for pats in ([b"a", b"Sherlock"], [b"e", b"gh", b"Sherlock"], [b"ij", b"HoLmes", b"klmnop"], [b"b", b"cd", b"efg", b"Watso"],
+                 [b"a", b"Baskerv", b"abcdefg"]):
+        for kw in (dict(), dict(case_sensitive=False), dict(count_lines=True), dict(count_lines=True, only_match=True), dict(max_count=99)):
+            _check(gpu, oracle_engine, text, pats, kw)
+        _check(gpu, oracle_engine, text[:9], pats, dict())
+        _check(gpu, oracle_engine, text[:8], pats, dict())
+        want = oracle_engine.call(abi.RA_AHO_CORASICK, abi.Params(pats), text)
+        for shards in (2, 5):
+            rc, cnt, pos = gpu.search_buffer(abi.Params(pats), text, num_gpus=shards)
+            assert rc == 0 and cnt == want[0] and np.array_equal(pos, want[1]), (pats, shards)
+        d = torch.from_numpy(text).cuda()
+        plan = gpu.plan(abi.Params(pats))
+        cap = int(want[0]) + 3
+        pos = torch.zeros(2 * cap, dtype=torch.int64, device="cuda")
+        for rep in range(3):  # (a dense dictionary: the later scans count first and emit every record)
+            pos.zero_()
+            out = plan.scan(d.data_ptr(), n, 0, n, 0, pos.data_ptr(), cap)
+            assert out.count == want[0]
+            assert np.array_equal(pos[:2 * out.count].cpu().numpy().astype(np.uint64).reshape(-1, 2), want[1]), (pats, rep)
+        plan.close()

@@ -20,7 +20,7 @@ for seed in range(7000, 7000 + nseeds):
         alpha = [b"ab", b"abc\n", b"abAB -\n", bytes(range(97, 105)) + b" \n", bytes(range(256)), b"\x00\x01a\n", b"etaoin shrdlu\n" * 3 + b"ETAOIN"][it % 7]
         n = [1, 2, 3, 4, 5, 17, 500, 8191, 8192, 8195, 16383, 16384, 16389, 40000, 131072, 140000, 300007, 1 << 20, (1 << 21) + 77][rng.randint(0, 19)]
         text = cases.rand_text(rng, n, alpha)
-        lens = [[1], [2], [1, 2], [1, 2, 3, 4], [2, 3, 4], [2, 4], [1, 4], [1, 3], [2, 2, 3]][rng.randint(0, 9)]
+        lens = [[1], [2], [1, 2], [1, 2, 3, 4], [2, 3, 4], [2, 4], [1, 4], [1, 3], [2, 2, 3], [1, 5], [2, 6, 6], [1, 3, 7], [2, 8]][rng.randint(0, 13)]
         pats = []
         for _ in range(60):
             if len(pats) >= [2, 3, 4, 6, 9][rng.randint(0, 5)]: break
