@@ -1227,9 +1227,9 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
             }
             const double density = (double)h_ctr->total / (double)(own_hi - la.anchor);
             int next = shape + 1;
-            while (next <= 2 && density > single_fused_max_density(next))
+            while (next <= kFusedShapeMax && density > single_fused_max_density(next))
                 ++next;
-            if (next > 2 || h_ctr->total == 0)
+            if (next > kFusedShapeMax || h_ctr->total == 0)
                 break;
             t->set_shape = next;
         }

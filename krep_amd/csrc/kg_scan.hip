@@ -232,9 +232,9 @@ static int lit_pass(krep_gpu_plan *pl, const Window &w, const LitPass &ps, hipSt
             // safety net fired (then the total is not to be trusted and the two-pass kernels take over)
             const double density = (double)pl->h_ctr->total / (double)(hi_match - a.anchor);
             int next = shape + 1;
-            while (next <= 2 && density > single_fused_max_density(next))
+            while (next <= kFusedShapeMax && density > single_fused_max_density(next))
                 ++next;
-            if (next > 2 || pl->h_ctr->total == 0)
+            if (next > kFusedShapeMax || pl->h_ctr->total == 0)
                 break;
             pl->fused1_shape = next;
         }

@@ -30,10 +30,10 @@
 //   subset of the grid runs.  (tests/test_gpu_literal.py::test_single_byte_one_pass_with_a_starved_grid forces 1-, 2- and 3-block
 //   grids over 8 192 tickets.)
 // A ticket with more hits than the ring holds raises ctr->overflow_units (the scan still COUNTS: the resolver's running sum is
-// the total).  Three shapes (template parameters UPT = 32-KiB units per ticket, RING = 16-bit entries per wave, WPE = waves per
+// the total).  Four shapes (template parameters UPT = 32-KiB units per ticket, RING = 16-bit entries per wave, WPE = waves per
 // SIMD): 128-KiB tickets / 8 KiB of ring / 16 waves per CU for up to ~1.5 % hits (BASELINE config 3); 64-KiB tickets / 16 KiB /
-// 8 waves for up to ~6 %; 32-KiB tickets / 16 KiB / 8 waves for up to ~12 % (80 tickets per microsecond is what one counter
-// gives: fine while the records, 16 bytes per hit, are most of the traffic).  The host picks the shape from the density the
+// 8 waves for up to ~5 %; 32-KiB tickets / 16 KiB / 8 waves for up to ~10 %; 32-KiB tickets / 32 KiB / 4 waves for up to ~20 %
+// (80 tickets per microsecond is what one counter gives: fine while the records, 16 bytes per hit, are most of the traffic).  The host picks the shape from the density the
 // first scan of a plan counted (kg_scan.hip, lit_pass) and falls back to the two-pass kernels beyond that.
 // SET: up to four needle bytes instead of one — a dictionary of single-byte patterns (`-e e -e t`) is this scan with a set
 // (aho_corasick_search reports such matches in text order, one per position: the records are memchr_search's).
@@ -62,6 +62,7 @@ constexpr u32 kUptStd = KG_S1_UPT;            // units (32 KiB each) per ticket:
 static_assert(kUptStd >= 1 && kUptStd <= 4, "flush() derives a record's unit from three boundaries");
 constexpr u32 kRingStd = 1024u * kUptStd;     // 16-bit entries per wave: the ticket being scanned + the one waiting
 constexpr u32 kRingDense = 8192u;             // ... of the two dense shapes (16 KiB per wave: 2 workgroups per CU)
+constexpr u32 kRingDensest = 16384u;          // ... of the densest one (32 KiB per wave: one workgroup per CU)
 constexpr u64 kReady = 1ull << 63;
 constexpr u32 kSpinLimit = 1u << 24;          // ~0.25 us per spin: seconds — only a logic error gets there (see the safety nets)
 constexpr u32 kResolveChunk = 8;              // tickets per resolver lane and pass (512 per pass)
@@ -186,8 +187,8 @@ __global__ __launch_bounds__(kBlock, WPE) void single_fused(const LitArgs a, u64
         return;
     }
 
-    __shared__ unsigned short s_ring[kWavesPerBlk][kRing];
-    unsigned short *ring = s_ring[wave];
+    extern __shared__ __attribute__((aligned(16))) unsigned short s_ring[]; // [kWavesPerBlk][kRing] (dynamic: the densest shape asks for 128 KiB)
+    unsigned short *ring = s_ring + (size_t)wave * kRing;
     const u64 hi_match = a.own_hi < a.text_len ? a.own_hi : a.text_len; // exclusive start bound (m == 1)
 
     // the ticket whose records are still in the ring (uniform)
@@ -435,9 +436,17 @@ int g_s1_force_grid = 0; // test hook: at most this many blocks (0 = auto)
 template <bool CI, u32 UPT, u32 RING, int WPE, bool SET>
 static hipError_t launch_fused(const LitArgs &a, u64 *agg, u64 *pref, u64 n_tickets, u32 num_cu, hipStream_t st)
 {
+    constexpr size_t kLds = (size_t)kWavesPerBlk * RING * sizeof(unsigned short);
+    if (kLds > 64 * 1024) // more than 64 KiB of dynamic LDS has to be asked for (per device; cheap next to a scan of >= 128 KiB)
+    {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&single_fused<CI, UPT, RING, WPE, SET>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
+        if (e != hipSuccess)
+            return e;
+    }
     static const u32 bpc = [] {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, single_fused<CI, UPT, RING, WPE, SET>, kBlock, 0) != hipSuccess || n < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, single_fused<CI, UPT, RING, WPE, SET>, kBlock, kLds) != hipSuccess || n < 1)
         {
             (void)hipGetLastError();
             n = 1;
@@ -449,18 +458,19 @@ static hipError_t launch_fused(const LitArgs &a, u64 *agg, u64 *pref, u64 n_tick
     u32 grid = (u32)std::max<u64>(1, std::min<u64>(want, (u64)num_cu * bpc));
     if (g_s1_force_grid > 0) // test hook: a starved grid (krep_gpu_debug_force_single_grid)
         grid = std::min<u32>(grid, (u32)g_s1_force_grid);
-    hipLaunchKernelGGL((single_fused<CI, UPT, RING, WPE, SET>), dim3(grid), dim3(kBlock), 0, st, a, agg, pref, n_tickets);
+    hipLaunchKernelGGL((single_fused<CI, UPT, RING, WPE, SET>), dim3(grid), dim3(kBlock), kLds, st, a, agg, pref, n_tickets);
     return hipGetLastError();
 }
 
-// shape 0: 128-KiB tickets (<= ~1.5 % hits); 1: 64-KiB tickets, 16-KiB rings (<= ~6 %); 2: 32-KiB tickets, 16-KiB rings (<= ~12 %)
+// shape 0: 128-KiB tickets (<= ~1.2 % hits); 1: 64-KiB tickets, 16-KiB rings (<= ~5 %); 2: 32-KiB tickets, 16-KiB rings (<= ~10 %);
+// 3: 32-KiB tickets, 32-KiB rings, one workgroup per CU (<= ~20 %: by then the records are 3 bytes per byte of text)
 static u32 shape_upt(int shape) { return shape == 0 ? kUptStd : (shape == 1 ? 2u : 1u); }
 uint64_t single_fused_tickets(uint64_t n_units, int shape) { return (n_units + shape_upt(shape) - 1) / shape_upt(shape); }
 uint64_t single_fused_scratch_words(uint64_t n_tickets) { return 2 * n_tickets; } // counts | prefixes
 // the densest text (hits per byte) a shape's ring is sure to hold: half a ring per ticket, with a margin for clustering
 double single_fused_max_density(int shape)
 {
-    const double ring = shape == 0 ? kRingStd : kRingDense, bytes = (double)shape_upt(shape) * (double)kUnitBytes1;
+    const double ring = shape == 0 ? kRingStd : (shape == 3 ? kRingDensest : kRingDense), bytes = (double)shape_upt(shape) * (double)kUnitBytes1;
     return 0.4 * ring / bytes;
 }
 
@@ -469,7 +479,8 @@ static hipError_t launch_shape(const LitArgs &a, u64 *agg, u64 *pref, u64 n_tick
 {
     if (shape == 0) return launch_fused<CI, kUptStd, kRingStd, 4, SET>(a, agg, pref, n_tickets, num_cu, st);
     if (shape == 1) return launch_fused<CI, 2u, kRingDense, 2, SET>(a, agg, pref, n_tickets, num_cu, st);
-    return launch_fused<CI, 1u, kRingDense, 2, SET>(a, agg, pref, n_tickets, num_cu, st);
+    if (shape == 2) return launch_fused<CI, 1u, kRingDense, 2, SET>(a, agg, pref, n_tickets, num_cu, st);
+    return launch_fused<CI, 1u, kRingDensest, 1, SET>(a, agg, pref, n_tickets, num_cu, st);
 }
 
 hipError_t launch_single_fused(const LitArgs &a, unsigned long long *d_agg, unsigned long long *d_pref, uint64_t n_tickets,

@@ -24,6 +24,8 @@ def _check(gpu, o, text, pats, kw, tiny=True):
     got = gpu.search(abi.Params(pats, **kw), text)
     assert got[0] == want[0], (pats, kw, len(text), got[0], want[0])
     assert np.array_equal(got[1], want[1]), (pats, kw, got[1][:8], want[1][:8])
+    if tiny and max(len(p) for p in pats) == 1:
+        tiny = None  # (single bytes: with records the one-pass byte-set scan of kg_single.hip, else the register compare)
     if tiny is not None and len(text) and kw.get("max_count", 1) != 0:
         assert (gpu.tiny_launches() > before) == tiny, (pats, kw, "tiny kernel expected" if tiny else "general kernel expected")
 
@@ -168,9 +170,9 @@ def test_a_dictionary_of_single_bytes_is_the_one_pass_byte_scan_with_a_set(gpu, 
     import torch
     rng = np.random.RandomState(5)
     n = 6 * (1 << 20) + 1234
-    # (alphabet, dictionary, one-pass expected): 7 % / 6 % / 10 % of the bytes match; 13 % and 100 % are beyond the largest rings
+    # (alphabet, dictionary, one-pass expected): 7 % / 6 % / 10 % / 13 % of the bytes match; 100 % is beyond the largest rings
     for alpha, pats, one_pass in ((b"etaoin shrdlu\n" * 2 + b"ET", [b"e", b"x"], True), (bytes(range(64, 128)), [b"a", b"B", b"c", b"\x7f"], True),
-                                  (b"abcdefghij" * 6 + b"\n", [b"x", b"a"], True), (b"etaoin shrdlu\n" * 2 + b"ET", [b"e", b"t"], False),
+                                  (b"abcdefghij" * 6 + b"\n", [b"x", b"a"], True), (b"etaoin shrdlu\n" * 2 + b"ET", [b"e", b"t"], True),
                                   (b"ab", [b"a", b"b"], False)):
         text = cases.rand_text(rng, n, alpha)
         for kw in (dict(), dict(case_sensitive=False), dict(max_count=1000)):
