@@ -146,6 +146,12 @@ def cpu_baseline(wl, sample_bytes, d_buf):
         ln = min(chunk + (m - 1 if i != threads - 1 else 0), n - b)
         counts[i] = fn(p.ref, C.c_void_p(base + b), ln, None)
 
+    def overlap_only(i):  # matches lying wholly inside chunk i's overlap: the next chunk counts them again (krep.c:2952)
+        b = i * chunk
+        if b >= n or i == threads - 1 or b + chunk >= n:
+            return 0
+        return fn(p.ref, C.c_void_p(base + b + chunk), min(m - 1, n - b - chunk), None)
+
     times = []
     t_all = time.time()
     while len(times) < 3 or (time.time() - t_all < 8 and len(times) < 20):
@@ -157,10 +163,22 @@ def cpu_baseline(wl, sample_bytes, d_buf):
             t.join()
         times.append(time.time() - t0)
     best = min(times)
+    # the correctness gate of this leg: the reference's count of the sample, each match owned once, against the HIP scan of the
+    # same bytes (count-only) — outside the timings above
+    exact = sum(counts) - sum(overlap_only(i) for i in range(threads))
+    gpu_cnt = None
+    try:
+        from krep_amd import load
+        gp = load().plan(p, device=d_buf.device.index or 0)
+        gpu_cnt = int(gp.scan(d_buf.data_ptr(), n).count)
+        gp.close()
+    except Exception as e:
+        gpu_cnt = f"failed: {e!r}"
     res = dict(value=round(n / best / 1e9, 3), unit="GB/s", cores=threads, kind=kind,
                sample=f"{n / 2**30:.1f} GiB slice of the same haystack, {threads} threads x {name}, chunk+overlap as "
                       f"krep.c:2851-2905, best of {len(times)} (median {n / statistics.median(times) / 1e9:.1f} GB/s), "
-                      f"count={sum(counts)}")
+                      f"count={sum(counts)}",
+               reference_count_owned_once=int(exact), gpu_count_same_sample=gpu_cnt, gpu_count_matches_reference=(gpu_cnt == exact))
     # The CLIs end to end on a /dev/shm copy of the sample, wall clock of the whole process (mmap + MAP_POPULATE, thread pool,
     # HIP runtime start, PCIe): the reference's own binary, and the SAME source with the backend wired in
     # (oracle/_ref/krep_gpu_cli, integration/make_krep_gpu_cli.py) — once forced onto the GPU (KREP_GPU_COST_MODEL=0: size alone
@@ -261,6 +279,95 @@ def traffic_for(name):
         return None, None
 
 
+
+# ---------------------------------------------------------------------------------------------- in-run correctness gate
+# The reference's own benchmark refuses a number whose count disagrees with a second implementation
+# (/root/reference/test/benchmark_krep_vs_rg.sh:62-75: krep -c against rg -c).  Here, outside every timed region: the 8-byte
+# literal against the closed form of the synthetic generator (count AND the complete start list), the single byte against an
+# independent device-side count and offset checksum, the 1000 patterns against list properties (and, in the cpu_baseline leg,
+# against the compiled reference on the CPU sample).  `verified: false` makes bench.py exit non-zero.
+_M64 = (1 << 64) - 1
+_GIB = 1 << 30
+
+
+def _splitmix64(x):
+    import numpy as np
+    x = (x + np.uint64(0x9E3779B97F4A7C15)) & np.uint64(_M64)
+    x = ((x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & np.uint64(_M64)
+    x = ((x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & np.uint64(_M64)
+    return x ^ (x >> np.uint64(31))
+
+
+def expected_literal8_starts(lo, hi, global_len, plen=len(PATTERN)):
+    """Start offsets in [lo, hi) of the plants of generator kind 2 in a text of global_len bytes (krep_amd/csrc/kg_synth.h:
+    one per PERIOD-byte stride at a hashed offset, suppressed next to a GiB boundary, plus one at every GiB boundary - 3)."""
+    import numpy as np
+    with np.errstate(over="ignore"):
+        k = np.arange(lo // PERIOD, (hi + PERIOD - 1) // PERIOD, dtype=np.uint64)
+        h = _splitmix64(np.uint64(SEED) ^ np.uint64(0xA5A5A5A5DEADBEEF) ^ (k * np.uint64(0x9FB21C651E98DF25)))
+        s = k * np.uint64(PERIOD) + h % np.uint64(PERIOD - plen + 1)
+    s = s.astype(np.int64)
+    b = ((s + _GIB // 2) // _GIB) * _GIB
+    near = (b != 0) & (s + 2 * plen + 3 > b) & (s < b + 2 * plen)
+    s = s[~near]
+    bp = np.arange(max(1, lo // _GIB), hi // _GIB + 2, dtype=np.int64) * _GIB - 3
+    allp = np.sort(np.concatenate([s, bp]))
+    return allp[(allp >= lo) & (allp < hi) & (allp + plen <= global_len)]
+
+
+def verify_step(name, wl, eng, plan, buf, pos, out, n, text_len, shard_off, world):
+    """-> (ok, what was compared).  Runs after the timed steps on the records the LAST timed step left in `pos`."""
+    import numpy as np
+    import torch
+    from krep_amd import abi
+    stored = int(out.stored)
+    rec = pos[: 2 * stored].view(-1, 2)
+    if stored != int(out.total_matches) or int(out.count) != int(out.total_matches):
+        return False, f"stored {stored} / count {int(out.count)} / total {int(out.total_matches)} disagree"
+    if name == "literal8":
+        want = expected_literal8_starts(shard_off, shard_off + n, world * n)
+        if len(want) != stored:
+            return False, f"closed-form count {len(want)} != {stored}"
+        w = torch.from_numpy(want).to(rec.device)
+        ok = bool(torch.equal(rec[:, 0], w)) and bool(torch.all(rec[:, 1] - rec[:, 0] == len(PATTERN)))
+        return ok, f"all {stored} (start, end) records == closed form of the generator (kg_synth.h kind 2)"
+    if wl["kind"] == 3:
+        b = wl["patterns"][0][0]
+        cnt = csum = 0
+        for lo in range(0, n, _GIB):
+            nz = torch.nonzero(buf[lo:min(n, lo + _GIB)] == b).flatten()
+            cnt += int(nz.numel())
+            csum += int(nz.sum().item()) + (lo + shard_off) * int(nz.numel())
+        if cnt != stored:
+            return False, f"torch count {cnt} != {stored}"
+        ok = (int(rec[:, 0].sum().item()) == csum and bool(torch.all(rec[1:, 0] > rec[:-1, 0]))
+              and bool(torch.all(rec[:, 1] == rec[:, 0] + 1)))
+        return ok, f"count {stored} == torch.nonzero count, offset checksum equal, strictly ascending"
+    # multi-pattern: a count-only scan of the same shard, the list's order (end ascending, longest first), every record's length in
+    # the dictionary's range, and a sample of records compared byte for byte with the dictionary on the host
+    cplan = eng.plan(abi.Params(wl["patterns"], count_lines=True, only_match=True), device=buf.device.index or 0)
+    c = cplan.scan(buf.data_ptr(), text_len, 0, n, shard_off, global_len=world * n)
+    cplan.close()
+    if int(c.count) != stored:
+        return False, f"count-only scan {int(c.count)} != {stored} records"
+    e, st = rec[:, 1], rec[:, 0]
+    ordered = bool(torch.all((e[1:] > e[:-1]) | ((e[1:] == e[:-1]) & (st[1:] >= st[:-1]))))
+    ln = e - st
+    lens = sorted({len(x) for x in wl["patterns"]})
+    in_range = bool(torch.all((ln >= lens[0]) & (ln <= lens[-1])))
+    idx = torch.randint(0, stored, (min(stored, 200000),), device=rec.device)
+    smp = rec[idx].cpu().numpy() - shard_off
+    pats = set(wl["patterns"])
+    okb = True
+    offs = torch.from_numpy(smp[:, 0].copy()).to(rec.device)
+    g = buf[(offs[:, None] + torch.arange(lens[-1], device=rec.device)[None, :]).clamp_(max=text_len - 1)].cpu().numpy()
+    for i in range(len(smp)):
+        if bytes(g[i, : smp[i, 1] - smp[i, 0]]) not in pats:
+            okb = False
+            break
+    return ordered and in_range and okb, (f"{stored} records == count-only scan, (end, longest-first) order, "
+                                          f"{len(smp)} sampled records are dictionary words")
+
 # ---------------------------------------------------------------------------------------------- one workload on this rank
 def positions_capacity(name, n):
     wl = WORKLOADS[name]
@@ -329,6 +436,14 @@ def run_workload(name, args, eng, buf, pos, dev, rank, world, local, use_dist):
         total_matches = int(out.total_matches)
     assert not out.overflow, "position buffer too small"
     stored = int(out.stored)
+    try:
+        verified, how = verify_step(name, wl, eng, plan, buf, pos, out, n, text_len, shard_off, world)
+    except Exception as e:
+        verified, how = False, f"verification failed to run: {e!r}"
+    if use_dist:
+        v = torch.tensor([1 if verified else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(v, op=dist.ReduceOp.MIN)  # every rank checks its own shard
+        verified = bool(int(v.item()))
     plan.close()
     if rank != 0:
         return None
@@ -337,7 +452,7 @@ def run_workload(name, args, eng, buf, pos, dev, rank, world, local, use_dist):
     k_avg, k_med = sum(k_ms) / len(k_ms), statistics.median(k_ms)
     achieved = n / (k_avg * 1e-3) / 1e9
     return {
-        "wl": wl, "collective": use_dist if use_dist else None,
+        "wl": wl, "collective": use_dist if use_dist else None, "verified": verified, "verified_how": how,
         "value": round(value, 1), "ms_per_step": round(ms_step, 4), "matches": total_matches,
         "matches_per_s": round(total_matches / (dt / args.steps), 1),
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -511,6 +626,7 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": config_of(args.workload, wl, args, world, n, res),
             "roofline": res["roofline"],
+            "verified": res["verified"], "verified_how": res["verified_how"],
         }
         if placement:
             line["config"]["placement"] = placement
@@ -529,7 +645,8 @@ def main():
             try:
                 r = run_workload(name, args, eng, buf, pos, dev, rank, world, local, use_dist)
                 e = {"value": r["value"], "unit": "GB/s", "ms_per_step": r["ms_per_step"],
-                     "config": config_of(name, r["wl"], args, world, n, r), "roofline": r["roofline"]}
+                     "config": config_of(name, r["wl"], args, world, n, r), "roofline": r["roofline"],
+                     "verified": r["verified"], "verified_how": r["verified_how"]}
                 if not args.no_cpu_baseline:
                     try:
                         e["cpu_baseline"] = cpu_baseline(r["wl"], min(n, int(min(args.cpu_sample_gib, 1.0) * (1 << 30))), buf)
@@ -540,8 +657,14 @@ def main():
                 extra[name] = {"value": None, "error": repr(ex)}
         if line is not None:
             line["extra"] = extra
+    bad = []
     if rank == 0:
         print(json.dumps(line), flush=True)
+        bad = [k for k, v in [(args.workload, line)] + list(line.get("extra", {}).items()) if v.get("verified") is False]
+        bad += [k + ".cpu_baseline" for k, v in [(args.workload, line)] + list(line.get("extra", {}).items())
+                if isinstance(v.get("cpu_baseline"), dict) and v["cpu_baseline"].get("gpu_count_matches_reference") is False]
+        if bad:
+            print(f"bench.py: VERIFICATION FAILED for {bad}: the numbers above are not valid", file=sys.stderr)
     if use_dist:
         if use_dist == "c":
             if rank == 0 and line is not None:
@@ -549,7 +672,7 @@ def main():
                       f"{eng.rccl_version()})", file=sys.stderr)
             eng.comm_destroy()
         dist.destroy_process_group()
-    return 0
+    return 3 if bad else 0
 
 
 if __name__ == "__main__":

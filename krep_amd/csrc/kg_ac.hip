@@ -1119,7 +1119,15 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
     // run up to own_hi + Lmax - 2.  -c owns by END index instead (a pattern without '\n' starts and ends
     // on the same line), which keeps the line bookkeeping inside the owned window.
     a.end_lo = own_lo;
-    a.end_hi = lines ? own_hi : std::min<u64>(text_len, (u64)own_hi + t->lmax - 1);
+    a.end_hi = (lines || lines_on_list) ? own_hi : std::min<u64>(text_len, (u64)own_hi + t->lmax - 1);
+    if (lines_on_list)
+    {
+        // the record list -c is counted on (kg_scan.hip scan_ac_lines_on_list) owns by END like the in-kernel -c road does: two
+        // neighbouring pieces / shards may take different roads, and a match across their cut must belong to exactly one of them
+        // (ADVICE r04).  No start clip: every start the buffer holds is in.
+        a.own_lo = 0;
+        a.own_hi = text_len;
+    }
     a.anchor = own_lo & ~(u64)15;
     const u64 unit_bytes = (u64)kAcUnitBytes;
     a.num_tiles = (a.end_hi - a.anchor + unit_bytes - 1) / unit_bytes;

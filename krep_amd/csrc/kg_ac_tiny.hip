@@ -122,7 +122,7 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
                 const bool fast_now = seg + kSegBytes <= a.text_len;
                 // interior: every END of the round lies in the launch's window, and so does the START of a 4-byte match at its
                 // first byte (starts own a match outside -c) — nothing to clip
-                const bool interior = seg >= a.own_lo + (lmax - 1u) && seg + kSegBytes <= a.own_hi && seg + kSegBytes <= a.end_hi;
+                const bool interior = seg >= a.own_lo + (lmax - 1u) && seg >= a.end_lo && seg + kSegBytes <= a.own_hi && seg + kSegBytes <= a.end_hi;
                 const uint4 *src = reinterpret_cast<const uint4 *>(a.text + seg) + lane;
                 auto cell = [&](auto interC, const int j, const u32 (&D)[4], const u32 P, const u32 P2) __attribute__((always_inline)) {
                     constexpr bool inter = decltype(interC)::value, kp = KEEP;

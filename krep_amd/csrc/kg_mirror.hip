@@ -23,32 +23,37 @@
 using namespace kg;
 
 
-// is_repetitive_pattern(), krep.c:1873-1914 (decides KMP vs BMH on builds without SIMD)
+// The predicate behind "KMP instead of BMH" on builds without a usable SIMD body (is_repetitive_pattern(), krep.c:1873-1914),
+// stated as the PROPERTY it computes: a pattern of m >= 3 bytes is repetitive iff it holds a run of more than m/2 equal bytes,
+// or it has a period p with 2 <= p <= m/2 (s[i] == s[i - p] for every i >= p).  The periods of a string are exactly m - b over
+// its borders b, so they are read off the border chain of the prefix function instead of being tried one by one.
 static bool repetitive_pattern(const char *s, size_t m)
 {
     if (m < 3)
         return false;
-    size_t run = 0;
-    char prev = s[0];
-    for (size_t i = 1; i < m; ++i)
+    size_t longest = 1;
+    for (size_t lo = 0; lo < m;)
     {
-        if (s[i] == prev)
-        {
-            if (++run >= m / 2)
-                return true;
-        }
-        else
-        {
-            run = 0;
-            prev = s[i];
-        }
+        size_t hi = lo + 1;
+        while (hi < m && s[hi] == s[lo])
+            ++hi;
+        longest = std::max(longest, hi - lo);
+        lo = hi;
     }
-    for (size_t per = 2; per <= m / 2; ++per)
+    if (longest > m / 2)
+        return true;
+    std::vector<size_t> border(m + 1, 0); // border[k]: longest proper border of s[0, k)
+    for (size_t k = 1, b = 0; k < m; ++k)
     {
-        bool ok = true;
-        for (size_t i = per; i < m && ok; ++i)
-            ok = s[i] == s[i % per];
-        if (ok)
+        while (b && s[k] != s[b])
+            b = border[b];
+        b += s[k] == s[b];
+        border[k + 1] = b;
+    }
+    for (size_t b = border[m]; b; b = border[b])
+    {
+        const size_t per = m - b;
+        if (per >= 2 && per <= m / 2)
             return true;
     }
     return false;

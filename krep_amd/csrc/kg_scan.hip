@@ -972,7 +972,7 @@ static int scan_ac_newline_lines(krep_gpu_plan *pl, const Window &w, hipStream_t
 // bitmaps per unit, a line pass over all 16 cells of every unit) runs at 0.43 of the HBM roofline on BASELINE config 4; this
 // road costs the records scan (0.61) plus ~2 cache lines per match.  The line summary of the window (has_newline / head / tail,
 // krep_gpu_combine_line_counts) comes from two early-exit newline sweeps and the first and last record.  Matches are owned by
-// START here, by END in the in-kernel road: the same lines either way (a match without '\n' starts and ends on one line).
+// their END (last byte in [own_lo, own_hi)) on both roads, so neighbouring pieces may take different roads (ac_scan).
 // Returns 1 when the text turns out to be too dense for the list (the caller takes the in-kernel road), 2 on error.
 constexpr size_t kAcLinesOnListMin = (size_t)32 << 20;
 static int scan_ac_lines_on_list(krep_gpu_plan *pl, const Window &w, hipStream_t st, int time_it, krep_gpu_scan_out_t *out)

@@ -157,7 +157,9 @@ __device__ __forceinline__ bool tail_gap_has_newline(const uint8_t *__restrict__
     // aligned 16-byte vectors only, four in flight per step (a 64-byte line: with 80-byte lines the first step decides more than
     // half of the gaps, and a step is one memory round trip however wide it is); the bytes in front of lo / behind hi are masked
     // out of the test (reading them is safe: they share an aligned 16-byte granule with a byte of the gap)
-    auto z = [](u32 x) -> u32 { const u32 y = x ^ 0x0a0a0a0au; return (y - 0x01010101u) & ~y & 0x80808080u; }; // 0x80 per '\n' byte
+    // 0x80 in every '\n' byte, exactly (the borrow-based (y - 0x01..) & ~y & 0x80.. test is exact only for "any zero byte": a real
+    // '\n' below a 0x0b byte flags that one too, and the window mask behind this test can cut the real one away — ADVICE r04)
+    auto z = [](u32 x) -> u32 { const u32 y = x ^ 0x0a0a0a0au; return ~(((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y | 0x7f7f7f7fu); };
     const size_t mis = ((size_t)(t + lo)) & 15u;
     const uint8_t *p = t + lo - mis; // aligned
     const u64 total = hi - lo + mis; // bytes from p to hi

@@ -66,6 +66,32 @@ def test_mirror_of_select_search_algorithm_matches_oracle(lib):
     e.set_reference_simd(abi.REF_AVX2)
 
 
+def test_repetitive_pattern_predicate_exhaustively_against_the_reference_selector(lib):
+    """KMP-or-BMH on a scalar build hangs on is_repetitive_pattern() (krep.c:1860-1865, :1873-1914).  The mirror states it as a
+    property (a run longer than m/2, or a period in [2, m/2], read off the border chain — kg_mirror.hip); here it is compared
+    with the compiled reference's own select_search_algorithm() for EVERY pattern of 3..9 bytes over {a, b, c} (and the
+    restatement where oracle/_ref is absent)."""
+    import itertools
+    import krep_amd
+    import oracle_lib as ol
+    e = krep_amd.load()
+    r = ol.ref(abi.REF_SCALAR)
+    o = ol.oracle()
+    e.set_reference_simd(abi.REF_SCALAR)
+    try:
+        n = 0
+        for m in range(3, 10):
+            for tup in itertools.product(b"abc", repeat=m):
+                pat = bytes(tup)
+                p = abi.Params([pat])
+                want = r.select(p) if r is not None else o.select(p, abi.REF_SCALAR)
+                assert e.mirror_select(p, 1000) == want, pat
+                n += 1
+        assert n == sum(3 ** m for m in range(3, 10))
+    finally:
+        e.set_reference_simd(abi.REF_AVX2)
+
+
 def test_fails_loudly_without_gpu():
     import krep_amd
     e = krep_amd.load()

@@ -201,6 +201,81 @@ def test_worst_legal_dictionary_1024_patterns_of_up_to_1024_bytes(gpu, oracle_en
         _check(gpu, oracle_engine, text[90:700], pats, dict())
 
 
+def test_count_lines_pieces_on_different_roads_own_a_straddling_match_once(gpu, oracle_engine, monkeypatch):
+    """multi-pattern -c picks its road per piece — in the kernel below 32 MiB of buffer (or when the plan has
+    seen a dense text), on the record list above.  Both roads own a match by its END, so a match across the cut between two
+    pieces on different roads is counted exactly once: a small piece followed by a >= 32 MiB piece (the default streaming
+    layout: a shard's short last chunk, then the next shard's first 128-MiB chunk), the opposite order, and the roads forced
+    alternately over many cuts of one buffer ("dense shard, then sparse shard").  Every straddling match is the only one on
+    its line, at every split of its bytes; general kernel and register-compare (tiny) dictionary; -w, -i."""
+    import torch
+    rng = np.random.RandomState(20260926)
+    n = 40 << 20
+    az = bytes(range(97, 123))
+    text = cases.rand_text(rng, n, az + b" \n")
+    big = [cases.pick_pattern(rng, text[: 1 << 20], int(rng.randint(5, 14)), az) for _ in range(40)]
+    big = [q for q in big if b"\n" not in q and b" " not in q]
+    for pats in (big + [b"QXJZKWVQ", b"QXJZ"], [b"QX", b"XJZ", b"JZKW"]):
+        strad = pats[-2] if len(pats) > 3 else b"XJZKW"   # (tiny: XJZ ends inside, JZKW ends behind the cut or on it)
+        L = len(strad)
+        cuts = [(i + 1) * (3 << 20) + 17 * i + 5 for i in range(12)]
+        t = text.copy()
+        for i, c in enumerate(cuts):
+            k = 1 + i % (L - 1)                    # bytes of the straddler in front of the cut
+            t[c - 200:c + 200] = ord("-")
+            t[c - 120] = t[c + 120] = 10
+            t[c - k:c - k + L] = np.frombuffer(strad, dtype=np.uint8)
+        d = torch.from_numpy(t).cuda()
+        for kw in (dict(), dict(whole_word=True), dict(case_sensitive=False)):
+            kwc = dict(count_lines=True, **kw)
+            want = oracle_engine.call(abi.RA_AHO_CORASICK, abi.Params(pats, **kwc), t)[0]
+            plan = gpu.plan(abi.Params(pats, **kwc))
+            assert plan.scan(d.data_ptr(), n).count == want
+            halo = 1100
+            # (1) buffers of their own: [0, c + halo) is below 32 MiB -> in-kernel road, [c - halo, n) is above -> list road
+            for c in cuts[:3]:
+                a = plan.scan(d.data_ptr(), c + halo, 0, c, 0, global_len=n)
+                b = plan.scan(d.data_ptr() + c - halo, n - (c - halo), halo, n - (c - halo), c - halo, global_len=n)
+                arr = (abi.ScanOut * 2)(a, b)
+                assert gpu.lib.krep_gpu_combine_line_counts(arr, 2) == want, ("small then large", kw, c)
+            # (2) the opposite order: [0, c + halo) large (list), [c - halo, n) small (in the kernel)
+            c = cuts[-1]
+            a = plan.scan(d.data_ptr(), c + halo, 0, c, 0, global_len=n)
+            b = plan.scan(d.data_ptr() + c - halo, n - (c - halo), halo, n - (c - halo), c - halo, global_len=n)
+            assert gpu.lib.krep_gpu_combine_line_counts((abi.ScanOut * 2)(a, b), 2) == want, ("large then small", kw)
+            # (3) windows of one buffer, the road forced alternately
+            edges = [0] + cuts + [n]
+            for first_inkernel in (0, 1):
+                outs = []
+                for j, (lo, hi) in enumerate(zip(edges[:-1], edges[1:])):
+                    if (j + first_inkernel) % 2:
+                        monkeypatch.setenv("KREP_GPU_AC_LINES_INKERNEL", "1")
+                    outs.append(plan.scan(d.data_ptr(), n, lo, hi))
+                    monkeypatch.delenv("KREP_GPU_AC_LINES_INKERNEL", raising=False)
+                arr = (abi.ScanOut * len(outs))(*outs)
+                assert gpu.lib.krep_gpu_combine_line_counts(arr, len(outs)) == want, ("alternating", kw, first_inkernel)
+            plan.close()
+        del d
+
+
+def test_count_lines_gap_test_is_exact_per_byte(gpu, oracle_engine):
+    """the newline test of the gap between two neighbouring records (kg_tail.hip tail_gap_has_newline) must be exact per
+    byte — with the borrow-based zero-byte trick a real '\\n' just in front of the gap flagged the 0x0b bytes behind it."""
+    import torch
+    rng = np.random.RandomState(77)
+    n = 33 << 20
+    text = cases.rand_text(rng, n, b"abcdefgh\x0b\x0b \n")
+    text[:6] = np.frombuffer(b"\n\x0b\x0ba \n", dtype=np.uint8)
+    d = torch.from_numpy(text).cuda()
+    for pats, kw in (([b"\x0b", b"zz"], dict(whole_word=True)), ([b"\x0b", b"a\x0b"], dict()), ([b"\x0b", b"\x0ba", b"cd"], dict(whole_word=True))):
+        kwc = dict(count_lines=True, **kw)
+        want = oracle_engine.call(abi.RA_AHO_CORASICK, abi.Params(pats, **kwc), text)[0]
+        plan = gpu.plan(abi.Params(pats, **kwc))
+        got = plan.scan(d.data_ptr(), n)
+        plan.close()
+        assert got.count == want, (pats, kw, got.count, want)
+
+
 def test_count_lines_on_the_record_list(gpu, oracle_engine, monkeypatch):
     """Multi-pattern -c on a text large enough for the list road (kg_scan.hip scan_ac_lines_on_list: records by the fast
     kernel, lines counted on the end-ordered list by their newline gaps): whole text and ownership windows (the line summary
