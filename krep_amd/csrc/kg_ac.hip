@@ -443,7 +443,19 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                     bool slA = false, slB = false;
                     u32 mA = 0, mB = 0;
                     if (!(a.flags & (1u << 30))) // (ablation hook KREP_GPU_AC_NOPROBE: candidate enumeration without the probes)
-                        ac_walk_probe2<CI, SHORT>(a, pos, liveA, liveB, LINES, mA, slA, mB, slB);
+                        ac_walk_probe2<CI, SHORT>(a, pos, liveA, liveB, LINES, mA, slA, mB, slB, [&](u32 E) -> bool {
+#ifndef KG_AC_NO_BTEST // (A/B switch of krep_amd/build.py --variant)
+                            if constexpr (PAIR && XB == 20)
+                            {
+                                // the filter's own lookup for a gram that lies in one dword (cell_body, k = 3 mod 4)
+                                typedef __attribute__((address_space(3))) const u32 lds_u32;
+                                const u32 u = ac_pair(E);
+                                return ((*(lds_u32 *)(size_t)(((u >> 3) ^ (u >> 13)) & 0x1fffcu) >> (u & 31u)) & 1u) != 0u;
+                            }
+                            else
+#endif
+                                return true;
+                        });
                     else
                         mA = liveA ? 1u : 0u; // ... and the count that comes back is the number of candidates
                     dmA = mA; dmB = mB;
@@ -1270,15 +1282,29 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
     const u32 grid = (u32)std::min<u64>((n_tickets + waves - 1) / waves, (u64)num_cu * per_cu);
     auto launch = [&](const AcArgs &args) { return tiny ? ac_tiny_launch(args, t->tiny, n_tickets, (u32)num_cu, st) : ac_launch(args, grid, lds, st); };
     if (time_it) SCHK(hipEventRecord(ev0, st));
+    // KREP_GPU_SYNC_DEBUG=1: synchronise behind every launch of this function and say which one faulted
+    const bool dbg_sync = getenv("KREP_GPU_SYNC_DEBUG") != nullptr;
+    auto dbg = [&](const char *what) -> int {
+        if (!dbg_sync)
+            return 0;
+        const hipError_t e = hipStreamSynchronize(st);
+        return e == hipSuccess ? 0 : fail("ac_scan: %s faulted: %s (tiny=%d stride=%u units=%llu stage_cap=%u lines=%d list=%d own=[%llu,%llu) end=[%llu,%llu) n=%llu)", what,
+                                          hipGetErrorString(e), (int)tiny, a.stride, (unsigned long long)n_units, a.stage_cap, (int)lines, (int)lines_on_list,
+                                          (unsigned long long)a.own_lo, (unsigned long long)a.own_hi, (unsigned long long)a.end_lo,
+                                          (unsigned long long)a.end_hi, (unsigned long long)text_len);
+    };
     SCHK(hipMemsetAsync(d_ctr, 0, sizeof(Counters), st));
     SCHK(launch(a));
+    if (dbg("scan kernel")) return 2;
     if (chain && post_order(post, n_units, a.stage_cap, 0, a.anchor + global_base, unit_bytes, lines, (uint64_t *)d_pos, want, d_ctr, num_cu, st))
         return 2;
     // lines_on_list (kg_scan.hip scan_ac_lines_on_list): the distinct lines of the record list just gathered, counted by the
     // newline gaps between neighbours, behind the post-pass on the same stream — valid when no unit overflowed its staging
     // slot and the list fitted (the caller checks both and repeats otherwise)
-    if (lines_on_list && want && tail_launch_line_gaps(d_text, global_base, (const uint64_t *)d_pos, &d_ctr->total, want, &d_ctr->lines, st))
+    if (dbg("post-pass")) return 2;
+    if (lines_on_list && want && tail_launch_line_gaps(d_text, text_len, global_base, (const uint64_t *)d_pos, &d_ctr->total, &d_ctr->overflow_units, want, &d_ctr->lines, st))
         return 2;
+    if (dbg("line-gap kernel")) return 2;
     if (time_it) SCHK(hipEventRecord(ev1, st));
     SCHK(hipMemcpyAsync(h_ctr, d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, st));
     SCHK(hipStreamSynchronize(st));

@@ -413,9 +413,14 @@ __device__ __forceinline__ u32 ac_walk_fast(const AcArgs &a, u64 i, bool own_by_
 // The same for the two end positions i and i + 1 of a stride-2 candidate: both text windows and both table probes
 // are in flight together (one latency for the pair).  No level walk in here: an end that needs it comes back with
 // slow = true and the caller runs ac_walk_slow from its single call site.
-template <bool CI, bool SHORT>
+// btest(E): can a pattern END with the four text bytes E (byte i + 1 on top)?  The caller answers from the class table it
+// already holds in LDS (round 5): the second end of a stride-2 candidate is probed only where that says yes.  Measured on
+// BASELINE config 4 (profiles/r05_ac1000_where_the_time_goes.txt): the two 64-byte buckets of every candidate were 0.8 ms of
+// the 6.5 — 700 M L2 requests against the stream's 270 M, most of them onto a few thousand hot lines — and nine second ends
+// in ten cannot be a match by their classes alone.
+template <bool CI, bool SHORT, typename BTest>
 __device__ __forceinline__ void ac_walk_probe2(const AcArgs &a, u64 i, bool liveA, bool liveB, bool own_by_end,
-                                               u32 &dmA, bool &slowA, u32 &dmB, bool &slowB)
+                                               u32 &dmA, bool &slowA, u32 &dmB, bool &slowB, BTest btest)
 {
     dmA = dmB = 0;
     slowA = slowB = false;
@@ -439,6 +444,7 @@ __device__ __forceinline__ void ac_walk_probe2(const AcArgs &a, u64 i, bool live
         TB[1] = __builtin_amdgcn_alignbyte(w2, w1, 1);
         TB[2] = __builtin_amdgcn_alignbyte(w3, w2, 1);
         TB[3] = __builtin_amdgcn_alignbyte(w4, w3, 1);
+        liveB = btest(TB[3]); // (classes ignore the case: asked before the fold)
     }
     if (CI)
     {
@@ -453,11 +459,21 @@ __device__ __forceinline__ void ac_walk_probe2(const AcArgs &a, u64 i, bool live
     u32 hA = (TA[3] * kHashMul) >> 9, hB = (TB[3] * kHashMul) >> 9;
     uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0, b0 = a0, b1 = a0;
     bool doneA = !liveA || !a.has4, doneB = !liveB || !a.has4, foundA = false, foundB = false;
+#if defined(KG_AC_ABLATE) && KG_AC_ABLATE == 1 // (measurement build: the text windows only — no table probe, no evaluation)
+    dmA = (liveA && TA[3] == 0x12345678u) ? 16u : 0u;
+    dmB = (liveB && TB[3] == 0x12345678u) ? 16u : 0u;
+    return;
+#endif
     if (a.g4x_mode)
     {
         const uint4 *ba = a.g4x + 4 * (size_t)(((TA[3] * a.g4x_mul) >> 9) & a.g4x_mask);
         const uint4 *bb = a.g4x + 4 * (size_t)(((TB[3] * a.g4x_mul) >> 9) & a.g4x_mask);
-        const uint4 x0 = ba[0], x1 = ba[1], x2 = ba[2], x3 = ba[3], y0 = bb[0], y1 = bb[1], y2 = bb[2], y3 = bb[3];
+        const uint4 x0 = ba[0], x1 = ba[1], x2 = ba[2], x3 = ba[3];
+        uint4 y0 = make_uint4(0, 0, 0, 0), y1 = y0, y2 = y0, y3 = y0;
+        if (!doneB) // (a lane whose second end is dead issues no requests for it; both buckets are still in flight together)
+        {
+            y0 = bb[0]; y1 = bb[1]; y2 = bb[2]; y3 = bb[3];
+        }
         const bool ha0 = x0.y != 0u && x0.x == TA[3], ha1 = x2.y != 0u && x2.x == TA[3];
         const bool hb0 = y0.y != 0u && y0.x == TB[3], hb1 = y2.y != 0u && y2.x == TB[3];
         a0 = ha0 ? x0 : x2; a1 = ha0 ? x1 : x3;
@@ -485,8 +501,15 @@ __device__ __forceinline__ void ac_walk_probe2(const AcArgs &a, u64 i, bool live
             else ++hB;
         }
     }
+#if defined(KG_AC_ABLATE) && KG_AC_ABLATE == 2 // (measurement build: windows + both buckets, no evaluation)
+    dmA = (liveA && (a0.x ^ a1.y ^ b0.z ^ b1.w) == 0x12345678u) ? 16u : 0u;
+    return;
+#endif
     if (liveA)
         ac_eval_entry(a, foundA, TA, a0, a1, sbA, i, own_by_end, dmA, slowA);
+#if defined(KG_AC_ABLATE) && KG_AC_ABLATE == 3 // (measurement build: the second end is not evaluated)
+    return;
+#endif
     if (liveB)
         ac_eval_entry(a, foundB, TB, b0, b1, sbB, i + 1, own_by_end, dmB, slowB);
 }

@@ -81,10 +81,10 @@ int tail_find_prev_newline(const uint8_t *d_text, uint64_t before, unsigned long
                            hipStream_t st, uint64_t *pos_plus1);
 int tail_count_changes(const uint64_t *d_v, uint64_t n, unsigned long long *d_slot, unsigned long long *h_slot, hipStream_t st,
                        uint64_t *changes);
-int tail_count_line_gaps(const uint8_t *d_text, uint64_t global_base, const uint64_t *d_rec, uint64_t n, unsigned long long *d_slot,
+int tail_count_line_gaps(const uint8_t *d_text, uint64_t text_len, uint64_t global_base, const uint64_t *d_rec, uint64_t n, unsigned long long *d_slot,
                          unsigned long long *h_slot, hipStream_t st, uint64_t *lines);
-int tail_launch_line_gaps(const uint8_t *d_text, uint64_t global_base, const uint64_t *d_rec, const unsigned long long *d_n, uint64_t cap,
-                          unsigned long long *d_out, hipStream_t st);
+int tail_launch_line_gaps(const uint8_t *d_text, uint64_t text_len, uint64_t global_base, const uint64_t *d_rec, const unsigned long long *d_n,
+                          const unsigned long long *d_skip_if, uint64_t cap, unsigned long long *d_out, hipStream_t st);
 int tail_run_replay(const ReplayIn &r, unsigned long long *d_slot, unsigned long long *h_slot, hipStream_t st, uint64_t *lines);
 
 // kg_ac.hip — multi-pattern scan

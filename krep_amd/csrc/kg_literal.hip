@@ -132,7 +132,7 @@ __global__ __launch_bounds__(kBlock, (KIND == 1 && LINES && R == 4) ? KG_LIT1_LI
 {
     const u32 lane = lane_id();
     const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const bool want_pos = (a.flags & F_POS) != 0;
+    const bool want_pos = !LINES && (a.flags & F_POS) != 0; // (-c never produces records: kg_scan.hip scan_literal)
     const bool ww = (a.flags & F_WW) != 0;
     const bool chain = want_pos || LINES;
     const u64 hi_match = (a.own_hi < a.text_len - a.m + 1) ? a.own_hi : (a.text_len - a.m + 1); // exclusive start bound
@@ -227,6 +227,31 @@ __global__ __launch_bounds__(kBlock, (KIND == 1 && LINES && R == 4) ? KG_LIT1_LI
         u32 M[kInline ? 1 : R][kInline ? 1 : kCells];
         u32 wcnt = 0;     // unit total (uniform)
         LS wls{0, false, false, false};
+        // ---- -c: the line bookkeeping of a unit (round 5).  A line that holds a match is counted at its FIRST match.  Inside a
+        // lane's 16 bytes that is carry arithmetic on the hit / newline masks (l_cnt: first match behind a newline OF THIS LANE,
+        // summed over the unit in a vector register, reduced once per unit); the part of a lane in front of its first newline
+        // continues whatever line enters the lane, and "does the entering line already hold a match" is a CARRY CHAIN over the 64
+        // lanes: generate = the lane ends with a match behind its last newline (or holds one and no newline), propagate = the lane
+        // holds neither — one 64-bit scalar add resolves all 64 lanes, its carry-out is the state entering the next cell.  Round 4
+        // resolved every cell with four ballots, a per-lane search for the nearest newline lane below and a ballot-plane sum:
+        // 0.44 of the HBM roofline for a single byte at 1 % hits where the count-only scan runs at 0.85.
+        u32 l_cnt = 0, l_hits = 0;                                  // per lane, summed at the unit's end
+        u32 s_new = 0;                                              // lines opened by the head part of some lane (uniform)
+        bool s_open = false, s_seen = false, s_head = false;        // open line entering the next cell | a newline seen | match before it
+        auto line_cell = [&](u64 B_nl, u64 B_any, u64 B_head, u64 B_tail) __attribute__((always_inline)) {
+            // (for a lane without a newline head == tail == any, by construction of both front ends)
+            const u64 G = B_tail, P = ~(B_nl | B_any);
+            const unsigned __int128 sum = (unsigned __int128)(G | P) + G + (s_open ? 1u : 0u);
+            const u64 O = (u64)sum ^ P; // bit l: the line entering lane l already holds a match
+            s_new += (u32)__popcll(B_head & ~O);
+            if (!s_seen && B_nl)
+            {
+                const int f = __builtin_ctzll(B_nl);
+                s_head = (((O | B_head) >> f) & 1ull) != 0ull;
+                s_seen = true;
+            }
+            s_open = (u64)(sum >> 64) != 0ull;
+        };
 
         // the rounds of a unit are a real loop for the sparse kinds (nothing is indexed by r any more): a quarter of the code
 #pragma unroll(KIND == 1 ? R : 1)
@@ -292,6 +317,44 @@ __global__ __launch_bounds__(kBlock, (KIND == 1 && LINES && R == 4) ? KG_LIT1_LI
                         D[w] = g.v[w];
                 }
 
+                if (KIND == 1 && LINES && fast && interior && !ww)
+                {
+                    // ---- single byte, -c, interior cell: everything on the 0x80-per-byte flag words (no movemask, no 16-bit
+                    //      masks): the lane's 16 bytes are ONE 128-bit integer with a flag at bit 8k + 7 for byte k ----
+                    u32 HF[4], NF[4];
+#pragma unroll
+                    for (int w = 0; w < 4; ++w)
+                    {
+                        HF[w] = eq_bytes(CI ? (D[w] | a.l0) : D[w], a.p0);
+                        NF[w] = eq_bytes(D[w], 0x0a0a0a0au);
+                        l_hits += (u32)__popc(HF[w]);
+                    }
+                    const u64 B_any = __ballot((HF[0] | HF[1] | HF[2] | HF[3]) != 0u);
+                    const u64 B_nl = __ballot((NF[0] | NF[1] | NF[2] | NF[3]) != 0u);
+                    if (!B_any)
+                    {
+                        if (B_nl)
+                        {
+                            if (!s_seen)
+                            {
+                                s_head = s_open;
+                                s_seen = true;
+                            }
+                            s_open = false;
+                        }
+                        continue;
+                    }
+                    typedef unsigned __int128 u128;
+                    auto pack = [](const u32 (&x)[4]) -> u128 {
+                        return ((u128)(((u64)x[3] << 32) | x[2]) << 64) | (((u64)x[1] << 32) | x[0]);
+                    };
+                    const u128 H = pack(HF), N = pack(NF), Hs = H | N;
+                    const u128 firsts = H & ~(Hs - (N << 8)); // the first match behind each newline of the lane
+                    l_cnt += (u32)(__popcll((u64)firsts) + __popcll((u64)(firsts >> 64)));
+                    const u128 low = H & (Hs ^ (Hs - 1));      // the lowest flag, if it is a match: a match in front of the first newline
+                    line_cell(B_nl, B_any, __ballot(low != 0), __ballot(N < H)); // N < H: the highest flag is a match
+                    continue;
+                }
                 // newline mask before folding (folding never touches '\n')
                 // interior cells only need "does this lane hold a newline" (a zero-byte test on D ^ '\n'); the exact
                 // 16-bit mask (a multiply per dword) is computed where it is consumed: in cells that hold a hit, and in
@@ -578,78 +641,47 @@ __global__ __launch_bounds__(kBlock, (KIND == 1 && LINES && R == 4) ? KG_LIT1_LI
                     }
                 }
 
-                // A hit-free interior cell only matters through "was there a newline", and only while that changes the running
-                // summary: a newline cell is {0, nl, -, -}, which sets nl and clears tail — idempotent.  Once the summary has
-                // nl && !tail, hit-free cells are not even looked at until the next hit (a wave-uniform test of two scalars):
-                // round 1 tested every cell and folded per-lane flags lazily (4.4-5.3 TB/s against 6.3-6.7 for -c -o).
+                // A hit-free interior cell only matters through "was there a newline", and only while that changes the state: a
+                // newline closes the open line and settles the unit's head — idempotent.  Once a newline has been seen and no line
+                // is open, hit-free cells are not even looked at until the next hit (a wave-uniform test of two scalars).
                 if (LINES && interior && !anyhit)
                 {
-                    if (!wls.nl || wls.tail)
+                    if (!s_seen || s_open)
                         if (__ballot(has_nl()))
-                            wls = ls_combine(wls, LS{0, true, false, false});
+                        {
+                            if (!s_seen)
+                            {
+                                s_head = s_open;
+                                s_seen = true;
+                            }
+                            s_open = false;
+                        }
                 }
                 else if (LINES)
                 {
-                    const bool nl_any = interior ? has_nl() : false;
-                    // per-lane summary of its 16 bytes
-                    const u32 H = m16;
-                    const bool l_nl = interior ? nl_any : (nlm != 0u);
-                    const u64 B_nl = __ballot(l_nl);
-                    LS cell{0, B_nl != 0, false, false};
-                    // the usual cell with a hit: ONE lane, one hit, no newline inside that lane's 16 bytes — then the summary is
-                    // three scalar mask tests (no exact newline mask, no further ballots)
-                    const int h1 = anyhit ? __builtin_ctzll(anyhit) : 0;
-                    const u32 hm = (u32)__builtin_amdgcn_readlane((int)H, h1);
-                    if (interior && anyhit && (anyhit & (anyhit - 1ull)) == 0ull && (hm & (hm - 1u)) == 0u && !((B_nl >> h1) & 1ull))
-                    {
-                        cell.cnt = 1;
-                        cell.head = (B_nl & ((1ull << h1) - 1ull)) == 0ull;
-                        cell.tail = h1 == 63 || (B_nl >> (h1 + 1)) == 0ull;
-                    }
-                    else if (anyhit)
-                    {
-                        // first hit of every newline-delimited segment: see DESIGN.md (line bookkeeping)
-                        const u32 N = interior ? exact_nl() : nlm; // (folding never touches '\n')
-                        const u32 S = ((N << 1) | 1u) & 0xffffu, Hs = H | N;
-                        const u32 firsts = H & Hs & ~(Hs - S);
-                        bool l_head, l_tail;
-                        if (l_nl)
-                        {
-                            const u32 lo_nl = N & (0u - N);
-                            l_head = (H & (lo_nl | (lo_nl - 1u))) != 0u;
-                            l_tail = (H >> (32 - __builtin_clz(N))) != 0u;
-                        }
-                        else
-                            l_head = l_tail = H != 0u;
-                        const u64 B_any = anyhit, B_tail = __ballot(l_tail), B_head = __ballot(l_head);
-                        // is the line that enters this lane already holding a match (within the cell)?
-                        const u64 lt = (1ull << lane) - 1ull;
-                        const u64 nl_below = B_nl & lt;
-                        bool open;
-                        if (nl_below)
-                        {
-                            const int q = 63 - __builtin_clzll(nl_below);
-                            open = ((B_tail >> q) & 1ull) || (B_any & lt & ~((2ull << q) - 1ull)) != 0;
-                        }
-                        else
-                            open = (B_any & lt) != 0;
-                        const u32 lc = __popc(firsts) - ((open && l_head) ? 1u : 0u);
-                        cell.cnt = wave_sum5(lc);
-                        if (cell.nl)
-                        {
-                            const int f = __builtin_ctzll(B_nl), l = 63 - __builtin_clzll(B_nl);
-                            cell.head = (B_any & ((1ull << f) - 1ull)) != 0 || ((B_head >> f) & 1ull);
-                            cell.tail = (l < 63 && (B_any >> (l + 1)) != 0) || ((B_tail >> l) & 1ull);
-                        }
-                        else
-                            cell.head = cell.tail = true;
-                    }
-                    wls = ls_combine(wls, cell);
+                    // the same on the 16-bit masks (cells with a hit of the sparse kinds, -w, boundary cells)
+                    const u32 N = interior ? exact_nl() : nlm, H = m16, Hs = H | N;
+                    l_cnt += (u32)__popc(H & ~(Hs - ((N << 1) & 0xffffu)));
+                    line_cell(__ballot(N != 0u), anyhit, __ballot((H & (Hs ^ (Hs - 1u))) != 0u), __ballot(H > N));
                 }
             }
 
         }
 
+        if (LINES)
+        {
+            u32 t = l_cnt, h = l_hits;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1)
+            {
+                t += __shfl_xor(t, o);
+                if (KIND == 1)
+                    h += __shfl_xor(h, o);
+            }
+            if (KIND == 1)
+                wcnt += h; // (the flag-word cells count their hits per lane)
+            wls = LS{t + s_new, s_seen, s_seen ? s_head : s_open, s_open};
+        }
         acc_total += wcnt;
         if (!chain)
             continue;

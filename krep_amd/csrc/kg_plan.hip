@@ -63,7 +63,8 @@ extern "C" krep_gpu_plan_t *krep_gpu_plan_create_ex(const search_params_t *p, co
         pl->pats.emplace_back((const uint8_t *)p->pattern, (const uint8_t *)p->pattern + p->pattern_len);
     for (auto &v : pl->pats)
     {
-        pl->pat_ptrs.push_back((const char *)v.data());
+        pl->pat_ptrs.push_back(v.empty() ? "" : (const char *)v.data()); // (an empty pattern is a pattern: the reference returns 0
+                                                                          //  for it, krep.c:1278, :1646 — not "no pattern")
         pl->pat_lens.push_back(v.size());
     }
     pl->sp = *p;

@@ -1022,7 +1022,7 @@ static int scan_ac_lines_on_list(krep_gpu_plan *pl, const Window &w, hipStream_t
     }
     const uint64_t total = o1.total_matches;
     uint64_t lines = o1.line_count; // counted behind the post-pass on the stream, unless some unit overflowed its staging slot
-    if (total && lines == ~0ull && tail_count_line_gaps(w.d_text, w.global_base, (const uint64_t *)pl->d_nl_rec, total, &pl->d_ctr->pad[0], &pl->h_ctr->pad[0],
+    if (total && lines == ~0ull && tail_count_line_gaps(w.d_text, w.text_len, w.global_base, (const uint64_t *)pl->d_nl_rec, total, &pl->d_ctr->pad[0], &pl->h_ctr->pad[0],
                                       st, &lines))
         return 2;
     if (time_it) HIPCHK(hipEventRecord(pl->ev1, st));

@@ -9,8 +9,9 @@
 //     positions per lane in registers) and puts every hit, already ranked inside the ticket (ballot bit-planes + v_mbcnt),
 //     as a 16-bit unit-relative offset into its LDS ring — nothing goes to memory while it streams;
 //   * it publishes the ticket's hit count (one 8-byte store) and goes on to the NEXT ticket;
-//   * one RESOLVER wave (wave 0 of block 0; it does not scan) turns the published counts, 512 tickets per step, into their
-//     exclusive prefix — the global index of each ticket's first record;
+//   * one RESOLVER wave — whichever wave 0 of a block arrives first claims the role (see "Progress" below); it does not scan —
+//     turns the published counts into their exclusive prefix, the global index of each ticket's first record, ticket by ticket
+//     as far as the run of published counts extends;
 //   * only after scanning that next ticket (~40 us later) does the wave pick up its previous ticket's prefix — by then the
 //     resolver has long passed it, nobody waits — and writes that ticket's records from the ring: coalesced 1-KiB stores,
 //     10 KiB per ticket, ascending with the ticket number.

@@ -192,9 +192,15 @@ __device__ __forceinline__ bool tail_gap_has_newline(const uint8_t *__restrict__
 }
 // n_dev != NULL: the number of records is read on the device (min(*n_dev, n)): the launch needs no host round trip behind
 // the scan that produced the list
-__global__ __launch_bounds__(256) void tail_line_gaps(const uint8_t *__restrict__ text, const u64 *__restrict__ rec, u64 n, const u64 *n_dev,
-                                                      u64 base, u64 *out)
+// skip_if != NULL: the launch does nothing when *skip_if is non-zero — the list is not complete yet when a unit overflowed its
+// staging slot (its records are written by the emit-mode launch that follows; until then their slots hold whatever the buffer
+// held: offsets far outside the text, r04's latent fault, found by tests/test_gpu_ac.py in round 5).  text_len bounds every gap
+// that is read, whatever the records say.
+__global__ __launch_bounds__(256) void tail_line_gaps(const uint8_t *__restrict__ text, u64 text_len, const u64 *__restrict__ rec, u64 n,
+                                                      const u64 *n_dev, const u64 *skip_if, u64 base, u64 *out)
 {
+    if (skip_if && *skip_if)
+        return;
     if (n_dev)
     {
         const u64 nd = *n_dev;
@@ -209,7 +215,7 @@ __global__ __launch_bounds__(256) void tail_line_gaps(const uint8_t *__restrict_
             continue;
         }
         const u64 pe = rec[2 * i - 1] - base, cs = rec[2 * i] - base; // end of the previous match (exclusive), start of this one
-        if (cs > pe && tail_gap_has_newline(text, pe, cs))
+        if (cs > pe && cs <= text_len && tail_gap_has_newline(text, pe, cs))
             ++c;
     }
 #pragma unroll
@@ -308,15 +314,15 @@ int tail_count_changes(const uint64_t *d_v, uint64_t n, unsigned long long *d_sl
     return 0;
 }
 
-int tail_count_line_gaps(const uint8_t *d_text, uint64_t global_base, const uint64_t *d_rec, uint64_t n, unsigned long long *d_slot,
+int tail_count_line_gaps(const uint8_t *d_text, uint64_t text_len, uint64_t global_base, const uint64_t *d_rec, uint64_t n, unsigned long long *d_slot,
                          unsigned long long *h_slot, hipStream_t st, uint64_t *lines)
 {
     TCHK(hipMemsetAsync(d_slot, 0, sizeof(u64), st));
     if (n)
     {
         const u32 grid = (u32)std::min<u64>((n + 255) / 256, 8192);
-        hipLaunchKernelGGL(tail_line_gaps, dim3(grid), dim3(256), 0, st, d_text, (const u64 *)d_rec, (u64)n, (const u64 *)nullptr, (u64)global_base,
-                           (u64 *)d_slot);
+        hipLaunchKernelGGL(tail_line_gaps, dim3(grid), dim3(256), 0, st, d_text, (u64)text_len, (const u64 *)d_rec, (u64)n, (const u64 *)nullptr,
+                           (const u64 *)nullptr, (u64)global_base, (u64 *)d_slot);
         TCHK(hipGetLastError());
     }
     TCHK(hipMemcpyAsync(h_slot, d_slot, sizeof(u64), hipMemcpyDeviceToHost, st));
@@ -326,14 +332,14 @@ int tail_count_line_gaps(const uint8_t *d_text, uint64_t global_base, const uint
 }
 
 // the same without a host round trip: at most `cap` records, their number read from *d_n on the device, the count ADDED to *d_out
-int tail_launch_line_gaps(const uint8_t *d_text, uint64_t global_base, const uint64_t *d_rec, const unsigned long long *d_n, uint64_t cap,
-                          unsigned long long *d_out, hipStream_t st)
+int tail_launch_line_gaps(const uint8_t *d_text, uint64_t text_len, uint64_t global_base, const uint64_t *d_rec, const unsigned long long *d_n,
+                          const unsigned long long *d_skip_if, uint64_t cap, unsigned long long *d_out, hipStream_t st)
 {
     if (!cap)
         return 0;
     const u32 grid = (u32)std::min<u64>((cap + 255) / 256, 8192);
-    hipLaunchKernelGGL(tail_line_gaps, dim3(grid), dim3(256), 0, st, d_text, (const u64 *)d_rec, (u64)cap, (const u64 *)d_n, (u64)global_base,
-                       (u64 *)d_out);
+    hipLaunchKernelGGL(tail_line_gaps, dim3(grid), dim3(256), 0, st, d_text, (u64)text_len, (const u64 *)d_rec, (u64)cap, (const u64 *)d_n,
+                       (const u64 *)d_skip_if, (u64)global_base, (u64 *)d_out);
     TCHK(hipGetLastError());
     return 0;
 }

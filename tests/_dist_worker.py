@@ -11,7 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_lib as ol  # noqa: E402
-from krep_amd import abi, shard  # noqa: E402
+from krep_amd import abi  # noqa: E402
+import shard_model as shard  # noqa: E402
 
 
 def owned_scan(o, algo, pats, kw, text, lo, hi, halo):

@@ -1,4 +1,5 @@
-"""Rank-level sharding for the one-process-per-GPU path (torch.distributed; backend "nccl" == RCCL on ROCm,
+"""TEST SUPPORT (moved out of the package in round 5: the product shards in C, kg_ops.hip run_pieces): a Python model of the
+rank-level sharding for the one-process-per-GPU path (torch.distributed; backend "nccl" == RCCL on ROCm,
 "gloo" in the CPU tests).  The haystack is sharded by CONTIGUOUS chunk; a rank reports a match iff its
 START lies in the rank's window (start-offset ownership) and reads `halo` bytes past the
 window so that such matches complete.  The only collective on the data path is ONE all-reduce of the

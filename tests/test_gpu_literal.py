@@ -97,6 +97,62 @@ def test_dense_single_byte(gpu, oracle_engine):
     _check(gpu, oracle_engine, text, b"A", dict(case_sensitive=False), abi.REF_AVX2)
 
 
+def test_line_counting_at_density(gpu, oracle_engine):
+    """-c where nearly every 1-KiB cell holds matches (round 5: the line bookkeeping is a carry chain over the 64 lanes of a cell,
+    kg_literal.hip line_cell; a single byte runs it on the 0x80 flag words of the lane's 16 bytes): single bytes at 0.5-30 %
+    hits with lines of every shape — none, only newlines, runs of blank lines, a newline every 15-17 bytes (one per lane, at the
+    lane's first / last byte), lines longer than a cell and longer than a unit — the pattern '\n' itself, -i, -w, two- and
+    four-byte patterns at density, whole text and ownership windows folded with krep_gpu_combine_line_counts, against
+    memchr_search / memchr_short_search / boyer_moore_search of the compiled reference."""
+    import torch
+    rng = np.random.RandomState(5150)
+    n = (3 << 20) + 4321
+    texts = []
+    for alpha in (b"ae\n", b"aaaaaaaaaaaaaaaaaaaaaaaaaaaaaae\n", b"abcdefghijklmnopqrstuvwxyz     \n", b"ab e", b"\n", b"e\n\n\n", b"Ee \n"):
+        texts.append(cases.rand_text(rng, n, alpha))
+    t = cases.rand_text(rng, n, b"abcde ")           # one newline per lane-sized stretch, drifting over the 16-byte grid
+    t[np.arange(0, n, 17)] = 10
+    texts.append(t)
+    t = cases.rand_text(rng, n, b"abcde ")
+    t[15::16] = 10                                    # the lane's last byte
+    texts.append(t)
+    t = cases.rand_text(rng, n, b"abcde ")
+    t[0::16] = 10                                     # the lane's first byte
+    texts.append(t)
+    t = cases.rand_text(rng, n, b"abcde ")           # lines longer than a 1-KiB cell / than a 32-KiB unit
+    t[rng.randint(0, n, 40)] = 10
+    t[np.arange(5000, n, 70001)] = 10
+    texts.append(t)
+    t = cases.rand_text(rng, n, b"xyz\n")            # sparse hits between many lines, some lines with several
+    t[rng.randint(0, n, 3000)] = ord("e")
+    texts.append(t)
+    pats = [(b"e", dict()), (b"e", dict(case_sensitive=False)), (b"E", dict(case_sensitive=False)), (b"e", dict(whole_word=True)),
+            (b"\n", dict()), (b" ", dict()), (b"ab", dict()), (b"e\n", dict()), (b"abcd", dict()), (b"a", dict(max_count=1000))]
+    for ti, text in enumerate(texts):
+        d = torch.from_numpy(text).cuda()
+        for pat, kw in pats:
+            kwc = dict(count_lines=True, **kw)
+            p = abi.Params([pat], **kwc)
+            gpu.set_reference_simd(abi.REF_SCALAR)
+            algo = gpu.mirror_select(p, text.size)
+            if b"\n" in pat and len(pat) > 1 and algo not in (abi.RA_BMH, abi.RA_MEMCHR_SHORT):
+                continue
+            want = oracle_engine.call(algo, abi.Params([pat], **kwc), text)[0]
+            got = gpu.search(p, text, want_result=False)[0]
+            assert got == want, (ti, pat, kw, abi.RA_NAMES[algo], got, want)
+            if "max_count" in kw or algo == abi.RA_KMP:
+                continue
+            # ownership windows: cuts on and off the 16-byte grid, inside a cell, at a unit boundary
+            plan = gpu.plan(p)
+            cuts = [0, 7, 1024 + 16, 32768, 32768 + 5, (1 << 20) + 1000, (2 << 20) + 15, n]
+            outs = [plan.scan(d.data_ptr(), n, lo, hi) for lo, hi in zip(cuts[:-1], cuts[1:])]
+            arr = (abi.ScanOut * len(outs))(*outs)
+            assert gpu.lib.krep_gpu_combine_line_counts(arr, len(outs)) == want, (ti, pat, kw, [o.line_count for o in outs])
+            plan.close()
+        del d
+    gpu.set_reference_simd(abi.REF_AVX2)
+
+
 def test_staging_overflow_takes_emit_mode(gpu, oracle_engine):
     """Units with more hits than their staging slot are re-scanned in emit mode: force tiny slots."""
     rng = np.random.RandomState(9)

@@ -1,12 +1,12 @@
 """The N > 1 path on CPU: world_size-2 (and 3) gloo ranks exercise the shard partition, start-offset
-ownership, the single count all-reduce and the line-carry combine of krep_amd/shard.py."""
+ownership, the single count all-reduce and the line-carry combine of tests/shard_model.py."""
 import os
 import subprocess
 import sys
 
 import pytest
 
-from krep_amd import shard
+import shard_model as shard
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -63,3 +63,24 @@ def test_bench_spawns_its_own_ranks_dry_run():
     r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo"], env=env2,
                         capture_output=True, text=True, timeout=60)
     assert r2.returncode == 2 and "WORLD_SIZE=3" in r2.stderr
+
+
+def test_bench_eight_ranks_dry_run():
+    """The driver's 8-GPU launch line, on CPU: `torch.distributed.run --nproc-per-node 8 ... bench.py
+    --gpus 8 --backend gloo` — eight ranks rendezvous on 127.0.0.1, barrier, ONE all-reduce of the counts per step, MAX over
+    ranks, one JSON line from rank 0 whose closed-form count is the sum over the eight contiguous shards."""
+    import json
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+           "--master-port", "29788", os.path.join(root, "bench.py"), "--gpus", "8", "--backend", "gloo", "--steps", "4",
+           "--warmup", "1", "--gib", "0.01"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["dry_run"] is True and j["steps"] == 4 and j["scaling"] == "weak"
+    assert j["config"]["matches"] == 8 * (int(0.01 * (1 << 30)) // 10000)
