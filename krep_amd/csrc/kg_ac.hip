@@ -442,10 +442,19 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 {
                     bool slA = false, slB = false;
                     u32 mA = 0, mB = 0;
+#ifndef KG_AC_NO_BTEST // (A/B switches of krep_amd/build.py --variant)
+                    constexpr bool kGram = PAIR && XB == 20; // the probe asks the class table about both ends (kg_ac_common.h)
+#else
+                    constexpr bool kGram = false;
+#endif
+#ifndef KG_AC_NO_STAGE
+                    constexpr bool kStaged = kGram;
+#else
+                    constexpr bool kStaged = false;
+#endif
                     if (!(a.flags & (1u << 30))) // (ablation hook KREP_GPU_AC_NOPROBE: candidate enumeration without the probes)
-                        ac_walk_probe2<CI, SHORT>(a, pos, liveA, liveB, LINES, mA, slA, mB, slB, [&](u32 E) -> bool {
-#ifndef KG_AC_NO_BTEST // (A/B switch of krep_amd/build.py --variant)
-                            if constexpr (PAIR && XB == 20)
+                        ac_walk_probe2<CI, SHORT, kStaged>(a, pos, liveA, liveB, LINES, mA, slA, mB, slB, [&](u32 E) -> bool {
+                            if constexpr (kGram)
                             {
                                 // the filter's own lookup for a gram that lies in one dword (cell_body, k = 3 mod 4)
                                 typedef __attribute__((address_space(3))) const u32 lds_u32;
@@ -453,7 +462,6 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                                 return ((*(lds_u32 *)(size_t)(((u >> 3) ^ (u >> 13)) & 0x1fffcu) >> (u & 31u)) & 1u) != 0u;
                             }
                             else
-#endif
                                 return true;
                         });
                     else

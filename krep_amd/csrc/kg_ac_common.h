@@ -413,14 +413,20 @@ __device__ __forceinline__ u32 ac_walk_fast(const AcArgs &a, u64 i, bool own_by_
 // The same for the two end positions i and i + 1 of a stride-2 candidate: both text windows and both table probes
 // are in flight together (one latency for the pair).  No level walk in here: an end that needs it comes back with
 // slow = true and the caller runs ac_walk_slow from its single call site.
-// btest(E): can a pattern END with the four text bytes E (byte i + 1 on top)?  The caller answers from the class table it
-// already holds in LDS (round 5): the second end of a stride-2 candidate is probed only where that says yes.  Measured on
-// BASELINE config 4 (profiles/r05_ac1000_where_the_time_goes.txt): the two 64-byte buckets of every candidate were 0.8 ms of
-// the 6.5 — 700 M L2 requests against the stream's 270 M, most of them onto a few thousand hot lines — and nine second ends
-// in ten cannot be a match by their classes alone.
-template <bool CI, bool SHORT, typename BTest>
+// gtest(E): is the class gram of the four text bytes E in the filter table the caller holds in LDS?  (round 5)  A candidate is a
+// tested position t whose gram is in the table — as some pattern's final gram (a match may end at t) or as some pattern's gram
+// one byte earlier (a match may end at t + 1).  The table cannot say which, but it can be asked twice more, for free, once the
+// text window is in registers: a match that ends at t also put ITS gram-one-byte-earlier into the table, i.e. the gram of
+// t - 1; a match that ends at t + 1 put its final gram there, i.e. the gram of t + 1.  An end is probed only where its second
+// gram is present as well — about one end in ten, where both 64-byte buckets of every candidate used to be read: they were
+// 0.8 ms of the 6.5 on BASELINE config 4 (700 M L2 requests against the stream's 270 M, most onto a few thousand hot lines;
+// profiles/r05_ac1000_where_the_time_goes.txt).
+// STAGED (the caller has a real gtest): the eight bytes i - 6 .. i + 1 come first — ONE request per candidate, and all that both
+// gram tests need; the 16-byte window in front of them is fetched only by the lanes an end survives in, together with their
+// buckets (the same two dependent round trips as before, a third of the requests).
+template <bool CI, bool SHORT, bool STAGED, typename GTest>
 __device__ __forceinline__ void ac_walk_probe2(const AcArgs &a, u64 i, bool liveA, bool liveB, bool own_by_end,
-                                               u32 &dmA, bool &slowA, u32 &dmB, bool &slowB, BTest btest)
+                                               u32 &dmA, bool &slowA, u32 &dmB, bool &slowB, GTest gtest)
 {
     dmA = dmB = 0;
     slowA = slowB = false;
@@ -430,12 +436,39 @@ __device__ __forceinline__ void ac_walk_probe2(const AcArgs &a, u64 i, bool live
         slowB = liveB;
         return;
     }
-    // ONE 20-byte window serves both ends: A = its first 16 bytes (the text up to i), B = the same one byte further (up to
-    // i + 1) by funnel shifts — five loads where two windows took eight.  Only the byte text[i + 1] is read behind A, and
-    // only when it exists (liveB): nothing is touched past the end of the buffer.
+    // ONE 17-byte window serves both ends: A = its first 16 bytes (the text up to i), B = the same one byte further (up to
+    // i + 1) by funnel shifts.  Only the byte text[i + 1] is read behind A, and only when it exists (liveB): nothing is
+    // touched past the end of the buffer.
     struct __attribute__((packed)) U32p { u32 v; };
-    const U32p *qa = reinterpret_cast<const U32p *>(a.text + (i - 15));
-    const u32 w0 = qa[0].v, w1 = qa[1].v, w2 = qa[2].v, w3 = qa[3].v, w4 = liveB ? (u32)a.text[i + 1] : 0u;
+    struct __attribute__((packed)) U64p { u64 v; };
+    u32 w0 = 0, w1 = 0, w2 = 0, w3 = 0, w4 = 0;
+    if constexpr (STAGED)
+    {
+        // bytes i - 6 .. i + 1 (without the last one where it does not exist: one byte lower, shifted back)
+        const u64 q8 = reinterpret_cast<const U64p *>(a.text + (i - (liveB ? 6u : 7u)))->v;
+        const u64 Q = liveB ? q8 : (q8 >> 8);
+        w3 = (u32)(Q >> 24);                                // bytes i - 3 .. i
+        w4 = (u32)(Q >> 56);                                // byte i + 1
+        if (liveA)
+            liveA = gtest((u32)(Q >> 16));                  // bytes i - 4 .. i - 1 (classes ignore the case: asked before the fold)
+        if (liveB)
+            liveB = gtest((u32)(Q >> 32));                  // bytes i - 2 .. i + 1
+        if (liveA || liveB)
+        {
+            const U32p *qa = reinterpret_cast<const U32p *>(a.text + (i - 15));
+            w0 = qa[0].v; w1 = qa[1].v; w2 = qa[2].v;
+        }
+    }
+    else
+    {
+        const U32p *qa = reinterpret_cast<const U32p *>(a.text + (i - 15));
+        w0 = qa[0].v; w1 = qa[1].v; w2 = qa[2].v; w3 = qa[3].v;
+        w4 = liveB ? (u32)a.text[i + 1] : 0u;
+        if (liveA)
+            liveA = gtest(__builtin_amdgcn_alignbyte(w3, w2, 3));
+        if (liveB)
+            liveB = gtest(__builtin_amdgcn_alignbyte(w4, w3, 1));
+    }
     u32 TA[4] = {w0, w1, w2, w3};
     u32 TB[4] = {w0, w1, w2, w3};
     if (liveB)
@@ -444,7 +477,6 @@ __device__ __forceinline__ void ac_walk_probe2(const AcArgs &a, u64 i, bool live
         TB[1] = __builtin_amdgcn_alignbyte(w2, w1, 1);
         TB[2] = __builtin_amdgcn_alignbyte(w3, w2, 1);
         TB[3] = __builtin_amdgcn_alignbyte(w4, w3, 1);
-        liveB = btest(TB[3]); // (classes ignore the case: asked before the fold)
     }
     if (CI)
     {
@@ -468,9 +500,12 @@ __device__ __forceinline__ void ac_walk_probe2(const AcArgs &a, u64 i, bool live
     {
         const uint4 *ba = a.g4x + 4 * (size_t)(((TA[3] * a.g4x_mul) >> 9) & a.g4x_mask);
         const uint4 *bb = a.g4x + 4 * (size_t)(((TB[3] * a.g4x_mul) >> 9) & a.g4x_mask);
-        const uint4 x0 = ba[0], x1 = ba[1], x2 = ba[2], x3 = ba[3];
-        uint4 y0 = make_uint4(0, 0, 0, 0), y1 = y0, y2 = y0, y3 = y0;
-        if (!doneB) // (a lane whose second end is dead issues no requests for it; both buckets are still in flight together)
+        uint4 x0 = make_uint4(0, 0, 0, 0), x1 = x0, x2 = x0, x3 = x0, y0 = x0, y1 = x0, y2 = x0, y3 = x0;
+        if (!doneA) // (a lane whose end is dead issues no requests for it; the buckets of both ends are still in flight together)
+        {
+            x0 = ba[0]; x1 = ba[1]; x2 = ba[2]; x3 = ba[3];
+        }
+        if (!doneB)
         {
             y0 = bb[0]; y1 = bb[1]; y2 = bb[2]; y3 = bb[3];
         }
