@@ -31,6 +31,7 @@ PERIOD = 10000
 SEED = 20260925
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 HBM_MEASURED_GBS = 6290.0  # the same guide: measured streaming (copy) ceiling
+SCAN_STREAM = None  # torch.cuda.Stream the scans are launched on (main())
 HBM_READ_CEILING_GBS = 7070.0  # bare non-temporal 32 GiB reader on this part (tools/ubench/read_ceiling.hip, profiles/r02_read_ceiling_ubench.txt)
 
 
@@ -393,7 +394,10 @@ def run_workload(name, args, eng, buf, pos, dev, rank, world, local, use_dist):
     plan = eng.plan(params, device=local)
     cap = positions_capacity(name, n)
     assert pos.numel() >= 2 * cap
-    stream = torch.cuda.current_stream().cuda_stream
+    # the scans run on a stream of their own, not on the legacy null stream: a launch on the null stream synchronises with every
+    # other blocking stream of the process, and the five launches of the multi-pattern step (memset, scan, three post-pass kernels)
+    # each paid for it — 6.29 against 6.20 ms in one process (profiles/r05_timing_modes.txt); kernel_ms is hipEvent time on THIS stream
+    stream = SCAN_STREAM.cuda_stream
     counts = torch.zeros(2, dtype=torch.int64, device=dev)
     host_counts = torch.zeros(2, dtype=torch.int64).pin_memory()
 
@@ -413,6 +417,7 @@ def run_workload(name, args, eng, buf, pos, dev, rank, world, local, use_dist):
             dist.all_reduce(counts)           # (torch.distributed's RCCL: only when the C-level communicator is unavailable)
         return out
 
+    torch.cuda.synchronize()              # (the generator ran on torch's current stream)
     for _ in range(args.warmup):
         out = step()
     if use_dist:
@@ -575,6 +580,8 @@ def main():
                 use_dist = "c"
             elif ok:
                 eng.comm_destroy()
+    global SCAN_STREAM
+    SCAN_STREAM = torch.cuda.Stream(device=dev)
     n = int(args.gib * (1 << 30))
     buf = torch.empty(n + 64, dtype=torch.uint8, device=dev)
     # ONE record buffer for every workload of this run.  Where the driver places a buffer physically decides, per ALLOCATION and

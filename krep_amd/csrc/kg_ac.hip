@@ -543,55 +543,11 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
         LS2 wls{0, false, false, false};
         if (LINES)
         {
-#pragma unroll 1
-            for (int rj = 0; rj < kAcRounds * kCells; ++rj)
-            {
+            wls = ac_line_pass(kAcRounds * kCells, [&](int rj, u32 &H, u32 &N) {
                 const u32 bitoff = (u32)rj * kCellBytes + lane * 16u;
-                const u32 H = (bitmap[bitoff >> 5] >> (bitoff & 31u)) & 0xffffu, N = nlmap[bitoff >> 4];
-                const u64 anyhit = __ballot(H != 0u);
-                const bool l_nl = N != 0u;
-                const u64 B_nl = __ballot(l_nl);
-                LS2 cell{0, B_nl != 0, false, false};
-                if (anyhit)
-                {
-                    const u32 S = ((N << 1) | 1u) & 0xffffu, Hs = H | N;
-                    const u32 firsts = H & Hs & ~(Hs - S);
-                    bool l_head, l_tail;
-                    if (l_nl)
-                    {
-                        const u32 lo_nl = N & (0u - N);
-                        l_head = (H & (lo_nl | (lo_nl - 1u))) != 0u;
-                        l_tail = (H >> (32 - __builtin_clz(N))) != 0u;
-                    }
-                    else
-                        l_head = l_tail = H != 0u;
-                    const u64 B_any = anyhit, B_tail = __ballot(l_tail), B_head = __ballot(l_head);
-                    const u64 lt = (1ull << lane) - 1ull;
-                    const u64 nl_below = B_nl & lt;
-                    bool open;
-                    if (nl_below)
-                    {
-                        const int q = 63 - __builtin_clzll(nl_below);
-                        open = ((B_tail >> q) & 1ull) || (B_any & lt & ~((2ull << q) - 1ull)) != 0;
-                    }
-                    else
-                        open = (B_any & lt) != 0;
-                    u32 lc = __popc(firsts) - ((open && l_head) ? 1u : 0u);
-#pragma unroll
-                    for (int o = 32; o >= 1; o >>= 1)
-                        lc += __shfl_xor(lc, o);
-                    cell.cnt = lc;
-                    if (cell.nl)
-                    {
-                        const int f = __builtin_ctzll(B_nl), l = 63 - __builtin_clzll(B_nl);
-                        cell.head = (B_any & ((1ull << f) - 1ull)) != 0 || ((B_head >> f) & 1ull);
-                        cell.tail = (l < 63 && (B_any >> (l + 1)) != 0) || ((B_tail >> l) & 1ull);
-                    }
-                    else
-                        cell.head = cell.tail = true;
-                }
-                wls = ls2_combine(wls, cell);
-            }
+                H = (bitmap[bitoff >> 5] >> (bitoff & 31u)) & 0xffffu;
+                N = nlmap[bitoff >> 4];
+            });
             for (u32 w = lane; w < kAcBitmapWords; w += 64)
                 bitmap[w] = 0u;
         }

@@ -89,6 +89,56 @@ __device__ __forceinline__ u32 ac_movemask4(u32 t) { return (((t >> 7) * 0x00204
 __device__ __forceinline__ bool ac_wordc(u32 c) { return (c - '0' < 10u) || ((c | 0x20u) - 'a' < 26u) || c == '_'; }
 
 struct LS2 { u32 cnt; bool nl, head, tail; };
+// The distinct lines of a unit that hold a match END, from the 16-bit hit / newline masks H, N of its lane-cells (get(rj, H, N),
+// rj = cell of the unit, this lane's 16 bytes): a line is counted at its first match.  Inside a lane that is carry arithmetic on
+// the two masks; across the 64 lanes of a cell "does the line that enters this lane already hold a match" is a carry chain —
+// generate = a match behind the lane's last newline (any match in a lane without one), propagate = neither a match nor a
+// newline — which ONE 64-bit scalar add resolves, its carry-out being the state that enters the next cell (round 5; the same
+// scheme as kg_literal.hip line_cell.  Round 4 resolved every cell with four ballots, a per-lane search for the nearest newline
+// lane below and a shuffle reduction, and the -c instantiations spilled 8-44 bytes per lane).
+template <typename Get>
+__device__ __forceinline__ LS2 ac_line_pass(int ncells, Get get)
+{
+    u32 l_cnt = 0, s_new = 0;
+    bool s_open = false, s_seen = false, s_head = false;
+#pragma unroll 1
+    for (int rj = 0; rj < ncells; ++rj)
+    {
+        u32 H, N;
+        get(rj, H, N);
+        const u64 B_any = __ballot(H != 0u), B_nl = __ballot(N != 0u);
+        if (!B_any)
+        {
+            if (B_nl)
+            {
+                if (!s_seen)
+                {
+                    s_head = s_open;
+                    s_seen = true;
+                }
+                s_open = false;
+            }
+            continue;
+        }
+        const u32 Hs = H | N;
+        l_cnt += (u32)__popc(H & ~(Hs - ((N << 1) & 0xffffu)));          // first match behind each newline of the lane
+        const u64 B_head = __ballot((H & (Hs ^ (Hs - 1u))) != 0u);       // the lane's lowest flag is a match
+        const u64 G = __ballot(H > N), P = ~(B_nl | B_any);              // the highest flag is a match | nothing in the lane
+        const unsigned __int128 sum = (unsigned __int128)(G | P) + G + (s_open ? 1u : 0u);
+        const u64 O = (u64)sum ^ P; // bit l: the line entering lane l already holds a match
+        s_new += (u32)__popcll(B_head & ~O);
+        if (!s_seen && B_nl)
+        {
+            s_head = (((O | B_head) >> __builtin_ctzll(B_nl)) & 1ull) != 0ull;
+            s_seen = true;
+        }
+        s_open = (u64)(sum >> 64) != 0ull;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1)
+        l_cnt += __shfl_xor(l_cnt, o);
+    return LS2{l_cnt + s_new, s_seen, s_seen ? s_head : s_open, s_open};
+}
 __device__ __forceinline__ LS2 ls2_combine(const LS2 &a, const LS2 &b)
 {
     return LS2{a.cnt + b.cnt - ((a.tail && b.head) ? 1u : 0u), a.nl || b.nl, a.nl ? a.head : (a.head || b.head),

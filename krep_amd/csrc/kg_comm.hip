@@ -50,6 +50,20 @@ struct Rccl
 std::mutex g_mu;                 // RCCL communicators are used by one thread at a time
 std::atomic<uint64_t> g_calls{0}; // collectives issued (diagnostic, krep_gpu_rccl_calls)
 
+// RCCL prints a banner ("RCCL version : ... Hostname ... Librccl path ...") to STDOUT when a process creates its first
+// communicator.  A drop-in must not add a byte to its host's output (krep's stdout IS its result).  Round 5: the banner belongs
+// to RCCL's logging and NCCL_DEBUG=NONE switches it off (measured on the GPU box: `KREP_GPU_RCCL_BANNER=1 bench.py --force-dist`
+// prints it, the same with NCCL_DEBUG=NONE in the environment does not) — so the library puts that into the environment before
+// it opens librccl, UNLESS the user has set NCCL_DEBUG themselves (then they asked for RCCL's output and get it).  Rounds 3-4
+// pointed file descriptor 1 at /dev/null while a communicator was created: process-wide, and whatever another thread of the
+// host printed in that second was lost — removed.  Failures stay visible: every RCCL call's result is checked and
+// reported through ncclGetErrorString / krep_gpu_last_error().
+static void quiet_rccl_banner()
+{
+    if (!getenv("KREP_GPU_RCCL_BANNER"))
+        (void)setenv("NCCL_DEBUG", "NONE", 0 /* keep the user's setting */);
+}
+
 Rccl *g_rccl = nullptr;
 Rccl *rccl() // g_mu held
 {
@@ -57,6 +71,7 @@ Rccl *rccl() // g_mu held
     if (r)
         return r->h ? r : nullptr;
     r = new Rccl();
+    quiet_rccl_banner(); // before librccl reads its environment
     for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
         if ((r->h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)))
             break;
@@ -105,35 +120,6 @@ const char *rccl_why() { return g_rccl && !g_rccl->why.empty() ? g_rccl->why.c_s
             return kg::fail("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
-// RCCL prints a banner ("RCCL version : ... Hostname ... Librccl path ...") to STDOUT when a process creates its first
-// communicator.  A drop-in must not add a byte to its host's output (krep's stdout IS its result): file descriptor 1 points
-// to /dev/null while a communicator is created.  stdio is flushed on both sides of the switch, so the host's pending output
-// reaches the real stdout and whatever RCCL left in a stdio buffer goes down the drain.  ($KREP_GPU_RCCL_BANNER=1 keeps it.)
-struct StdoutMute
-{
-    int saved = -1;
-    StdoutMute()
-    {
-        if (getenv("KREP_GPU_RCCL_BANNER"))
-            return;
-        fflush(stdout);
-        saved = dup(1);
-        const int nul = open("/dev/null", O_WRONLY);
-        if (saved >= 0 && nul >= 0)
-            (void)dup2(nul, 1);
-        if (nul >= 0)
-            close(nul);
-    }
-    ~StdoutMute()
-    {
-        if (saved < 0)
-            return;
-        fflush(stdout);
-        (void)dup2(saved, 1);
-        close(saved);
-    }
-};
-
 // ---- one process, several devices ---------------------------------------------------------------------------------
 struct Clique
 {
@@ -157,7 +143,6 @@ int clique_for(Rccl *R, const std::vector<int> &devs, size_t n, Clique **out) //
         nc->comms.resize(devs.size());
         ncclResult_t e;
         {
-            StdoutMute mute;
             e = R->CommInitAll(nc->comms.data(), (int)devs.size(), devs.data());
         }
         if (e != ncclSuccess)
@@ -257,10 +242,8 @@ int allreduce_across_devices(const std::vector<int> &devs, std::vector<std::vect
     return rc;
 }
 
-// Creates (and caches) the communicator of a device list ahead of the first search.  RCCL prints its version banner to
-// stdout when a process creates its first communicator; the StdoutMute above hides it, but for about a second every byte the
-// HOST writes to stdout from another thread would vanish with it.  A host calls this — through
-// krep_gpu_select_search_algorithm(), i.e. before it has printed anything — so that no search ever creates one.
+// Creates (and caches) the communicator of a device list ahead of the first search (ncclCommInitAll costs ~1 s): a host calls
+// this — through krep_gpu_select_search_algorithm() — so that no search ever creates one.
 int comm_warmup(const std::vector<int> &devs)
 {
     if (devs.size() < 2)
@@ -339,7 +322,6 @@ extern "C" int krep_gpu_comm_init_rank(const void *id128, int nranks, int rank, 
     ncclUniqueId id;
     memcpy(&id, id128, sizeof id);
     {
-        StdoutMute mute;
         const ncclResult_t e = R->CommInitRank(&g_rank.comm, nranks, id, rank);
         if (e != ncclSuccess)
         {
