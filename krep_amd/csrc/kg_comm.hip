@@ -51,18 +51,39 @@ std::mutex g_mu;                 // RCCL communicators are used by one thread at
 std::atomic<uint64_t> g_calls{0}; // collectives issued (diagnostic, krep_gpu_rccl_calls)
 
 // RCCL prints a banner ("RCCL version : ... Hostname ... Librccl path ...") to STDOUT when a process creates its first
-// communicator.  A drop-in must not add a byte to its host's output (krep's stdout IS its result).  Round 5: the banner belongs
-// to RCCL's logging and NCCL_DEBUG=NONE switches it off (measured on the GPU box: `KREP_GPU_RCCL_BANNER=1 bench.py --force-dist`
-// prints it, the same with NCCL_DEBUG=NONE in the environment does not) — so the library puts that into the environment before
-// it opens librccl, UNLESS the user has set NCCL_DEBUG themselves (then they asked for RCCL's output and get it).  Rounds 3-4
-// pointed file descriptor 1 at /dev/null while a communicator was created: process-wide, and whatever another thread of the
-// host printed in that second was lost — removed.  Failures stay visible: every RCCL call's result is checked and
-// reported through ncclGetErrorString / krep_gpu_last_error().
-static void quiet_rccl_banner()
+// communicator.  A drop-in must not add a byte to its host's output (krep's stdout IS its result).  The banner belongs to RCCL's
+// logging: a process STARTED with NCCL_DEBUG=NONE does not print it (measured, round 5) — and then nothing is done here.  Putting
+// the variable into the environment from inside the process, before librccl is opened, does NOT work (measured with RCCL 2.27.7:
+// the patched CLI still printed the banner), so without it file descriptor 1 points to /dev/null while the communicator is
+// created: stdio is flushed on both sides of the switch, the host's pending output reaches the real stdout and whatever RCCL left
+// in a stdio buffer goes down the drain.  The switch is process-wide — a host that prints from other threads while a search runs
+// should export NCCL_DEBUG=NONE — and it happens once, at selector time (comm_warmup), before the host has
+// printed anything.  ($KREP_GPU_RCCL_BANNER=1 keeps the banner.)
+struct StdoutMute
 {
-    if (!getenv("KREP_GPU_RCCL_BANNER"))
-        (void)setenv("NCCL_DEBUG", "NONE", 0 /* keep the user's setting */);
-}
+    int saved = -1;
+    StdoutMute()
+    {
+        const char *dbg = getenv("NCCL_DEBUG");
+        if (getenv("KREP_GPU_RCCL_BANNER") || (dbg && (!strcmp(dbg, "NONE") || !strcmp(dbg, "none"))))
+            return;
+        fflush(stdout);
+        saved = dup(1);
+        const int nul = open("/dev/null", O_WRONLY);
+        if (saved >= 0 && nul >= 0)
+            (void)dup2(nul, 1);
+        if (nul >= 0)
+            close(nul);
+    }
+    ~StdoutMute()
+    {
+        if (saved < 0)
+            return;
+        fflush(stdout);
+        (void)dup2(saved, 1);
+        close(saved);
+    }
+};
 
 Rccl *g_rccl = nullptr;
 Rccl *rccl() // g_mu held
@@ -71,7 +92,6 @@ Rccl *rccl() // g_mu held
     if (r)
         return r->h ? r : nullptr;
     r = new Rccl();
-    quiet_rccl_banner(); // before librccl reads its environment
     for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
         if ((r->h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)))
             break;
@@ -143,6 +163,7 @@ int clique_for(Rccl *R, const std::vector<int> &devs, size_t n, Clique **out) //
         nc->comms.resize(devs.size());
         ncclResult_t e;
         {
+            StdoutMute mute;
             e = R->CommInitAll(nc->comms.data(), (int)devs.size(), devs.data());
         }
         if (e != ncclSuccess)
@@ -322,6 +343,7 @@ extern "C" int krep_gpu_comm_init_rank(const void *id128, int nranks, int rank, 
     ncclUniqueId id;
     memcpy(&id, id128, sizeof id);
     {
+        StdoutMute mute;
         const ncclResult_t e = R->CommInitRank(&g_rank.comm, nranks, id, rank);
         if (e != ncclSuccess)
         {

@@ -143,10 +143,15 @@ __global__ __launch_bounds__(kBlock, (KIND == 1 && LINES && R == 4) ? KG_LIT1_LI
     // written out in one burst of ~12 store instructions; at 32 GiB a wave scans ~256 units, i.e. it stores twice.
     constexpr u32 kPark = (KIND == 4 || KIND == 8) ? 240u : 8u; // 30 tickets of 8 units: 4 x (240 x 40 + 240) B x 4 blocks = 154 KiB
     __shared__ u64 s_info[kWavesPerBlk][kPark];
-    __shared__ __attribute__((aligned(16))) unsigned short s_slots[kWavesPerBlk][kPark][16];
-    // (only the plain offsets-producing scan with its regular 16-entry slots: -c measured 1 % slower parked, 64-entry slots
-    //  would not fit, emit mode writes final records; m > 8 measured 3 % slower parked)
-    const bool park = (KIND == 4 || KIND == 8) && !LINES && want_pos && !a.emit_mode && a.stage_cap == 16u && (a.upt == 0u || a.upt >= 4u) && a.num_tiles < (1ull << 29);
+    __shared__ __attribute__((aligned(16))) unsigned short s_slots[kWavesPerBlk][kPark * 16u];
+    // (only the plain offsets-producing scan: -c measured 1 % slower parked, emit mode writes final records; m > 8 measured 3 %
+    //  slower parked.  Round 5: the pool is shared out by the plan's slot size — 240 units of 16 entries, 56 of 64, 24 of 128 — so a
+    //  plan whose slot has grown (`-i th`: 35 hits per unit) still stores nothing while it streams: its 37 M scattered 2-byte
+    //  stores were why it ran at 0.52 of the roofline.)
+    const bool park = (KIND == 4 || KIND == 8) && !LINES && want_pos && !a.emit_mode && a.stage_cap >= 16u && a.stage_cap <= 128u &&
+                      (a.stage_cap & 7u) == 0u && (a.upt == 0u || a.upt >= 4u) && a.num_tiles < (1ull << 29);
+    // units the pool holds: whole tickets only (s_tk maps a parked unit to its ticket)
+    const u32 park_max = park ? (a.upt ? (kPark * 16u / a.stage_cap) / a.upt * a.upt : kPark * 16u / a.stage_cap) : kPark;
     u32 n_park = 0;     // parked units (uniform); they are the units of the wave's last tickets, a.upt consecutive ones each
     __shared__ u32 s_tk[kWavesPerBlk][kPark / 4u]; // first unit of each parked ticket (4 or 8 units each)
     u64 park_first = 0;                            // static deal: the first parked unit, the others follow at the wave's stride
@@ -158,9 +163,10 @@ __global__ __launch_bounds__(kBlock, (KIND == 1 && LINES && R == 4) ? KG_LIT1_LI
             if (want_pos && (s_info[wave][i] & kUiCountMask))
             {
                 uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<unsigned short *>(a.stage) + u * (u64)a.stage_cap);
-                const uint4 *src = reinterpret_cast<const uint4 *>(&s_slots[wave][i][0]);
-                dst[0] = src[0];
-                dst[1] = src[1];
+                const uint4 *src = reinterpret_cast<const uint4 *>(&s_slots[wave][i * a.stage_cap]);
+                const u32 c = (u32)(s_info[wave][i] & kUiCountMask), nv = ((c < a.stage_cap ? c : a.stage_cap) + 7u) >> 3;
+                for (u32 q = 0; q < nv; ++q) // (16-entry slots: at most two)
+                    dst[q] = src[q];
             }
         }
         n_park = 0;
@@ -609,7 +615,7 @@ __global__ __launch_bounds__(kBlock, (KIND == 1 && LINES && R == 4) ? KG_LIT1_LI
                         u32 rest = m16;
                         if (!a.emit_mode)
                         {
-                            unsigned short *slot = park ? &s_slots[wave][n_park][0]
+                            unsigned short *slot = park ? &s_slots[wave][n_park * a.stage_cap]
                                                         : reinterpret_cast<unsigned short *>(a.stage) + unit * (u64)a.stage_cap;
                             const u32 rel0 = (u32)(r * kCells + j) * kCellBytes + lane * 16u;
                             while (rest)
@@ -710,7 +716,7 @@ __global__ __launch_bounds__(kBlock, (KIND == 1 && LINES && R == 4) ? KG_LIT1_LI
             {
                 if (n_park == 0)
                     park_first = unit;
-                if (++n_park == kPark)
+                if (++n_park == park_max)
                     flush_parked();
             }
             if (!kInline && want_pos && wcnt)
