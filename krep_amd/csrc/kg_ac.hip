@@ -944,7 +944,8 @@ AcTables *ac_build(const search_params_t &sp, int device)
             // worth it while the denser table keeps the candidate volume in the same range (per byte e2 / 2^21 against
             // e1 / 2^20, two ends to verify per candidate) or small in absolute terms (<= 0.4 % of the even positions,
             // the rate of BASELINE config 4).  KREP_GPU_AC_STRIDE1=1 forces the one-position filter.
-            if ((e2 <= 6 * e1 + 64 || e2 <= 4096) && e2 < (1u << kXBitsBig) / 64 && !getenv("KREP_GPU_AC_STRIDE1"))
+            const bool force2 = getenv("KREP_GPU_AC_STRIDE2") != nullptr; // (measurement hook: the stride-2 filter whatever its density)
+            if ((((e2 <= 6 * e1 + 64 || e2 <= 4096) && e2 < (1u << kXBitsBig) / 64) || force2) && !getenv("KREP_GPU_AC_STRIDE1"))
             {
                 ACHK(hipMalloc(&t->d_filters20, S20.size() * sizeof(u32)));
                 ACHK(hipMemcpy(t->d_filters20, S20.data(), S20.size() * sizeof(u32), hipMemcpyHostToDevice));

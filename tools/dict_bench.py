@@ -12,8 +12,12 @@ buf = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
 e.generate(buf.data_ptr(), n, 0, 2, 42, b"Sherlock", 10000)
 cap = n // 12
 pos = torch.empty(2 * cap, dtype=torch.int64, device="cuda")
-for pats in ([b"he", b"she", b"hers"], [b"xq", b"zj"], [b"the", b"and", b"ing"], [b"er", b"th", b"an"], [b"e", b"t"],
-             [b"error", b"warning", b"fatal"], [b"Sherlock", b"Holmes"], [b"a", b"Sherlock"]):
+DICTS = ([b"he", b"she", b"hers"], [b"xq", b"zj"], [b"the", b"and", b"ing"], [b"er", b"th", b"an"], [b"e", b"t"],
+         [b"error", b"warning", b"fatal"], [b"Sherlock", b"Holmes"], [b"a", b"Sherlock"],
+         [b"if", b"else", b"while"], [b"the", b"quick", b"brown"])  # several long lengths beside a short pattern
+if len(sys.argv) > 2:  # a subset: indices, e.g. 8,9
+    DICTS = [DICTS[int(i)] for i in sys.argv[2].split(",")]
+for pats in DICTS:
     row = []
     for name, kw, wp in (("-c -o", dict(count_lines=True, only_match=True), False), ("offsets", {}, True),
                          ("-c", dict(count_lines=True), False), ("-i -c -o", dict(count_lines=True, only_match=True, case_sensitive=False), False)):
