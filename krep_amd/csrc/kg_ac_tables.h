@@ -1,0 +1,37 @@
+// kg_ac_tables.h — the device-resident tables of one dictionary (built on the host by kg_ac_build.hip, read by the scan drivers of
+// kg_ac.hip): class-filter tables for LDS, the chain-compressed 4-gram buckets, exact bitmaps of the 1-3-byte patterns, the
+// reversed trie's edge table, and what the scans have learnt about the dictionary's density.
+#pragma once
+#include "kg_ac_common.h"
+
+namespace kg {
+
+struct AcTables
+{
+    int device = 0;
+    u32 npat = 0, lmin = 0, lmax = 0;
+    bool ci = false, has_nl = false, has_empty = false;
+    u32 has1 = 0, has2 = 0, has3 = 0, has4 = 0;
+    bool short_dup = false;     // a 1-3-byte pattern occurs more than once (the bitmaps cannot count copies)
+    u32 *d_filterx20 = nullptr, *d_filterx19 = nullptr; // exact-class filter tables (2^20 bits; 2^19 for -c)
+    u32 *d_filters20 = nullptr, *d_filters19 = nullptr; // the same for the stride-2 filter (nullptr: stride 2 not worth it)
+    u32 *d_s1 = nullptr, *d_s2 = nullptr, *d_s3 = nullptr; // exact bitmaps of the 1-/2-/3-byte patterns
+    uint2 *d_edges = nullptr;
+    u32 emask = 0;
+    u32 *d_copies = nullptr;
+    u32 nnodes = 0;
+    uint2 *d_gram4 = nullptr;
+    uint4 *d_g4x = nullptr; // chain-compressed entries, same slots as d_gram4
+    u32 g4mask = 0;
+    u32 g4x_mode = 0, g4x_mask = 0, g4x_mul = 0;
+    u32 stage_cap = 16; // staged matches per unit (16, raised to 64 by a scan whose units overflowed; see ac_scan)
+    AcTiny tiny{};      // ok: the dictionary runs in kg_ac_tiny.hip (every pattern <= 4 bytes, few of them)
+    // a dictionary of 2..4 distinct single bytes: with records it is the one-pass single-byte scan with a needle SET
+    // (kg_single.hip: records at their final index, nothing staged) — until a scan proves too dense for its largest rings
+    u32 set_n = 0;
+    uint8_t set_b[4] = {0, 0, 0, 0};
+    bool set_ok = true;
+    int set_shape = 0;
+};
+
+} // namespace kg
