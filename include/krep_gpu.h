@@ -348,6 +348,15 @@ typedef struct krep_gpu_seq_carry
      * but the earlier occurrence lies in front of it: g0 = in.q1 ? (in.nl1 ? in.nl1 : local_first_nl1) : 0; 3 q's line started
      * in front of this piece: g0 = in.q1 ? (in.nl1 ? in.nl1 : in.g0) : 0.                                                    */
     uint64_t g0, local_g0, local_g0_kind;
+    /* multi-pattern -c with a '\n' inside a pattern (aho_corasick.c:383-396: the counter is bumped whenever the line of a match
+     * START differs from the line of the previously counted one, matches visited in emission order — end ascending): a piece
+     * owns the matches that END in it, its list continues its predecessor's, and the coupling is two numbers:             */
+    uint64_t nl_before;   /* '\n' bytes of the text in front of this piece's own_hi (carry_out) / own_lo (carry_in)         */
+    uint64_t last_line;   /* 1-based line number of the START of the last match of the text so far (0: no match yet)        */
+    uint64_t local_nl;    /* this piece alone: '\n' bytes in [own_lo, own_hi) ...                                           */
+    uint64_t local_last;  /* ... and the line of its last match's start RELATIVE to own_lo, biased by 2^62 (0: no match):   */
+                          /* a caller folding out-of-order pieces: nl_before = in.nl_before + local_nl,                      */
+                          /* last_line = local_last ? in.nl_before + 1 + (local_last - 2^62) : in.last_line                  */
 } krep_gpu_seq_carry_t;
 /* krep_gpu_scan_device_ex() for the pieces of one text IN TEXT ORDER: carry_in = the record the previous piece left
  * (NULL: nothing in front of this window is consumed — the piece that starts the text, or an optimistic first pass of a
@@ -363,9 +372,10 @@ int krep_gpu_scan_device_seq(krep_gpu_plan_t *plan, const void *d_text, size_t t
 enum krep_gpu_split
 {
     KREP_GPU_SPLIT_WHOLE = 0,  /* one window only: -c through simd_sse42_search / kmp_search with a newline inside the pattern,
-                                  neon_search's max_count == 0 corner, multi-pattern -c with a newline inside a pattern   */
+                                  neon_search's max_count == 0 corner                                                     */
     KREP_GPU_SPLIT_PIECES = 1, /* independent pieces: start-offset ownership + halo, results concatenate / merge          */
-    KREP_GPU_SPLIT_CHAIN = 2   /* pieces in text order through krep_gpu_scan_device_seq()                                 */
+    KREP_GPU_SPLIT_CHAIN = 2   /* pieces in text order through krep_gpu_scan_device_seq() (round 5: also multi-pattern -c
+                                  with a newline inside a pattern)                                                        */
 };
 int krep_gpu_split_mode(const search_params_t *params, size_t text_len);
 /* test hook (host only, no GPU needed): the left fold of the boundary record exactly as the library applies it — a piece's

@@ -650,8 +650,11 @@ static hipError_t ac_launch(const AcArgs &a, u32 grid, u32 lds, hipStream_t st)
 int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, int num_cu, const uint8_t *d_text, size_t text_len,
             size_t own_lo, size_t own_hi, size_t global_base, match_position_t *d_pos, uint64_t cap, bool ww, bool lines,
             bool track, size_t max_count, hipStream_t st, int time_it, hipEvent_t ev0, hipEvent_t ev1, krep_gpu_scan_out_t *out,
-            bool lines_on_list)
+            int list_mode)
 {
+    // list_mode 1: the record list multi-pattern -c is counted on (END-owned, line gaps counted behind the post-pass);
+    // 2: END-owned records only (the emission-order list of -c with a newline inside a pattern: kg_scan.hip)
+    const bool lines_on_list = list_mode == 1, own_by_end = list_mode != 0;
     memset(out, 0, sizeof *out);
     if (max_count == 0) // aho_corasick.c:316
         return 0;
@@ -688,8 +691,8 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
     // run up to own_hi + Lmax - 2.  -c owns by END index instead (a pattern without '\n' starts and ends
     // on the same line), which keeps the line bookkeeping inside the owned window.
     a.end_lo = own_lo;
-    a.end_hi = (lines || lines_on_list) ? own_hi : std::min<u64>(text_len, (u64)own_hi + t->lmax - 1);
-    if (lines_on_list)
+    a.end_hi = (lines || own_by_end) ? own_hi : std::min<u64>(text_len, (u64)own_hi + t->lmax - 1);
+    if (own_by_end)
     {
         // the record list -c is counted on (kg_scan.hip scan_ac_lines_on_list) owns by END like the in-kernel -c road does: two
         // neighbouring pieces / shards may take different roads, and a match across their cut must belong to exactly one of them
@@ -734,7 +737,7 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
     // ---- a dictionary of single bytes, records wanted: memchr_search's one-pass kernel with a needle set (kg_single.hip).  The
     // matches of aho_corasick_search for such a dictionary are one (i, i + 1) per matching position in text order
     // (aho_corasick.c:383-437) — exactly that kernel's records.  Shapes by counted density as in lit_pass (kg_scan.hip).
-    if (t->set_n && want && !ww && !lines_on_list && t->set_ok && text_len >= (size_t)16 * kSegBytes && !g_ac_force_stage_cap &&
+    if (t->set_n && want && !ww && !own_by_end && t->set_ok && text_len >= (size_t)16 * kSegBytes && !g_ac_force_stage_cap &&
         !getenv("KREP_GPU_NO_FUSED1") && !getenv("KREP_GPU_AC_NO_TINY"))
     {
         LitArgs la{};

@@ -85,6 +85,9 @@ int tail_count_line_gaps(const uint8_t *d_text, uint64_t text_len, uint64_t glob
                          unsigned long long *h_slot, hipStream_t st, uint64_t *lines);
 int tail_launch_line_gaps(const uint8_t *d_text, uint64_t text_len, uint64_t global_base, const uint64_t *d_rec, const unsigned long long *d_n,
                           const unsigned long long *d_skip_if, uint64_t cap, unsigned long long *d_out, hipStream_t st);
+// '\n' bytes of d_text[lo, hi) -> *count (kg_tail.hip; results through the plan's pinned counter block)
+int tail_count_newlines(const uint8_t *d_text, uint64_t lo, uint64_t hi, unsigned long long *d_slot, unsigned long long *h_slot,
+                        hipStream_t st, uint64_t *count);
 int tail_run_replay(const ReplayIn &r, unsigned long long *d_slot, unsigned long long *h_slot, hipStream_t st, uint64_t *lines);
 
 // kg_ac.hip — multi-pattern scan
@@ -94,7 +97,7 @@ void ac_free(AcTables *t);
 int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, int num_cu,
             const uint8_t *d_text, size_t text_len, size_t own_lo, size_t own_hi, size_t global_base,
             match_position_t *d_pos, uint64_t cap, bool ww, bool lines, bool track, size_t max_count, hipStream_t st,
-            int time_it, hipEvent_t ev0, hipEvent_t ev1, krep_gpu_scan_out_t *out, bool lines_on_list = false);
+            int time_it, hipEvent_t ev0, hipEvent_t ev1, krep_gpu_scan_out_t *out, int list_mode = 0);
 
 // kg_config.hip — test hooks shared with the scan drivers
 extern std::atomic<int> g_force_rounds, g_force_stage_cap;   // krep_gpu_debug_force_rounds / _stage_cap

@@ -852,8 +852,11 @@ static int run_pieces(const search_params_t *params, const krep_gpu_config_t &cf
         {
             // walks: the piece's own list depends on where the scan stands at its start; block-loop -c: only the piece that
             // ends the text depends on the line-skip history
+            // (multi-pattern -c with a newline inside a pattern: every piece's count depends on the newlines and the last match's
+            //  line in front of it — for every other family these two fields stay 0)
             const bool stale = std::max<uint64_t>(p.carry_used.resume, p.lo) != std::max<uint64_t>(tc.resume, p.lo) ||
-                               (p.hi == len && (p.carry_used.q1 != tc.q1 || p.carry_used.nl1 != tc.nl1 || p.carry_used.g0 != tc.g0));
+                               (p.hi == len && (p.carry_used.q1 != tc.q1 || p.carry_used.nl1 != tc.nl1 || p.carry_used.g0 != tc.g0)) ||
+                               p.carry_used.nl_before != tc.nl_before || p.carry_used.last_line != tc.last_line;
             if (stale)
             {
                 DeviceCtx &cx = *ctx_for(p.device);

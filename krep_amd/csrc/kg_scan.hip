@@ -367,8 +367,9 @@ namespace kg {
 // How may the text be cut?  kSplitPieces: independent pieces (start-offset ownership + halo) whose results merge.
 // kSplitChain: pieces in text order, each taking the boundary record of the one before it (the greedy / -o walks: where the
 // reference's scan stands; -c through simd_avx512_search / simd_avx2_search -w: the line-skip history the end-of-text replay
-// needs, for neon_search with its grid origin — krep_gpu_seq_carry_t).  kSplitWhole: one window only — the newline-pattern -c
-// walk of kg_greedy.hip (3), neon_search's max_count == 0 corner, multi-pattern -c with a '\n' inside a pattern.
+// needs, for neon_search with its grid origin; multi-pattern -c with a '\n' inside a pattern: newlines so far and the line of
+// the last match — krep_gpu_seq_carry_t).  kSplitWhole: one window only — the newline-pattern -c walk of kg_greedy.hip (3),
+// neon_search's max_count == 0 corner.
 int split_mode(const search_params_t *p, const krep_gpu_config_t &c, size_t text_len)
 {
     if (!p || p->use_regex || p->num_patterns == 0)
@@ -379,7 +380,7 @@ int split_mode(const search_params_t *p, const krep_gpu_config_t &c, size_t text
             return kSplitPieces;
         for (size_t i = 0; i < p->num_patterns; ++i)
             if (p->pattern_lens[i] && memchr(p->patterns[i], '\n', p->pattern_lens[i]))
-                return kSplitWhole;
+                return kSplitChain; // emission-order line changes: pieces owned by END, chained by (newlines, last line) — round 5
         return kSplitPieces;
     }
     const char *pat = p->patterns && p->pattern_lens ? p->patterns[0] : p->pattern;
@@ -407,6 +408,9 @@ krep_gpu_seq_carry_t fold_carry(const krep_gpu_seq_carry_t &in, const krep_gpu_s
 {
     krep_gpu_seq_carry_t o = pc; // keeps the piece's local_* fields
     o.resume = std::max<uint64_t>(in.resume, pc.resume);
+    // multi-pattern -c with a newline inside a pattern: newlines so far, line of the last match's start (include/krep_gpu.h)
+    o.nl_before = in.nl_before + pc.local_nl;
+    o.last_line = pc.local_last ? in.nl_before + 1ull + (pc.local_last - (1ull << 62)) : in.last_line;
     if (!pc.local_q1)
     {
         o.q1 = in.q1;
@@ -910,21 +914,37 @@ static int scan_literal(krep_gpu_plan *pl, int algo, const Window &w, match_posi
 // one (aho_corasick.c:383-396) — with a newline inside a pattern a later match may start on an EARLIER line, so a line
 // can be counted more than once.  Reproduced literally: the ordered match list, the line number of every start
 // (kg_format.hip), the number of changes along the list.
-static int scan_ac_newline_lines(krep_gpu_plan *pl, const Window &w, hipStream_t st, int time_it, krep_gpu_scan_out_t *out)
+// Pieces (round 5): a piece owns the matches that END in [own_lo, own_hi) — the pieces' lists, concatenated in text order, ARE
+// the emission order — and what couples it to the text in front of it is two numbers (krep_gpu_seq_carry_t): the newlines so
+// far (its line numbers are global) and the line of the last match's start (its first match counts only on another line).
+// The buffer must hold the longest pattern's length in front of own_lo (every piece of run_pieces does).
+static int scan_ac_newline_lines(krep_gpu_plan *pl, const Window &w, hipStream_t st, int time_it, const krep_gpu_seq_carry_t *carry_in,
+                                 krep_gpu_seq_carry_t *carry_out, krep_gpu_scan_out_t *out)
 {
-    if (!(w.global_base == 0 && w.own_lo == 0 && w.own_hi >= w.text_len && w.global_len == w.text_len))
-        return kg::fail("multi-pattern -c with a newline inside a pattern counts emission-order line changes: scan the whole "
-                        "text in one window");
-    if (pl->max_count == 0) // aho_corasick.c:316
+    const krep_gpu_seq_carry_t in = carry_in ? *carry_in : krep_gpu_seq_carry_t{};
+    krep_gpu_seq_carry_t local{};
+    const size_t own_hi = std::min(w.own_hi, w.text_len);
+    auto leave = [&]() {
+        if (carry_out)
+            *carry_out = kg::fold_carry(in, local);
+    };
+    if (pl->max_count == 0 || w.own_lo >= own_hi) // aho_corasick.c:316
+    {
+        leave();
         return 0;
+    }
     if (time_it) HIPCHK(hipEventRecord(pl->ev0, st));
+    unsigned long long *d_slot = &pl->d_ctr->pad[0], *h_slot = &pl->h_ctr->pad[0];
     krep_gpu_scan_out_t o1;
-    int rc = ac_scan(pl->ac, pl->d_ctr, pl->h_ctr, pl->post, pl->num_cu, w.d_text, w.text_len, 0, w.text_len, 0, nullptr, 0, pl->ww,
-                     false, false, SIZE_MAX, st, 0, pl->ev0, pl->ev1, &o1);
+    int rc = ac_scan(pl->ac, pl->d_ctr, pl->h_ctr, pl->post, pl->num_cu, w.d_text, w.text_len, w.own_lo, own_hi, w.global_base, nullptr, 0,
+                     pl->ww, false, false, SIZE_MAX, st, 0, pl->ev0, pl->ev1, &o1, 2);
     if (rc)
         return rc;
     const uint64_t total = o1.total_matches;
-    uint64_t changes = 0;
+    uint64_t changes = 0, nl_halo = 0, nl_own = 0;
+    if (tail_count_newlines(w.d_text, 0, w.own_lo, d_slot, h_slot, st, &nl_halo) || tail_count_newlines(w.d_text, w.own_lo, own_hi, d_slot, h_slot, st, &nl_own))
+        return 2;
+    local.local_nl = nl_own;
     if (total)
     {
         if (total > pl->nl_cap) // grow-only scratch of the plan (no allocation per call)
@@ -939,16 +959,28 @@ static int scan_ac_newline_lines(krep_gpu_plan *pl, const Window &w, hipStream_t
             HIPCHK(hipMalloc(&pl->d_nl_ln, want * sizeof(uint64_t)));
             pl->nl_cap = want;
         }
+        if (!pl->d_nl_ln) // (the list road of plain -c sizes only the records)
+            HIPCHK(hipMalloc(&pl->d_nl_ln, pl->nl_cap * sizeof(uint64_t)));
         match_position_t *d_rec = pl->d_nl_rec;
         uint64_t *d_ln = pl->d_nl_ln;
-        rc = ac_scan(pl->ac, pl->d_ctr, pl->h_ctr, pl->post, pl->num_cu, w.d_text, w.text_len, 0, w.text_len, 0, d_rec, total, pl->ww,
-                     false, true, SIZE_MAX, st, 0, pl->ev0, pl->ev1, &o1);
+        rc = ac_scan(pl->ac, pl->d_ctr, pl->h_ctr, pl->post, pl->num_cu, w.d_text, w.text_len, w.own_lo, own_hi, w.global_base, d_rec, total,
+                     pl->ww, false, true, SIZE_MAX, st, 0, pl->ev0, pl->ev1, &o1, 2);
         if (!rc)
-            rc = krep_gpu_line_numbers(w.d_text, w.text_len, d_rec, total, d_ln, st);
+            rc = krep_gpu_line_numbers_ex(w.d_text, w.text_len, w.global_base, d_rec, total, d_ln, st); // 1 + newlines in [buffer start, start)
         if (!rc)
-            rc = tail_count_changes(d_ln, total, &pl->d_ctr->pad[0], &pl->h_ctr->pad[0], st, &changes);
+            rc = tail_count_changes(d_ln, total, d_slot, h_slot, st, &changes);
         if (rc)
             return rc;
+        uint64_t ends[2] = {0, 0};
+        HIPCHK(hipMemcpyAsync(&ends[0], d_ln, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(&ends[1], d_ln + (total - 1), sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        // line of a start relative to own_lo (negative for a start in the halo): (ln - 1) - newlines of the halo
+        const uint64_t bias = 1ull << 62;
+        const uint64_t first_rel = bias + (ends[0] - 1ull) - nl_halo, last_rel = bias + (ends[1] - 1ull) - nl_halo;
+        if (in.last_line && in.nl_before + 1ull + (first_rel - bias) == in.last_line)
+            changes -= 1; // the first match of this piece starts on the line of the text's last match so far: not counted again
+        local.local_last = last_rel;
     }
     if (time_it)
     {
@@ -958,9 +990,11 @@ static int scan_ac_newline_lines(krep_gpu_plan *pl, const Window &w, hipStream_t
         HIPCHK(hipEventElapsedTime(&ms, pl->ev0, pl->ev1));
         out->kernel_ms = ms;
     }
+    leave();
     out->total_matches = total;
     out->line_count = changes;
-    out->head_line_hit = out->tail_line_hit = changes != 0;
+    out->has_newline = 1; // (krep_gpu_combine_line_counts then adds the pieces' counts up: nothing merges across a cut that the record has not settled)
+    out->head_line_hit = out->tail_line_hit = 0;
     out->count = std::min<uint64_t>(changes, pl->max_count);
     return 0;
 }
@@ -1093,7 +1127,7 @@ static int scan_device_impl(krep_gpu_plan_t *pl, const void *d_text, size_t text
     if (pl->ref_algo == KREP_RA_AHO_CORASICK && pl->lines && pl->ac_has_newline)
     {
         Window w{(const uint8_t *)d_text, text_len, own_lo, own_hi, global_base, global_len};
-        return scan_ac_newline_lines(pl, w, st, time_it, out);
+        return scan_ac_newline_lines(pl, w, st, time_it, carry_in, carry_out, out);
     }
     if (pl->ref_algo == KREP_RA_AHO_CORASICK && pl->lines && text_len >= kAcLinesOnListMin && !getenv("KREP_GPU_AC_LINES_INKERNEL"))
     {

@@ -225,6 +225,34 @@ __global__ __launch_bounds__(256) void tail_line_gaps(const uint8_t *__restrict_
         atomicAdd(out, (u64)c);
 }
 
+// out[0] += number of '\n' bytes in text[lo, hi): aligned 16-byte vectors, the ragged ends bytewise
+__global__ __launch_bounds__(256) void tail_newlines(const uint8_t *__restrict__ text, u64 lo, u64 hi, u64 *out)
+{
+    const u64 alo = (lo + 15ull) & ~15ull, ahi = hi & ~15ull; // (text itself is 16-byte aligned: a device allocation or a piece of one)
+    u32 c = 0;
+    const u64 tid = (u64)blockIdx.x * blockDim.x + threadIdx.x, nth = (u64)gridDim.x * blockDim.x;
+    if (alo < ahi)
+    {
+        const size_t mis = ((size_t)text) & 15u; // a buffer that is not 16-byte aligned: count everything bytewise below
+        if (mis == 0)
+            for (u64 q = alo + tid * 16ull; q < ahi; q += nth * 16ull)
+                c += (u32)__popc(nl_mask16(*reinterpret_cast<const uint4 *>(text + q)));
+        else
+            for (u64 q = alo + tid; q < ahi; q += nth)
+                c += text[q] == '\n' ? 1u : 0u;
+    }
+    const u64 head_end = alo < hi ? alo : hi, tail_beg = (ahi > alo ? ahi : head_end);
+    for (u64 q = lo + tid; q < head_end; q += nth)
+        c += text[q] == '\n' ? 1u : 0u;
+    for (u64 q = tail_beg + tid; q < hi; q += nth)
+        c += text[q] == '\n' ? 1u : 0u;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1)
+        c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0 && c)
+        atomicAdd(out, (u64)c);
+}
+
 __global__ void tail_replay(ReplayIn r, u64 *out)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0)
@@ -341,6 +369,22 @@ int tail_launch_line_gaps(const uint8_t *d_text, uint64_t text_len, uint64_t glo
     hipLaunchKernelGGL(tail_line_gaps, dim3(grid), dim3(256), 0, st, d_text, (u64)text_len, (const u64 *)d_rec, (u64)cap, (const u64 *)d_n,
                        (const u64 *)d_skip_if, (u64)global_base, (u64 *)d_out);
     TCHK(hipGetLastError());
+    return 0;
+}
+
+int tail_count_newlines(const uint8_t *d_text, uint64_t lo, uint64_t hi, unsigned long long *d_slot, unsigned long long *h_slot,
+                        hipStream_t st, uint64_t *count)
+{
+    *count = 0;
+    if (lo >= hi)
+        return 0;
+    TCHK(hipMemsetAsync(d_slot, 0, sizeof(u64), st));
+    const u32 grid = (u32)std::min<u64>(((hi - lo) / 16 + 255) / 256 + 1, 2048);
+    hipLaunchKernelGGL(tail_newlines, dim3(grid), dim3(256), 0, st, d_text, (u64)lo, (u64)hi, (u64 *)d_slot);
+    TCHK(hipGetLastError());
+    TCHK(hipMemcpyAsync(h_slot, d_slot, sizeof(u64), hipMemcpyDeviceToHost, st));
+    TCHK(hipStreamSynchronize(st));
+    *count = *h_slot;
     return 0;
 }
 

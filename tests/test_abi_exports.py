@@ -134,7 +134,7 @@ def test_header_is_plain_c_and_python_mirrors_its_structs(tmp_path):
 
 def test_split_mode_table():
     """Host logic, no GPU: which families may be cut how (krep_gpu_split_mode).  Independent pieces for the
-    all-occurrence functions, chained pieces (one boundary record) for the sequential ones, one window for the three classes
+    all-occurrence functions, chained pieces (one boundary record) for the sequential ones, one window for the two classes
     DESIGN.md §7 names."""
     import krep_amd
     e = krep_amd.load()
@@ -162,7 +162,7 @@ def test_split_mode_table():
         (abi.REF_AVX2, False, [b"a\nb"], {}, P),
         (abi.REF_AVX2, False, [b"ab", b"cd"], {}, P),
         (abi.REF_AVX2, False, [b"ab", b"cd"], dict(count_lines=True), P),
-        (abi.REF_AVX2, False, [b"a\nb", b"cd"], dict(count_lines=True), W),            # multi-pattern -c, newline inside a pattern
+        (abi.REF_AVX2, False, [b"a\nb", b"cd"], dict(count_lines=True), CH),           # multi-pattern -c, newline inside a pattern (r05: chained)
         (abi.REF_AVX2, False, [b"e"], {}, P),
     ]
     try:

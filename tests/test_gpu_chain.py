@@ -250,3 +250,54 @@ def test_rank_communicator_one_rank(gpu):
         assert gpu.rccl_calls() == before + 1
     finally:
         gpu.comm_destroy()
+
+
+def test_multi_pattern_count_lines_with_a_newline_pattern_in_pieces(gpu, oracle_engine):
+    """Round 5: aho_corasick_search -c with a '\\n' inside a pattern counts emission-order line CHANGES
+    (aho_corasick.c:383-396) — one window only until now.  A piece owns the matches that END in it; what it needs from the text in
+    front of it is the number of newlines so far and the line of the last match's start (krep_gpu_seq_carry_t::nl_before /
+    last_line).  Whole text == device windows chained through krep_gpu_scan_device_seq() == the streamed host operator == logical
+    shards on several devices, against the compiled reference: patterns that span one and two line breaks, nested ones whose
+    longer match starts on an EARLIER line than the shorter one before it, -w, -i, cuts inside a multi-line match."""
+    import torch
+    rng = np.random.RandomState(9090)
+    n = 3 * (1 << 20) + 4567
+    text = cases.rand_text(rng, n, b"ab \n")
+    dicts = [[b"a\nb", b"ab"], [b"b\na\nb", b"\nb", b"aa"], [b"ab\n", b"\n\n", b"b a"], [b" \na", b"a \na b", b"ba"]]
+    for pats in dicts:
+        for kw in (dict(), dict(whole_word=True), dict(case_sensitive=False)):
+            kwc = dict(count_lines=True, **kw)
+            p = abi.Params(pats, **kwc)
+            assert gpu.split_mode(p, n) == abi.SPLIT_CHAIN
+            want = oracle_engine.call(abi.RA_AHO_CORASICK, abi.Params(pats, **kwc), text)[0]
+            assert gpu.search(p, text, want_result=False)[0] == want, (pats, kw, "whole")
+            # device windows in text order, each with its predecessor's record; cuts everywhere, also one byte apart
+            d = torch.from_numpy(text).cuda()
+            plan = gpu.plan(p)
+            cuts = [0, 1, 2, 777, 65536, 65537, (1 << 20) + 3, (2 << 20) - 1, 2 << 20, n]
+            carry, total = None, 0
+            for lo, hi in zip(cuts[:-1], cuts[1:]):
+                out, carry = plan.scan_seq(d.data_ptr(), n, lo, hi, 0, global_len=n, carry_in=carry)
+                total += out.line_count
+            assert total == want, (pats, kw, "device windows", total, want)
+            # the same windows as buffers of their own (a halo of the longest pattern in front, global_base behind it)
+            lmax = max(len(q) for q in pats)
+            carry, total = None, 0
+            for lo, hi in zip(cuts[:-1], cuts[1:]):
+                b0 = max(0, lo - lmax - 1)
+                b1 = min(n, hi + lmax + 1)
+                out, carry = plan.scan_seq(d.data_ptr() + b0, b1 - b0, lo - b0, hi - b0, b0, global_len=n, carry_in=carry)
+                total += out.line_count
+            assert total == want, (pats, kw, "own buffers", total, want)
+            plan.close()
+            del d
+            # the host operator: streamed in 1 MiB pieces, and sharded over 2 and 3 logical devices (optimistic first pieces,
+            # the fix-up re-scans what the true record changes)
+            gpu.set_stream_chunk(1 << 20)
+            try:
+                assert gpu.search(p, text, want_result=False)[0] == want, (pats, kw, "streamed")
+                for shards in (2, 3):
+                    rc, cnt, _ = gpu.search_buffer(p, text, num_gpus=shards, want_result=False)
+                    assert cnt == want and rc == (0 if want else 1), (pats, kw, "shards", shards, cnt, want)
+            finally:
+                gpu.set_stream_chunk(0)
