@@ -198,8 +198,9 @@ int krep_gpu_last_status(void);
  *   t_gpu = (device not yet initialised in this process ? gpu_init_ms : 0) + gpu_launch_us + text_len / host-path rate
  *   t_cpu = text_len / min(cpu_threads x per-thread rate of the function select_search_algorithm() would run, its cap)
  * cpu_threads <= 0: what search_file() itself would use, min(cores, text_len / 4 MiB), at least 1 (krep.c:2748-2759).
- * The host-path rate and the device-start time are calibrated once per process by the library itself (the first large
- * operator call, the availability probe); everything is overridable: krep_gpu_set_cost_rates(), $KREP_GPU_COST
+ * The host-path rate is calibrated per process by the library itself (large operator calls after the first one, which also pays
+ * for tables, arena and staging ring); the device-start term is dropped once the availability probe has run in this process (its
+ * measured time is not used as a value).  Everything is overridable: krep_gpu_set_cost_rates(), $KREP_GPU_COST
  * ("host=50,launch=100,init=450,memchr=12:180,simd=6:150,scalar=1.5:100,ac=0.4:100": GB/s per thread : cap).
  * rates.enabled = 0 or $KREP_GPU_COST_MODEL=0: size and input class alone decide (the round-3 rule). */
 typedef struct krep_gpu_cost_rates
@@ -294,6 +295,9 @@ typedef struct krep_gpu_scan_out
     float kernel_ms;         /* hipEvent time of the scan kernels on `stream` (0 if not timed)     */
 } krep_gpu_scan_out_t;
 
+/* A plan is used by ONE thread at a time: it owns scratch buffers, events and what its scans have learnt about the text's density
+ * (staging-slot size, ring shape of the one-pass kernels, which -c road pays off) — re-evaluated by every scan, not synchronised.
+ * Concurrent scans take one plan each (the host operators keep a small plan cache per device behind the device's mutex). */
 krep_gpu_plan_t *krep_gpu_plan_create(const search_params_t *params, int only_matching, int device);
 krep_gpu_plan_t *krep_gpu_plan_create_ex(const search_params_t *params, const krep_gpu_config_t *cfg /* NULL = current */);
 void krep_gpu_plan_destroy(krep_gpu_plan_t *plan);

@@ -795,6 +795,8 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
                     out->kernel_ms = ms;
                 }
                 const u64 total = h_ctr->total;
+                if (shape > 0 && (double)total / (double)(own_hi - la.anchor) < 0.5 * single_fused_max_density(shape - 1))
+                    t->set_shape = shape - 1; // (re-evaluated by every scan: a sparser text goes back to the larger tickets)
                 out->total_matches = total;
                 out->head_line_hit = out->tail_line_hit = total != 0;
                 out->count = std::min<u64>(total, (u64)max_count);
@@ -877,6 +879,12 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
             t->stage_cap = 0;
         else if (t->stage_cap && h_ctr->overflow_units * 64 > n_units)
             t->stage_cap = 64;
+        else if (!t->stage_cap && h_ctr->total < n_units * 32)
+            t->stage_cap = 64; // the dense road (count pass + emit pass) is left again when a text holds < 32 matches per unit
+        // a byte-set dictionary that proved too dense for the one-pass rings gets them back on a text half as dense as they hold
+        if (t->set_n && !t->set_ok && own_hi > a.anchor &&
+            (double)h_ctr->total / (double)(own_hi - a.anchor) < 0.5 * single_fused_max_density(kFusedShapeMax))
+            t->set_ok = true;
     }
     const bool list_lines_valid = lines_on_list && want && !h_ctr->overflow_units && h_ctr->total <= want;
     const u64 list_lines = h_ctr->lines;

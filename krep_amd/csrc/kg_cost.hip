@@ -33,7 +33,8 @@ std::mutex g_mu;
 krep_gpu_cost_rates_t g_rates;
 bool g_rates_init = false;
 std::atomic<double> g_meas_host_gbps{0.0}; // calibrated: the host path of this process (0 = not measured yet)
-std::atomic<double> g_meas_init_ms{-1.0};  // calibrated: what the first device call of this process cost (-1 = none yet)
+std::atomic<double> g_meas_init_ms{-1.0};  // what the first device call of this process cost (-1 = none yet): only its PRESENCE is used —
+                                           // a process whose device is up no longer pays r.gpu_init_ms (the figure itself is a rate default)
 
 krep_gpu_cost_rates_t defaults()
 {
@@ -102,8 +103,15 @@ void cost_note_host_path(size_t bytes, double seconds) // an operator call that 
 {
     if (bytes < ((size_t)64 << 20) || seconds <= 0)
         return; // small calls are launch-bound: they say nothing about the rate
+    // The first large call of a process also pays for the plan / table build, the multi-GiB arena allocation, the pinned staging
+    // ring and the copy-thread probe: several times below the real PCIe rate, and averaged in it would bias every later
+    // krep_gpu_worthwhile() towards the CPU.  It is not a sample.  Setup can only make a call SLOWER, never faster:
+    // a later sample above the running figure replaces it, one below it is averaged in.
+    static std::atomic<int> n_seen{0};
+    if (n_seen.fetch_add(1) == 0)
+        return;
     const double gbps = (double)bytes / seconds / 1e9, old = g_meas_host_gbps.load();
-    g_meas_host_gbps.store(old > 0 ? 0.5 * old + 0.5 * gbps : gbps);
+    g_meas_host_gbps.store(old > 0 ? (gbps > old ? gbps : 0.5 * old + 0.5 * gbps) : gbps);
 }
 } // namespace kg
 

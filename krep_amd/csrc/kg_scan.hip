@@ -226,6 +226,10 @@ static int lit_pass(krep_gpu_plan *pl, const Window &w, const LitPass &ps, hipSt
             {
                 res->total = pl->h_ctr->total;
                 res->summary = res->total ? (kLnHead | kLnTail) : 0;
+                // the decision is re-evaluated by every scan: a text half as dense as the next smaller shape holds
+                // sends the plan's following scans back to it (larger tickets, more waves per CU)
+                if (shape > 0 && (double)res->total / (double)(hi_match - a.anchor) < 0.5 * single_fused_max_density(shape - 1))
+                    pl->fused1_shape = shape - 1;
                 return 0;
             }
             // the scan counted every ticket (the resolver's running sum): the density chooses the shape — unless the spin-limit
@@ -318,6 +322,9 @@ static int lit_pass(krep_gpu_plan *pl, const Window &w, const LitPass &ps, hipSt
     }
     res->total = pl->h_ctr->total;
     res->lines = pl->h_ctr->lines;
+    if (!pl->fused1_ok && m_scan == 1 && hi_match > a.anchor &&
+        (double)pl->h_ctr->total / (double)(hi_match - a.anchor) < 0.5 * single_fused_max_density(kFusedShapeMax))
+        pl->fused1_ok = true; // (a later, sparser text of the same plan takes the one-pass kernel again)
     res->summary = chain ? pl->h_ctr->summary : (res->total ? (kLnHead | kLnTail) : 0);
     return 0;
 }
@@ -1138,9 +1145,16 @@ static int scan_device_impl(krep_gpu_plan_t *pl, const void *d_text, size_t text
             return rc;
     }
     if (pl->ref_algo == KREP_RA_AHO_CORASICK)
-        return ac_scan(pl->ac, pl->d_ctr, pl->h_ctr, pl->post, pl->num_cu, (const uint8_t *)d_text,
-                       text_len, own_lo, own_hi, global_base, d_positions, position_capacity, pl->ww, pl->lines, pl->track,
-                       pl->max_count, st, time_it, pl->ev0, pl->ev1, out);
+    {
+        const int rc = ac_scan(pl->ac, pl->d_ctr, pl->h_ctr, pl->post, pl->num_cu, (const uint8_t *)d_text, text_len, own_lo, own_hi,
+                               global_base, d_positions, position_capacity, pl->ww, pl->lines, pl->track, pl->max_count, st, time_it,
+                               pl->ev0, pl->ev1, out);
+        // the in-kernel road knows the match count too: a text at half the list's break-even density re-opens the list road for
+        // the plan's next pieces (the decision was one-way until round 5)
+        if (!rc && pl->lines && pl->lines_list_off && out->total_matches < text_len / 800)
+            pl->lines_list_off = false;
+        return rc;
+    }
     if (pl->sp.num_patterns != 1)
         return kg::fail("scan_device: no pattern");
     const int algo = mirror_effective(pl->ref_algo, &pl->sp, global_len);

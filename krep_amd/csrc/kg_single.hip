@@ -40,6 +40,7 @@
 // (aho_corasick_search reports such matches in text order, one per position: the records are memchr_search's).
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include "kg_common.h"
 #include "kg_internal.h"
@@ -438,22 +439,32 @@ template <bool CI, u32 UPT, u32 RING, int WPE, bool SET>
 static hipError_t launch_fused(const LitArgs &a, u64 *agg, u64 *pref, u64 n_tickets, u32 num_cu, hipStream_t st)
 {
     constexpr size_t kLds = (size_t)kWavesPerBlk * RING * sizeof(unsigned short);
-    if (kLds > 64 * 1024) // more than 64 KiB of dynamic LDS has to be asked for (per device; cheap next to a scan of >= 128 KiB)
+    // per DEVICE: the granted-LDS attribute and the resident blocks per CU of this instantiation are properties of the
+    // device the launch goes to — asked once per device, not once per process (multi-device searches launch from one process) and
+    // not on every launch
+    static std::atomic<u32> s_bpc[64]; // 0 = not asked yet
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const u32 slot = (u32)dev < 64u ? (u32)dev : 63u;
+    u32 bpc = s_bpc[slot].load(std::memory_order_acquire);
+    if (!bpc)
     {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&single_fused<CI, UPT, RING, WPE, SET>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
-        if (e != hipSuccess)
-            return e;
-    }
-    static const u32 bpc = [] {
+        if (kLds > 64 * 1024) // more than 64 KiB of dynamic LDS has to be asked for
+        {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&single_fused<CI, UPT, RING, WPE, SET>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
+            if (e != hipSuccess)
+                return e;
+        }
         int n = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, single_fused<CI, UPT, RING, WPE, SET>, kBlock, kLds) != hipSuccess || n < 1)
         {
             (void)hipGetLastError();
             n = 1;
         }
-        return (u32)std::min(n, 4);
-    }();
+        bpc = (u32)std::min(n, 4);
+        s_bpc[slot].store(bpc, std::memory_order_release);
+    }
     // one block more than the tickets need is never useful; at least 1 scanning wave next to the resolver
     const u64 want = (n_tickets + kWavesPerBlk - 1) / kWavesPerBlk + 1;
     u32 grid = (u32)std::max<u64>(1, std::min<u64>(want, (u64)num_cu * bpc));
