@@ -336,3 +336,33 @@ def test_single_byte_one_pass_dense_shapes(gpu, oracle_engine):
             plan.close()
     finally:
         gpu.force_rounds(0)
+
+
+def test_one_plan_across_texts_of_changing_density(gpu, oracle_engine):
+    """What a plan has learnt about density is re-evaluated by every scan (ring shape of the one-pass kernel, the
+    two-pass fallback, the byte-set dictionary, the dense road of a tiny dictionary were one-way): ONE plan scans a sparse text,
+    a text too dense for any ring, a medium one and the sparse one again — every list exact each time, single byte and byte set."""
+    import torch
+    rng = np.random.RandomState(4242)
+    n = 5 * (1 << 20) + 77
+    gpu.force_rounds(4)
+    try:
+        texts = [cases.rand_text(rng, n, alpha) for alpha in (b"e" + bytes(range(65, 91)) * 30, b"eta", b"et" + b"abcdfghijk" * 2,
+                                                            b"e" + bytes(range(65, 91)) * 30)]
+        for pats in ([b"e"], [b"e", b"t"], [b"he", b"e"]):
+            algo = abi.RA_AHO_CORASICK if len(pats) > 1 else gpu.mirror_select(abi.Params(pats), n)
+            plan = gpu.plan(abi.Params(pats))
+            for rep in range(2):
+                for ti, text in enumerate(texts):
+                    want = oracle_engine.call(algo, abi.Params(pats), text)
+                    d = torch.from_numpy(text).cuda()
+                    cap = int(want[0]) + 5
+                    pos = torch.zeros(2 * cap, dtype=torch.int64, device="cuda")
+                    out = plan.scan(d.data_ptr(), n, 0, n, 0, pos.data_ptr(), cap)
+                    assert out.count == want[0] and not out.overflow, (pats, rep, ti, out.count, want[0])
+                    got = pos[:2 * out.count].cpu().numpy().astype(np.uint64).reshape(-1, 2)
+                    assert np.array_equal(got, want[1]), (pats, rep, ti)
+                    del d, pos
+            plan.close()
+    finally:
+        gpu.force_rounds(0)
