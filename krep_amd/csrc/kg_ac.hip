@@ -817,6 +817,61 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
         }
         t->set_ok = false; // denser than the largest rings hold: the register-compare kernel below, for good
     }
+    // ---- a tiny dictionary, records wanted: ONE pass (kg_ac_tiny.hip FUSED, round 5) — matches ranked into an LDS ring per
+    // 128-KiB ticket, the tickets' counts resolved into prefixes by one wave, records written at their final index: no masks kept,
+    // no staging, no info words, no post-pass.  A ticket with more matches than its ring holds (~0.6 % of the bytes) is counted,
+    // not recorded: the staging road below takes this scan, and the dictionary's next ones until a text is sparse again.
+    if (t->tiny.ok && !t->tiny.llong && want && !ww && list_mode != 2 && t->tiny_fused_ok && track && !g_ac_force_stage_cap &&
+        text_len >= (size_t)64 * kAcUnitBytes && !getenv("KREP_GPU_AC_NO_TINY_FUSED") && !getenv("KREP_GPU_AC_NO_TINY"))
+    {
+        AcArgs f = a;
+        f.upt = (u32)std::min<u64>(kAcUnitsPerTicketMax, std::max<u64>(1, f.num_tiles / ((u64)num_cu * kTinyWaves * 4)));
+        const u64 n_tk = (f.num_tiles + f.upt - 1) / f.upt;
+        if (n_tk > post.tk_cap)
+        {
+            if (post.d_tk) (void)hipFree(post.d_tk);
+            post.d_tk = nullptr;
+            post.tk_cap = 0;
+            SCHK(hipMalloc(&post.d_tk, single_fused_scratch_words(n_tk) * sizeof(unsigned long long)));
+            post.tk_cap = n_tk;
+        }
+        f.tk_agg = post.d_tk;
+        f.tk_pref = post.d_tk + n_tk;
+        f.n_tk = n_tk;
+        f.stage_cap = 0;
+        SCHK(hipSetDevice(t->device));
+        if (time_it) SCHK(hipEventRecord(ev0, st));
+        SCHK(hipMemsetAsync(d_ctr, 0, sizeof(Counters), st));
+        SCHK(hipMemsetAsync(post.d_tk, 0, single_fused_scratch_words(n_tk) * sizeof(unsigned long long), st));
+        SCHK(ac_tiny_launch_fused(f, t->tiny, n_tk, (u32)num_cu, st));
+        // (the record list -c is counted on: its line gaps behind the scan on the same stream, skipped by the kernel itself when
+        //  a ticket overflowed its ring)
+        if (lines_on_list && tail_launch_line_gaps(d_text, text_len, global_base, (const uint64_t *)d_pos, &d_ctr->total, &d_ctr->overflow_units,
+                                                   want, &d_ctr->lines, st))
+            return 2;
+        if (time_it) SCHK(hipEventRecord(ev1, st));
+        SCHK(hipMemcpyAsync(h_ctr, d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, st));
+        SCHK(hipStreamSynchronize(st));
+        if (!h_ctr->overflow_units)
+        {
+            if (time_it)
+            {
+                float ms = 0;
+                SCHK(hipEventElapsedTime(&ms, ev0, ev1));
+                out->kernel_ms = ms;
+            }
+            const u64 total = h_ctr->total;
+            out->total_matches = total;
+            out->head_line_hit = out->tail_line_hit = total != 0;
+            out->count = std::min<u64>(total, (u64)max_count);
+            out->stored = std::min<u64>(out->count, want);
+            out->overflow = out->count > cap;
+            if (lines_on_list)
+                out->line_count = total <= want ? h_ctr->lines : ~0ull; // ~0: the list did not fit when the gaps were counted
+            return 0;
+        }
+        t->tiny_fused_ok = false; // (re-opened below by a text sparse enough for the rings)
+    }
     const bool chain = want || lines;
     const u64 n_units = a.num_tiles;
     // 16 staged matches (32-bit words: unit-relative start + length) = one 64-byte slot per 16 KiB unit; BASELINE config 4 puts 5.3
@@ -881,6 +936,8 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
             t->stage_cap = 64;
         else if (!t->stage_cap && h_ctr->total < n_units * 32)
             t->stage_cap = 64; // the dense road (count pass + emit pass) is left again when a text holds < 32 matches per unit
+        if (tiny && !t->tiny_fused_ok && h_ctr->total < n_units * 20) // (a 128-KiB ticket's ring holds ~1000: 125 per unit)
+            t->tiny_fused_ok = true;
         // a byte-set dictionary that proved too dense for the one-pass rings gets them back on a text half as dense as they hold
         if (t->set_n && !t->set_ok && own_hi > a.anchor &&
             (double)h_ctr->total / (double)(own_hi - a.anchor) < 0.5 * single_fused_max_density(kFusedShapeMax))

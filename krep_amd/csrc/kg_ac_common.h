@@ -47,6 +47,10 @@ struct AcArgs
     const u64 *offsets;
     u64 *positions;
     u64 pos_cap;
+    // one-pass records of the register-compare kernel (kg_ac_tiny.hip, FUSED): per ticket its published match count and the
+    // exclusive prefix the resolver wave derives from them (kg_single.hip's scheme); n_tk tickets of `upt` units
+    u64 *tk_agg, *tk_pref;
+    u64 n_tk;
 };
 
 // Tiny dictionaries (kg_ac_tiny.hip): every pattern 1..4 bytes (or 1..3 and ONE length of 5..8), at most kTinyPer of each length,
@@ -69,6 +73,9 @@ struct AcTiny
     u32 pk2[kTinyPer], lf2[kTinyPer];
 };
 hipError_t ac_tiny_launch(const AcArgs &a, const AcTiny &td, u64 n_tickets, u32 num_cu, hipStream_t st); // sizes its own grid
+hipError_t ac_tiny_launch_fused(const AcArgs &a, const AcTiny &td, u64 n_tickets, u32 num_cu, hipStream_t st); // one-pass records
+constexpr u32 kTinyRing = 1024; // items (12 bytes: a lane-cell's two length words + its index) per wave of the one-pass kernel's LDS ring:
+                                // the ticket being scanned + the one waiting
 
 __device__ __forceinline__ u32 ac_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 __device__ __forceinline__ u64 ac_rfl64(u64 v)

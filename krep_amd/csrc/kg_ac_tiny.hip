@@ -26,14 +26,29 @@
 
 #include "kg_ac_common.h"
 #include "kg_internal.h"
+#include "kg_tickets.h"
 
 namespace kg {
 
 bool ac_tiny_keeps(const AcArgs &a);
+extern int g_s1_force_grid; // (kg_single.hip)
 #ifndef KG_TINY_KEEP_WAVES
 #define KG_TINY_KEEP_WAVES 2
 #endif
-#define KG_TINY_KEEP_WAVES_ARG ((KEEP && !EMIT) ? KG_TINY_KEEP_WAVES : 3)
+#ifndef KG_TINY_FUSED_WAVES
+#define KG_TINY_FUSED_WAVES 3
+#endif
+#define KG_TINY_KEEP_WAVES_ARG ((KEEP && !EMIT) ? KG_TINY_KEEP_WAVES : (FUSED ? KG_TINY_FUSED_WAVES : 3))
+// FUSED (round 5): records in ONE pass and nothing else — no masks kept per unit, no staging slot, no info word, no post-pass.
+// A lane-cell that holds a match leaves ONE item in the wave's LDS ring — its two length words and its index in the ticket,
+// 12 bytes, ranked by a single ballot; the matches themselves are only counted (a per-lane sum, reduced once per ticket).  The
+// ticket's count is published, a resolver wave turns the counts into prefixes (kg_tickets.h, kg_single.hip's scheme), and a ticket
+// later the wave expands the parked items DENSELY — 64 items at a time, one per lane, a wave prefix of their match counts — into
+// records at their final index, END ascending and longest first.  (Decoding a cell's matches where they are found, as the first
+// version did, runs the walk with 1-2 of 64 lanes active in 70 % of the cells: 3.5 TB/s, no faster than the staging road.)
+// The streaming KEEP instantiation keeps a unit's length words in 8 KiB of LDS per wave, walks them once per unit and needs 200
+// VGPRs (2 waves per SIMD).  A ticket with more match-holding lane-cells than the ring has room for is counted, not recorded
+// (ctr->overflow_units): the host falls back to the staging road (ac_scan).
 constexpr int kTinyBlock = kTinyWaves * 64;
 constexpr u32 kTinyEntries = kAcUnitBytes / 16; // lane-cells of a unit (1024)
 
@@ -51,16 +66,34 @@ __device__ __forceinline__ u32 tiny_scramble16(u32 m) // position-ordered 16 bit
 // because its record walk holds a unit's 32 length words in registers — in the streaming launch those registers spilled, and a
 // scratch reload waits in the same in-order vmcnt queue as the prefetched text: the pipeline drained once per unit)
 // LONG: the dictionary holds a long length (AcTiny::llong) — its own instantiations, so that the others carry none of its code
-template <bool CI, bool LINES, bool KEEP, bool EMIT, bool LONG>
+template <bool CI, bool LINES, bool KEEP, bool EMIT, bool LONG, bool FUSED = false>
 __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_kernel(const AcArgs a, const AcTiny td)
 {
     extern __shared__ __attribute__((aligned(16))) u32 s_tiny[];
     const u32 lane = ac_lane(), wave = threadIdx.x >> 6;
+    static_assert(!FUSED || (!LINES && !KEEP && !EMIT), "the one-pass record writer is its own mode");
+    if constexpr (FUSED)
+    {
+        // the resolver: whichever wave 0 of a block gets here first (a wave that runs, whatever part of the grid is resident)
+        bool resolver = false;
+        if (__builtin_amdgcn_readfirstlane(wave) == 0u)
+        {
+            u64 r = 1;
+            if (lane == 0)
+                r = __hip_atomic_fetch_add(&a.ctr->pad[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            resolver = ac_rfl64(r) == 0ull;
+        }
+        if (resolver)
+        {
+            tk_resolve(a.tk_agg, a.tk_pref, a.n_tk, a.ctr, lane);
+            return;
+        }
+    }
     // per wave, -c: END mask + newline mask per lane-cell, position order (2 + 2 KiB); records: the length words per lane-cell (8 KiB)
     //           + the staging slots (<= 64 words) and info words of a ticket's <= 8 units, parked until the ticket ends: a wave
     //           stores nothing while it streams (on gfx9 a store waits in the same in-order vmcnt queue as the prefetched loads)
     constexpr u32 kPark = kAcUnitsPerTicketMax * 64 + kAcUnitsPerTicketMax * 2;
-    constexpr u32 kPerWave = LINES ? kTinyEntries : kTinyEntries * 2 + kPark;
+    constexpr u32 kPerWave = FUSED ? kTinyRing * 3u : (LINES ? kTinyEntries : kTinyEntries * 2 + kPark);
     u32 *base = s_tiny + wave * kPerWave;
     u32 *park_slots = base + kTinyEntries * 2;                                                     // [unit of the ticket][64]
     u64 *park_info = reinterpret_cast<u64 *>(base + kTinyEntries * 2 + kAcUnitsPerTicketMax * 64); // [unit of the ticket]
@@ -69,8 +102,77 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
     uint2 *cw = reinterpret_cast<uint2 *>(base);
 
     const bool want_pos = (a.flags & F_POS) != 0;
-    const bool chain = want_pos || LINES;
+    const bool chain = !FUSED && (want_pos || LINES); // (the one-pass writer publishes per ticket, not per unit)
     constexpr bool emit_final = EMIT; // (== a.emit_mode != 0: ac_tiny_launch)
+    // ---- FUSED: the wave's ring (length words | lane-cell index) and the ticket whose items still wait in it (uniform)
+    uint2 *ring_m = reinterpret_cast<uint2 *>(base);
+    u32 *ring_id = base + 2u * kTinyRing;
+    bool pend = false, overflowed = false;
+    u64 pend_t = 0;
+    u32 pend_at = 0, pend_items = 0, wp = 0; // ring position / items of the waiting ticket; write position (modulo kTinyRing at use)
+    u32 f_at = 0, f_room = 0, f_items = 0;   // the ticket being scanned: where its items start, how many fit, how many it holds so far
+    u32 lane_cnt = 0;                        // ... and this LANE's matches in it (summed over the wave when the ticket ends)
+    // the matches of one lane-cell from its two length words, in the reference's order — END ascending, longest first
+    // (aho_corasick.c:383-437): put(position e of the END inside the lane's 16 bytes, length)
+    auto walk_lane_cell = [&](const u32 cx, const u32 cy, const u32 l4, auto put) __attribute__((always_inline)) {
+        // ENDs of the lane-cell in position order: bit 8 b + w of the any-length word is position 4 w + b
+        const u32 hs = (cx | (cx >> 4) | cy | (cy >> 4)) & 0x0f0f0f0fu;
+        u32 h = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+        { // bit w of the byte's nibble -> bit 4 w + b (shifts and ORs: a multiply would carry where two bits meet)
+            const u32 x = (hs >> (8 * b)) & 0xfu;
+            h |= ((x | (x << 3) | (x << 6) | (x << 9)) & 0x1111u) << b;
+        }
+        while (h)
+        {
+            const u32 e = (u32)__builtin_ctz(h);
+            h &= h - 1u;
+            const u32 bit = 8u * (e & 3u) + (e >> 2);
+            if ((cy >> (bit + 4u)) & 1u) put(e, l4);
+            if ((cy >> bit) & 1u) put(e, 3u);
+            if ((cx >> (bit + 4u)) & 1u) put(e, 2u);
+            if ((cx >> bit) & 1u) put(e, 1u);
+        }
+    };
+    auto flush = [&](const u32 l4) __attribute__((always_inline)) {
+        const u64 first = tk_wait_prefix(a.tk_pref, pend_t, a.ctr, lane);
+        const u64 tbase = a.anchor + pend_t * (u64)a.upt * kAcUnitBytes + a.global_base;
+        u64 run = first; // record index of the batch's first match (uniform)
+        for (u32 b0 = 0; b0 < pend_items; b0 += 64u)
+        {
+            const bool live = b0 + lane < pend_items;
+            const u32 slot = (pend_at + b0 + lane) & (kTinyRing - 1u);
+            const uint2 m = live ? ring_m[slot] : make_uint2(0u, 0u);
+            const u32 id = live ? ring_id[slot] : 0u;
+            const u32 c = (u32)(__popc(m.x) + __popc(m.y));
+            u32 incl = c;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1)
+            {
+                const u32 t = __shfl_up(incl, o);
+                if (lane >= (u32)o)
+                    incl += t;
+            }
+            u64 idx = run + (incl - c);
+            run += __shfl(incl, 63);
+            if (c)
+            {
+                const u64 end0 = tbase + (u64)id * 16u + 1u; // one past the END at position 0 of the lane-cell
+                walk_lane_cell(m.x, m.y, l4, [&](const u32 e, const u32 len) {
+                    if (idx < a.pos_cap)
+                    {
+                        const u64 en = end0 + e, st = en - len;
+                        typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+                        const u32x4 rec = {(u32)st, (u32)(st >> 32), (u32)en, (u32)(en >> 32)};
+                        __builtin_nontemporal_store(rec, reinterpret_cast<u32x4 *>(a.positions + 2 * idx));
+                    }
+                    ++idx;
+                });
+            }
+        }
+        pend = false;
+    };
     u64 acc_total = 0; // chain: wave total (uniform); else this LANE's hits (reduced once, at the end)
     u64 ovf_units = 0; // units of this wave whose matches exceeded the staging slot, and the largest such count (lane 0's copy counts)
     u32 ovf_max = 0;
@@ -102,6 +204,13 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
         uint4 d[kCells]; // the round about to be filtered (or on its way)
         bool have = false;
         u32 carry = 0, carry2 = 0;
+        if (FUSED)
+        {
+            f_at = wp;
+            f_room = kTinyRing - pend_items; // items this ticket may use while the previous one is still parked
+            f_items = 0;
+            lane_cnt = 0;
+        }
         for (u64 unit = u_begin; unit < u_end; ++unit)
         {
             const u64 useg = a.anchor + unit * (u64)kAcUnitBytes;
@@ -249,7 +358,7 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
                             }
                             if (inter)
                             {
-                                if (!kp)
+                                if (!kp && !FUSED)
                                 { // a count: the flags are all that is needed
 #pragma unroll
                                     for (int w = 0; w < 4; ++w) // (v_bcnt_u32_b32 adds its second operand: one instruction per dword)
@@ -278,7 +387,7 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
                                     pm &= clip(a.own_lo + lm1, a.own_hi + lm1);
                                 m16 |= pm;
                                 F[L - 1] = tiny_scramble16(pm);
-                                mycnt += kp ? 0u : (u32)__popc(pm);
+                                mycnt += (kp || FUSED) ? 0u : (u32)__popc(pm);
                             }
                         }
                     };
@@ -286,6 +395,24 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
                     cls(std::integral_constant<int, 2>{}, c2);
                     cls(std::integral_constant<int, 3>{}, c3);
                     cls(std::integral_constant<int, 4>{}, c4);
+                    if constexpr (FUSED)
+                    {
+                        const u32 cx = F[0] | (F[1] << 4), cy = F[2] | (F[3] << 4);
+                        const u32 c = (u32)(__popc(cx) + __popc(cy)); // this lane's matches in the cell
+                        lane_cnt += c;
+                        const u64 bm = __ballot(c != 0u);
+                        if (bm)
+                        {
+                            const u32 idx = f_items + __builtin_amdgcn_mbcnt_hi((u32)(bm >> 32), __builtin_amdgcn_mbcnt_lo((u32)bm, 0u));
+                            if (c && idx < f_room)
+                            {
+                                const u32 slot = (f_at + idx) & (kTinyRing - 1u);
+                                ring_m[slot] = make_uint2(cx, cy);
+                                ring_id[slot] = (u32)(unit - u_begin) * kTinyEntries + (u32)r * (kSegBytes / 16) + (u32)j * kWave + lane;
+                            }
+                            f_items += (u32)__popcll(bm);
+                        }
+                    }
                     if (kp)
                     {
                         if (inter && LINES)
@@ -549,6 +676,30 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
                 }
             }
         }
+        if constexpr (FUSED)
+        {
+            u32 tcnt = lane_cnt; // the ticket's matches
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1)
+                tcnt += __shfl_xor(tcnt, o);
+            if (f_items > f_room)
+                overflowed = true; // too dense for the ring: counted, not recorded — the host takes the staging road
+            // publish the count BEFORE waiting for anything; the ticket drawn next is behind every ticket this wave has parked
+            if (lane == 0)
+                __hip_atomic_store(&a.tk_agg[tk], (u64)tcnt | kTkReady, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (pend)
+                flush(len4);
+            if (f_items && f_items <= f_room)
+            {
+                pend = true;
+                pend_t = tk;
+                pend_at = f_at;
+                pend_items = f_items;
+                wp = (f_at + f_items) & (kTinyRing - 1u);
+            }
+            else
+                pend_items = 0;
+        }
         if (KEEP && !LINES && want_pos && !emit_final && a.stage_cap <= 64u && a.upt <= kAcUnitsPerTicketMax)
         { // the ticket's parked info words and staging slots, in a few stores of consecutive lanes
             const u32 nun = (u32)(u_end - u_begin);
@@ -558,6 +709,14 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
             for (u32 k = lane; k < nun * a.stage_cap; k += 64u)
                 dst[k] = park_slots[(k / a.stage_cap) * 64u + k % a.stage_cap];
         }
+    }
+    if constexpr (FUSED)
+    {
+        if (pend)
+            flush(len4);
+        if (overflowed && lane == 0)
+            atomicAdd(&a.ctr->overflow_units, 1ull);
+        return; // (the resolver's running sum is the total)
     }
     if (!chain)
     { // count only: the lanes' own totals, reduced once
@@ -624,6 +783,26 @@ static hipError_t tiny_launch3(const AcArgs &a, const AcTiny &td, u32 grid, hipS
 bool ac_tiny_keeps(const AcArgs &a)
 {
     return (a.flags & F_LINES) || ((a.flags & F_POS) && (a.emit_mode || a.stage_cap));
+}
+
+// the one-pass record writer: 48 KiB of rings per workgroup, 3 workgroups per CU (registers and LDS alike); one block more than the
+// tickets need is never useful, and at least one scanning wave stands next to the resolver
+template <bool CI>
+static hipError_t tiny_launch_fused2(const AcArgs &a, const AcTiny &td, u32 grid, hipStream_t st)
+{
+    constexpr u32 lds = kTinyWaves * kTinyRing * 3u * (u32)sizeof(u32);
+    if (td.llong) // (a long length beside the short ones: that instantiation spills — such dictionaries keep the staging road, ac_scan)
+        return hipErrorInvalidValue;
+    hipLaunchKernelGGL((ac_tiny_kernel<CI, false, false, false, false, true>), dim3(grid), dim3(kTinyBlock), lds, st, a, td);
+    return hipGetLastError();
+}
+hipError_t ac_tiny_launch_fused(const AcArgs &a, const AcTiny &td, u64 n_tickets, u32 num_cu, hipStream_t st)
+{
+    u32 grid = (u32)std::max<u64>(1, std::min<u64>((n_tickets + kTinyWaves - 1) / kTinyWaves + 1, (u64)num_cu * (u32)KG_TINY_FUSED_WAVES));
+    if (g_s1_force_grid > 0) // test hook: a starved grid (krep_gpu_debug_force_single_grid) — the progress argument of kg_tickets.h
+        grid = std::min<u32>(grid, (u32)g_s1_force_grid);
+    g_tiny_launches.fetch_add(1, std::memory_order_relaxed);
+    return (a.flags & F_CI) ? tiny_launch_fused2<true>(a, td, grid, st) : tiny_launch_fused2<false>(a, td, grid, st);
 }
 
 hipError_t ac_tiny_launch(const AcArgs &a, const AcTiny &td, u64 n_tickets, u32 num_cu, hipStream_t st)

@@ -44,6 +44,7 @@
 #include <cstdlib>
 #include "kg_common.h"
 #include "kg_internal.h"
+#include "kg_tickets.h"
 
 namespace kg {
 
@@ -65,9 +66,7 @@ static_assert(kUptStd >= 1 && kUptStd <= 4, "flush() derives a record's unit fro
 constexpr u32 kRingStd = 1024u * kUptStd;     // 16-bit entries per wave: the ticket being scanned + the one waiting
 constexpr u32 kRingDense = 8192u;             // ... of the two dense shapes (16 KiB per wave: 2 workgroups per CU)
 constexpr u32 kRingDensest = 16384u;          // ... of the densest one (32 KiB per wave: one workgroup per CU)
-constexpr u64 kReady = 1ull << 63;
-constexpr u32 kSpinLimit = 1u << 24;          // ~0.25 us per spin: seconds — only a logic error gets there (see the safety nets)
-constexpr u32 kResolveChunk = 8;              // tickets per resolver lane and pass (512 per pass)
+constexpr u64 kReady = kTkReady;              // (the resolver itself: kg_tickets.h, shared with kg_ac_tiny.hip)
 constexpr u64 kUnitBytes1 = (u64)kRoundsBig * kSegBytes;
 
 __device__ __forceinline__ u32 s_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
@@ -116,76 +115,7 @@ __global__ __launch_bounds__(kBlock, WPE) void single_fused(const LitArgs a, u64
     }
     if (resolver)
     {
-        // Window of 64 x kResolveChunk tickets from `base`; every pass publishes the prefixes of the leading run of ready
-        // tickets and moves the window behind it.  In the steady state the scanners are far ahead and a pass takes the whole
-        // window; what matters is that the prefix of ticket p never waits for a ticket BEHIND p.
-        u64 running = 0, base = 0;
-        u32 spins = 0;
-        while (base < n_tickets)
-        {
-            const u64 mine = base + (u64)lane * kResolveChunk;
-            u64 v[kResolveChunk];
-            u32 lead = 0, nvalid = 0;
-            bool run = true;
-#pragma unroll
-            for (u32 k = 0; k < kResolveChunk; ++k)
-            {
-                const bool valid = mine + k < n_tickets;
-                v[k] = valid ? __hip_atomic_load(&agg[mine + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-                nvalid += valid ? 1u : 0u;
-                run = run && valid && (v[k] & kReady);
-                lead += run ? 1u : 0u;
-            }
-            const u64 open = __ballot(lead != nvalid);                 // lanes whose chunk holds a count that has not arrived
-            const u32 f = open ? (u32)__builtin_ctzll(open) : 64u;     // the first of them: the ready run ends inside its chunk
-            const u32 take = lane < f ? nvalid : (lane == f ? lead : 0u);
-            u64 s = 0;
-#pragma unroll
-            for (u32 k = 0; k < kResolveChunk; ++k)
-                s += k < take ? (v[k] & ~kReady) : 0ull;
-            u64 incl = s;
-            u32 tincl = take;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1)
-            {
-                const u64 up = __shfl_up(incl, o);
-                const u32 tup = __shfl_up(tincl, o);
-                if (lane >= (u32)o)
-                {
-                    incl += up;
-                    tincl += tup;
-                }
-            }
-            u64 e = running + incl - s;
-#pragma unroll
-            for (u32 k = 0; k < kResolveChunk; ++k)
-            {
-                if (k < take)
-                    __hip_atomic_store(&pref[mine + k], e | kReady, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                e += k < take ? (v[k] & ~kReady) : 0ull;
-            }
-            const u32 published = __shfl(tincl, 63);
-            running += __shfl(incl, 63);
-            base += published;
-            if (published)
-                spins = 0;
-            else
-            {
-                if (++spins > kSpinLimit)
-                {
-                    // safety net (never expected): a count that does not arrive within seconds must not hang the device.  Flag the
-                    // scan as failed-over (the host re-runs the two-pass kernels) and release every waiter with a made-up prefix.
-                    if (lane == 0)
-                        atomicAdd(&a.ctr->overflow_units, 1ull);
-                    for (u64 t = base + lane; t < n_tickets; t += 64)
-                        __hip_atomic_store(&pref[t], kReady, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    return;
-                }
-                __builtin_amdgcn_s_sleep(8);
-            }
-        }
-        if (lane == 0)
-            a.ctr->total = running;
+        tk_resolve(agg, pref, n_tickets, a.ctr, lane);
         return;
     }
 
@@ -201,28 +131,11 @@ __global__ __launch_bounds__(kBlock, WPE) void single_fused(const LitArgs a, u64
     bool overflowed = false;
 
     auto flush = [&]() __attribute__((always_inline)) {
-        u64 p = 0;
 #ifdef KG_S1_NOWAIT // (ablation build: records at a made-up index, nobody waits for the resolver)
-        p = pend_t * 1400ull;
+        const u64 first = pend_t * 1400ull;
 #else
-        if (lane == 0)
-        {
-            for (u32 spins = 0;; ++spins)
-            {
-                p = __hip_atomic_load(&pref[pend_t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (p & kReady)
-                    break;
-                if (spins > 2u * kSpinLimit) // safety net, as in the resolver: flag the scan, go on with a made-up prefix
-                {
-                    atomicAdd(&a.ctr->overflow_units, 1ull);
-                    p = kReady;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(4);
-            }
-        }
+        const u64 first = tk_wait_prefix(pref, pend_t, a.ctr, lane);
 #endif
-        const u64 first = s_rfl64(p) & ~kReady;
         const u64 tbase = a.anchor + pend_t * (u64)kUpt * kUnitBytes1 + a.global_base;
         const u32 b1 = pend_c0, b2 = pend_c0 + pend_c1, b3 = pend_c0 + pend_c1 + pend_c2;
         // Lanes are mapped to GLOBAL record indices rounded down to 8 (= one 128-byte line), so every store instruction covers

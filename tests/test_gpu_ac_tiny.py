@@ -231,3 +231,88 @@ def test_one_long_length_beside_short_patterns(gpu, oracle_engine):
             assert out.count == want[0]
             assert np.array_equal(pos[:2 * out.count].cpu().numpy().astype(np.uint64).reshape(-1, 2), want[1]), (pats, rep)
         plan.close()
+
+
+def test_one_pass_records_of_tiny_dictionaries(gpu, oracle_engine, monkeypatch):
+    """Round 5: a tiny dictionary's records in ONE pass (kg_ac_tiny.hip FUSED: matches ranked into an LDS ring per 128-KiB ticket,
+    the tickets' counts resolved into prefixes by one wave, records written at their final index — kg_tickets.h).  Texts of
+    1-6 MiB (the road opens at 1 MiB), the complete list in the reference's order (END ascending, longest first,
+    aho_corasick.c:383-437), -i, max_count, ownership windows with a global base, a text too dense for the rings (counted, not
+    recorded: the staging road takes it — and the plan goes back to one pass on a sparse text), a starved grid of 1-3 workgroups,
+    and the same answers with the road switched off."""
+    import torch
+    rng = np.random.RandomState(31337)
+    n = 6 * (1 << 20) + 1234
+    sparse = cases.rand_text(rng, n, bytes(range(97, 123)) + b"    \n")
+    sparse[rng.randint(0, n - 8, 4000)] = ord("h")
+    dense = cases.rand_text(rng, n, b"hes r\n")
+    nested = np.frombuffer((b"ushers and she said hers " * 40 + b"\n") * (n // 1001), dtype=np.uint8).copy()
+    for text, tag in ((sparse, "sparse"), (nested[: 3 << 20], "nested"), (dense, "dense"), (sparse[: (1 << 20) + 5], "1 MiB")):
+        tn = text.size
+        for pats in ([b"he", b"she", b"hers"], [b"h", b"er", b"s s"], [b"xq", b"zj", b"he"], [b"e", b"he", b"she", b"shes"]):
+            for kw in (dict(), dict(case_sensitive=False), dict(max_count=777)):
+                want = oracle_engine.call(abi.RA_AHO_CORASICK, abi.Params(pats, **kw), text)
+                got = gpu.search(abi.Params(pats, **kw), text)
+                assert got[0] == want[0] and np.array_equal(got[1], want[1]), (tag, pats, kw, got[0], want[0])
+        # device windows with a global base: start-offset ownership, the records of all windows concatenate to the whole list
+        pats = [b"he", b"she", b"hers"]
+        want = oracle_engine.call(abi.RA_AHO_CORASICK, abi.Params(pats), text)
+        d = torch.from_numpy(text).cuda()
+        plan = gpu.plan(abi.Params(pats))
+        cap = int(want[0]) + 16
+        pos = torch.zeros(2 * cap, dtype=torch.int64, device="cuda")
+        cuts = [0, 3, (1 << 20) + 17, (2 << 20) + 1, tn] if tn > (3 << 20) else [0, tn]
+        parts = []
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            out = plan.scan(d.data_ptr(), tn, lo, hi, 1000, pos.data_ptr(), cap)
+            parts.append(pos[: 2 * out.stored].cpu().numpy().astype(np.uint64).reshape(-1, 2) - 1000)
+        allp = np.concatenate(parts)
+        order = np.lexsort((allp[:, 0], allp[:, 1]))  # windows own by START: merge into (end, start) order
+        assert np.array_equal(allp[order], want[1]), (tag, "windows")
+        # one plan: dense (falls back) then sparse (one pass again) — exact each time
+        plan.close()
+        del d, pos
+    plan = gpu.plan(abi.Params([b"he", b"she", b"hers"]))
+    for text in (dense, sparse, dense[: 2 << 20], sparse):
+        want = oracle_engine.call(abi.RA_AHO_CORASICK, abi.Params([b"he", b"she", b"hers"]), text)
+        d = torch.from_numpy(text).cuda()
+        cap = int(want[0]) + 16
+        pos = torch.zeros(2 * cap, dtype=torch.int64, device="cuda")
+        out = plan.scan(d.data_ptr(), text.size, 0, text.size, 0, pos.data_ptr(), cap)
+        assert out.count == want[0] and np.array_equal(pos[: 2 * out.stored].cpu().numpy().astype(np.uint64).reshape(-1, 2), want[1])
+        del d, pos
+    plan.close()
+    # a starved grid: 1, 2, 3 workgroups over ~48 tickets each (no circular wait whatever part of the grid runs)
+    want = oracle_engine.call(abi.RA_AHO_CORASICK, abi.Params([b"he", b"she", b"hers"]), sparse)
+    for blocks in (1, 2, 3):
+        gpu.force_single_grid(blocks)
+        try:
+            got = gpu.search(abi.Params([b"he", b"she", b"hers"]), sparse)
+        finally:
+            gpu.force_single_grid(0)
+        assert got[0] == want[0] and np.array_equal(got[1], want[1]), blocks
+    # and the road switched off gives the same
+    monkeypatch.setenv("KREP_GPU_AC_NO_TINY_FUSED", "1")
+    got = gpu.search(abi.Params([b"he", b"she", b"hers"]), sparse)
+    assert got[0] == want[0] and np.array_equal(got[1], want[1])
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_one_pass_records_random_dictionaries(gpu, oracle_engine, seed):
+    """Random tiny dictionaries (1-4-byte patterns, nested and overlapping ones included) on 2-3 MiB texts over alphabets of 3 to 30
+    symbols: from a match in every lane-cell (the rings overflow, the staging road takes over) down to a handful per ticket — the
+    complete list against the compiled reference each time."""
+    rng = np.random.RandomState(7700 + seed)
+    for it in range(8):
+        alpha = [b"abc", b"abcdefgh \n", bytes(range(97, 123)) + b"   \n", b"abAB -\n"][it % 4]
+        n = (2 << 20) + int(rng.randint(0, 1 << 20))
+        text = cases.rand_text(rng, n, alpha)
+        lens = [[1, 2, 3, 4], [2, 3, 4], [2, 4], [1, 4], [2, 3], [3, 4]][rng.randint(0, 6)]
+        pats = _distinct(rng, text, alpha, lens, int(rng.randint(2, 9)))
+        if len(pats) < 2 or min(len(p) for p in pats) > 2:
+            pats.append(text[5:7].tobytes())  # (a tiny dictionary needs a 1- or 2-byte pattern)
+            pats = list(dict.fromkeys(pats))
+        kw = dict(case_sensitive=bool(rng.rand() < 0.6), max_count=[abi.SIZE_MAX, abi.SIZE_MAX, 5000][rng.randint(0, 3)])
+        want = oracle_engine.call(abi.RA_AHO_CORASICK, abi.Params(pats, **kw), text)
+        got = gpu.search(abi.Params(pats, **kw), text)
+        assert got[0] == want[0] and np.array_equal(got[1], want[1]), (seed, it, pats, kw, got[0], want[0])
