@@ -888,7 +888,9 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
     }
     SCHK(hipSetDevice(t->device));
     // tiny dictionaries run in kg_ac_tiny.hip (same units, staging, info words and post-pass); -w takes the general kernel
-    const bool tiny = t->tiny.ok && !ww;
+    // (4-byte patterns beside a long length — AcTiny::five: only the case-sensitive COUNT runs in the register-compare kernel, every
+    //  other mode of such a dictionary measured faster here)
+    const bool tiny = t->tiny.ok && !ww && (!t->tiny.five || (!want && !lines && !t->ci));
     const u32 waves = tiny ? (u32)kTinyWaves : (u32)kAcWaves;
     const u32 lds = ac_lds_bytes(a.filter_words, lines);
     const u32 per_cu = lds <= 80 * 1024 ? 2u : 1u;

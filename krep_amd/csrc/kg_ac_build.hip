@@ -94,14 +94,39 @@ AcTables *ac_build(const search_params_t &sp, int device)
         // Lengths: 1..4, or 1..3 beside ONE length of 5..8 (`-e a -e Sherlock`), which then takes the place of length 4
         bool ok = !pats.empty() && !t->has_empty && t->lmax <= 8 && t->lmin <= 2 && !getenv("KREP_GPU_AC_NO_TINY");
         const u32 llong = t->lmax > 4 ? t->lmax : 0u;
+        bool five = false; // 4-byte patterns beside the long length: the long ones become a fifth class (AcTiny::five)
+        for (auto &q : pats)
+            five = five || (llong && q.size() == 4);
         for (size_t i = 0; ok && i < pats.size(); ++i)
         {
             for (size_t k = 0; k < i; ++k)
                 if (pats[k] == pats[i])
                     ok = false; // a duplicate reports twice (aho_corasick.c:383-437): the masks cannot count copies
             const size_t L = pats[i].size();
-            if (llong && L >= 4 && L != llong)
-                ok = false; // a second length beyond 3 bytes
+            if (llong && L > 4 && L != llong)
+                ok = false; // a second length beyond 4 bytes
+            if (five && L > 4)
+            {
+                if (!ok || td.n5 >= kTinyPer)
+                {
+                    ok = false;
+                    break;
+                }
+                const u32 p = td.n5++;
+                for (size_t s = 0; s < 4; ++s) // its LAST four bytes
+                {
+                    const uint8_t c = pats[i][L - 1 - s];
+                    td.pk5[p] |= (u32)c << (8 * s);
+                    td.lf5[p] |= (t->ci && c >= 'a' && c <= 'z') ? 1u << s : 0u;
+                }
+                for (size_t s = 0; s < L - 4; ++s) // ... and its first L - 4, byte s = s places before the end of that part
+                {
+                    const uint8_t c = pats[i][L - 5 - s];
+                    td.pk2[p] |= (u32)c << (8 * s);
+                    td.lf2[p] |= (t->ci && c >= 'a' && c <= 'z') ? 1u << s : 0u;
+                }
+                continue;
+            }
             const size_t cls = L > 4 ? 4 : L; // the class a pattern is compared and reported in
             if (!ok || td.n[cls - 1] >= kTinyPer)
             {
@@ -123,6 +148,7 @@ AcTables *ac_build(const search_params_t &sp, int device)
             }
         }
         td.llong = ok ? llong : 0u;
+        td.five = (ok && five) ? 1u : 0u;
         td.lmax = t->lmax;
         for (int L = 0; L < 4; ++L)
             td.ncls += td.n[L] ? 1u : 0u;

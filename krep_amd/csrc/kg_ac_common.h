@@ -71,6 +71,11 @@ struct AcTiny
     // those patterns and pk2 / lf2 their first llong - 4 bytes (byte s = s places before the end of that part)
     u32 llong;
     u32 pk2[kTinyPer], lf2[kTinyPer];
+    // five: 4-byte patterns AND a long length (`-e if -e else -e while`, round 5): the long patterns are a FIFTH class — pk5 / lf5
+    // their last four bytes, pk2 / lf2 their first llong - 4 — which only the counting and the one-pass (FUSED) instantiations
+    // know; every other mode of such a dictionary runs in the general kernel (ac_scan)
+    u32 five, n5;
+    u32 pk5[kTinyPer], lf5[kTinyPer];
 };
 hipError_t ac_tiny_launch(const AcArgs &a, const AcTiny &td, u64 n_tickets, u32 num_cu, hipStream_t st); // sizes its own grid
 hipError_t ac_tiny_launch_fused(const AcArgs &a, const AcTiny &td, u64 n_tickets, u32 num_cu, hipStream_t st); // one-pass records

@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <atomic>
 #include <type_traits>
+#include <utility>
 
 #include "kg_ac_common.h"
 #include "kg_internal.h"
@@ -38,7 +39,10 @@ extern int g_s1_force_grid; // (kg_single.hip)
 #ifndef KG_TINY_FUSED_WAVES
 #define KG_TINY_FUSED_WAVES 3
 #endif
-#define KG_TINY_KEEP_WAVES_ARG ((KEEP && !EMIT) ? KG_TINY_KEEP_WAVES : (FUSED ? KG_TINY_FUSED_WAVES : 3))
+#ifndef KG_TINY_FIVE_WAVES
+#define KG_TINY_FIVE_WAVES 2 // (a fifth class: under the 168 registers of 3 waves per SIMD those instantiations spill 144-176 bytes per lane)
+#endif
+#define KG_TINY_KEEP_WAVES_ARG ((KEEP && !EMIT) ? KG_TINY_KEEP_WAVES : (FIVE ? KG_TINY_FIVE_WAVES : (FUSED ? KG_TINY_FUSED_WAVES : 3)))
 // FUSED (round 5): records in ONE pass and nothing else — no masks kept per unit, no staging slot, no info word, no post-pass.
 // A lane-cell that holds a match leaves ONE item in the wave's LDS ring — its two length words and its index in the ticket,
 // 12 bytes, ranked by a single ballot; the matches themselves are only counted (a per-lane sum, reduced once per ticket).  The
@@ -52,6 +56,11 @@ extern int g_s1_force_grid; // (kg_single.hip)
 constexpr int kTinyBlock = kTinyWaves * 64;
 constexpr u32 kTinyEntries = kAcUnitBytes / 16; // lane-cells of a unit (1024)
 
+template <int... J, typename F>
+__device__ __forceinline__ void tiny_static_for(std::integer_sequence<int, J...>, F &&f)
+{
+    (f(std::integral_constant<int, J>{}), ...);
+}
 __device__ __forceinline__ u32 tiny_scramble16(u32 m) // position-ordered 16 bits -> bit 8 b + w for position 4 w + b
 {
     u32 f = 0;
@@ -66,12 +75,16 @@ __device__ __forceinline__ u32 tiny_scramble16(u32 m) // position-ordered 16 bit
 // because its record walk holds a unit's 32 length words in registers — in the streaming launch those registers spilled, and a
 // scratch reload waits in the same in-order vmcnt queue as the prefetched text: the pipeline drained once per unit)
 // LONG: the dictionary holds a long length (AcTiny::llong) — its own instantiations, so that the others carry none of its code
-template <bool CI, bool LINES, bool KEEP, bool EMIT, bool LONG, bool FUSED = false>
+// FIVE: 4-byte patterns AND a long length (AcTiny::five): the long patterns are a fifth class.  Shipped for case-sensitive
+// COUNTING only (168 VGPRs, 3 waves per SIMD: `if else while` 3.4 -> 4.2 TB/s); its one-pass and -i instantiations compile but
+// measured slower than the general kernel at the 2 waves per SIMD they need, and are not dispatched
+template <bool CI, bool LINES, bool KEEP, bool EMIT, bool LONG, bool FUSED = false, bool FIVE = false>
 __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_kernel(const AcArgs a, const AcTiny td)
 {
     extern __shared__ __attribute__((aligned(16))) u32 s_tiny[];
     const u32 lane = ac_lane(), wave = threadIdx.x >> 6;
     static_assert(!FUSED || (!LINES && !KEEP && !EMIT), "the one-pass record writer is its own mode");
+    static_assert(!FIVE || (!LINES && !KEEP && !EMIT && !LONG), "a fifth class: counting and one-pass records only");
     if constexpr (FUSED)
     {
         // the resolver: whichever wave 0 of a block gets here first (a wave that runs, whatever part of the grid is resident)
@@ -114,9 +127,9 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
     u32 lane_cnt = 0;                        // ... and this LANE's matches in it (summed over the wave when the ticket ends)
     // the matches of one lane-cell from its two length words, in the reference's order — END ascending, longest first
     // (aho_corasick.c:383-437): put(position e of the END inside the lane's 16 bytes, length)
-    auto walk_lane_cell = [&](const u32 cx, const u32 cy, const u32 l4, auto put) __attribute__((always_inline)) {
+    auto walk_lane_cell = [&](const u32 cx, const u32 cy, const u32 cz, const u32 l4, const u32 l5, auto put) __attribute__((always_inline)) {
         // ENDs of the lane-cell in position order: bit 8 b + w of the any-length word is position 4 w + b
-        const u32 hs = (cx | (cx >> 4) | cy | (cy >> 4)) & 0x0f0f0f0fu;
+        const u32 hs = (cx | (cx >> 4) | cy | (cy >> 4) | cz) & 0x0f0f0f0fu;
         u32 h = 0;
 #pragma unroll
         for (int b = 0; b < 4; ++b)
@@ -129,13 +142,14 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
             const u32 e = (u32)__builtin_ctz(h);
             h &= h - 1u;
             const u32 bit = 8u * (e & 3u) + (e >> 2);
+            if (FIVE && ((cz >> bit) & 1u)) put(e, l5);
             if ((cy >> (bit + 4u)) & 1u) put(e, l4);
             if ((cy >> bit) & 1u) put(e, 3u);
             if ((cx >> (bit + 4u)) & 1u) put(e, 2u);
             if ((cx >> bit) & 1u) put(e, 1u);
         }
     };
-    auto flush = [&](const u32 l4) __attribute__((always_inline)) {
+    auto flush = [&](const u32 l4, const u32 l5) __attribute__((always_inline)) {
         const u64 first = tk_wait_prefix(a.tk_pref, pend_t, a.ctr, lane);
         const u64 tbase = a.anchor + pend_t * (u64)a.upt * kAcUnitBytes + a.global_base;
         u64 run = first; // record index of the batch's first match (uniform)
@@ -144,8 +158,11 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
             const bool live = b0 + lane < pend_items;
             const u32 slot = (pend_at + b0 + lane) & (kTinyRing - 1u);
             const uint2 m = live ? ring_m[slot] : make_uint2(0u, 0u);
-            const u32 id = live ? ring_id[slot] : 0u;
-            const u32 c = (u32)(__popc(m.x) + __popc(m.y));
+            const u32 w3 = live ? ring_id[slot] : 0u;
+            // (FIVE: the third word holds the fifth class's length word in the low nibbles and the index in the high ones)
+            const u32 cz = FIVE ? (w3 & 0x0f0f0f0fu) : 0u;
+            const u32 id = FIVE ? (((w3 >> 4) & 0xfu) | ((w3 >> 8) & 0xf0u) | ((w3 >> 12) & 0xf00u) | ((w3 >> 16) & 0xf000u)) : w3;
+            const u32 c = (u32)(__popc(m.x) + __popc(m.y) + __popc(cz));
             u32 incl = c;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1)
@@ -159,7 +176,7 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
             if (c)
             {
                 const u64 end0 = tbase + (u64)id * 16u + 1u; // one past the END at position 0 of the lane-cell
-                walk_lane_cell(m.x, m.y, l4, [&](const u32 e, const u32 len) {
+                walk_lane_cell(m.x, m.y, cz, l4, l5, [&](const u32 e, const u32 len) {
                     if (idx < a.pos_cap)
                     {
                         const u64 en = end0 + e, st = en - len;
@@ -180,8 +197,9 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
     static_assert(!EMIT || (KEEP && !LINES), "emit mode writes records");
     u32 k7f;
     asm volatile("v_mov_b32 %0, 0x7f7f7f7f" : "=v"(k7f)); // (a vector register on purpose: see the splats in the cell)
-    const u32 lmax = __builtin_amdgcn_readfirstlane(td.lmax), llong = LONG ? __builtin_amdgcn_readfirstlane(td.llong) : 0u;
-    const u32 len4 = llong ? llong : 4u; // the length behind class 4 (a LONG class of 5..8 bytes takes its place: AcTiny)
+    const u32 lmax = __builtin_amdgcn_readfirstlane(td.lmax), llong = (LONG || FIVE) ? __builtin_amdgcn_readfirstlane(td.llong) : 0u;
+    const u32 len4 = (LONG && llong) ? llong : 4u; // the length behind class 4 (a LONG class of 5..8 bytes takes its place: AcTiny)
+    const u32 n5 = FIVE ? __builtin_amdgcn_readfirstlane(td.n5) : 0u;
     const u32 n1 = __builtin_amdgcn_readfirstlane(td.n[0]), n2 = __builtin_amdgcn_readfirstlane(td.n[1]),
               n3 = __builtin_amdgcn_readfirstlane(td.n[2]), n4 = __builtin_amdgcn_readfirstlane(td.n[3]);
 
@@ -240,8 +258,11 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
                     // v_readlane before every branch; as fresh scalars each is one s_cmp in front of its branch.
                     u32 c1 = n1, c2 = n2, c3 = n3, c4 = n4, lmx = lmax, ll = llong;
                     asm volatile("" : "+s"(c1), "+s"(c2), "+s"(c3), "+s"(c4), "+s"(lmx));
-                    if (LONG)
+                    u32 c5 = n5;
+                    if (LONG || FIVE)
                         asm volatile("" : "+s"(ll));
+                    if (FIVE)
+                        asm volatile("" : "+s"(c5));
                     u32 NL = 0;
                     if (LINES)
                     {
@@ -276,7 +297,7 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
                     // a LONG pattern (5..8 bytes) = its last four bytes ending here AND its first ll - 4 bytes ending one dword
                     // earlier: the same shifted copies one dword to the left, whose first dword comes from the 8 bytes in front
                     u32 XP[4] = {P, 0u, 0u, 0u};
-                    if (LONG && ll)
+                    if ((LONG || FIVE) && ll)
                     {
                         XP[1] = __builtin_amdgcn_alignbyte(P, P2, 3u);
                         XP[2] = __builtin_amdgcn_alignbyte(P, P2, 2u);
@@ -295,9 +316,12 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
                     // ---- per length: 0x80 in every byte at which a pattern of that length ENDS.  One pattern = one scalar
                     //      register (its bytes, last one lowest) + under -i one of letter flags; splats on the scalar unit.
                     u32 HA[4] = {0u, 0u, 0u, 0u}, F[4] = {0u, 0u, 0u, 0u}; // any length, per dword | scrambled mask per length
+                    u32 F5 = 0u;                                           // ... of the fifth class (FIVE)
                     u32 m16 = 0;                                           // END mask in position order
-                    auto one = [&](auto Lc, u32 (&Z)[4], const bool first, const u32 pk, const u32 lf, const u32 pk2, const u32 lf2) __attribute__((always_inline)) {
+                    auto one = [&](auto Lc, u32 (&Z)[4], const bool first, const u32 pk, const u32 lf, const u32 pk2, const u32 lf2,
+                                   auto longc) __attribute__((always_inline)) {
                         constexpr int L = decltype(Lc)::value;
+                        constexpr bool kLongCls = decltype(longc)::value; // the fifth class: a long pattern's last four bytes
                         // the splats are made on the scalar unit and MOVED to vector registers: v_bitop3_b32 / v_and / v_xor with
                         // vector operands only issue every ~2.2 cycles, with a scalar operand every ~3.7 (profiles/r04_valu_issue_rates.txt)
                         u32 c[L], m[L];
@@ -317,7 +341,7 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
 #pragma unroll
                             for (int s = 0; s < L; ++s) // s bytes before the end: pattern byte L - 1 - s
                                 V |= (CI ? (X[s][w] | m[s]) : X[s][w]) ^ c[s];
-                            if (LONG && L == 4 && ll) // (uniform) the long pattern's first ll - 4 bytes, one dword earlier
+                            if (((LONG && L == 4) || kLongCls) && ll) // (uniform) the long pattern's first ll - 4 bytes, one dword earlier
                             {
                                 auto xa = [&](const int sa) -> u32 { return w ? X[sa][w ? w - 1 : 0] : XP[sa]; };
                                 auto term = [&](const int sa) -> u32 {
@@ -345,15 +369,15 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
                         if (n) // (uniform, like the three below)
                         {
                             u32 Z[4];
-                            one(Lc, Z, true, td.pk[L - 1][0], td.lf[L - 1][0], td.pk2[0], td.lf2[0]);
+                            one(Lc, Z, true, td.pk[L - 1][0], td.lf[L - 1][0], td.pk2[0], td.lf2[0], std::false_type{});
                             if (n > 1)
                             {
-                                one(Lc, Z, false, td.pk[L - 1][1], td.lf[L - 1][1], td.pk2[1], td.lf2[1]);
+                                one(Lc, Z, false, td.pk[L - 1][1], td.lf[L - 1][1], td.pk2[1], td.lf2[1], std::false_type{});
                                 if (n > 2)
                                 {
-                                    one(Lc, Z, false, td.pk[L - 1][2], td.lf[L - 1][2], td.pk2[2], td.lf2[2]);
+                                    one(Lc, Z, false, td.pk[L - 1][2], td.lf[L - 1][2], td.pk2[2], td.lf2[2], std::false_type{});
                                     if (n > 3)
-                                        one(Lc, Z, false, td.pk[L - 1][3], td.lf[L - 1][3], td.pk2[3], td.lf2[3]);
+                                        one(Lc, Z, false, td.pk[L - 1][3], td.lf[L - 1][3], td.pk2[3], td.lf2[3], std::false_type{});
                                 }
                             }
                             if (inter)
@@ -395,10 +419,51 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
                     cls(std::integral_constant<int, 2>{}, c2);
                     cls(std::integral_constant<int, 3>{}, c3);
                     cls(std::integral_constant<int, 4>{}, c4);
+                    if constexpr (FIVE)
+                    {
+                        if (c5 && ll) // (uniform) the long patterns: last four bytes ending here, the first ll - 4 one dword earlier
+                        {
+                            u32 Z[4];
+                            const std::integral_constant<int, 4> L4{};
+                            one(L4, Z, true, td.pk5[0], td.lf5[0], td.pk2[0], td.lf2[0], std::true_type{});
+                            if (c5 > 1)
+                            {
+                                one(L4, Z, false, td.pk5[1], td.lf5[1], td.pk2[1], td.lf2[1], std::true_type{});
+                                if (c5 > 2)
+                                {
+                                    one(L4, Z, false, td.pk5[2], td.lf5[2], td.pk2[2], td.lf2[2], std::true_type{});
+                                    if (c5 > 3)
+                                        one(L4, Z, false, td.pk5[3], td.lf5[3], td.pk2[3], td.lf2[3], std::true_type{});
+                                }
+                            }
+                            if (inter)
+                            {
+                                if (!FUSED)
+                                {
+#pragma unroll
+                                    for (int w = 0; w < 4; ++w)
+                                        asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(mycnt) : "v"(Z[w]));
+                                }
+                                else
+                                    F5 = (Z[0] >> 7) | (Z[1] >> 6) | (Z[2] >> 5) | (Z[3] >> 4);
+                            }
+                            else
+                            {
+                                u32 pm = 0;
+#pragma unroll
+                                for (int w = 0; w < 4; ++w)
+                                    pm |= ac_movemask4(Z[w]) << (4 * w);
+                                const u64 lm1 = (u64)ll - 1ull;
+                                pm &= clip(a.end_lo, a.end_hi) & clip(lm1, ~0ull) & clip(a.own_lo + lm1, a.own_hi + lm1);
+                                F5 = tiny_scramble16(pm);
+                                mycnt += FUSED ? 0u : (u32)__popc(pm);
+                            }
+                        }
+                    }
                     if constexpr (FUSED)
                     {
                         const u32 cx = F[0] | (F[1] << 4), cy = F[2] | (F[3] << 4);
-                        const u32 c = (u32)(__popc(cx) + __popc(cy)); // this lane's matches in the cell
+                        const u32 c = (u32)(__popc(cx) + __popc(cy) + __popc(F5)); // this lane's matches in the cell
                         lane_cnt += c;
                         const u64 bm = __ballot(c != 0u);
                         if (bm)
@@ -408,7 +473,9 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
                             {
                                 const u32 slot = (f_at + idx) & (kTinyRing - 1u);
                                 ring_m[slot] = make_uint2(cx, cy);
-                                ring_id[slot] = (u32)(unit - u_begin) * kTinyEntries + (u32)r * (kSegBytes / 16) + (u32)j * kWave + lane;
+                                const u32 id = (u32)(unit - u_begin) * kTinyEntries + (u32)r * (kSegBytes / 16) + (u32)j * kWave + lane;
+                                // (FIVE: the fifth length word sits in the low nibbles, the 13-bit index goes into the high ones)
+                                ring_id[slot] = FIVE ? (F5 | ((id & 0xfu) << 4) | ((id & 0xf0u) << 8) | ((id & 0xf00u) << 12) | ((id & 0xf000u) << 16)) : id;
                             }
                             f_items += (u32)__popcll(bm);
                         }
@@ -456,7 +523,7 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
                     {
                         if (seg >= 4)
                             before = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const u32 *>(a.text + seg - 4));
-                        if (LONG && llong && seg >= 8)
+                        if ((LONG || FIVE) && llong && seg >= 8)
                             before2 = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const u32 *>(a.text + seg - 8));
 #pragma unroll
                         for (int j = 0; j < kCells; ++j)
@@ -465,20 +532,30 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
                     const bool pf_next = !emit_final && seg + 2 * (u64)kSegBytes <= a.text_len && (r + 1 < kAcRounds || unit + 1 < u_end);
                     const uint4 *nsrc = pf_next ? src + kSegBytes / 16 : reinterpret_cast<const uint4 *>(a.text + seg); // (none: one cached line)
                     auto cells = [&](auto interC) __attribute__((always_inline)) {
-#pragma unroll
-                        for (int j = 0; j < kCells; ++j)
-                        {
+                        auto one_cell = [&](const int j) __attribute__((always_inline)) {
                             const u32 D[4] = {d[j].x, d[j].y, d[j].z, d[j].w};
                             d[j] = ntload(nsrc + j * kWave);
                             const u32 P = (u32)__builtin_amdgcn_update_dpp((int)before, (int)D[3], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
                             before = __builtin_amdgcn_readlane(D[3], 63);
                             u32 P2 = 0;
-                            if (LONG && llong) // (uniform: only a long pattern looks eight bytes back)
+                            if ((LONG || FIVE) && llong) // (uniform: only a long pattern looks eight bytes back)
                             {
                                 P2 = (u32)__builtin_amdgcn_update_dpp((int)before2, (int)D[2], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
                                 before2 = __builtin_amdgcn_readlane(D[2], 63);
                             }
                             cell(interC, j, D, P, P2);
+                        };
+                        if constexpr (FIVE)
+                        {
+                            // unrolled by construction: with a fifth class the body outgrows the unroller's budget, `#pragma unroll`
+                            // is dropped, d[j] is indexed at run time and the round's 128 bytes live in scratch (144 B/lane, 2.3 TB/s)
+                            tiny_static_for(std::make_integer_sequence<int, kCells>{}, [&](auto jc) __attribute__((always_inline)) { one_cell(decltype(jc)::value); });
+                        }
+                        else
+                        {
+#pragma unroll
+                            for (int j = 0; j < kCells; ++j)
+                                one_cell(j);
                         }
                     };
                     if (interior) // two copies of the round: the window clipping of a boundary round costs the interior ones nothing
@@ -688,7 +765,7 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
             if (lane == 0)
                 __hip_atomic_store(&a.tk_agg[tk], (u64)tcnt | kTkReady, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (pend)
-                flush(len4);
+                flush(len4, llong);
             if (f_items && f_items <= f_room)
             {
                 pend = true;
@@ -713,7 +790,7 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
     if constexpr (FUSED)
     {
         if (pend)
-            flush(len4);
+            flush(len4, llong);
         if (overflowed && lane == 0)
             atomicAdd(&a.ctr->overflow_units, 1ull);
         return; // (the resolver's running sum is the total)
@@ -791,9 +868,12 @@ template <bool CI>
 static hipError_t tiny_launch_fused2(const AcArgs &a, const AcTiny &td, u32 grid, hipStream_t st)
 {
     constexpr u32 lds = kTinyWaves * kTinyRing * 3u * (u32)sizeof(u32);
-    if (td.llong) // (a long length beside the short ones: that instantiation spills — such dictionaries keep the staging road, ac_scan)
+    // (a fifth class — 4-byte patterns beside a long length — needs 211-217 VGPRs here: at 2 waves per SIMD it measured SLOWER than the
+    //  general kernel, `if else while` 2.8 against 3.3 TB/s with offsets; ac_scan does not send such dictionaries this way)
+    if (td.five || td.llong) // (a long length in the place of class 4: that instantiation spills — such dictionaries keep the staging road, ac_scan)
         return hipErrorInvalidValue;
-    hipLaunchKernelGGL((ac_tiny_kernel<CI, false, false, false, false, true>), dim3(grid), dim3(kTinyBlock), lds, st, a, td);
+    else
+        hipLaunchKernelGGL((ac_tiny_kernel<CI, false, false, false, false, true>), dim3(grid), dim3(kTinyBlock), lds, st, a, td);
     return hipGetLastError();
 }
 hipError_t ac_tiny_launch_fused(const AcArgs &a, const AcTiny &td, u64 n_tickets, u32 num_cu, hipStream_t st)
@@ -811,6 +891,13 @@ hipError_t ac_tiny_launch(const AcArgs &a, const AcTiny &td, u64 n_tickets, u32 
     const bool ci = a.flags & F_CI, ln = a.flags & F_LINES, keep = ac_tiny_keeps(a);
     g_tiny_launches.fetch_add(1, std::memory_order_relaxed);
     const bool emit = a.emit_mode != 0;
+    if (td.five) // a fifth class: only the counting instantiation knows it (ac_scan sends every other mode of such a dictionary elsewhere)
+    {
+        if (ln || emit || keep || ci) // (-i: 173 VGPRs = 2 waves per SIMD, 3.0 TB/s against the general kernel's 3.4 — not sent here)
+            return hipErrorInvalidValue;
+        hipLaunchKernelGGL((ac_tiny_kernel<false, false, false, false, false, false, true>), dim3(grid), dim3(kTinyBlock), 0, st, a, td);
+        return hipGetLastError();
+    }
     if (ln) return ci ? tiny_launch3<true, true, true, false>(a, td, grid, st) : tiny_launch3<false, true, true, false>(a, td, grid, st);
     if (emit) return ci ? tiny_launch3<true, false, true, true>(a, td, grid, st) : tiny_launch3<false, false, true, true>(a, td, grid, st);
     if (keep) return ci ? tiny_launch3<true, false, true, false>(a, td, grid, st) : tiny_launch3<false, false, true, false>(a, td, grid, st);

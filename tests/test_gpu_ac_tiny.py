@@ -316,3 +316,43 @@ def test_one_pass_records_random_dictionaries(gpu, oracle_engine, seed):
         want = oracle_engine.call(abi.RA_AHO_CORASICK, abi.Params(pats, **kw), text)
         got = gpu.search(abi.Params(pats, **kw), text)
         assert got[0] == want[0] and np.array_equal(got[1], want[1]), (seed, it, pats, kw, got[0], want[0])
+
+
+def test_four_byte_patterns_beside_a_long_length(gpu, oracle_engine, monkeypatch):
+    """Round 5: `-e if -e else -e while` — a 2-byte pattern, 4-byte patterns AND one longer length: the long
+    patterns are a FIFTH class of the register-compare kernel, used for the case-sensitive count (every other mode of such a
+    dictionary runs in the general kernel, which measured faster for them).  Counting, the complete list (END ascending, longest first — `else`
+    inside `elsewhile`, `he` / `here` / `where` ending together), -i, max_count, -c, -w, small and large texts, windows."""
+    import torch
+    rng = np.random.RandomState(1234)
+    n = 3 * (1 << 20) + 99
+    text = cases.rand_text(rng, n, b"ehilsw ;\n")
+    words = np.frombuffer(b"if else while elsewhile where here he ifelse", dtype=np.uint8)
+    for s0 in rng.randint(0, n - 64, 3000):
+        text[s0:s0 + words.size] = words
+    for pats in ([b"if", b"else", b"while"], [b"he", b"here", b"where", b"e"], [b"se", b"else", b"elsew", b"while", b"ilsew"],
+                 [b"e", b"hile", b"elsewhil", b"sewhilee"]):
+        for kw in (dict(), dict(case_sensitive=False), dict(max_count=1000), dict(count_lines=True, only_match=True),
+                   dict(count_lines=True), dict(whole_word=True)):
+            for t in (text, text[:70000], text[: (1 << 20) + 3]):
+                want = oracle_engine.call(abi.RA_AHO_CORASICK, abi.Params(pats, **kw), t)
+                got = gpu.search(abi.Params(pats, **kw), t)
+                assert got[0] == want[0] and np.array_equal(got[1], want[1]), (pats, kw, t.size, got[0], want[0])
+        # the register-compare kernel really took the (case-sensitive) count; the list stays in the general kernel (measured faster)
+        before = gpu.tiny_launches()
+        gpu.search(abi.Params(pats, count_lines=True, only_match=True), text, want_result=False)
+        assert gpu.tiny_launches() >= before + 1, pats
+        d = torch.from_numpy(text).cuda()
+        want = oracle_engine.call(abi.RA_AHO_CORASICK, abi.Params(pats), text)
+        plan = gpu.plan(abi.Params(pats))
+        cap = int(want[0]) + 16
+        pos = torch.zeros(2 * cap, dtype=torch.int64, device="cuda")
+        parts = []
+        for lo, hi in ((0, 5), (5, (1 << 20) + 1), ((1 << 20) + 1, n)):
+            out = plan.scan(d.data_ptr(), n, lo, hi, 0, pos.data_ptr(), cap)
+            parts.append(pos[: 2 * out.stored].cpu().numpy().astype(np.uint64).reshape(-1, 2))
+        allp = np.concatenate(parts)
+        order = np.lexsort((allp[:, 0], allp[:, 1]))
+        assert np.array_equal(allp[order], want[1]), (pats, "windows")
+        plan.close()
+        del d, pos
