@@ -116,7 +116,11 @@ __device__ __noinline__ W6 load_window_guarded(const uint8_t *text, u64 text_len
     return r;
 }
 
-// KIND: 1 -> m == 1 (SWAR), 4 -> 2..4 bytes (one word), 8 -> 5..8 bytes (two words), 9 -> m > 8 (filter+verify)
+// KIND: 1 -> m == 1 (SWAR), 4 -> 2..4 bytes (one word), 8 -> 5..8 bytes (two words), 9 -> m > 8 (filter+verify),
+//       10 -> m > 16 without -c (round 5): the same 8-byte filter, but the tail of every candidate of a UNIT is verified at the
+//       unit's end, one candidate per lane — one memory round trip per 32-KiB unit where KIND 9 pays one in every cell that
+//       holds a candidate (a verify load waits behind the round's stream loads in the in-order queue): m = 128 0.69 -> see
+//       profiles/r05_literal_sweep_32gib.txt
 // MASKED: the last compared word is partial (m = 2,3 or 5,6,7), so its compare needs the byte mask.
 // R: load rounds per UNIT.  A wave scans one contiguous R x 8 KiB unit at a time (statically dealt, see below), keeps the
 // R x 8 per-lane hit masks in registers and publishes the unit's aggregate + staged hits; no wave waits for another.
@@ -152,6 +156,9 @@ __global__ __launch_bounds__(kBlock, (KIND == 1 && LINES && R == 4) ? KG_LIT1_LI
                       (a.stage_cap & 7u) == 0u && (a.upt == 0u || a.upt >= 4u) && a.num_tiles < (1ull << 29);
     // units the pool holds: whole tickets only (s_tk maps a parked unit to its ticket)
     const u32 park_max = park ? (a.upt ? (kPark * 16u / a.stage_cap) / a.upt * a.upt : kPark * 16u / a.stage_cap) : kPark;
+    // KIND 10: the unit's candidate lane-cells, {lane-cell of the unit (11 bits) | its 16-bit candidate mask << 16}, in position order
+    constexpr u32 kCandCap = KIND == 10 ? 256u : 1u;
+    __shared__ u32 s_cand[kWavesPerBlk][kCandCap];
     u32 n_park = 0;     // parked units (uniform); they are the units of the wave's last tickets, a.upt consecutive ones each
     __shared__ u32 s_tk[kWavesPerBlk][kPark / 4u]; // first unit of each parked ticket (4 or 8 units each)
     u64 park_first = 0;                            // static deal: the first parked unit, the others follow at the wave's stride
@@ -232,6 +239,120 @@ __global__ __launch_bounds__(kBlock, (KIND == 1 && LINES && R == 4) ? KG_LIT1_LI
         constexpr bool kInline = KIND != 1;
         u32 M[kInline ? 1 : R][kInline ? 1 : kCells];
         u32 wcnt = 0;     // unit total (uniform)
+        u32 n_cand = 0;   // KIND 10: parked candidate lane-cells of the unit (uniform)
+        // KIND 10: verify the parked candidates, 64 lane-cells at a time, ONE candidate per lane and iteration (a lane-cell with two
+        // candidates — a pattern that overlaps itself within 16 bytes — takes a second iteration), every lane's loads in flight
+        // together; the survivors are ranked behind the unit's hits so far and staged (or, in emit mode, written out) in order
+        auto verify_parked = [&]() __attribute__((always_inline)) {
+            struct __attribute__((packed)) U64p { unsigned long long v; };
+            typedef const __attribute__((address_space(4))) unsigned long long cu64;
+            cu64 *pc = (cu64 *)(size_t)a.pat_chunks;
+            const u32 last = a.n_chunks - 1u;
+            for (u32 b0 = 0; b0 < n_cand; b0 += 64u)
+            {
+                const bool live = b0 + lane < n_cand;
+                const u32 it = live ? s_cand[wave][b0 + lane] : 0u;
+                const u32 rel0 = (it & 0xffffu) * 16u; // unit-relative offset of the lane-cell's first byte
+                u32 rest = it >> 16, okm = 0;
+                while (__ballot(rest != 0u))
+                {
+                    const bool act = rest != 0u;
+                    const u32 k = act ? (u32)__builtin_ctz(rest) : 0u;
+                    rest &= rest - 1u;
+                    const u64 p = ubase + rel0 + k;
+                    bool ok = act;
+                    if (act)
+                    {
+                        u32 cL = 0, cR = 0;
+                        if (ww)
+                        {
+                            if (p > 0)
+                                cL = a.text[p - 1];
+                            if (p + a.m < a.text_len)
+                                cR = a.text[p + a.m];
+                        }
+                        const unsigned char *tp = a.text + p;
+                        unsigned long long diff = 0;
+                        // bytes 8..m-1 in independent 8-byte chunks, sixteen loads in flight, the last chunk re-anchored at m - 8
+                        // (inside the match, hence inside the text); pattern words and -i letter masks as scalar loads
+                        auto group = [&](auto width_c, u32 g0) {
+                            constexpr u32 W = decltype(width_c)::value;
+                            unsigned long long t[W];
+#pragma unroll
+                            for (u32 i = 0; i < W; ++i)
+                            {
+                                const u32 kk = g0 + i < last ? g0 + i : last;
+                                const u32 q = 8u + 8u * kk < a.m - 8u ? 8u + 8u * kk : a.m - 8u;
+                                t[i] = reinterpret_cast<const U64p *>(tp + q)->v;
+                            }
+#pragma unroll
+                            for (u32 i = 0; i < W; ++i)
+                            {
+                                const u32 kk = g0 + i < last ? g0 + i : last;
+                                const unsigned long long x = CI ? (t[i] | pc[a.n_chunks + kk]) : t[i];
+                                diff |= x ^ pc[kk];
+                            }
+                        };
+                        if (a.n_chunks <= 4u) // m <= 40
+                            group(std::integral_constant<u32, 4>{}, 0u);
+                        else if (a.n_chunks <= 8u) // m <= 72
+                            group(std::integral_constant<u32, 8>{}, 0u);
+                        else
+                            for (u32 g0 = 0; g0 < a.n_chunks; g0 += 16u)
+                                group(std::integral_constant<u32, 16>{}, g0);
+                        ok = diff == 0;
+                        if (ok && ww)
+                        {
+                            if (p > 0 && p != a.ww_exempt_left && is_wordc(cL))
+                                ok = false;
+                            else if (p + a.m < a.text_len && is_wordc(cR))
+                                ok = false;
+                        }
+                    }
+                    okm |= ok ? (1u << k) : 0u;
+                }
+                // rank the survivors (a lane holds at most 16) and write them out in position order
+                const u32 c = __popc(okm);
+                if (__ballot(c != 0u))
+                {
+                    const u32 idx0 = wcnt + wave_excl5(c);
+                    wcnt += wave_sum5(c);
+                    if (want_pos)
+                    {
+                        u32 idx = idx0, bits = okm;
+                        if (!a.emit_mode)
+                        {
+                            unsigned short *slot = reinterpret_cast<unsigned short *>(a.stage) + unit * (u64)a.stage_cap;
+                            while (bits)
+                            {
+                                const u32 k = __builtin_ctz(bits);
+                                bits &= bits - 1u;
+                                if (idx < a.stage_cap)
+                                    slot[idx] = (unsigned short)(rel0 + k);
+                                ++idx;
+                            }
+                        }
+                        else
+                        {
+                            u64 o = a.offsets[unit] + idx;
+                            while (bits)
+                            {
+                                const u32 k = __builtin_ctz(bits);
+                                bits &= bits - 1u;
+                                if (o < a.pos_cap)
+                                {
+                                    const u64 st = ubase + rel0 + k + a.global_base, en = st + a.m;
+                                    *reinterpret_cast<uint4 *>(a.positions + 2 * o) =
+                                        make_uint4((u32)st, (u32)(st >> 32), (u32)en, (u32)(en >> 32));
+                                }
+                                ++o;
+                            }
+                        }
+                    }
+                }
+            }
+            n_cand = 0;
+        };
         LS wls{0, false, false, false};
         // ---- -c: the line bookkeeping of a unit (round 5).  A line that holds a match is counted at its FIRST match.  Inside a
         // lane's 16 bytes that is carry arithmetic on the hit / newline masks (l_cnt: first match behind a newline OF THIS LANE,
@@ -265,6 +386,7 @@ __global__ __launch_bounds__(kBlock, (KIND == 1 && LINES && R == 4) ? KG_LIT1_LI
         {
             const u64 seg = ubase + (u64)r * kSegBytes;
             const bool fast = seg + kSegBytes + (KIND == 9 ? 16 : 8) <= a.text_len;
+            static_assert(KIND != 10 || !LINES, "the deferred verify has no per-cell hit masks for the line bookkeeping");
             const bool interior = seg >= a.own_lo && seg + kSegBytes <= hi_match &&
                                   (seg + kSegBytes <= a.excl_lo || seg >= a.excl_hi);
 
@@ -464,8 +586,23 @@ __global__ __launch_bounds__(kBlock, (KIND == 1 && LINES && R == 4) ? KG_LIT1_LI
                         nlm &= clip(a.own_lo, a.own_hi);
                 }
 
+                if (KIND == 10)
+                {
+                    // candidates of the 8-byte filter: parked as lane-cell items, verified once per unit (verify_parked)
+                    const u64 bm = __ballot(m16 != 0u);
+                    if (bm)
+                    {
+                        const u32 nb = (u32)__popcll(bm);
+                        if (n_cand + nb > kCandCap)
+                            verify_parked(); // (a unit with more than 256 candidate lane-cells: what is parked goes first, in order)
+                        if (m16)
+                            s_cand[wave][n_cand + mbcnt64(bm)] = ((u32)(r * kCells + j) * kWave + lane) | (m16 << 16);
+                        n_cand += nb;
+                        m16 = 0;
+                    }
+                }
                 // rare refinement on candidate lanes: verify the pattern tail (m > 8) and -w
-                if ((KIND == 9 || ww) && __ballot(m16 != 0u))
+                if (KIND != 10 && (KIND == 9 || ww) && __ballot(m16 != 0u))
                 {
                     // (wave-uniform branch) the next lane's bytes 8..15 for the in-register verify of m = 9..16
                     const bool inreg = KIND == 9 && fast && a.m <= 16u;
@@ -586,7 +723,7 @@ __global__ __launch_bounds__(kBlock, (KIND == 1 && LINES && R == 4) ? KG_LIT1_LI
                     if (anyhit)
                         wcnt += wave_sum5(__popc(m16));
                 }
-                else if (anyhit)
+                else if (KIND != 10 && anyhit)
                 {
                     // the cell holds hits (10 % of the cells at 1e-4 hits per byte): rank them inside the unit — running unit
                     // count + exclusive lane prefix, both from the same ballot bit-planes — and write them out HERE, in order:
@@ -674,6 +811,8 @@ __global__ __launch_bounds__(kBlock, (KIND == 1 && LINES && R == 4) ? KG_LIT1_LI
 
         }
 
+        if (KIND == 10 && n_cand)
+            verify_parked();
         if (LINES)
         {
             u32 t = l_cnt, h = l_hits;
@@ -862,6 +1001,12 @@ hipError_t launch_literal(const LitArgs &a, u32 num_cu, hipStream_t st)
         return launch1<8, true>(a, num_cu, st);
     if (a.m == 8)
         return launch1<8, false>(a, num_cu, st);
+    if (a.m > 16 && !(a.flags & F_LINES) && !getenv("KREP_GPU_LIT_NO_DEFER"))
+    { // the tail verified once per unit (KIND 10; -c keeps the per-cell verify: its line bookkeeping wants the hits cell by cell)
+        if (a.flags & F_CI)
+            return a.rounds == kRoundsBig ? launch4<10, false, true, false, kRoundsBig>(a, num_cu, st) : launch4<10, false, true, false, 1>(a, num_cu, st);
+        return a.rounds == kRoundsBig ? launch4<10, false, false, false, kRoundsBig>(a, num_cu, st) : launch4<10, false, false, false, 1>(a, num_cu, st);
+    }
     return launch1<9, false>(a, num_cu, st);
 }
 
