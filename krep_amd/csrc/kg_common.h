@@ -49,7 +49,7 @@ struct Counters {
     unsigned long long summary;      // line bits (kLnNl|kLnHead|kLnTail) of the whole owned window
     unsigned long long overflow_units; // units whose hit count exceeded the staging capacity
     unsigned long long max_unit_count; // largest per-unit hit count seen
-    unsigned long long pad[2];
+    unsigned long long pad[4];       // scratch slots of the small tail kernels (pad[0]: one value; pad[1..3]: the newline-pattern walk)
 };
 
 // Parameters of a literal scan launch.

@@ -335,7 +335,11 @@ struct NlWalkSpec
 {
     u32 mode, m, k0; // kNlWalkSse42 / kNlWalkKmp; pattern length; offset of the first '\n' in the pattern
     bool ww, om;     // -w; only_matching (simd_sse42_search advances by 1 instead of m)
-    u64 n, maxc;     // text length; max_count (SIZE_MAX = unlimited)
+    u64 n, maxc;     // length of the WHOLE text; max_count (SIZE_MAX = unlimited)
+    // a PIECE of the text (round 5): the occurrence list is the piece's (global starts, buffer-relative line numbers);
+    u64 line_off;    // global line number = lineno + line_off
+    u64 cp_in;       // where the reference's scan stands when it enters the piece (global; 0 at the start of the text)
+    u64 seen_in;     // global line number of the last counted match (~0: none)
 };
 
 __global__ void g_nlwalk(const u64 *__restrict__ occ, u64 n_occ, const u64 *__restrict__ lineno, const uint8_t *__restrict__ keep,
@@ -344,8 +348,8 @@ __global__ void g_nlwalk(const u64 *__restrict__ occ, u64 n_occ, const u64 *__re
     if (threadIdx.x != 0 || blockIdx.x != 0)
         return;
     const u64 n = ws.n, m = ws.m, step = 17ull - m;
-    u64 cp = 0, cnt = 0, seen = ~0ull, i = 0;
-    while (n - cp >= m)
+    u64 cp = ws.cp_in, cnt = 0, seen = ws.seen_in, i = 0;
+    while (cp <= n && n - cp >= m)
     {
         // first occurrence with start >= cp: gallop from the current index, then bisect
         if (i < n_occ && occ[2 * i] < cp)
@@ -369,17 +373,17 @@ __global__ void g_nlwalk(const u64 *__restrict__ occ, u64 n_occ, const u64 *__re
             i = lo;
         }
         if (i >= n_occ)
-            break;
-        const u64 at = occ[2 * i];
+            break; // (a piece: the scan goes on in the next one, from cp)
+        const u64 at = occ[2 * i], ln = lineno[i] + ws.line_off; // (the records carry global offsets)
         const bool ok = !ws.ww || (keep[i] & kKeep);
         if (ws.mode == kNlWalkKmp)
         {
-            if (ok && lineno[i] != seen)
+            if (ok && ln != seen)
             {
                 if (ws.maxc != ~0ull && cnt >= ws.maxc)
                     break;
                 ++cnt;
-                seen = lineno[i];
+                seen = ln;
                 const u64 le = at + ws.k0;
                 cp = le < n ? le + 1 : n;
             }
@@ -396,12 +400,12 @@ __global__ void g_nlwalk(const u64 *__restrict__ occ, u64 n_occ, const u64 *__re
             j = jt < j ? jt : j;
         }
         const u64 win = cp + j * step;
-        if (ok && lineno[i] != seen)
+        if (ok && ln != seen)
         {
             if (cnt >= ws.maxc)
                 break;
             ++cnt;
-            seen = lineno[i];
+            seen = ln;
             const u64 le = at + ws.k0;
             if (le < n)
             {
@@ -416,6 +420,8 @@ __global__ void g_nlwalk(const u64 *__restrict__ occ, u64 n_occ, const u64 *__re
             cp = n;
     }
     out[0] = cnt;
+    out[1] = cp;   // where the scan stands when it leaves the piece
+    out[2] = seen; // ... and the line it counted last
 }
 
 #define GCHK(x)                                                                                \
@@ -527,9 +533,12 @@ int post_walk(PostScratch &s, const uint8_t *d_text, uint64_t text_len, uint64_t
 // occ: n_occ ALL-occurrence records in s.d_occ (whole text, global_base 0); d_lineno[n_occ] = line number of every start.
 int post_nlwalk(PostScratch &s, const uint8_t *d_text, uint64_t text_len, uint32_t mode, uint32_t m, uint32_t k0, bool ww, bool om,
                 uint64_t maxc, uint64_t n_occ, const uint64_t *d_lineno, Counters *d_ctr, Counters *h_ctr, hipStream_t st,
-                uint64_t *count)
+                uint64_t *count, uint64_t global_base, uint64_t global_len, uint64_t line_off, uint64_t cp_in, uint64_t seen_in,
+                uint64_t *cp_out, uint64_t *seen_out)
 {
     *count = 0;
+    *cp_out = cp_in;
+    *seen_out = seen_in;
     if (n_occ == 0)
         return 0;
     if (n_occ > s.keep_cap)
@@ -547,16 +556,19 @@ int post_nlwalk(PostScratch &s, const uint8_t *d_text, uint64_t text_len, uint32
     const u64 *occ = (const u64 *)s.d_occ;
     GCHK(hipMemsetAsync(s.d_keep, kKeep, n_occ, st));
     if (ww)
-        hipLaunchKernelGGL(g_ww, dim3((u32)((n_occ + kGB - 1) / kGB)), dim3(kGB), 0, st, occ, (u64)n_occ, 0ull, d_text, (u64)text_len, m,
+        hipLaunchKernelGGL(g_ww, dim3((u32)((n_occ + kGB - 1) / kGB)), dim3(kGB), 0, st, occ, (u64)n_occ, (u64)global_base, d_text, (u64)text_len, m,
                            s.d_keep);
     NlWalkSpec ws{};
-    ws.mode = mode; ws.m = m; ws.k0 = k0; ws.ww = ww; ws.om = om; ws.n = text_len; ws.maxc = maxc;
+    ws.mode = mode; ws.m = m; ws.k0 = k0; ws.ww = ww; ws.om = om; ws.n = global_len; ws.maxc = maxc;
+    ws.line_off = line_off; ws.cp_in = cp_in; ws.seen_in = seen_in;
     hipLaunchKernelGGL(g_nlwalk, dim3(1), dim3(64), 0, st, occ, (u64)n_occ, (const u64 *)d_lineno, (const uint8_t *)s.d_keep, ws,
                        (u64 *)&d_ctr->pad[1]);
     GCHK(hipGetLastError());
     GCHK(hipMemcpyAsync(h_ctr, d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, st));
     GCHK(hipStreamSynchronize(st));
     *count = h_ctr->pad[1];
+    *cp_out = h_ctr->pad[2];
+    *seen_out = h_ctr->pad[3];
     return 0;
 }
 

@@ -69,7 +69,8 @@ int post_walk(PostScratch &s, const uint8_t *d_text, uint64_t text_len, uint64_t
 constexpr uint32_t kNlWalkSse42 = 0, kNlWalkKmp = 1; // post_nlwalk modes
 int post_nlwalk(PostScratch &s, const uint8_t *d_text, uint64_t text_len, uint32_t mode, uint32_t m, uint32_t k0, bool ww, bool om,
                 uint64_t maxc, uint64_t n_occ, const uint64_t *d_lineno, Counters *d_ctr, Counters *h_ctr, hipStream_t st,
-                uint64_t *count);
+                uint64_t *count, uint64_t global_base, uint64_t global_len, uint64_t line_off, uint64_t cp_in, uint64_t seen_in,
+                uint64_t *cp_out, uint64_t *seen_out);
 
 // kg_tail.hip — end-of-text replay of the block-structured -c paths (kg_replay.h)
 struct ReplayIn;

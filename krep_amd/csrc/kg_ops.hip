@@ -848,6 +848,12 @@ static int run_pieces(const search_params_t *params, const krep_gpu_config_t &cf
         // shard); that piece is staged and scanned again with the true record — and, should its own record change, the one
         // behind it.
         krep_gpu_seq_carry_t tc{}; // what the text in front of the current piece REALLY leaves
+        // -c with a newline inside a pattern (the emission-order line changes of aho_corasick_search, the window-grid walk of
+        // simd_sse42_search / kmp_search): the piece's count depends on the EXACT record in front of it
+        bool nl_chain = false;
+        if (params->count_lines_mode)
+            for (size_t i = 0; i < params->num_patterns; ++i)
+                nl_chain = nl_chain || (params->pattern_lens[i] && memchr(params->patterns[i], '\n', params->pattern_lens[i]));
         for (Piece &p : pcs)
         {
             // walks: the piece's own list depends on where the scan stands at its start; block-loop -c: only the piece that
@@ -856,7 +862,8 @@ static int run_pieces(const search_params_t *params, const krep_gpu_config_t &cf
             //  line in front of it — for every other family these two fields stay 0)
             const bool stale = std::max<uint64_t>(p.carry_used.resume, p.lo) != std::max<uint64_t>(tc.resume, p.lo) ||
                                (p.hi == len && (p.carry_used.q1 != tc.q1 || p.carry_used.nl1 != tc.nl1 || p.carry_used.g0 != tc.g0)) ||
-                               p.carry_used.nl_before != tc.nl_before || p.carry_used.last_line != tc.last_line;
+                               p.carry_used.nl_before != tc.nl_before || p.carry_used.last_line != tc.last_line ||
+                               (nl_chain && p.carry_used.resume != tc.resume);
             if (stale)
             {
                 DeviceCtx &cx = *ctx_for(p.device);

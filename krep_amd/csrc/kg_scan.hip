@@ -404,9 +404,9 @@ int split_mode(const search_params_t *p, const krep_gpu_config_t &c, size_t text
             b = lo8(b);
     const Family fam = family_of(algo, c.only_matching != 0, p->count_lines_mode, p->whole_word, p->track_positions, p->max_count,
                                  pattern_has_border(f.data(), m), (uint32_t)m, memchr(pat, '\n', m) != nullptr);
-    if (fam.neon_zero || fam.nlwalk)
+    if (fam.neon_zero)
         return kSplitWhole;
-    return (fam.need_walk || fam.replay) ? kSplitChain : kSplitPieces;
+    return (fam.need_walk || fam.replay || fam.nlwalk) ? kSplitChain : kSplitPieces;
 }
 bool shardable(const search_params_t *p, const krep_gpu_config_t &c, size_t text_len) { return split_mode(p, c, text_len) != kSplitWhole; }
 // The left fold of the boundary record (include/krep_gpu.h, krep_gpu_seq_carry_t): used by a piece that knows its predecessor's
@@ -562,20 +562,30 @@ static int scan_literal(krep_gpu_plan *pl, int algo, const Window &w, match_posi
     if (fam.nlwalk)
     {
         // -c through simd_sse42_search / kmp_search with a newline inside the pattern: all occurrences, the line number of every
-        // start, the -w verdicts — then ONE thread walks the list the way the reference's loop moves (kg_greedy.hip (3))
-        if (!whole)
+        // start, the -w verdicts — then ONE thread walks the list the way the reference's loop moves (kg_greedy.hip (3)).
+        // Pieces (round 5): a piece owns the occurrences that START in it; what couples it to the text in front of it is where
+        // the reference's scan stands (resume), the line it counted last and the newlines so far (krep_gpu_seq_carry_t).
+        const krep_gpu_seq_carry_t in = carry_in ? *carry_in : krep_gpu_seq_carry_t{};
+        krep_gpu_seq_carry_t local{};
+        if (!whole && !carry_in && w.global_base + w.own_lo != 0)
             return kg::fail("-c through %s with a newline inside the pattern is a chain over every counted match: scan the whole "
-                            "text in one window", krep_gpu_algorithm_name(algo));
+                            "text in one window, or its pieces in text order through krep_gpu_scan_device_seq()", krep_gpu_algorithm_name(algo));
         if (pl->max_count == 0)
             return 0; // krep.c:4713, :1634
         HIPCHK(hipSetDevice(pl->device));
         if (time_it) HIPCHK(hipEventRecord(pl->ev0, st));
+        unsigned long long *d_slot = &pl->d_ctr->pad[0], *h_slot = &pl->h_ctr->pad[0];
+        uint64_t nl_halo = 0, nl_own = 0;
+        if (tail_count_newlines(w.d_text, 0, w.own_lo, d_slot, h_slot, st, &nl_halo) ||
+            tail_count_newlines(w.d_text, w.own_lo, own_hi, d_slot, h_slot, st, &nl_own))
+            return 2;
+        local.local_nl = nl_own;
         LitPass ps;
-        ps.own_lo = 0; ps.own_hi = own_hi; ps.sink = LitPass::OCC; ps.post = &pl->post;
+        ps.own_lo = w.own_lo; ps.own_hi = own_hi; ps.sink = LitPass::OCC; ps.post = &pl->post;
         LitResult lr0;
         if (lit_pass(pl, w, ps, st, &lr0))
             return 2;
-        uint64_t lines_counted = 0;
+        uint64_t lines_counted = 0, cp_out = in.resume, seen_out = in.last_line ? in.last_line : ~0ull;
         if (lr0.total)
         {
             if (lr0.total > pl->nl_cap)
@@ -588,12 +598,15 @@ static int scan_literal(krep_gpu_plan *pl, int algo, const Window &w, match_posi
                 HIPCHK(hipMalloc(&pl->d_nl_ln, want_n * sizeof(uint64_t)));
                 pl->nl_cap = want_n;
             }
-            if (krep_gpu_line_numbers(w.d_text, w.text_len, (const match_position_t *)pl->post.d_occ, lr0.total, pl->d_nl_ln, st))
+            if (krep_gpu_line_numbers_ex(w.d_text, w.text_len, w.global_base, (const match_position_t *)pl->post.d_occ, lr0.total, pl->d_nl_ln, st))
                 return 2;
             const uint32_t k0 = (uint32_t)((const uint8_t *)memchr(pl->pats[0].data(), '\n', m) - pl->pats[0].data());
+            // buffer-relative line numbers (1 + newlines in [0, start)) -> global ones: + newlines in front of the buffer
+            const uint64_t line_off = in.nl_before - nl_halo;
             if (post_nlwalk(pl->post, w.d_text, w.text_len, algo == KREP_RA_KMP ? kNlWalkKmp : kNlWalkSse42, m, k0, pl->ww,
                             pl->only_matching, pl->max_count == SIZE_MAX ? ~0ull : (uint64_t)pl->max_count, lr0.total, pl->d_nl_ln,
-                            pl->d_ctr, pl->h_ctr, st, &lines_counted))
+                            pl->d_ctr, pl->h_ctr, st, &lines_counted, w.global_base, w.global_len, line_off, in.resume,
+                            in.last_line ? in.last_line : ~0ull, &cp_out, &seen_out))
                 return 2;
         }
         if (time_it)
@@ -604,9 +617,21 @@ static int scan_literal(krep_gpu_plan *pl, int algo, const Window &w, match_posi
             HIPCHK(hipEventElapsedTime(&ms, pl->ev0, pl->ev1));
             out->kernel_ms = ms;
         }
+        if (carry_out)
+        {
+            // (the line counted last, relative to own_lo and biased like the multi-pattern record's, so that fold_carry() re-bases it)
+            if (seen_out != ~0ull && seen_out != (in.last_line ? in.last_line : ~0ull))
+                local.local_last = (1ull << 62) + (seen_out - (in.nl_before + 1ull));
+            krep_gpu_seq_carry_t o = kg::fold_carry(in, local);
+            if (!local.local_last)
+                o.last_line = in.last_line;
+            o.resume = std::max<uint64_t>(in.resume, cp_out);
+            *carry_out = o;
+        }
         out->total_matches = lines_counted;
         out->line_count = lines_counted;
-        out->head_line_hit = out->tail_line_hit = lines_counted != 0;
+        out->has_newline = whole ? 0 : 1; // (pieces: krep_gpu_combine_line_counts adds the counts up, the record has settled the cuts)
+        out->head_line_hit = out->tail_line_hit = whole ? lines_counted != 0 : 0;
         out->count = lines_counted; // the walk applies max_count the way the functions do (a break before the increment)
         return 0;
     }

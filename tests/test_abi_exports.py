@@ -134,7 +134,7 @@ def test_header_is_plain_c_and_python_mirrors_its_structs(tmp_path):
 
 def test_split_mode_table():
     """Host logic, no GPU: which families may be cut how (krep_gpu_split_mode).  Independent pieces for the
-    all-occurrence functions, chained pieces (one boundary record) for the sequential ones, one window for the two classes
+    all-occurrence functions, chained pieces (one boundary record) for the sequential ones, one window for the one class
     DESIGN.md §7 names."""
     import krep_amd
     e = krep_amd.load()
@@ -158,7 +158,7 @@ def test_split_mode_table():
         (abi.REF_AVX512, False, [b"x" * 40], {}, P),
         (abi.REF_NEON, False, [b"xyz"], dict(count_lines=True), CH),
         (abi.REF_NEON, False, [b"xyz"], dict(max_count=0, track_positions=False), W),  # neon_search's max_count == 0 corner
-        (abi.REF_AVX2, False, [b"a\nb"], dict(count_lines=True), W),                   # the newline-pattern -c walk
+        (abi.REF_AVX2, False, [b"a\nb"], dict(count_lines=True), CH),                  # the newline-pattern -c walk (r05: chained)
         (abi.REF_AVX2, False, [b"a\nb"], {}, P),
         (abi.REF_AVX2, False, [b"ab", b"cd"], {}, P),
         (abi.REF_AVX2, False, [b"ab", b"cd"], dict(count_lines=True), P),

@@ -301,3 +301,59 @@ def test_multi_pattern_count_lines_with_a_newline_pattern_in_pieces(gpu, oracle_
                     assert cnt == want and rc == (0 if want else 1), (pats, kw, "shards", shards, cnt, want)
             finally:
                 gpu.set_stream_chunk(0)
+
+
+def test_count_lines_with_a_newline_inside_a_single_pattern_in_pieces(gpu, oracle_engine):
+    """Round 5 (second half): -c through simd_sse42_search / kmp_search with a '\\n' inside the pattern
+    (krep.c:4785-4795, :1703-1707) — after a counted line the scan resumes INSIDE the match, for SSE4.2 at a point that depends on
+    the phase of its window grid.  One window only until now; a piece now takes where the reference's scan stands, the line it
+    counted last and the newlines so far from the text in front of it (krep_gpu_seq_carry_t::resume / last_line / nl_before).
+    Device windows chained through krep_gpu_scan_device_seq(), windows as buffers of their own, the streamed host operator and
+    logical shards — every layout the whole-text count of the compiled reference; -w, max_count, the KMP override."""
+    import torch
+    rng = np.random.RandomState(4711)
+    n = 2 * (1 << 20) + 333
+    for alpha in (b"ab\n", b"ab \n\n"):
+        text = cases.rand_text(rng, n, alpha)
+        d = torch.from_numpy(text).cuda()
+        for pat in (b"a\nb", b"a\n", b"\na", b"ab\nab", b"b\na\nb", b"\n\n"):
+            for level, override in ((abi.REF_AVX2, abi.ALGO_AUTO), (abi.REF_SSE42, abi.ALGO_AUTO), (abi.REF_AVX2, abi.ALGO_KMP)):
+                for kw in (dict(), dict(whole_word=True)):
+                    gpu.set_reference_simd(level)
+                    gpu.set_algo_override(override)
+                    try:
+                        p = abi.Params([pat], count_lines=True, **kw)
+                        algo = gpu.mirror_select(p, n)
+                        if algo not in (abi.RA_SSE42, abi.RA_KMP):
+                            continue
+                        assert gpu.split_mode(p, n) == abi.SPLIT_CHAIN
+                        want = oracle_engine.call(algo, abi.Params([pat], count_lines=True, **kw), text)[0]
+                        assert gpu.search(p, text, want_result=False)[0] == want, (pat, level, override, kw, "whole")
+                        plan = gpu.plan(p)
+                        cuts = [0, 1, 777, 65536, 65537, (1 << 20) + 3, n]
+                        carry, total = None, 0
+                        for lo, hi in zip(cuts[:-1], cuts[1:]):
+                            out, carry = plan.scan_seq(d.data_ptr(), n, lo, hi, 0, global_len=n, carry_in=carry)
+                            total += out.line_count
+                        assert total == want, (pat, level, override, kw, "device windows", total, want)
+                        carry, total = None, 0
+                        for lo, hi in zip(cuts[:-1], cuts[1:]):
+                            b0, b1 = max(0, lo - 40), min(n, hi + 40)
+                            out, carry = plan.scan_seq(d.data_ptr() + b0, b1 - b0, lo - b0, hi - b0, b0, global_len=n, carry_in=carry)
+                            total += out.line_count
+                        assert total == want, (pat, level, override, kw, "own buffers", total, want)
+                        plan.close()
+                        gpu.set_stream_chunk(1 << 19)
+                        try:
+                            assert gpu.search(p, text, want_result=False)[0] == want, (pat, level, override, kw, "streamed")
+                            for shards in (2, 3):
+                                cfg = gpu.default_config()
+                                cfg.reference_simd, cfg.algo_override = level, override
+                                rc, cnt, _ = gpu.search_buffer(p, text, num_gpus=shards, want_result=False, cfg=cfg)
+                                assert cnt == want, (pat, level, override, kw, "shards", shards, cnt, want)
+                        finally:
+                            gpu.set_stream_chunk(0)
+                    finally:
+                        gpu.set_algo_override(abi.ALGO_AUTO)
+        del d
+    gpu.set_reference_simd(abi.REF_AVX2)
