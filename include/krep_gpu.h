@@ -352,9 +352,11 @@ typedef struct krep_gpu_seq_carry
      * but the earlier occurrence lies in front of it: g0 = in.q1 ? (in.nl1 ? in.nl1 : local_first_nl1) : 0; 3 q's line started
      * in front of this piece: g0 = in.q1 ? (in.nl1 ? in.nl1 : in.g0) : 0.                                                    */
     uint64_t g0, local_g0, local_g0_kind;
-    /* multi-pattern -c with a '\n' inside a pattern (aho_corasick.c:383-396: the counter is bumped whenever the line of a match
+    /* -c with a '\n' inside a pattern.  Multi-pattern (aho_corasick.c:383-396: the counter is bumped whenever the line of a match
      * START differs from the line of the previously counted one, matches visited in emission order — end ascending): a piece
-     * owns the matches that END in it, its list continues its predecessor's, and the coupling is two numbers:             */
+     * owns the matches that END in it, its list continues its predecessor's, and the coupling is two numbers.  Through
+     * simd_sse42_search / kmp_search (krep.c:4785-4795, :1703-1707): a piece owns the occurrences that START in it; the
+     * coupling is `resume` above (where the reference's scan stands) plus the same two numbers:                           */
     uint64_t nl_before;   /* '\n' bytes of the text in front of this piece's own_hi (carry_out) / own_lo (carry_in)         */
     uint64_t last_line;   /* 1-based line number of the START of the last match of the text so far (0: no match yet)        */
     uint64_t local_nl;    /* this piece alone: '\n' bytes in [own_lo, own_hi) ...                                           */
@@ -375,11 +377,10 @@ int krep_gpu_scan_device_seq(krep_gpu_plan_t *plan, const void *d_text, size_t t
 /* How a text of text_len bytes may be cut for `params` under the current configuration. */
 enum krep_gpu_split
 {
-    KREP_GPU_SPLIT_WHOLE = 0,  /* one window only: -c through simd_sse42_search / kmp_search with a newline inside the pattern,
-                                  neon_search's max_count == 0 corner                                                     */
+    KREP_GPU_SPLIT_WHOLE = 0,  /* one window only: neon_search's max_count == 0 corner                                     */
     KREP_GPU_SPLIT_PIECES = 1, /* independent pieces: start-offset ownership + halo, results concatenate / merge          */
-    KREP_GPU_SPLIT_CHAIN = 2   /* pieces in text order through krep_gpu_scan_device_seq() (round 5: also multi-pattern -c
-                                  with a newline inside a pattern)                                                        */
+    KREP_GPU_SPLIT_CHAIN = 2   /* pieces in text order through krep_gpu_scan_device_seq() (round 5: also -c with a newline
+                                  inside a pattern, multi-pattern and through simd_sse42_search / kmp_search)             */
 };
 int krep_gpu_split_mode(const search_params_t *params, size_t text_len);
 /* test hook (host only, no GPU needed): the left fold of the boundary record exactly as the library applies it — a piece's
