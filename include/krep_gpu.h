@@ -158,6 +158,9 @@ void krep_gpu_debug_force_stage_cap(int records);
  * dense text, or the spin-limit safety net) since the process started */
 void krep_gpu_debug_force_single_grid(int blocks);
 uint64_t krep_gpu_debug_single_failovers(void);
+/* ... and how many launches of that kernel there were (its 2..8-byte instantiations included: a plan takes them for records of a
+ * dense short literal once a two-pass scan has counted the density) */
+uint64_t krep_gpu_debug_single_launches(void);
 /* test hook: launches of the tiny-dictionary kernel (kg_ac_tiny.hip: every pattern <= 4 bytes, compared in registers) since the
  * process started; $KREP_GPU_AC_NO_TINY=1 (read when a plan is built) keeps such dictionaries on the general kernel */
 uint64_t krep_gpu_debug_tiny_launches(void);

@@ -260,6 +260,10 @@ std::atomic<uint64_t> g_fused1_failovers{0}; // one-pass single-byte scans that 
 extern "C" void krep_gpu_debug_force_single_grid(int blocks) { kg::g_s1_force_grid = blocks < 0 ? 0 : blocks; }
 extern "C" uint64_t krep_gpu_debug_single_failovers(void) { return g_fused1_failovers.load(); }
 namespace kg {
+std::atomic<uint64_t> g_fused1_launches{0};
+}
+extern "C" uint64_t krep_gpu_debug_single_launches(void) { return kg::g_fused1_launches.load(); }
+namespace kg {
 std::atomic<uint64_t> g_tiny_launches{0}; // launches of ac_tiny_kernel
 }
 extern "C" uint64_t krep_gpu_debug_tiny_launches(void) { return kg::g_tiny_launches.load(); }

@@ -112,6 +112,16 @@ struct LitResult
 };
 } // namespace
 
+// hits per 32-KiB unit from which a 2..8-byte literal with records takes the one-pass kernel (KREP_GPU_FUSEDK_MIN: measurement aid)
+static double fusedk_min_hits_per_unit()
+{
+    static const double v = [] {
+        const char *e = getenv("KREP_GPU_FUSEDK_MIN");
+        return e ? atof(e) : 24.0;
+    }();
+    return v;
+}
+
 static int lit_pass(krep_gpu_plan *pl, const Window &w, const LitPass &ps, hipStream_t st, LitResult *res)
 {
     *res = LitResult{};
@@ -199,14 +209,19 @@ static int lit_pass(krep_gpu_plan *pl, const Window &w, const LitPass &ps, hipSt
     // at their final index (kg_single.hip) — no staging, no info words, no post-pass.  A scan too dense for the rings of its
     // shape is counted but not recorded: the count picks the shape that holds it (up to ~10 % hits) and the scan runs again in
     // that shape — the plan keeps it; beyond that the two-pass kernels below take this scan and the plan's later ones.
-    if (m_scan == 1 && ps.sink == LitPass::RECORDS && !ps.ww && !ps.lines && !ps.first_byte && a.rounds == kRoundsBig && fsc == 0 &&
-        ps.excl_lo == ps.excl_hi && pl->fused1_ok && w.text_len >= 2 * (size_t)kSegBytes && !getenv("KREP_GPU_NO_FUSED1"))
+    // The same kernel takes a literal of 2..8 bytes (its MULTI instantiations) once a two-pass scan of the plan has counted a
+    // density at which the staging slots of the sparse kinds overflow (`-i sh`: 35 hits per unit; ` a`: 180): pl->fusedk_on.
+    const bool fusedk = m_scan >= 2 && m_scan <= 8 && pl->fusedk_on;
+    if ((m_scan == 1 ? pl->fused1_ok : fusedk) && ps.sink == LitPass::RECORDS && !ps.ww && !ps.lines && !ps.first_byte &&
+        a.rounds == kRoundsBig && fsc == 0 && ps.excl_lo == ps.excl_hi && w.text_len >= 2 * (size_t)kSegBytes &&
+        !getenv("KREP_GPU_NO_FUSED1"))
     {
         a.positions = ps.d_out;
         a.pos_cap = ps.out_cap;
+        int &plan_shape = m_scan == 1 ? pl->fused1_shape : pl->fusedk_shape;
         for (;;)
         {
-            const int shape = pl->fused1_shape;
+            const int shape = plan_shape;
             const uint64_t n_tk = single_fused_tickets(n_units, shape);
             if (n_tk > post.tk_cap)
             {
@@ -219,6 +234,7 @@ static int lit_pass(krep_gpu_plan *pl, const Window &w, const LitPass &ps, hipSt
             HIPCHK(hipMemsetAsync(pl->d_ctr, 0, sizeof(Counters), st));
             HIPCHK(hipMemsetAsync(post.d_tk, 0, single_fused_scratch_words(n_tk) * sizeof(unsigned long long), st));
             HIPCHK(launch_single_fused(a, post.d_tk, post.d_tk + n_tk, n_tk, grid, shape, st));
+            g_fused1_launches.fetch_add(1);
             if (ps.ev_end) HIPCHK(hipEventRecord(ps.ev_end, st));
             HIPCHK(hipMemcpyAsync(pl->h_ctr, pl->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
@@ -228,8 +244,11 @@ static int lit_pass(krep_gpu_plan *pl, const Window &w, const LitPass &ps, hipSt
                 res->summary = res->total ? (kLnHead | kLnTail) : 0;
                 // the decision is re-evaluated by every scan: a text half as dense as the next smaller shape holds
                 // sends the plan's following scans back to it (larger tickets, more waves per CU)
-                if (shape > 0 && (double)res->total / (double)(hi_match - a.anchor) < 0.5 * single_fused_max_density(shape - 1))
-                    pl->fused1_shape = shape - 1;
+                const double density = (double)res->total / (double)(hi_match - a.anchor);
+                if (shape > 0 && density < 0.5 * single_fused_max_density(shape - 1))
+                    plan_shape = shape - 1;
+                if (m_scan != 1 && density * 32768.0 < 0.5 * fusedk_min_hits_per_unit())
+                    pl->fusedk_on = false; // (a sparser text: the staging road is faster there)
                 return 0;
             }
             // the scan counted every ticket (the resolver's running sum): the density chooses the shape — unless the spin-limit
@@ -240,9 +259,12 @@ static int lit_pass(krep_gpu_plan *pl, const Window &w, const LitPass &ps, hipSt
                 ++next;
             if (next > kFusedShapeMax || pl->h_ctr->total == 0)
                 break;
-            pl->fused1_shape = next;
+            plan_shape = next;
         }
-        pl->fused1_ok = false;
+        if (m_scan == 1)
+            pl->fused1_ok = false;
+        else
+            pl->fusedk_on = false, pl->fusedk_never = true;
         g_fused1_failovers.fetch_add(1);
     }
     if (chain)
@@ -275,9 +297,24 @@ static int lit_pass(krep_gpu_plan *pl, const Window &w, const LitPass &ps, hipSt
                 for (want = 128; want < 256 && want < pl->h_ctr->max_unit_count; want *= 2) {}
             pl->sparse_cap = std::max(pl->sparse_cap, want);
         }
+        if ((a.flags & F_POS) && m_scan >= 2 && m_scan <= 8 && a.rounds == kRoundsBig && !fsc && !pl->fusedk_never &&
+            ps.sink == LitPass::RECORDS && !ps.ww && !ps.lines && hi_match > a.anchor)
+        {
+            // dense enough for the one-pass record writer (kg_single.hip, MULTI)?  Its shape from the density just counted.
+            const double density = (double)pl->h_ctr->total / (double)(hi_match - a.anchor);
+            if (density * 32768.0 >= fusedk_min_hits_per_unit() && density <= single_fused_max_density(kFusedShapeMax))
+            {
+                int shape = 0;
+                while (shape < kFusedShapeMax && density > single_fused_max_density(shape))
+                    ++shape;
+                pl->fusedk_on = true;
+                pl->fusedk_shape = shape;
+            }
+        }
         if (getenv("KREP_GPU_DEBUG") && (a.flags & F_POS))
-            fprintf(stderr, "krep-gpu: literal scan: %llu of %llu units overflowed a %u-entry slot (fullest: %llu)\n", pl->h_ctr->overflow_units,
-                    (unsigned long long)n_units, a.stage_cap, pl->h_ctr->max_unit_count);
+            fprintf(stderr, "krep-gpu: literal scan: %llu of %llu units overflowed a %u-entry slot (fullest: %llu); one-pass next: %d (shape %d)\n",
+                    pl->h_ctr->overflow_units, (unsigned long long)n_units, a.stage_cap, pl->h_ctr->max_unit_count, (int)pl->fusedk_on,
+                    pl->fusedk_shape);
         if ((a.flags & F_POS) && pl->h_ctr->overflow_units)
         {
             // some units held more hits than their staging slot: re-scan exactly those, writing in place

@@ -94,10 +94,16 @@ __device__ __noinline__ uint4 s_load16_guarded(const uint8_t *text, u64 text_len
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-template <bool CI, u32 kUpt, u32 kRing, int WPE, bool SET>
+// MULTI (round 5): a literal of 2..8 bytes instead of one byte — the same ring, resolver and deferred stores, the match test is
+// lit_scan's (kg_literal.hip: the 16 start positions of a lane compared in registers against the pattern's first word, and its
+// second word where the pattern is longer than four bytes); the 8 bytes behind a lane come from its right neighbour, behind the
+// round from one extra 8-byte load.  For DENSE short literals with records (`-i sh`: 35 hits per 32-KiB unit, ` a`: 180), whose
+// staging slots overflow and whose text the two-pass kernels then read twice: chosen by lit_pass from the density a scan counted.
+template <bool CI, u32 kUpt, u32 kRing, int WPE, bool SET, bool MULTI = false>
 __global__ __launch_bounds__(kBlock, WPE) void single_fused(const LitArgs a, u64 *__restrict__ agg, u64 *__restrict__ pref,
                                                             const u64 n_tickets)
 {
+    static_assert(!MULTI || !SET, "a byte set is a single-byte scan");
     static_assert(kUpt >= 1 && kUpt <= 4 && (kRing & (kRing - 1u)) == 0u, "ticket / ring shape");
     const u32 lane = s_lane();
     const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -121,7 +127,7 @@ __global__ __launch_bounds__(kBlock, WPE) void single_fused(const LitArgs a, u64
 
     extern __shared__ __attribute__((aligned(16))) unsigned short s_ring[]; // [kWavesPerBlk][kRing] (dynamic: the densest shape asks for 128 KiB)
     unsigned short *ring = s_ring + (size_t)wave * kRing;
-    const u64 hi_match = a.own_hi < a.text_len ? a.own_hi : a.text_len; // exclusive start bound (m == 1)
+    const u64 hi_match = a.own_hi < a.text_len - a.m + 1 ? a.own_hi : a.text_len - a.m + 1; // exclusive start bound
 
     // the ticket whose records are still in the ring (uniform)
     bool pend = false;
@@ -157,7 +163,7 @@ __global__ __launch_bounds__(kBlock, WPE) void single_fused(const LitArgs a, u64
             if (idx < a.pos_cap)
 #endif
             {
-                const u64 st = tbase + (u64)unit * kUnitBytes1 + off, en = st + 1;
+                const u64 st = tbase + (u64)unit * kUnitBytes1 + off, en = st + (MULTI ? (u64)a.m : 1ull);
                 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
                 const u32x4 rec = {(u32)st, (u32)(st >> 32), (u32)en, (u32)(en >> 32)};
 #ifdef KG_S1_PLAIN_STORES
@@ -206,12 +212,56 @@ __global__ __launch_bounds__(kBlock, WPE) void single_fused(const LitArgs a, u64
             }
         }
         const bool interior = seg >= a.own_lo && seg + kSegBytes <= hi_match;
+        // MULTI: the 8 bytes behind the round (the last lane of its last cell looks that far); zeros behind the end of the text
+        u32 aft0 = 0, aft1 = 0;
+        if (MULTI)
+        {
+            const u64 q = seg + kSegBytes;
+            if (q + 8 <= a.text_len)
+            {
+                const uint2 t2 = *reinterpret_cast<const uint2 *>(a.text + q);
+                aft0 = __builtin_amdgcn_readfirstlane(t2.x);
+                aft1 = __builtin_amdgcn_readfirstlane(t2.y);
+            }
+            else
+            {
+                u32 w2[2] = {0, 0};
+                for (u32 b = 0; b < 8; ++b)
+                    if (q + b < a.text_len)
+                        w2[b >> 2] |= (u32)a.text[q + b] << (8 * (b & 3u));
+                aft0 = __builtin_amdgcn_readfirstlane(w2[0]);
+                aft1 = __builtin_amdgcn_readfirstlane(w2[1]);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < kCells; ++j)
         {
             const u32 D[4] = {X[j].x, X[j].y, X[j].z, X[j].w};
             u32 m16 = 0;
-            if (SET)
+            if (MULTI)
+            {
+                // the lane's 16 bytes + the 8 behind them: the right neighbour's first two dwords, for the last lane the next cell's
+                // (the round's cells are all in registers) or the bytes behind the round
+                const u32 n0 = __shfl_down(D[0], 1), n1 = __shfl_down(D[1], 1);
+                const u32 e0 = j + 1 < kCells ? __builtin_amdgcn_readfirstlane(X[j + 1 < kCells ? j + 1 : j].x) : aft0;
+                const u32 e1 = j + 1 < kCells ? __builtin_amdgcn_readfirstlane(X[j + 1 < kCells ? j + 1 : j].y) : aft1;
+                const u32 W[6] = {D[0], D[1], D[2], D[3], lane == 63u ? e0 : n0, lane == 63u ? e1 : n1};
+                auto A = [&](int k) -> u32 {
+                    return ((k & 3) == 0) ? W[k >> 2] : __builtin_amdgcn_alignbyte(W[(k >> 2) + 1], W[k >> 2], (u32)(k & 3));
+                };
+                // (x | l) == p on the compared bytes: exact with and without -i (l = 0x20 under the pattern's letters, p folded)
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    m16 |= ((((CI ? (A(k) | a.l0) : A(k)) ^ a.p0) & a.k0) == 0u) ? (1u << k) : 0u;
+                if (a.m > 4u && __ballot(m16 != 0u)) // (uniform) a second word to compare, where the first one matched
+                {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k)
+                        if ((((CI ? (A(k + 4) | a.l1) : A(k + 4)) ^ a.p1) & a.k1) != 0u)
+                            m16 &= ~(1u << k);
+                }
+            }
+            else if (SET)
             { // a byte SET: the equality flags of its (<= 4) needles OR-ed before the one movemask per dword
 #pragma unroll
                 for (int w = 0; w < 4; ++w)
@@ -348,7 +398,7 @@ __global__ __launch_bounds__(kBlock, WPE) void single_fused(const LitArgs a, u64
 
 int g_s1_force_grid = 0; // test hook: at most this many blocks (0 = auto)
 // grid = the resident blocks of the instantiation x CUs
-template <bool CI, u32 UPT, u32 RING, int WPE, bool SET>
+template <bool CI, u32 UPT, u32 RING, int WPE, bool SET, bool MULTI>
 static hipError_t launch_fused(const LitArgs &a, u64 *agg, u64 *pref, u64 n_tickets, u32 num_cu, hipStream_t st)
 {
     constexpr size_t kLds = (size_t)kWavesPerBlk * RING * sizeof(unsigned short);
@@ -364,13 +414,13 @@ static hipError_t launch_fused(const LitArgs &a, u64 *agg, u64 *pref, u64 n_tick
     {
         if (kLds > 64 * 1024) // more than 64 KiB of dynamic LDS has to be asked for
         {
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&single_fused<CI, UPT, RING, WPE, SET>),
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&single_fused<CI, UPT, RING, WPE, SET, MULTI>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
             if (e != hipSuccess)
                 return e;
         }
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, single_fused<CI, UPT, RING, WPE, SET>, kBlock, kLds) != hipSuccess || n < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, single_fused<CI, UPT, RING, WPE, SET, MULTI>, kBlock, kLds) != hipSuccess || n < 1)
         {
             (void)hipGetLastError();
             n = 1;
@@ -383,7 +433,7 @@ static hipError_t launch_fused(const LitArgs &a, u64 *agg, u64 *pref, u64 n_tick
     u32 grid = (u32)std::max<u64>(1, std::min<u64>(want, (u64)num_cu * bpc));
     if (g_s1_force_grid > 0) // test hook: a starved grid (krep_gpu_debug_force_single_grid)
         grid = std::min<u32>(grid, (u32)g_s1_force_grid);
-    hipLaunchKernelGGL((single_fused<CI, UPT, RING, WPE, SET>), dim3(grid), dim3(kBlock), kLds, st, a, agg, pref, n_tickets);
+    hipLaunchKernelGGL((single_fused<CI, UPT, RING, WPE, SET, MULTI>), dim3(grid), dim3(kBlock), kLds, st, a, agg, pref, n_tickets);
     return hipGetLastError();
 }
 
@@ -399,19 +449,26 @@ double single_fused_max_density(int shape)
     return 0.4 * ring / bytes;
 }
 
-template <bool CI, bool SET>
+template <bool CI, bool SET, bool MULTI = false>
 static hipError_t launch_shape(const LitArgs &a, u64 *agg, u64 *pref, u64 n_tickets, u32 num_cu, int shape, hipStream_t st)
 {
-    if (shape == 0) return launch_fused<CI, kUptStd, kRingStd, 4, SET>(a, agg, pref, n_tickets, num_cu, st);
-    if (shape == 1) return launch_fused<CI, 2u, kRingDense, 2, SET>(a, agg, pref, n_tickets, num_cu, st);
-    if (shape == 2) return launch_fused<CI, 1u, kRingDense, 2, SET>(a, agg, pref, n_tickets, num_cu, st);
-    return launch_fused<CI, 1u, kRingDensest, 1, SET>(a, agg, pref, n_tickets, num_cu, st);
+    if (shape == 0) return launch_fused<CI, kUptStd, kRingStd, 4, SET, MULTI>(a, agg, pref, n_tickets, num_cu, st);
+    if (shape == 1) return launch_fused<CI, 2u, kRingDense, 2, SET, MULTI>(a, agg, pref, n_tickets, num_cu, st);
+    if (shape == 2) return launch_fused<CI, 1u, kRingDense, 2, SET, MULTI>(a, agg, pref, n_tickets, num_cu, st);
+    return launch_fused<CI, 1u, kRingDensest, 1, SET, MULTI>(a, agg, pref, n_tickets, num_cu, st);
 }
 
 hipError_t launch_single_fused(const LitArgs &a, unsigned long long *d_agg, unsigned long long *d_pref, uint64_t n_tickets,
                                uint32_t num_cu, int shape, hipStream_t st)
 {
     const bool ci = (a.flags & F_CI) != 0, set = a.set_n != 0u;
+    if (!set && a.m > 1u)
+    {
+        if (a.m > 8u)
+            return hipErrorInvalidValue;
+        return ci ? launch_shape<true, false, true>(a, d_agg, d_pref, n_tickets, num_cu, shape, st)
+                  : launch_shape<false, false, true>(a, d_agg, d_pref, n_tickets, num_cu, shape, st);
+    }
     if (set)
         return ci ? launch_shape<true, true>(a, d_agg, d_pref, n_tickets, num_cu, shape, st)
                   : launch_shape<false, true>(a, d_agg, d_pref, n_tickets, num_cu, shape, st);

@@ -115,6 +115,7 @@ class Engine:
         L.krep_gpu_debug_force_single_grid.restype = None
         L.krep_gpu_debug_force_single_grid.argtypes = [C.c_int]
         L.krep_gpu_debug_single_failovers.restype = C.c_uint64
+        L.krep_gpu_debug_single_launches.restype = C.c_uint64
         L.krep_gpu_debug_tiny_launches.restype = C.c_uint64
         L.krep_gpu_last_shard_info.restype = None
         L.krep_gpu_last_shard_info.argtypes = [C.POINTER(abi.ShardInfo)]
@@ -161,6 +162,9 @@ class Engine:
 
     def single_failovers(self) -> int:
         return int(self.lib.krep_gpu_debug_single_failovers())
+
+    def single_launches(self) -> int:
+        return int(self.lib.krep_gpu_debug_single_launches())
 
     def tiny_launches(self) -> int:
         return int(self.lib.krep_gpu_debug_tiny_launches())

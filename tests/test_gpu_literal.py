@@ -366,3 +366,59 @@ def test_one_plan_across_texts_of_changing_density(gpu, oracle_engine):
             plan.close()
     finally:
         gpu.force_rounds(0)
+
+
+def test_dense_short_literals_take_the_one_pass_record_writer(gpu, oracle_engine):
+    """A 2..8-byte literal with records on a DENSE text (more than ~24 hits per 32-KiB unit: the staging slots of the sparse kinds
+    overflow there): the first scan of a plan counts the density through the two-pass kernels, the following ones write their
+    records in one pass (kg_single.hip, MULTI) — every list exact, case-insensitive too, with hits in the last bytes of the
+    text and straddling rounds and cells; a later sparse text sends the plan back to the staging road.
+    The all-occurrence functions, /root/reference/krep.c:3421-3530 (BMH), :3891-4041 (memchr_short for m <= 3)."""
+    import torch
+    rng = np.random.RandomState(909)
+    n = 5 * (1 << 20) + 1234
+    gpu.force_rounds(4)
+    try:
+        for pat in (b"ab", b"abc", b"xy z", b"hello", b"abcabd", b"Sherloc", b"a1b2c3d4"):
+            # dense: the pattern, its prefixes and fillers as tokens in random order — one token in ~30 is the pattern
+            toks = [pat] + [pat[:-1], pat[1:], b" ", b"q", pat[:1] * 2] * 5
+            dense = np.frombuffer(b"".join(toks[i] for i in rng.randint(0, len(toks), n))[:n], dtype=np.uint8).copy()
+            assert len(dense) == n
+            alpha = pat
+            # occurrences planted across every kind of boundary: cells (1 KiB), rounds (8 KiB), units (32 KiB), the end of the text
+            for at in (1024 - 1, 8192 - 3, 32768 - 2, 131072 - 1, 3 * 131072 - 4, n - len(pat), n - len(pat) - 1):
+                dense[at:at + len(pat)] = np.frombuffer(pat, dtype=np.uint8)
+            sparse = cases.rand_text(rng, n, bytes(range(65, 91)) * 4 + alpha)
+            for kw in (dict(), dict(case_sensitive=False)):
+                if kw:
+                    up = np.frombuffer(pat.upper(), dtype=np.uint8)
+                    dense[40000:40000 + len(pat)] = up
+                p = abi.Params([pat], **kw)
+                algo = gpu.mirror_select(p, n)
+                fam_all = oracle_engine.call(algo, abi.Params([pat], **kw), dense)
+                plan = gpu.plan(abi.Params([pat], **kw))
+                launches = []
+                for ti, text in enumerate((dense, dense, dense, sparse, dense, dense)):
+                    want = fam_all if text is dense else oracle_engine.call(algo, abi.Params([pat], **kw), text)
+                    d = torch.from_numpy(text).cuda()
+                    cap = int(want[0]) + 3
+                    pos = torch.zeros(2 * cap, dtype=torch.int64, device="cuda")
+                    before = gpu.single_launches()
+                    out = plan.scan(d.data_ptr(), n, 0, n, 0, pos.data_ptr(), cap)
+                    launches.append(gpu.single_launches() - before)
+                    assert out.count == want[0] and not out.overflow, (pat, kw, ti, out.count, want[0])
+                    got = pos[:2 * out.count].cpu().numpy().astype(np.uint64).reshape(-1, 2)
+                    assert np.array_equal(got, want[1]), (pat, kw, ti)
+                    del d, pos
+                plan.close()
+                if plan_is_all_occurrence(gpu, p, n):
+                    # scan 0 learns, 1 and 2 take the one-pass kernel; the sparse text (3) takes it once more and switches it off,
+                    # so 4 learns again and 5 is one pass
+                    assert launches[0] == 0 and launches[1] >= 1 and launches[2] >= 1 and launches[5] >= 1, (pat, kw, launches)
+    finally:
+        gpu.force_rounds(0)
+
+
+def plan_is_all_occurrence(gpu, p, n):
+    """the literal kernels with a RECORDS sink serve the all-occurrence functions directly; greedy families go through the walk"""
+    return gpu.mirror_select(p, n) in (abi.RA_BMH, abi.RA_MEMCHR_SHORT, abi.RA_MEMCHR)
