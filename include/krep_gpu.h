@@ -164,6 +164,8 @@ uint64_t krep_gpu_debug_single_launches(void);
 /* test hook: launches of the tiny-dictionary kernel (kg_ac_tiny.hip: every pattern <= 4 bytes, compared in registers) since the
  * process started; $KREP_GPU_AC_NO_TINY=1 (read when a plan is built) keeps such dictionaries on the general kernel */
 uint64_t krep_gpu_debug_tiny_launches(void);
+/* ... and those of its one-pass record writer in the DENSE flavour (16-bit ring entries, tickets sized by the counted density) */
+uint64_t krep_gpu_debug_tiny_dense_launches(void);
 /* Twin of select_search_algorithm() (krep.c:1771): the algorithm the reference build would END UP
  * executing for `params` on a text of `text_len` bytes (text_len matters: the SIMD functions fall back
  * to BMH when text_len < pattern_len, and so on). */

@@ -43,6 +43,9 @@ namespace kg {
 // pattern's final 4-gram (a match ends at the tested position t), the 4-gram one byte earlier (the match ends at t + 1;
 // for a 4-byte pattern that gram has an unknown first byte: all 32 classes are set).  Half the LDS lookups — the
 // bank-conflict wall of 4.2 — and half the lookup VALU; a candidate verifies both ends, with both probes in flight.
+#ifndef KG_AC_LINES_ROLL_CELLS
+#define KG_AC_LINES_ROLL_CELLS 4 // cells (1 KiB each) of the next round a -c scan prefetches (A/B: krep_amd/build.py --variant x -DKG_AC_LINES_ROLL_CELLS=8)
+#endif
 template <bool CI, bool LINES, bool SHORT, int STRIDE>
 __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
 {
@@ -143,16 +146,22 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                         bb |= (u32)a.text[seg + b - 4] << (8 * b);
             before = __builtin_amdgcn_readfirstlane(bb);
         }
-        if (fast_now && !have)
+        // -c prefetches only the first kRoll cells of the next round with the stride-1 filter and none with the pair filter (every
+        // -c instantiation then fits the 128 VGPRs of a 1024-thread block without scratch; with the full prefetch they spilled 8-44
+        // bytes per lane.  Measured at 32 GiB on the 1000-pattern dictionary, in-kernel -c road: 9.90 ms without the prefetch,
+        // 9.61 ms with it and 20 bytes of scratch, profiles/r05_line_counting.txt; texts of 32 MiB and more count their lines on the
+        // record list, kg_scan.hip, at 6.8 ms); the rest of a prefetched round is requested here, at its start
+        constexpr int kRoll = LINES ? (STRIDE == 2 ? 0 : KG_AC_LINES_ROLL_CELLS) : kCells;
+        if (fast_now)
         {
 #pragma unroll
             for (int j = 0; j < kCells; ++j)
-                d[j] = src[j * kWave]; // (temporal on purpose: non-temporal stream loads measured 7.45 vs 6.87 ms, the verifier's text windows hit in cache)
+                if (!have || j >= kRoll)
+                    d[j] = src[j * kWave]; // (temporal on purpose: non-temporal stream loads measured 7.45 vs 6.87 ms, the verifier's text windows hit in cache)
         }
         // the next round of this ticket, if it is a full one, streams in behind this one
-        // (not in the -c variant of the stride-2 kernel: with the prefetch registers live across the verify stage it
-        //  spilled 50-69 VGPRs under the 128 cap)
-        const bool pf_next = fast_now && !emit_final && seg + 2 * (u64)kSegBytes <= a.text_len &&
+        constexpr bool ROLL = kRoll > 0;
+        const bool pf_next = ROLL && fast_now && !emit_final && seg + 2 * (u64)kSegBytes <= a.text_len &&
                              (r + 1 < kAcRounds || unit + 1 < u_end);
         // always issued in the fast path (a uniform address select, not a branch: the s_waitcnt counts stay static);
         // without a next round every lane re-reads the first bytes of this one (one cached line per load, dropped)
@@ -225,22 +234,35 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 // all table reads of the cell are issued before the first one is consumed (the scheduler otherwise
                 // serialises read -> wait -> shift through the accumulator chain: 8-16 LDS latencies per cell)
                 constexpr int NK = 16 / STRIDE;
-                u32 xs[NK], dws[NK];
+                // (stride 1 with the rolling prefetch: in two batches of 8 — 32 index / data registers at once spilled 12-20 bytes
+                //  per lane under the 128-VGPR cap)
+#ifndef KG_AC_S1_ONE_BATCH // (A/B switch)
+                constexpr int NB = (NK == 16 && !LINES) ? 8 : NK;
+#else
+                constexpr int NB = NK;
+#endif
                 typedef __attribute__((address_space(3))) const u32 lds_u32;
-#pragma unroll
-                for (int q = 0; q < NK; ++q)
-                {
-                    const int o = 5 * (q * STRIDE + 1);
-                    xs[q] = (o & 31) ? __builtin_amdgcn_alignbit(R[(o >> 5) + 1], R[o >> 5], (u32)(o & 31)) : R[o >> 5];
-                    // the table sits at LDS address 0 (checked at kernel entry): an absolute LDS pointer saves the
-                    // v_add of the (link-time) base of s_mem on every lookup
-                    dws[q] = *(lds_u32 *)(size_t)((xs[q] >> 3) & ((1u << (XB - 3)) - 4u));
-                }
-                __builtin_amdgcn_sched_barrier(0);
                 u32 acc = 0;
 #pragma unroll
-                for (int q = 0; q < NK; ++q)
-                    acc = __builtin_amdgcn_alignbit(dws[q] >> (xs[q] & 31u), acc, (u32)STRIDE);
+                for (int q0 = 0; q0 < NK; q0 += NB)
+                {
+                    u32 xs[NB], dws[NB];
+#pragma unroll
+                    for (int q = 0; q < NB; ++q)
+                    {
+                        const int o = 5 * ((q0 + q) * STRIDE + 1);
+                        xs[q] = (o & 31) ? __builtin_amdgcn_alignbit(R[(o >> 5) + 1], R[o >> 5], (u32)(o & 31)) : R[o >> 5];
+                        // the table sits at LDS address 0 (checked at kernel entry): an absolute LDS pointer saves the
+                        // v_add of the (link-time) base of s_mem on every lookup
+                        dws[q] = *(lds_u32 *)(size_t)((xs[q] >> 3) & ((1u << (XB - 3)) - 4u));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < NB; ++q)
+                        acc = __builtin_amdgcn_alignbit(dws[q] >> (xs[q] & 31u), acc, (u32)STRIDE);
+                    if (q0 + NB < NK)
+                        __builtin_amdgcn_sched_barrier(0);
+                }
                 cand = STRIDE == 2 ? (acc >> 16) & 0x5555u : acc >> 16;
             }
             u32 nlm = NL;
@@ -325,7 +347,8 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
             {
                 u32 W[5];
                 W[1] = d[j].x; W[2] = d[j].y; W[3] = d[j].z; W[4] = d[j].w;
-                d[j] = nsrc[j * kWave];
+                if (j < kRoll)
+                    d[j] = nsrc[j * kWave];
                 {
                     // the class word of the 4 bytes in front of the lane = the left neighbour's last one: a DPP wave shift
                     // (lane 0 keeps `old` = the classes of `before`, uniform: scalar ALU) — no LDS permute, no branch
@@ -820,12 +843,26 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
     // ---- a tiny dictionary, records wanted: ONE pass (kg_ac_tiny.hip FUSED, round 5) — matches ranked into an LDS ring per
     // 128-KiB ticket, the tickets' counts resolved into prefixes by one wave, records written at their final index: no masks kept,
     // no staging, no info words, no post-pass.  A ticket with more matches than its ring holds (~0.6 % of the bytes) is counted,
-    // not recorded: the staging road below takes this scan, and the dictionary's next ones until a text is sparse again.
-    if (t->tiny.ok && !t->tiny.llong && want && !ww && list_mode != 2 && t->tiny_fused_ok && track && !g_ac_force_stage_cap &&
-        text_len >= (size_t)64 * kAcUnitBytes && !getenv("KREP_GPU_AC_NO_TINY_FUSED") && !getenv("KREP_GPU_AC_NO_TINY"))
+    // not recorded; the count gives the density, and the density the ticket size (1..4 units) of the DENSE flavour — 16-bit ring
+    // entries, matches decoded where they are found — which takes the scan again and the dictionary's next ones (up to ~15 % of
+    // the bytes; a long length included, which the item flavour does not take).  Beyond that, and for 4-byte patterns beside a long
+    // length, the staging road below; every decision is re-evaluated by the following scans.
+    const bool one_pass_ok = t->tiny.ok && !t->tiny.five && want && !ww && list_mode != 2 && track && !g_ac_force_stage_cap &&
+                             text_len >= (size_t)64 * kAcUnitBytes && !getenv("KREP_GPU_AC_NO_TINY_FUSED") && !getenv("KREP_GPU_AC_NO_TINY");
+    // tickets of the DENSE flavour for e matches per unit: two consecutive tickets share the ring, a quarter is left for clustering
+    auto dense_upt = [&](const double e) -> u32 {
+        if (e <= 0.0)
+            return 4u;
+        const double u = (double)ac_tiny_dense_ring() / (2.5 * e);
+        return u >= 4.0 ? 4u : (u32)u;
+    };
+    for (int attempt = 0; one_pass_ok && attempt < 3; ++attempt)
     {
+        const bool dense = t->tiny_dense_upt != 0 && !getenv("KREP_GPU_AC_NO_TINY_DENSE");
+        if (!dense && (!t->tiny_fused_ok || t->tiny.llong))
+            break;
         AcArgs f = a;
-        f.upt = (u32)std::min<u64>(kAcUnitsPerTicketMax, std::max<u64>(1, f.num_tiles / ((u64)num_cu * kTinyWaves * 4)));
+        f.upt = dense ? t->tiny_dense_upt : (u32)std::min<u64>(kAcUnitsPerTicketMax, std::max<u64>(1, f.num_tiles / ((u64)num_cu * kTinyWaves * 4)));
         const u64 n_tk = (f.num_tiles + f.upt - 1) / f.upt;
         if (n_tk > post.tk_cap)
         {
@@ -843,7 +880,7 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
         if (time_it) SCHK(hipEventRecord(ev0, st));
         SCHK(hipMemsetAsync(d_ctr, 0, sizeof(Counters), st));
         SCHK(hipMemsetAsync(post.d_tk, 0, single_fused_scratch_words(n_tk) * sizeof(unsigned long long), st));
-        SCHK(ac_tiny_launch_fused(f, t->tiny, n_tk, (u32)num_cu, st));
+        SCHK(ac_tiny_launch_fused(f, t->tiny, n_tk, (u32)num_cu, st, dense));
         // (the record list -c is counted on: its line gaps behind the scan on the same stream, skipped by the kernel itself when
         //  a ticket overflowed its ring)
         if (lines_on_list && tail_launch_line_gaps(d_text, text_len, global_base, (const uint64_t *)d_pos, &d_ctr->total, &d_ctr->overflow_units,
@@ -852,6 +889,10 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
         if (time_it) SCHK(hipEventRecord(ev1, st));
         SCHK(hipMemcpyAsync(h_ctr, d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, st));
         SCHK(hipStreamSynchronize(st));
+        const double per_unit = (double)h_ctr->total / (double)f.num_tiles;
+        if (getenv("KREP_GPU_DEBUG"))
+            fprintf(stderr, "krep-gpu: tiny one-pass (%s, %u units per ticket): %llu matches, %.1f per unit, %llu waves overflowed\n",
+                    dense ? "dense" : "items", f.upt, (unsigned long long)h_ctr->total, per_unit, (unsigned long long)h_ctr->overflow_units);
         if (!h_ctr->overflow_units)
         {
             if (time_it)
@@ -868,9 +909,32 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
             out->overflow = out->count > cap;
             if (lines_on_list)
                 out->line_count = total <= want ? h_ctr->lines : ~0ull; // ~0: the list did not fit when the gaps were counted
+            if (dense)
+            {
+                // re-evaluated by every scan: the ticket size follows the density, and a text with fewer than 24 matches per unit
+                // goes back to the item flavour (or, with a long length, to the staging road)
+                if (per_unit < 24.0)
+                {
+                    t->tiny_dense_upt = 0;
+                    t->tiny_fused_ok = true;
+                }
+                else
+                    t->tiny_dense_upt = std::max(1u, dense_upt(per_unit));
+            }
             return 0;
         }
-        t->tiny_fused_ok = false; // (re-opened below by a text sparse enough for the rings)
+        // counted, not recorded (the resolver's running sum is the total — unless the spin-limit safety net fired: total 0)
+        u32 nu = (t->tiny_dense_ok && h_ctr->total) ? dense_upt(per_unit) : 0u;
+        if (dense && nu >= t->tiny_dense_upt)
+            nu = t->tiny_dense_upt - 1u; // (clustered matches: the next smaller ticket)
+        if (!dense)
+            t->tiny_fused_ok = false; // (re-opened below by a text sparse enough for the rings)
+        t->tiny_dense_upt = nu;
+        if (!nu)
+        {
+            t->tiny_dense_ok = false; // (re-opened below, like tiny_fused_ok)
+            break;
+        }
     }
     const bool chain = want || lines;
     const u64 n_units = a.num_tiles;
@@ -940,6 +1004,12 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
             t->stage_cap = 64; // the dense road (count pass + emit pass) is left again when a text holds < 32 matches per unit
         if (tiny && !t->tiny_fused_ok && h_ctr->total < n_units * 20) // (a 128-KiB ticket's ring holds ~1000: 125 per unit)
             t->tiny_fused_ok = true;
+        if (tiny && !t->tiny_dense_ok && h_ctr->total < n_units * 20)
+            t->tiny_dense_ok = true;
+        // a dense text through the staging road (a dictionary with a long length starts here: the item flavour of the one-pass
+        // writer does not take it): its next scans take the DENSE flavour, in tickets sized by the density just counted
+        if (tiny && !t->tiny.five && t->tiny_dense_ok && !t->tiny_dense_upt && h_ctr->total >= n_units * 48)
+            t->tiny_dense_upt = dense_upt((double)h_ctr->total / (double)n_units);
         // a byte-set dictionary that proved too dense for the one-pass rings gets them back on a text half as dense as they hold
         if (t->set_n && !t->set_ok && own_hi > a.anchor &&
             (double)h_ctr->total / (double)(own_hi - a.anchor) < 0.5 * single_fused_max_density(kFusedShapeMax))

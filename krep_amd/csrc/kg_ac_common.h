@@ -78,7 +78,8 @@ struct AcTiny
     u32 pk5[kTinyPer], lf5[kTinyPer];
 };
 hipError_t ac_tiny_launch(const AcArgs &a, const AcTiny &td, u64 n_tickets, u32 num_cu, hipStream_t st); // sizes its own grid
-hipError_t ac_tiny_launch_fused(const AcArgs &a, const AcTiny &td, u64 n_tickets, u32 num_cu, hipStream_t st); // one-pass records
+hipError_t ac_tiny_launch_fused(const AcArgs &a, const AcTiny &td, u64 n_tickets, u32 num_cu, hipStream_t st, bool dense = false); // one-pass records
+u32 ac_tiny_dense_ring(); // 16-bit ring entries per wave of its DENSE flavour
 constexpr u32 kTinyRing = 1024; // items (12 bytes: a lane-cell's two length words + its index) per wave of the one-pass kernel's LDS ring:
                                 // the ticket being scanned + the one waiting
 

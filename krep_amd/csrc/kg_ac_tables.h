@@ -26,6 +26,8 @@ struct AcTables
     u32 g4x_mode = 0, g4x_mask = 0, g4x_mul = 0;
     u32 stage_cap = 16; // staged matches per unit (16, raised to 64 by a scan whose units overflowed; see ac_scan)
     AcTiny tiny{};      // ok: the dictionary runs in kg_ac_tiny.hip (every pattern <= 4 bytes, few of them)
+    u32 tiny_dense_upt = 0;    // ... in its DENSE flavour, with tickets of this many units (0: not; set from the density a scan counted)
+    bool tiny_dense_ok = true; // ... until a scan proves too dense for that as well (re-evaluated)
     bool tiny_fused_ok = true; // ... its records in ONE pass (FUSED) — until a scan proves too dense for the rings (re-evaluated)
     // a dictionary of 2..4 distinct single bytes: with records it is the one-pass single-byte scan with a needle SET
     // (kg_single.hip: records at their final index, nothing staged) — until a scan proves too dense for its largest rings

@@ -78,9 +78,15 @@ __device__ __forceinline__ u32 tiny_scramble16(u32 m) // position-ordered 16 bit
 // FIVE: 4-byte patterns AND a long length (AcTiny::five): the long patterns are a fifth class.  Shipped for case-sensitive
 // COUNTING only (168 VGPRs, 3 waves per SIMD: `if else while` 3.4 -> 4.2 TB/s); its one-pass and -i instantiations compile but
 // measured slower than the general kernel at the 2 waves per SIMD they need, and are not dispatched
-template <bool CI, bool LINES, bool KEEP, bool EMIT, bool LONG, bool FUSED = false, bool FIVE = false>
+// DENSE (with FUSED): the one-pass writer for texts on which most lane-cells hold a match (`-e a -e Sherlock`: 3.5 % of the bytes,
+// 577 matches per 16-KiB unit — 440 twelve-byte items, three units and the ring is full).  The matches are decoded WHERE THEY ARE
+// FOUND — at that density a third of the lanes walk, not one in sixty — into 16-bit ring entries, the END's offset in the unit and a
+// two-bit length code, ranked by ballot bit-planes: kg_single.hip's ring with this kernel's compare in front.  Tickets of 1..4
+// units, chosen by the host from the density a scan counted (ac_scan).
+template <bool CI, bool LINES, bool KEEP, bool EMIT, bool LONG, bool FUSED = false, bool FIVE = false, bool DENSE = false>
 __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_kernel(const AcArgs a, const AcTiny td)
 {
+    static_assert(!DENSE || (FUSED && !FIVE), "DENSE is a flavour of the one-pass writer");
     extern __shared__ __attribute__((aligned(16))) u32 s_tiny[];
     const u32 lane = ac_lane(), wave = threadIdx.x >> 6;
     static_assert(!FUSED || (!LINES && !KEEP && !EMIT), "the one-pass record writer is its own mode");
@@ -125,6 +131,36 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
     u32 pend_at = 0, pend_items = 0, wp = 0; // ring position / items of the waiting ticket; write position (modulo kTinyRing at use)
     u32 f_at = 0, f_room = 0, f_items = 0;   // the ticket being scanned: where its items start, how many fit, how many it holds so far
     u32 lane_cnt = 0;                        // ... and this LANE's matches in it (summed over the wave when the ticket ends)
+    // DENSE: 16-bit entries (END offset in the unit << 2 | length code) in the same 12 KiB; f_items / pend_items count MATCHES, and
+    // the matches of the ticket's first three units tell a record's unit (as in kg_single.hip)
+    constexpr u32 kDenseRing = kTinyRing * 6u; // entries
+    unsigned short *ring16 = reinterpret_cast<unsigned short *>(base);
+    u32 u_c0 = 0, u_c1 = 0, u_c2 = 0, u_before = 0, pend_c0 = 0, pend_c1 = 0, pend_c2 = 0;
+    auto dwrap = [](const u32 x) -> u32 { return x >= kDenseRing ? x - kDenseRing : x; };
+    auto flush_dense = [&](const u32 l4) __attribute__((always_inline)) {
+        const u64 first = tk_wait_prefix(a.tk_pref, pend_t, a.ctr, lane);
+        const u64 tbase = a.anchor + pend_t * (u64)a.upt * kAcUnitBytes + a.global_base + 1u; // (+1: one past the END)
+        const u32 b1 = pend_c0, b2 = pend_c0 + pend_c1, b3 = pend_c0 + pend_c1 + pend_c2;
+        const u32 pad = (u32)(first & 7ull); // lanes <-> record indices rounded down to a 128-byte line (kg_single.hip)
+        for (u32 g = lane; g < pend_items + pad; g += 64u)
+        {
+            if (g < pad)
+                continue;
+            const u32 i = g - pad;
+            const u32 ent = ring16[dwrap(pend_at + i)];
+            const u32 unit = (i >= b1 ? 1u : 0u) + (i >= b2 ? 1u : 0u) + (i >= b3 ? 1u : 0u);
+            const u64 idx = first + i;
+            if (idx < a.pos_cap)
+            {
+                const u32 code = ent & 3u, len = code == 3u ? l4 : code + 1u;
+                const u64 en = tbase + (u64)unit * kAcUnitBytes + (ent >> 2), st = en - len;
+                typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 rec = {(u32)st, (u32)(st >> 32), (u32)en, (u32)(en >> 32)};
+                __builtin_nontemporal_store(rec, reinterpret_cast<u32x4 *>(a.positions + 2 * idx));
+            }
+        }
+        pend = false;
+    };
     // the matches of one lane-cell from its two length words, in the reference's order — END ascending, longest first
     // (aho_corasick.c:383-437): put(position e of the END inside the lane's 16 bytes, length)
     auto walk_lane_cell = [&](const u32 cx, const u32 cy, const u32 cz, const u32 l4, const u32 l5, auto put) __attribute__((always_inline)) {
@@ -225,9 +261,10 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
         if (FUSED)
         {
             f_at = wp;
-            f_room = kTinyRing - pend_items; // items this ticket may use while the previous one is still parked
+            f_room = (DENSE ? kDenseRing : kTinyRing) - pend_items; // what this ticket may use while the previous one is still parked
             f_items = 0;
             lane_cnt = 0;
+            u_c0 = u_c1 = u_c2 = u_before = 0;
         }
         for (u64 unit = u_begin; unit < u_end; ++unit)
         {
@@ -460,7 +497,45 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
                             }
                         }
                     }
-                    if constexpr (FUSED)
+                    if constexpr (FUSED && DENSE)
+                    {
+                        const u32 cx = F[0] | (F[1] << 4), cy = F[2] | (F[3] << 4);
+                        const u32 c = (u32)(__popc(cx) + __popc(cy)); // this lane's matches in the cell (<= 64)
+                        if (__ballot(c != 0u))
+                        {
+                            // rank inside the ticket: matches so far (uniform) + exclusive lane prefix, from ballot bit-planes
+                            u32 idx = f_items, tot = 0;
+                            auto plane = [&](const int b) __attribute__((always_inline)) {
+                                const u64 bm = __ballot((c >> b) & 1u);
+                                idx += __builtin_amdgcn_mbcnt_hi((u32)(bm >> 32), __builtin_amdgcn_mbcnt_lo((u32)bm, 0u)) << b;
+                                tot += (u32)__popcll(bm) << b;
+                            };
+                            plane(0);
+                            plane(1);
+                            if (__ballot(c > 3u))
+                            {
+                                plane(2);
+                                plane(3);
+                                if (__ballot(c > 15u))
+                                {
+                                    plane(4);
+                                    plane(5);
+                                    plane(6);
+                                }
+                            }
+                            f_items += tot;
+                            if (c)
+                            {
+                                const u32 rel0 = ((u32)r * (kSegBytes / 16) + (u32)j * kWave + lane) * 16u; // the lane-cell's first byte in the unit
+                                walk_lane_cell(cx, cy, 0u, 4u, 0u, [&](const u32 e, const u32 len) {
+                                    if (idx < f_room)
+                                        ring16[dwrap(f_at + idx)] = (unsigned short)(((rel0 + e) << 2) | (len - 1u)); // (class 4 arrives as 4: code 3)
+                                    ++idx;
+                                });
+                            }
+                        }
+                    }
+                    else if constexpr (FUSED)
                     {
                         const u32 cx = F[0] | (F[1] << 4), cy = F[2] | (F[3] << 4);
                         const u32 c = (u32)(__popc(cx) + __popc(cy) + __popc(F5)); // this lane's matches in the cell
@@ -545,9 +620,9 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
                             }
                             cell(interC, j, D, P, P2);
                         };
-                        if constexpr (FIVE)
+                        if constexpr (FIVE || DENSE)
                         {
-                            // unrolled by construction: with a fifth class the body outgrows the unroller's budget, `#pragma unroll`
+                            // unrolled by construction (the DENSE -i instantiation with a long length has the same problem): with a fifth class the body outgrows the unroller's budget, `#pragma unroll`
                             // is dropped, d[j] is indexed at run time and the round's 128 bytes live in scratch (144 B/lane, 2.3 TB/s)
                             tiny_static_for(std::make_integer_sequence<int, kCells>{}, [&](auto jc) __attribute__((always_inline)) { one_cell(decltype(jc)::value); });
                         }
@@ -592,6 +667,14 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
                 }
             } // rounds
 
+            if constexpr (FUSED && DENSE)
+            { // the unit's matches (selects, not an indexed array: that would live in scratch)
+                const u32 cu = f_items - u_before, uu = (u32)(unit - u_begin);
+                u_before = f_items;
+                u_c0 = uu == 0u ? cu : u_c0;
+                u_c1 = uu == 1u ? cu : u_c1;
+                u_c2 = uu == 2u ? cu : u_c2;
+            }
             u32 wcnt = 0; // matches of the unit (uniform)
             if (KEEP && !LINES && want_pos) // (-c never asks for records: ac_scan)
             {
@@ -753,7 +836,29 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
                 }
             }
         }
-        if constexpr (FUSED)
+        if constexpr (FUSED && DENSE)
+        {
+            if (f_items > f_room)
+                overflowed = true; // too dense for the ring: counted, not recorded — the host picks smaller tickets or the staging road
+            if (lane == 0)
+                __hip_atomic_store(&a.tk_agg[tk], (u64)f_items | kTkReady, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (pend)
+                flush_dense(len4);
+            if (f_items && f_items <= f_room)
+            {
+                pend = true;
+                pend_t = tk;
+                pend_at = f_at;
+                pend_items = f_items;
+                pend_c0 = u_c0;
+                pend_c1 = u_c1;
+                pend_c2 = u_c2;
+                wp = dwrap(f_at + f_items);
+            }
+            else
+                pend_items = 0;
+        }
+        else if constexpr (FUSED)
         {
             u32 tcnt = lane_cnt; // the ticket's matches
 #pragma unroll
@@ -790,7 +895,12 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
     if constexpr (FUSED)
     {
         if (pend)
-            flush(len4, llong);
+        {
+            if constexpr (DENSE)
+                flush_dense(len4);
+            else
+                flush(len4, llong);
+        }
         if (overflowed && lane == 0)
             atomicAdd(&a.ctr->overflow_units, 1ull);
         return; // (the resolver's running sum is the total)
@@ -876,8 +986,31 @@ static hipError_t tiny_launch_fused2(const AcArgs &a, const AcTiny &td, u32 grid
         hipLaunchKernelGGL((ac_tiny_kernel<CI, false, false, false, false, true>), dim3(grid), dim3(kTinyBlock), lds, st, a, td);
     return hipGetLastError();
 }
-hipError_t ac_tiny_launch_fused(const AcArgs &a, const AcTiny &td, u64 n_tickets, u32 num_cu, hipStream_t st)
+// the DENSE flavour: any tiny dictionary without a fifth class, a long length included (tickets of at most 4 units: ac_scan)
+template <bool CI, bool LONG>
+static hipError_t tiny_launch_dense2(const AcArgs &a, const AcTiny &td, u32 grid, hipStream_t st)
 {
+    constexpr u32 lds = kTinyWaves * kTinyRing * 3u * (u32)sizeof(u32);
+    hipLaunchKernelGGL((ac_tiny_kernel<CI, false, false, false, LONG, true, false, true>), dim3(grid), dim3(kTinyBlock), lds, st, a, td);
+    return hipGetLastError();
+}
+u32 ac_tiny_dense_ring() { return kTinyRing * 6u; } // 16-bit entries per wave
+hipError_t ac_tiny_launch_fused(const AcArgs &a, const AcTiny &td, u64 n_tickets, u32 num_cu, hipStream_t st, bool dense)
+{
+    if (dense)
+    {
+        if (td.five || a.upt < 1u || a.upt > 4u)
+            return hipErrorInvalidValue;
+        u32 grid = (u32)std::max<u64>(1, std::min<u64>((n_tickets + kTinyWaves - 1) / kTinyWaves + 1, (u64)num_cu * (u32)KG_TINY_FUSED_WAVES));
+        if (g_s1_force_grid > 0)
+            grid = std::min<u32>(grid, (u32)g_s1_force_grid);
+        g_tiny_launches.fetch_add(1, std::memory_order_relaxed);
+        g_tiny_dense_launches.fetch_add(1, std::memory_order_relaxed);
+        const bool ci = (a.flags & F_CI) != 0;
+        if (td.llong)
+            return ci ? tiny_launch_dense2<true, true>(a, td, grid, st) : tiny_launch_dense2<false, true>(a, td, grid, st);
+        return ci ? tiny_launch_dense2<true, false>(a, td, grid, st) : tiny_launch_dense2<false, false>(a, td, grid, st);
+    }
     u32 grid = (u32)std::max<u64>(1, std::min<u64>((n_tickets + kTinyWaves - 1) / kTinyWaves + 1, (u64)num_cu * (u32)KG_TINY_FUSED_WAVES));
     if (g_s1_force_grid > 0) // test hook: a starved grid (krep_gpu_debug_force_single_grid) — the progress argument of kg_tickets.h
         grid = std::min<u32>(grid, (u32)g_s1_force_grid);

@@ -267,4 +267,8 @@ namespace kg {
 std::atomic<uint64_t> g_tiny_launches{0}; // launches of ac_tiny_kernel
 }
 extern "C" uint64_t krep_gpu_debug_tiny_launches(void) { return kg::g_tiny_launches.load(); }
+namespace kg {
+std::atomic<uint64_t> g_tiny_dense_launches{0}; // ... of its DENSE one-pass flavour
+}
+extern "C" uint64_t krep_gpu_debug_tiny_dense_launches(void) { return kg::g_tiny_dense_launches.load(); }
 

@@ -117,6 +117,7 @@ class Engine:
         L.krep_gpu_debug_single_failovers.restype = C.c_uint64
         L.krep_gpu_debug_single_launches.restype = C.c_uint64
         L.krep_gpu_debug_tiny_launches.restype = C.c_uint64
+        L.krep_gpu_debug_tiny_dense_launches.restype = C.c_uint64
         L.krep_gpu_last_shard_info.restype = None
         L.krep_gpu_last_shard_info.argtypes = [C.POINTER(abi.ShardInfo)]
         L.krep_gpu_available.restype = C.c_int
@@ -165,6 +166,9 @@ class Engine:
 
     def single_launches(self) -> int:
         return int(self.lib.krep_gpu_debug_single_launches())
+
+    def tiny_dense_launches(self) -> int:
+        return int(self.lib.krep_gpu_debug_tiny_dense_launches())
 
     def tiny_launches(self) -> int:
         return int(self.lib.krep_gpu_debug_tiny_launches())

@@ -356,3 +356,79 @@ def test_four_byte_patterns_beside_a_long_length(gpu, oracle_engine, monkeypatch
         assert np.array_equal(allp[order], want[1]), (pats, "windows")
         plan.close()
         del d, pos
+
+
+def test_one_pass_records_on_dense_texts(gpu, oracle_engine):
+    """The DENSE flavour of the one-pass record writer (kg_ac_tiny.hip: matches decoded where they are found into 16-bit ring
+    entries, tickets of 1..4 units sized by the density a scan counted): dictionaries with and without a long length on texts where
+    1-12 % of the bytes end a match.  One plan per dictionary scans a dense text three times (the first scan learns the density —
+    through the overflowing item rings or, with a long length, through the staging road — the next ones write in one pass), a
+    sparse text (back to the other roads), a very dense one (beyond every ring: the staging road) and the dense one again; then
+    ownership windows with a global base, -i, max_count and a starved grid.  Order: aho_corasick.c:383-437."""
+    import torch
+    rng = np.random.RandomState(4711)
+    n = 5 * (1 << 20) + 777
+    mid = cases.rand_text(rng, n, b"aSherlock helo\n" + bytes(range(97, 123)))       # ~3 % 'a', words planted below
+    for w, k in ((b"Sherlock", 3000), (b"hello", 3000), (b"she", 5000)):
+        for at in rng.randint(0, n - 16, k):
+            mid[at:at + len(w)] = np.frombuffer(w, dtype=np.uint8)
+    for at in (16384 - 3, 16384 * 2 - 1, 65536 - 4, 65536 * 3 - 7, n - 8, n - 5):  # across units, tickets and at the end
+        mid[at:at + 5] = np.frombuffer(b"hello", dtype=np.uint8)
+    mid[n - 8:] = np.frombuffer(b"Sherlock", dtype=np.uint8)
+    sparse = cases.rand_text(rng, n, bytes(range(98, 123)) * 3 + b"   \n")
+    thick = cases.rand_text(rng, n, b"ae")                                            # every second byte
+    for pats in ([b"a", b"Sherlock"], [b"e", b"hello"], [b"a", b"e"][:1] + [b"he", b"she"], [b"k", b"lo", b"ello", b"c"],
+                 [b"a", b"b", b"c", b"Sherloc"]):
+        for kw in (dict(), dict(case_sensitive=False)):
+            plan = gpu.plan(abi.Params(pats, **kw))
+            seen_dense = 0
+            for ti, text in enumerate((mid, mid, mid, sparse, thick, mid, mid)):
+                want = oracle_engine.call(abi.RA_AHO_CORASICK, abi.Params(pats, **kw), text)
+                d = torch.from_numpy(text).cuda()
+                cap = int(want[0]) + 9
+                pos = torch.zeros(2 * cap, dtype=torch.int64, device="cuda")
+                before = gpu.tiny_dense_launches()
+                # (six workgroups: every wave scans a dozen tickets, as on a large text — on 5 MiB with the whole chip a wave gets one
+                #  ticket, nothing waits in its ring while it scans, and even the item rings hold this text)
+                gpu.force_single_grid(6)
+                try:
+                    out = plan.scan(d.data_ptr(), n, 0, n, 0, pos.data_ptr(), cap)
+                finally:
+                    gpu.force_single_grid(0)
+                seen_dense += gpu.tiny_dense_launches() - before
+                assert out.count == want[0] and not out.overflow, (pats, kw, ti, out.count, want[0])
+                got = pos[: 2 * out.stored].cpu().numpy().astype(np.uint64).reshape(-1, 2)
+                assert np.array_equal(got, want[1]), (pats, kw, ti)
+                del d, pos
+            assert seen_dense >= 3, (pats, kw, seen_dense)
+            # windows with a global base on the plan that now knows the density: start-offset ownership, merged by (end, start)
+            want = oracle_engine.call(abi.RA_AHO_CORASICK, abi.Params(pats, **kw), mid)
+            d = torch.from_numpy(mid).cuda()
+            cap = int(want[0]) + 16
+            pos = torch.zeros(2 * cap, dtype=torch.int64, device="cuda")
+            parts = []
+            cuts = [0, 5, (1 << 20) + 17, (3 << 20) + 16383, n]
+            for lo, hi in zip(cuts[:-1], cuts[1:]):
+                out = plan.scan(d.data_ptr(), n, lo, hi, 12345, pos.data_ptr(), cap)
+                parts.append(pos[: 2 * out.stored].cpu().numpy().astype(np.uint64).reshape(-1, 2) - 12345)
+            allp = np.concatenate(parts)
+            order = np.lexsort((allp[:, 0], allp[:, 1]))
+            assert np.array_equal(allp[order], want[1]), (pats, kw, "windows")
+            # a starved grid (no circular wait whatever part of the grid runs)
+            for blocks in (1, 3):
+                gpu.force_single_grid(blocks)
+                try:
+                    out = plan.scan(d.data_ptr(), n, 0, n, 0, pos.data_ptr(), cap)
+                finally:
+                    gpu.force_single_grid(0)
+                assert out.count == want[0], (pats, kw, blocks)
+                assert np.array_equal(pos[: 2 * out.stored].cpu().numpy().astype(np.uint64).reshape(-1, 2), want[1]), (pats, kw, blocks)
+            plan.close()
+            del d, pos
+    # max_count through the one-shot entry (two scans of one plan are not available there: the dense road is reached by the retry
+    # of the overflowing item rings)
+    for pats in ([b"a", b"he"], [b"e", b"o", b"lo"]):
+        kw = dict(max_count=4321)
+        want = oracle_engine.call(abi.RA_AHO_CORASICK, abi.Params(pats, **kw), mid)
+        got = gpu.search(abi.Params(pats, **kw), mid)
+        assert got[0] == want[0] and np.array_equal(got[1], want[1]), (pats, got[0], want[0])
