@@ -856,6 +856,9 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
         const double u = (double)ac_tiny_dense_ring() / (2.5 * e);
         return u >= 4.0 ? 4u : (u32)u;
     };
+    const bool dense_first = getenv("KREP_GPU_AC_TINY_DENSE_FIRST") != nullptr; // measurement hook: the DENSE flavour at any density
+    if (dense_first && one_pass_ok && !t->tiny_dense_upt && t->tiny_dense_ok)
+        t->tiny_dense_upt = 4;
     for (int attempt = 0; one_pass_ok && attempt < 3; ++attempt)
     {
         const bool dense = t->tiny_dense_upt != 0 && !getenv("KREP_GPU_AC_NO_TINY_DENSE");
@@ -913,7 +916,7 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
             {
                 // re-evaluated by every scan: the ticket size follows the density, and a text with fewer than 24 matches per unit
                 // goes back to the item flavour (or, with a long length, to the staging road)
-                if (per_unit < 24.0)
+                if (per_unit < 24.0 && !dense_first)
                 {
                     t->tiny_dense_upt = 0;
                     t->tiny_fused_ok = true;

@@ -354,6 +354,11 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
                     //      register (its bytes, last one lowest) + under -i one of letter flags; splats on the scalar unit.
                     u32 HA[4] = {0u, 0u, 0u, 0u}, F[4] = {0u, 0u, 0u, 0u}; // any length, per dword | scrambled mask per length
                     u32 F5 = 0u;                                           // ... of the fifth class (FIVE)
+                    // DENSE: the lane-cell's matches as ONE 64-bit word in emission order — bit 4 e + (4 - class) for a match of that
+                    // class ending at position e: END ascending, longest class first.  Interior rounds build it per dword (Y[w]: a
+                    // nibble per position at bit 8 b, compressed below), boundary rounds from the clipped 16-bit masks.
+                    u32 Y[4] = {0u, 0u, 0u, 0u};
+                    u64 Bx = 0;
                     u32 m16 = 0;                                           // END mask in position order
                     auto one = [&](auto Lc, u32 (&Z)[4], const bool first, const u32 pk, const u32 lf, const u32 pk2, const u32 lf2,
                                    auto longc) __attribute__((always_inline)) {
@@ -419,7 +424,13 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
                             }
                             if (inter)
                             {
-                                if (!kp && !FUSED)
+                                if constexpr (FUSED && DENSE)
+                                {
+#pragma unroll
+                                    for (int w = 0; w < 4; ++w)
+                                        Y[w] |= Z[w] >> (3 + L); // the byte's 0x80 flag -> bit (4 - L) of its nibble
+                                }
+                                else if (!kp && !FUSED)
                                 { // a count: the flags are all that is needed
 #pragma unroll
                                     for (int w = 0; w < 4; ++w) // (v_bcnt_u32_b32 adds its second operand: one instruction per dword)
@@ -447,7 +458,17 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
                                 if (!LINES)
                                     pm &= clip(a.own_lo + lm1, a.own_hi + lm1);
                                 m16 |= pm;
-                                F[L - 1] = tiny_scramble16(pm);
+                                if constexpr (FUSED && DENSE)
+                                { // bit e -> bit 4 e + (4 - L)
+                                    u64 x = pm;
+                                    x = (x | (x << 24)) & 0x000000ff000000ffull;
+                                    x = (x | (x << 12)) & 0x000f000f000f000full;
+                                    x = (x | (x << 6)) & 0x0303030303030303ull;
+                                    x = (x | (x << 3)) & 0x1111111111111111ull;
+                                    Bx |= x << (4 - L);
+                                }
+                                else
+                                    F[L - 1] = tiny_scramble16(pm);
                                 mycnt += (kp || FUSED) ? 0u : (u32)__popc(pm);
                             }
                         }
@@ -499,8 +520,25 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
                     }
                     if constexpr (FUSED && DENSE)
                     {
-                        const u32 cx = F[0] | (F[1] << 4), cy = F[2] | (F[3] << 4);
-                        const u32 c = (u32)(__popc(cx) + __popc(cy)); // this lane's matches in the cell (<= 64)
+                        u32 Blo, Bhi;
+                        if constexpr (inter)
+                        {
+                            u32 g[4];
+#pragma unroll
+                            for (int w = 0; w < 4; ++w)
+                            { // nibbles at bits 0, 8, 16, 24 -> 16 contiguous bits
+                                const u32 t = (Y[w] | (Y[w] >> 4)) & 0x00ff00ffu;
+                                g[w] = (t | (t >> 8)) & 0xffffu;
+                            }
+                            Blo = g[0] | (g[1] << 16);
+                            Bhi = g[2] | (g[3] << 16);
+                        }
+                        else
+                        {
+                            Blo = (u32)Bx;
+                            Bhi = (u32)(Bx >> 32);
+                        }
+                        const u32 c = (u32)(__popc(Blo) + __popc(Bhi)); // this lane's matches in the cell (<= 64)
                         if (__ballot(c != 0u))
                         {
                             // rank inside the ticket: matches so far (uniform) + exclusive lane prefix, from ballot bit-planes
@@ -524,14 +562,23 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
                                 }
                             }
                             f_items += tot;
-                            if (c)
+                            // (a ticket that outgrows its room is lost as a whole — counted, not recorded: no per-entry test)
+                            if (f_items <= f_room)
                             {
-                                const u32 rel0 = ((u32)r * (kSegBytes / 16) + (u32)j * kWave + lane) * 16u; // the lane-cell's first byte in the unit
-                                walk_lane_cell(cx, cy, 0u, 4u, 0u, [&](const u32 e, const u32 len) {
-                                    if (idx < f_room)
-                                        ring16[dwrap(f_at + idx)] = (unsigned short)(((rel0 + e) << 2) | (len - 1u)); // (class 4 arrives as 4: code 3)
-                                    ++idx;
-                                });
+                                // entry = (END offset in the unit << 2) | length code = (lane-cell's first byte << 2) + (bit ^ 3)
+                                const u32 e0 = (((u32)r * (kSegBytes / 16) + (u32)j * kWave + lane) * 16u) << 2;
+                                u32 slot = dwrap(f_at + idx);
+                                auto half = [&](u32 x, const u32 eb) __attribute__((always_inline)) {
+                                    while (x)
+                                    {
+                                        const u32 b = (u32)__builtin_ctz(x);
+                                        x &= x - 1u;
+                                        ring16[slot] = (unsigned short)(eb + (b ^ 3u));
+                                        slot = slot + 1u == kDenseRing ? 0u : slot + 1u;
+                                    }
+                                };
+                                half(Blo, e0);
+                                half(Bhi, e0 + 32u);
                             }
                         }
                     }
