@@ -199,16 +199,28 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
             const u32 cz = FIVE ? (w3 & 0x0f0f0f0fu) : 0u;
             const u32 id = FIVE ? (((w3 >> 4) & 0xfu) | ((w3 >> 8) & 0xf0u) | ((w3 >> 12) & 0xf00u) | ((w3 >> 16) & 0xf000u)) : w3;
             const u32 c = (u32)(__popc(m.x) + __popc(m.y) + __popc(cz));
-            u32 incl = c;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1)
+            // exclusive lane prefix of the match counts from ballot bit-planes (an item holds 1-3 matches: two planes as a rule)
+            u32 excl = 0, tot = 0;
+            auto plane = [&](const int b) __attribute__((always_inline)) {
+                const u64 bm = __ballot((c >> b) & 1u);
+                excl += __builtin_amdgcn_mbcnt_hi((u32)(bm >> 32), __builtin_amdgcn_mbcnt_lo((u32)bm, 0u)) << b;
+                tot += (u32)__popcll(bm) << b;
+            };
+            plane(0);
+            plane(1);
+            if (__ballot(c > 3u))
             {
-                const u32 t = __shfl_up(incl, o);
-                if (lane >= (u32)o)
-                    incl += t;
+                plane(2);
+                plane(3);
+                if (__ballot(c > 15u))
+                {
+                    plane(4);
+                    plane(5);
+                    plane(6);
+                }
             }
-            u64 idx = run + (incl - c);
-            run += __shfl(incl, 63);
+            u64 idx = run + excl;
+            run += tot;
             if (c)
             {
                 const u64 end0 = tbase + (u64)id * 16u + 1u; // one past the END at position 0 of the lane-cell
@@ -229,7 +241,9 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
     u64 acc_total = 0; // chain: wave total (uniform); else this LANE's hits (reduced once, at the end)
     u64 ovf_units = 0; // units of this wave whose matches exceeded the staging slot, and the largest such count (lane 0's copy counts)
     u32 ovf_max = 0;
-    static_assert(KEEP || !LINES, "-c keeps the masks");
+    // LINES without KEEP (round 5): the lines are counted IN the cell — the carry chain of ac_line_pass on the END and newline masks
+    // while they are in registers; nothing goes to LDS, no second pass over the unit, 3 waves per SIMD instead of 2
+    constexpr bool LINL = LINES && !KEEP;
     static_assert(!EMIT || (KEEP && !LINES), "emit mode writes records");
     u32 k7f;
     asm volatile("v_mov_b32 %0, 0x7f7f7f7f" : "=v"(k7f)); // (a vector register on purpose: see the splats in the cell)
@@ -278,6 +292,38 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
             const bool parked = KEEP && !LINES && do_stage && a.stage_cap <= 64u && a.upt <= kAcUnitsPerTicketMax;
             const u64 fbase = do_final ? a.offsets[unit] : 0ull;
             u32 mycnt = 0; // hits in the lane-cells this lane FILTERED (count-only modes)
+            // LINL: the unit's line state (kg_ac_common.h ac_line_pass; l_cnt per lane, the rest uniform)
+            u32 l_cnt = 0, s_new = 0;
+            bool s_open = false, s_seen = false, s_head = false;
+            auto line_cell = [&](const u32 H, const u32 N) __attribute__((always_inline)) {
+                const u64 B_any = __ballot(H != 0u), B_nl = __ballot(N != 0u);
+                if (!B_any)
+                {
+                    if (B_nl)
+                    {
+                        if (!s_seen)
+                        {
+                            s_head = s_open;
+                            s_seen = true;
+                        }
+                        s_open = false;
+                    }
+                    return;
+                }
+                const u32 Hs = H | N;
+                l_cnt += (u32)__popc(H & ~(Hs - ((N << 1) & 0xffffu)));    // first match behind each newline of the lane
+                const u64 B_head = __ballot((H & (Hs ^ (Hs - 1u))) != 0u); // the lane's lowest flag is a match
+                const u64 G = __ballot(H > N), P = ~(B_nl | B_any);        // the highest flag is a match | nothing in the lane
+                const unsigned __int128 sum = (unsigned __int128)(G | P) + G + (s_open ? 1u : 0u);
+                const u64 O = (u64)sum ^ P; // bit l: the line entering lane l already holds a match
+                s_new += (u32)__popcll(B_head & ~O);
+                if (!s_seen && B_nl)
+                {
+                    s_head = (((O | B_head) >> __builtin_ctzll(B_nl)) & 1ull) != 0ull;
+                    s_seen = true;
+                }
+                s_open = (u64)(sum >> 64) != 0ull;
+            };
 
 #pragma unroll 1
             for (int r = 0; r < kAcRounds; ++r)
@@ -435,6 +481,12 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
 #pragma unroll
                                     for (int w = 0; w < 4; ++w) // (v_bcnt_u32_b32 adds its second operand: one instruction per dword)
                                         asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(mycnt) : "v"(Z[w]));
+                                    if (LINL) // (the line cell wants the ENDs of every length)
+                                    {
+#pragma unroll
+                                        for (int w = 0; w < 4; ++w)
+                                            HA[w] |= Z[w];
+                                    }
                                 }
                                 else
                                 { // the length's mask in the scrambled order: 4 shifts instead of 4 multiplies
@@ -601,6 +653,19 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
                             }
                             f_items += (u32)__popcll(bm);
                         }
+                    }
+                    if constexpr (LINL)
+                    {
+                        if (inter)
+                        {
+#pragma unroll
+                            for (int w = 0; w < 4; ++w)
+                                m16 |= ac_movemask4(HA[w]) << (4 * w);
+                        }
+                        u32 nlm = NL;
+                        if (!inter)
+                            nlm &= clip(a.own_lo, a.own_hi);
+                        line_cell(m16, nlm);
                     }
                     if (kp)
                     {
@@ -856,7 +921,14 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
             }
 
             LS2 wls{0, false, false, false};
-            if (LINES) // the distinct lines of the unit that hold a match END, on this lane's own masks
+            if constexpr (LINL)
+            {
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1)
+                    l_cnt += __shfl_xor(l_cnt, o);
+                wls = LS2{l_cnt + s_new, s_seen, s_seen ? s_head : s_open, s_open};
+            }
+            else if (LINES) // the distinct lines of the unit that hold a match END, on this lane's own masks
                 wls = ac_line_pass(kAcRounds * kCells, [&](int rj, u32 &H, u32 &N) {
                     H = h16[(u32)rj * kWave + lane];
                     N = n16[(u32)rj * kWave + lane];
@@ -1016,7 +1088,7 @@ static hipError_t tiny_launch3(const AcArgs &a, const AcTiny &td, u32 grid, hipS
 // staging slot and gets its records from the emit-mode launch; see ac_scan)
 bool ac_tiny_keeps(const AcArgs &a)
 {
-    return (a.flags & F_LINES) || ((a.flags & F_POS) && (a.emit_mode || a.stage_cap));
+    return !(a.flags & F_LINES) && (a.flags & F_POS) && (a.emit_mode || a.stage_cap); // (-c counts its lines in the cell: nothing kept)
 }
 
 // the one-pass record writer: 48 KiB of rings per workgroup, 3 workgroups per CU (registers and LDS alike); one block more than the
@@ -1078,7 +1150,7 @@ hipError_t ac_tiny_launch(const AcArgs &a, const AcTiny &td, u64 n_tickets, u32 
         hipLaunchKernelGGL((ac_tiny_kernel<false, false, false, false, false, false, true>), dim3(grid), dim3(kTinyBlock), 0, st, a, td);
         return hipGetLastError();
     }
-    if (ln) return ci ? tiny_launch3<true, true, true, false>(a, td, grid, st) : tiny_launch3<false, true, true, false>(a, td, grid, st);
+    if (ln) return ci ? tiny_launch3<true, true, false, false>(a, td, grid, st) : tiny_launch3<false, true, false, false>(a, td, grid, st);
     if (emit) return ci ? tiny_launch3<true, false, true, true>(a, td, grid, st) : tiny_launch3<false, false, true, true>(a, td, grid, st);
     if (keep) return ci ? tiny_launch3<true, false, true, false>(a, td, grid, st) : tiny_launch3<false, false, true, false>(a, td, grid, st);
     return ci ? tiny_launch3<true, false, false, false>(a, td, grid, st) : tiny_launch3<false, false, false, false>(a, td, grid, st);
