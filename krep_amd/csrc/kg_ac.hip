@@ -623,6 +623,8 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
 
 int g_ac_force_stage_cap = 0; // test hook (krep_gpu_debug_force_stage_cap)
 
+bool ac_counts_lines_in_registers(const AcTables *t) { return t && t->tiny.ok && !t->tiny.five; }
+
 static u32 ac_lds_bytes(u32 filter_words, bool lines)
 {
     const u32 per_wave = kAcBitmapWords + (lines ? 2u * kAcBitmapWords : 0u);

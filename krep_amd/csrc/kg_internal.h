@@ -95,6 +95,7 @@ int tail_run_replay(const ReplayIn &r, unsigned long long *d_slot, unsigned long
 struct AcTables;
 AcTables *ac_build(const search_params_t &sp, int device);
 void ac_free(AcTables *t);
+bool ac_counts_lines_in_registers(const AcTables *t); // a tiny dictionary: its in-kernel -c road keeps nothing in LDS (kg_ac_tiny.hip)
 int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, int num_cu,
             const uint8_t *d_text, size_t text_len, size_t own_lo, size_t own_hi, size_t global_base,
             match_position_t *d_pos, uint64_t cap, bool ww, bool lines, bool track, size_t max_count, hipStream_t st,

@@ -1091,7 +1091,9 @@ static int scan_ac_lines_on_list(krep_gpu_plan *pl, const Window &w, hipStream_t
     // (~48 ps), the in-kernel line pass 0.1-0.13 ps per byte of text — break-even at one match per ~400 bytes (measured at
     // 32 GiB, profiles/r04_dictionaries.txt: `xq zj`, one per 500 bytes, 3.1 TB/s on the list against 2.2 in the kernel;
     // `er th an`, one per 300, 1.8 against 2.0; `a Sherlock`, one per 28, 0.65 against 2.4).  The plan remembers.
-    const uint64_t dense = w.text_len / 400 + 4096;
+    // (a tiny dictionary counts its lines in registers since round 5 — 3.4-4.4 TB/s whatever the density: the list is ahead only
+    //  below one match per ~1000 bytes; profiles/r05_dictionaries.txt: `he she hers`, one per 811, 3.34 on the list against 3.44)
+    const uint64_t dense = w.text_len / (ac_counts_lines_in_registers(pl->ac) ? 1000 : 400) + 4096;
     if (pl->lines_list_off)
         return 1;
     if (pl->nl_cap == 0)
@@ -1213,7 +1215,7 @@ static int scan_device_impl(krep_gpu_plan_t *pl, const void *d_text, size_t text
                                pl->ev0, pl->ev1, out);
         // the in-kernel road knows the match count too: a text at half the list's break-even density re-opens the list road for
         // the plan's next pieces (the decision was one-way until round 5)
-        if (!rc && pl->lines && pl->lines_list_off && out->total_matches < text_len / 800)
+        if (!rc && pl->lines && pl->lines_list_off && out->total_matches < text_len / (ac_counts_lines_in_registers(pl->ac) ? 2000 : 800))
             pl->lines_list_off = false;
         return rc;
     }
