@@ -57,10 +57,15 @@ for seed in range(7000, 7000 + nseeds):
             cap = int(want[0]) + 3
             pos = torch.zeros(2 * max(cap, 1), dtype=torch.int64, device="cuda")
             plan = gpu.plan(abi.Params(pats, **kw))
-            for rep in range(3):
+            starve = n >= (1 << 20) and rng.rand() < 0.7  # a few workgroups: every wave scans many tickets, the one-pass rings fill
+            for rep in range(4 if starve else 3):         # up as on a large text and the plan moves to the DENSE flavour
                 pos.zero_()
-                out = plan.scan(d.data_ptr(), n, 0, n, 0, pos.data_ptr(), cap)
+                if starve: gpu.force_single_grid(int(rng.randint(2, 8)))
+                try:
+                    out = plan.scan(d.data_ptr(), n, 0, n, 0, pos.data_ptr(), cap)
+                finally:
+                    gpu.force_single_grid(0)
                 g2 = pos[:2 * out.count].cpu().numpy().astype(np.uint64).reshape(-1, 2)
                 if out.count != want[0] or not np.array_equal(g2, want[1]): fail("plan rep", rep, seed, it, pats, kw, n, out.count, want[0])
             plan.close()
-print("soak done:", cases_run, "cases, failures:", bad)
+print("soak done:", cases_run, "cases, failures:", bad, "- launches of the one-pass DENSE flavour:", gpu.tiny_dense_launches())
