@@ -368,6 +368,8 @@ typedef struct krep_gpu_seq_carry
     uint64_t local_last;  /* ... and the line of its last match's start RELATIVE to own_lo, biased by 2^62 (0: no match):   */
                           /* a caller folding out-of-order pieces: nl_before = in.nl_before + local_nl,                      */
                           /* last_line = local_last ? in.nl_before + 1 + (local_last - 2^62) : in.last_line                  */
+    uint64_t local_lines; /* -c through the block loops, the piece that ENDS the text: its canonical line count in front of the   */
+                          /* end-of-text replay, stored + 1 (0: not that piece) — what krep_gpu_replay_tail() starts from         */
 } krep_gpu_seq_carry_t;
 /* krep_gpu_scan_device_ex() for the pieces of one text IN TEXT ORDER: carry_in = the record the previous piece left
  * (NULL: nothing in front of this window is consumed — the piece that starts the text, or an optimistic first pass of a
@@ -379,6 +381,18 @@ int krep_gpu_scan_device_seq(krep_gpu_plan_t *plan, const void *d_text, size_t t
                              size_t global_base, size_t global_len, match_position_t *d_positions, uint64_t position_capacity,
                              void *stream, int time_it, const krep_gpu_seq_carry_t *carry_in, krep_gpu_seq_carry_t *carry_out,
                              krep_gpu_scan_out_t *out);
+/* The end-of-text replay ALONE (-c through the block loops).  The piece that ends the text was scanned with a guessed record
+ * (its shard started before its left neighbours had finished); `carry_true` is what the text in front of it really leaves,
+ * `piece` the record that piece produced (its local_* fields: its own line-skip contribution and local_lines).  d_tail holds the
+ * last tail_len bytes of the text (at least 512, or the whole text) — nothing else of the piece is read again.  Returns in
+ * *lines what krep_gpu_scan_device_seq() would have reported as line_count / count for that piece had it been given carry_true,
+ * and in *carry_out the record it would have left.  (the multi-shard operators re-staged and re-scanned that piece.) */
+int krep_gpu_replay_tail(krep_gpu_plan_t *plan, const void *d_tail, size_t tail_len, size_t global_len, void *stream,
+                         const krep_gpu_seq_carry_t *carry_true, const krep_gpu_seq_carry_t *piece, krep_gpu_seq_carry_t *carry_out,
+                         uint64_t *lines);
+/* test hook: pieces the multi-shard operators scanned AGAIN because their boundary record turned out different (rescans) and
+ * end pieces that only re-ran the end-of-text replay (replays), since the process started */
+void krep_gpu_debug_chain_fixups(uint64_t *rescans, uint64_t *replays);
 /* How a text of text_len bytes may be cut for `params` under the current configuration. */
 enum krep_gpu_split
 {

@@ -92,7 +92,7 @@ class SeqCarry(C.Structure):
     _fields_ = [("resume", C.c_uint64), ("q1", C.c_uint64), ("nl1", C.c_uint64), ("local_q1", C.c_uint64),
                 ("local_nl1", C.c_uint64), ("local_first_nl1", C.c_uint64), ("g0", C.c_uint64), ("local_g0", C.c_uint64),
                 ("local_g0_kind", C.c_uint64), ("nl_before", C.c_uint64), ("last_line", C.c_uint64), ("local_nl", C.c_uint64),
-                ("local_last", C.c_uint64)]
+                ("local_last", C.c_uint64), ("local_lines", C.c_uint64)]
 
 
 SEARCH_FUNC = C.CFUNCTYPE(C.c_uint64, C.POINTER(SearchParams), C.c_char_p, C.c_size_t,

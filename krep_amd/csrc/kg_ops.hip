@@ -508,6 +508,12 @@ static int run_whole(DeviceCtx &cx, const search_params_t *params, const krep_gp
 }
 
 // ------------------------------------------------------------------------------------------------ pieces
+static std::atomic<uint64_t> g_chain_rescans{0}, g_chain_replays{0}; // chain fix-ups since the process started (test hook)
+extern "C" void krep_gpu_debug_chain_fixups(uint64_t *rescans, uint64_t *replays)
+{
+    if (rescans) *rescans = g_chain_rescans.load();
+    if (replays) *replays = g_chain_replays.load();
+}
 namespace {
 struct Piece
 {
@@ -864,7 +870,34 @@ static int run_pieces(const search_params_t *params, const krep_gpu_config_t &cf
                                (p.hi == len && (p.carry_used.q1 != tc.q1 || p.carry_used.nl1 != tc.nl1 || p.carry_used.g0 != tc.g0)) ||
                                p.carry_used.nl_before != tc.nl_before || p.carry_used.last_line != tc.last_line ||
                                (nl_chain && p.carry_used.resume != tc.resume);
-            if (stale)
+            // ... and when the line-skip history is ALL that differs for the piece that ends the text (the rule: every shard
+            // starts from a zero record, so this is every multi-shard -c search through the block loops with an occurrence in an
+            // earlier shard), only the end-of-text replay runs again — on the last 512 bytes of the text, with the piece's own
+            // canonical count and contribution as they stand in its record (krep_gpu_replay_tail)
+            const bool replay_only = stale && p.hi == len && p.carry_out.local_lines != 0 && !nl_chain &&
+                                     std::max<uint64_t>(p.carry_used.resume, p.lo) == std::max<uint64_t>(tc.resume, p.lo) &&
+                                     p.carry_used.nl_before == tc.nl_before && p.carry_used.last_line == tc.last_line &&
+                                     !getenv("KREP_GPU_NO_REPLAY_FIXUP");
+            if (replay_only)
+            {
+                DeviceCtx &cx = *ctx_for(p.device);
+                std::lock_guard<std::mutex> lk(cx.mu);
+                search_params_t local = *params;
+                local.max_count = SIZE_MAX;
+                krep_gpu_plan_t *pl = cx.plan_for(&local, cfg);
+                const size_t tail = std::min<size_t>(len, 512);
+                uint64_t lines = 0;
+                krep_gpu_seq_carry_t co{};
+                if (!pl || cx.mem.ensure(tail + 64, 1, cx.device) || cx.stager.init(cx.device) ||
+                    cx.stager.copy(cx.mem.text(0), buf + (len - tail), tail) ||
+                    krep_gpu_replay_tail(pl, cx.mem.text(0), tail, len, nullptr, &tc, &p.carry_out, &co, &lines))
+                    return 2;
+                p.carry_used = tc;
+                p.carry_out = co;
+                p.out.line_count = p.out.count = p.out.total_matches = lines; // (a -c scan: the count IS the line count; max_count is applied to the fold)
+                g_chain_replays.fetch_add(1, std::memory_order_relaxed);
+            }
+            else if (stale)
             {
                 DeviceCtx &cx = *ctx_for(p.device);
                 std::lock_guard<std::mutex> lk(cx.mu);
@@ -874,6 +907,7 @@ static int run_pieces(const search_params_t *params, const krep_gpu_config_t &cf
                 if (!pl || cx.mem.ensure(p.b1 - p.b0 + 64, 1, cx.device) || cx.stager.init(cx.device) ||
                     cx.stager.copy(cx.mem.text(0), buf + p.b0, p.b1 - p.b0) || scan_one_piece(cx, pl, cx.mem.text(0), &p, len, want_pos, &tc))
                     return 2;
+                g_chain_rescans.fetch_add(1, std::memory_order_relaxed);
             }
             // fold this piece's own contribution onto the true record (for a piece scanned with the true record this
             // reproduces its carry_out)

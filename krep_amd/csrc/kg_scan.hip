@@ -527,6 +527,35 @@ static int last_accepted_before(krep_gpu_plan *pl, const Window &w, const LitRes
     return 0;
 }
 
+// The end-of-text replay of a PIECE: where the reference's block loop stands when it enters the last kReplayWindow bytes follows
+// from the folded boundary record alone (global offsets, stored + 1); `text_g` is indexed with global offsets.
+static int replay_from_record(krep_gpu_plan *pl, int algo, const krep_gpu_seq_carry_t &co, const uint8_t *text_g, uint64_t G,
+                              hipStream_t st, uint64_t *extra)
+{
+    *extra = 0;
+    const uint64_t X = G > kReplayWindow ? G - kReplayWindow : 0, B = algo == KREP_RA_AVX512 ? 64 : algo == KREP_RA_AVX2 ? 32 : 16;
+    uint64_t cur;
+    int open = 0;
+    if (!co.q1)
+        cur = (X / B) * B; // the block grid never left offset 0
+    else if (co.nl1)
+        cur = co.nl1 <= X ? co.nl1 + ((X - co.nl1) / B) * B : co.nl1; // restarted at the line start behind q
+    else if (algo == KREP_RA_NEON)
+    {
+        cur = co.g0 + ((X - co.g0) / B) * B; // no restart on an unterminated line: the previous counted line's grid
+        open = 1;
+    }
+    else
+        cur = G; // unterminated line counted: the clamped advance ended the scan (krep.c:5006-5008, :5211-5213)
+    ReplayIn r{};
+    r.algo = algo; r.m = pl->m; r.ww = pl->ww; r.n = G; r.cur = cur; r.open = open;
+    r.text = text_g;
+    r.pat = pl->d_pat;
+    if (cur < G && tail_run_replay(r, &pl->d_ctr->pad[0], &pl->h_ctr->pad[0], st, extra))
+        return 2;
+    return 0;
+}
+
 static int replay_entry(krep_gpu_plan *pl, int algo, const Window &w, const LitResult &lr, uint64_t X, hipStream_t st,
                         uint64_t *cur_out, int *open_out)
 {
@@ -792,31 +821,16 @@ static int scan_literal(krep_gpu_plan *pl, int algo, const Window &w, match_posi
                     }
                 }
             }
+            if (final_piece)
+                pc.local_lines = lr.lines + 1; // (what krep_gpu_replay_tail() starts from when the record turns out different)
             const krep_gpu_seq_carry_t co = kg::fold_carry(in, pc);
             if (carry_out)
                 *carry_out = co;
             total = lr.total; lines = lr.lines; summary = lr.summary;
             if (final_piece)
             {
-                // where the reference's block loop stands when it enters the last kReplayWindow bytes (replay_entry, global offsets)
-                uint64_t cur, extra = 0;
-                int open = 0;
-                if (!co.q1)
-                    cur = (X / B) * B; // the block grid never left offset 0
-                else if (co.nl1)
-                    cur = co.nl1 <= X ? co.nl1 + ((X - co.nl1) / B) * B : co.nl1; // restarted at the line start behind q
-                else if (algo == KREP_RA_NEON)
-                {
-                    cur = co.g0 + ((X - co.g0) / B) * B; // no restart on an unterminated line: the previous counted line's grid
-                    open = 1;
-                }
-                else
-                    cur = G; // unterminated line counted: the clamped advance ended the scan (krep.c:5006-5008, :5211-5213)
-                ReplayIn r{};
-                r.algo = algo; r.m = m; r.ww = pl->ww; r.n = G; r.cur = cur; r.open = open;
-                r.text = w.d_text - base; // indexed with global offsets >= cur - 1 >= base: inside the buffer
-                r.pat = pl->d_pat;
-                if (cur < G && tail_run_replay(r, d_slot, h_slot, st, &extra))
+                uint64_t extra = 0;
+                if (replay_from_record(pl, algo, co, w.d_text - base, G, st, &extra)) // (global offsets >= cur - 1 >= base: inside the buffer)
                     return 2;
                 // the lines the replay counts are new ones (it starts behind the line of q), and the line open at the piece's
                 // start can only be among them when nothing in front of the piece counted it: the canonical head bit stands
@@ -1243,6 +1257,40 @@ extern "C" int krep_gpu_scan_device_seq(krep_gpu_plan_t *pl, const void *d_text,
     krep_gpu_seq_carry_t zero{};
     return scan_device_impl(pl, d_text, text_len, own_lo, own_hi, global_base, global_len, d_positions, position_capacity, stream,
                             time_it, carry_in ? carry_in : &zero, carry_out, out);
+}
+// The end-of-text replay alone (include/krep_gpu.h): the piece's canonical count and own contribution are in `piece`, the true
+// record of the text in front of it in `carry_true`; only the last bytes of the text are read.
+extern "C" int krep_gpu_replay_tail(krep_gpu_plan_t *pl, const void *d_tail, size_t tail_len, size_t global_len, void *stream,
+                                    const krep_gpu_seq_carry_t *carry_true, const krep_gpu_seq_carry_t *piece,
+                                    krep_gpu_seq_carry_t *carry_out, uint64_t *lines)
+{
+    if (!pl || !d_tail || !piece || !lines)
+        return kg::fail("krep_gpu_replay_tail: NULL argument");
+    if (pl->unsupported)
+        return kg::fail("%s", pl->unsupported);
+    if (pl->ref_algo == KREP_RA_AHO_CORASICK || pl->sp.num_patterns != 1)
+        return kg::fail("krep_gpu_replay_tail: not a single-literal plan");
+    const int algo = mirror_effective(pl->ref_algo, &pl->sp, global_len);
+    const Family fam = family_of(algo, pl->only_matching, pl->lines, pl->ww, pl->track, pl->max_count, pl->has_border, pl->m, pl->has_newline);
+    if (!fam.replay)
+        return kg::fail("krep_gpu_replay_tail: %s under these parameters has no end-of-text replay", krep_gpu_algorithm_name(algo));
+    if (!piece->local_lines)
+        return kg::fail("krep_gpu_replay_tail: the record is not that of the piece that ends the text");
+    const uint64_t G = global_len, need = std::min<uint64_t>(G, 512);
+    if (tail_len > G || tail_len < need)
+        return kg::fail("krep_gpu_replay_tail: the tail must hold the last %llu bytes of the text", (unsigned long long)need);
+    const krep_gpu_seq_carry_t zero{};
+    const krep_gpu_seq_carry_t co = kg::fold_carry(carry_true ? *carry_true : zero, *piece);
+    uint64_t extra = 0;
+    hipStream_t st = (hipStream_t)stream;
+    // (the replay reads global offsets >= cur - 1 with cur >= the block in front of the last kReplayWindow bytes: > G - 512)
+    if (replay_from_record(pl, algo, co, (const uint8_t *)d_tail - (G - tail_len), G, st, &extra))
+        return 2;
+    HIPCHK(hipStreamSynchronize(st));
+    if (carry_out)
+        *carry_out = co;
+    *lines = (piece->local_lines - 1) + extra;
+    return 0;
 }
 extern "C" int krep_gpu_scan_device(krep_gpu_plan_t *pl, const void *d_text, size_t text_len, size_t own_lo, size_t own_hi,
                                     size_t global_base, match_position_t *d_positions, uint64_t position_capacity,

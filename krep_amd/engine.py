@@ -117,6 +117,8 @@ class Engine:
         L.krep_gpu_debug_single_failovers.restype = C.c_uint64
         L.krep_gpu_debug_single_launches.restype = C.c_uint64
         L.krep_gpu_debug_tiny_launches.restype = C.c_uint64
+        L.krep_gpu_debug_chain_fixups.restype = None
+        L.krep_gpu_debug_chain_fixups.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.krep_gpu_debug_tiny_dense_launches.restype = C.c_uint64
         L.krep_gpu_last_shard_info.restype = None
         L.krep_gpu_last_shard_info.argtypes = [C.POINTER(abi.ShardInfo)]
@@ -166,6 +168,12 @@ class Engine:
 
     def single_launches(self) -> int:
         return int(self.lib.krep_gpu_debug_single_launches())
+
+    def chain_fixups(self):
+        """(pieces scanned again, end pieces that only re-ran the end-of-text replay) since the process started"""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self.lib.krep_gpu_debug_chain_fixups(C.byref(a), C.byref(b))
+        return int(a.value), int(b.value)
 
     def tiny_dense_launches(self) -> int:
         return int(self.lib.krep_gpu_debug_tiny_dense_launches())

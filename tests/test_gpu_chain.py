@@ -160,6 +160,7 @@ def test_block_loop_count_lines_in_pieces(gpu, oracle_engine, shards):
     only the last one replays the end; the history {last accepted occurrence, first newline behind it} rides on the boundary
     record.  Sharded and streamed, against the compiled reference."""
     rng = np.random.RandomState(900 + shards)
+    fix0 = gpu.chain_fixups()
     jobs = [(abi.REF_AVX512, 40, dict(count_lines=True)), (abi.REF_AVX512, 64, dict(count_lines=True, whole_word=True)),
             (abi.REF_AVX2, 20, dict(count_lines=True, whole_word=True)), (abi.REF_AVX2, 32, dict(count_lines=True, whole_word=True)),
             (abi.REF_AVX512, 33, dict(count_lines=True)),
@@ -208,6 +209,11 @@ def test_block_loop_count_lines_in_pieces(gpu, oracle_engine, shards):
                     finally:
                         gpu.set_stream_chunk(0)
     gpu.set_reference_simd(abi.REF_AVX2)
+    # the piece that ends the text is the only one that depends on the record, and only through its end-of-text replay: where
+    # the record of the text in front of it turned out different, the replay alone ran again (krep_gpu_replay_tail) — no piece
+    # of this family was staged and scanned a second time
+    rescans, replays = (b - a for a, b in zip(fix0, gpu.chain_fixups()))
+    assert replays > 0 and rescans == 0, (rescans, replays)
 
 
 def test_rccl_all_reduce_really_runs(gpu, oracle_engine):
