@@ -254,9 +254,9 @@ search_func_t krep_gpu_select_search_algorithm(const search_params_t *params);
 /* 1 when the backend takes the search for `params` under the current configuration, 0 when not:
  *   - no usable gfx950 device (krep_gpu_available() == 0);
  *   - no pattern at all (num_patterns == 0 and pattern == NULL);
- *   - use_regex;
- *   - count_lines_mode together with only_matching through memchr_short_search (unreachable from the reference CLI,
- *     krep.c:3811-3814).
+ *   - use_regex.
+ * (count_lines_mode together with only_matching through memchr_short_search — a combination krep's main() never produces,
+ * krep.c:3811-3814 — was refused until round 5 and is reproduced now: one window, krep_gpu_split_mode() = WHOLE.)
  * An operator called with such params anyway treats it like a run-time failure (see the top of this header): the
  * registered CPU function answers, or status KREP_GPU_FAILED; nothing is silently approximated. */
 int krep_gpu_can_accelerate(const search_params_t *params);
@@ -396,7 +396,8 @@ void krep_gpu_debug_chain_fixups(uint64_t *rescans, uint64_t *replays);
 /* How a text of text_len bytes may be cut for `params` under the current configuration. */
 enum krep_gpu_split
 {
-    KREP_GPU_SPLIT_WHOLE = 0,  /* one window only: neon_search's max_count == 0 corner                                     */
+    KREP_GPU_SPLIT_WHOLE = 0,  /* one window only: neon_search's max_count == 0 corner, and -c with -o through
+                                  memchr_short_search (never produced by krep's main())                                    */
     KREP_GPU_SPLIT_PIECES = 1, /* independent pieces: start-offset ownership + halo, results concatenate / merge          */
     KREP_GPU_SPLIT_CHAIN = 2   /* pieces in text order through krep_gpu_scan_device_seq() (round 5: also -c with a newline
                                   inside a pattern, multi-pattern and through simd_sse42_search / kmp_search)             */

@@ -67,6 +67,16 @@ __device__ __forceinline__ Visit g_visit(const WalkSpec &ws, u64 sj, u64 base, c
         else if (p + m < text_len && g_wordc(text[p + m]))
             ok = false;
     }
+    if (ok && ws.mode == kWalkShortOLines)
+    {
+        // -c: the line is counted and the scan continues at the start of the next line (krep.c:4460-4468: find_line_end from the
+        // line's start = the first '\n' at or behind the match start — there is none between the two)
+        u64 q = p;
+        while (q < text_len && text[q] != '\n')
+            ++q;
+        const u64 next = q < text_len ? q + 1 : text_len;
+        return Visit{true, (u32)std::min<u64>(next - p, 0xffffffffull)};
+    }
     return Visit{ok, ok ? m : 1u}; // krep.c:4441-4446: a -w rejected match resumes one byte further
 }
 
@@ -137,7 +147,8 @@ __global__ __launch_bounds__(kGB) void g_next(const u64 *__restrict__ occ, u64 n
             hi = mid;
     }
     jump[i] = lo; // n = end of the list
-    visited[i] = (i == 0 || s - occ[2 * (i - 1)] >= ws.m) ? 1 : 0;
+    // (-c -o through memchr_short_search: a line jump passes any number of candidates — only the list's first one is a head)
+    visited[i] = (i == 0 || (ws.mode != kWalkShortOLines && s - occ[2 * (i - 1)] >= ws.m)) ? 1 : 0;
 }
 __global__ __launch_bounds__(kGB) void g_jump_mark(const u64 *__restrict__ jump, u64 n, const uint8_t *__restrict__ vin,
                                                    uint8_t *__restrict__ vout)
@@ -459,14 +470,18 @@ int post_walk(PostScratch &s, const uint8_t *d_text, uint64_t text_len, uint64_t
     }
     const u64 *occ = (const u64 *)s.d_occ;
     const u32 g1 = (u32)((n_occ + kGB - 1) / kGB);
-    const u32 set_len = ws.mode == kWalkShortO ? ws.m : 0u;
+    const u32 set_len = ws.mode != kWalkGreedy ? ws.m : 0u;
+    const bool chain_only = ws.mode == kWalkShortOLines; // no cluster structure: the parallel form from the list's first element
     GCHK(hipMemsetAsync(s.d_keep, 0, n_occ, st));
     GCHK(hipMemsetAsync(&d_ctr->pad[1], 0, sizeof(u64), st));
-    hipLaunchKernelGGL(g_walk, dim3(g1), dim3(kGB), 0, st, occ, (u64)n_occ, (u64)global_base, d_text, (u64)text_len, ws, s.d_keep,
-                       (u32 *)&d_ctr->pad[1]);
-    GCHK(hipMemcpyAsync(h_ctr, d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, st));
-    GCHK(hipStreamSynchronize(st));
-    if (h_ctr->pad[1] || getenv("KREP_GPU_FORCE_POINTER_JUMPING"))
+    if (!chain_only)
+    {
+        hipLaunchKernelGGL(g_walk, dim3(g1), dim3(kGB), 0, st, occ, (u64)n_occ, (u64)global_base, d_text, (u64)text_len, ws, s.d_keep,
+                           (u32 *)&d_ctr->pad[1]);
+        GCHK(hipMemcpyAsync(h_ctr, d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, st));
+        GCHK(hipStreamSynchronize(st));
+    }
+    if (chain_only || h_ctr->pad[1] || getenv("KREP_GPU_FORCE_POINTER_JUMPING"))
     {
         // a giant cluster: redo the pass in its parallel form (pointer jumping, ceil(log2 n) rounds)
         u64 *jmp = nullptr;
@@ -503,7 +518,7 @@ int post_walk(PostScratch &s, const uint8_t *d_text, uint64_t text_len, uint64_t
         hipLaunchKernelGGL(g_ww, dim3(g1), dim3(kGB), 0, st, occ, (u64)n_occ, (u64)global_base, d_text, (u64)text_len, ws.m, s.d_keep);
     hipLaunchKernelGGL(g_count, dim3((u32)nb), dim3(kGB), 0, st, (const uint8_t *)s.d_keep, (u64)n_occ, (u64 *)s.d_gblk);
     hipLaunchKernelGGL(g_scan, dim3(1), dim3(64), 0, st, (u64)nb, (u64 *)s.d_gblk, d_ctr);
-    if (ws.lines)
+    if (ws.lines && !chain_only) // (kWalkShortOLines: every kept element IS a counted line — the count is the answer)
     {
         hipLaunchKernelGGL(g_scatter, dim3((u32)nb), dim3(kGB), 0, st, occ, (const uint8_t *)s.d_keep, (u64)n_occ,
                            (const u64 *)s.d_gblk, (u64 *)s.d_surv, (u64)n_occ, set_len);
@@ -524,7 +539,7 @@ int post_walk(PostScratch &s, const uint8_t *d_text, uint64_t text_len, uint64_t
     GCHK(hipMemcpyAsync(h_ctr, d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, st));
     GCHK(hipStreamSynchronize(st));
     *total = h_ctr->total;
-    *nlines = ws.lines ? h_ctr->lines : 0;
+    *nlines = chain_only ? h_ctr->total : (ws.lines ? h_ctr->lines : 0);
     if (resume)
         *resume = h_ctr->pad[1];
     return 0;

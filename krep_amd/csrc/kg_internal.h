@@ -56,6 +56,8 @@ int post_gather_pass(PostScratch &s, uint64_t n_units, uint32_t stage_cap, uint3
 // kg_greedy.hip — the sequential match-set families, walked cluster by cluster on the ordered list in s.d_occ
 constexpr uint32_t kWalkGreedy = 0; // simd_sse42_search / kmp_search (and BMH under -o): greedy non-overlapping occurrences
 constexpr uint32_t kWalkShortO = 1; // memchr_short_search under -o: first-byte candidates, m skipped after a failed one too
+constexpr uint32_t kWalkShortOLines = 2; // ... with -c as well (krep.c:4449-4470): an accepted match counts its line and sends the
+                                         // walk to the next line start — every visited accepted candidate is one counted line
 struct WalkSpec
 {
     uint32_t mode, m;

@@ -174,11 +174,8 @@ const char *unsupported_reason(const search_params_t *p, const krep_gpu_config_t
         q.pattern_len = p->pattern_lens[0];
     }
     p = &q;
-    const int top = mirror_top(p, c);
-    const int eff = mirror_effective(top, p, SIZE_MAX / 2);
-    if (p->count_lines_mode && c.only_matching && eff == KREP_RA_MEMCHR_SHORT)
-        return "memchr_short_search with count_lines_mode AND only_matching is not accelerated (unreachable from the "
-               "reference CLI, krep.c:3811-3814)";
+    // (round 5: count_lines_mode AND only_matching through memchr_short_search — a combination krep's main() never produces,
+    //  krep.c:3811-3814 — is taken too: kg_greedy.hip, kWalkShortOLines; nothing on this path is refused any more)
     return nullptr;
 }
 } // namespace kg

@@ -441,8 +441,8 @@ int split_mode(const search_params_t *p, const krep_gpu_config_t &c, size_t text
             b = lo8(b);
     const Family fam = family_of(algo, c.only_matching != 0, p->count_lines_mode, p->whole_word, p->track_positions, p->max_count,
                                  pattern_has_border(f.data(), m), (uint32_t)m, memchr(pat, '\n', m) != nullptr);
-    if (fam.neon_zero)
-        return kSplitWhole;
+    if (fam.neon_zero || (fam.mshort_o && p->count_lines_mode))
+        return kSplitWhole; // (the second: a class krep's main() never produces, krep.c:3811-3814 — one window, no boundary record)
     return (fam.need_walk || fam.replay || fam.nlwalk) ? kSplitChain : kSplitPieces;
 }
 bool shardable(const search_params_t *p, const krep_gpu_config_t &c, size_t text_len) { return split_mode(p, c, text_len) != kSplitWhole; }
@@ -918,7 +918,10 @@ static int scan_literal(krep_gpu_plan *pl, int algo, const Window &w, match_posi
             return 2;
         uint64_t resume_out = 0;
         WalkSpec ws{};
-        ws.mode = mshort_o ? kWalkShortO : kWalkGreedy;
+        ws.mode = mshort_o ? (pl->lines ? kWalkShortOLines : kWalkShortO) : kWalkGreedy;
+        if (ws.mode == kWalkShortOLines && !whole)
+            return kg::fail("-c -o through memchr_short_search jumps to the next line start after every counted line: scan the whole "
+                            "text in one window");
         ws.m = m;
         ws.ww = pl->ww && !ww_first;
         ws.lines = pl->lines;

@@ -3,7 +3,7 @@
   * memchr_short_search under -o (skip after a failed candidate, krep.c:4495),
   * multi-pattern -c with a newline inside a pattern (emission-order line changes, aho_corasick.c:383-396),
   * neon_search (krep.c:4506-4694) as a reproduced reference build,
-  * the two classes left to the CPU: the selector returns NULL and the operator refuses loudly,
+  * what is left to the CPU (regex): the selector returns NULL; -c with -o through memchr_short_search, refused until round 5,
   * sharded scans place the AVX-512 / AVX2 tail quirks by the WHOLE text's length; bordered -o patterns stay whole.
 Everything is compared bit-exactly with the oracle restatement (itself pinned to the compiled reference)."""
 import threading
@@ -154,6 +154,26 @@ def test_memchr_short_under_only_matching(gpu, oracle_engine, seed):
         algo = _check(gpu, oracle_engine, text, [pat], kw, level, only_matching=True)
         n_short += algo == abi.RA_MEMCHR_SHORT
     assert n_short > 40
+    # count_lines_mode AND the file-static only_matching together — a combination krep's main() never produces (krep.c:3811-3814:
+    # -c with -o counts matches), refused until round 5, reproduced now: an accepted match counts its line and sends the scan to
+    # the next line start, a failed first-byte candidate still skips pattern_len bytes (krep.c:4449-4470, :4495).  The restatement
+    # is the only oracle this class can have (the compiled reference's only_matching is file-static and the CLI cannot set both).
+    n_lines = 0
+    for i in range(60):
+        alpha = [b"ab\n", b"abA \n", b"aAbB \n", b"ab_ \n\n", b"aab\n", b"ab"][i % 6]
+        n = [2, 3, 17, 100, 1000, 8200, 33000, 70001, 300000, (1 << 20) + 13][rng.randint(0, 10)]
+        text = cases.rand_text(rng, n, alpha)
+        m = 2 + (i % 2)
+        pat = cases.pick_pattern(rng, text, m, alpha) if i % 7 else cases.pick_pattern(rng, text, m, alpha.replace(b"\n", b""))
+        if n < m:
+            continue
+        cs = bool(rng.rand() < 0.4)
+        level = abi.REF_SCALAR if cs else abi.REF_AVX2
+        kw = dict(case_sensitive=cs, whole_word=bool(rng.rand() < 0.3), count_lines=True,
+                  max_count=[abi.SIZE_MAX, abi.SIZE_MAX, abi.SIZE_MAX, 0, 1, 5][rng.randint(0, 6)])
+        algo = _check(gpu, oracle_engine, text, [pat], kw, level, only_matching=True)
+        n_lines += algo == abi.RA_MEMCHR_SHORT
+    assert n_lines > 30
     # the textbook case: "ab" in "aab" — the failed candidate at 0 hides the match at 1
     t = np.frombuffer(b"aab aab xaab", dtype=np.uint8)
     gpu.set_reference_simd(abi.REF_SCALAR)
@@ -193,11 +213,13 @@ def test_classes_left_to_the_cpu_are_refused_loudly(gpu):
     assert gpu.can_accelerate(abi.Params([b"a\nb" * 7], count_lines=True))  # 21 bytes -> AVX2 body: reproduced
     gpu.set_only_matching(True)
     try:
-        q = abi.Params([b"ab"], case_sensitive=False, count_lines=True)   # memchr_short -c with -o: unreachable from the CLI
-        assert not gpu.can_accelerate(q) and gpu.select(q) is None
-        with pytest.raises(krep_amd.KrepGpuError):
-            gpu.search(q, t)
-        assert gpu.search_buffer(q, t, only_matching=True)[0] == 2
+        q = abi.Params([b"ab"], case_sensitive=False, count_lines=True)   # memchr_short -c with -o: unreachable from the CLI,
+        assert gpu.can_accelerate(q) and gpu.select(q) is not None        # refused until round 5, reproduced now (one window)
+        assert gpu.split_mode(q, t.size) == abi.SPLIT_WHOLE
+        assert gpu.search(q, t)[0] == 0                                   # no "ab" in the text: no line
+        q2 = abi.Params([b"a\n"], count_lines=True)
+        assert gpu.search(q2, t)[0] == 100                                 # every "a\n" counts the line that ends with it
+        assert gpu.search_buffer(q2, t, only_matching=True, num_gpus=3)[1] == 100  # (one window whatever the shards asked for)
     finally:
         gpu.set_only_matching(False)
     r = abi.Params([b"a.*b"])
