@@ -334,3 +334,62 @@ def test_dense_literal_1gib_overflowing_slots(gpu):
     inside = first[(first >= lo) & (first + len(PAT) <= hi)].cpu().numpy()
     assert np.array_equal(wpos[:, 0].astype(np.int64) + lo, inside)
     plan.close()
+
+
+def test_one_pass_writers_8gib_properties(gpu):
+    """The round-5 one-pass record writers at a size where a wave scans hundreds of tickets and the resolver runs over 10^5 of them
+    (the small-text tests reach them through starved grids): a dense 2-byte literal (kg_single.hip MULTI), a dense dictionary with
+    a long length (kg_ac_tiny.hip DENSE) and a sparse one (its item flavour), 8 GiB of the config-2 text.  Properties that do not
+    need the oracle: the count equals the count-only scan's; the list is in the reference's order (END ascending, longest first)
+    and has no duplicates; every record holds one of the patterns; the number of records of a single-byte pattern equals an
+    independent device-side count of that byte — and windows of the list equal the compiled reference's."""
+    import torch
+    n = 8 * GIB
+    free, _ = torch.cuda.mem_get_info()
+    if free < n + (24 << 30):
+        pytest.skip("not enough free HBM")
+    buf = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+    gpu.generate(buf.data_ptr(), n, 0, 2, SEED, PAT, PERIOD)
+    o = ol.checker()
+    jobs = [([b" a"], "single"), ([b"a", b"Sherlock"], "dense"), ([b"he", b"she", b"hers"], "items")]
+    for pats, road in jobs:
+        algo = abi.RA_AHO_CORASICK if len(pats) > 1 else gpu.mirror_select(abi.Params(pats), n)
+        cnt = gpu.plan(abi.Params(pats, count_lines=True, only_match=True)).scan(buf.data_ptr(), n).count
+        cap = cnt + 4096
+        pos = torch.empty(2 * cap, dtype=torch.int64, device="cuda")
+        plan = gpu.plan(abi.Params(pats))
+        before = (gpu.single_launches(), gpu.tiny_dense_launches(), gpu.tiny_launches())
+        for rep in range(3):  # (the first scan of a plan learns the density; the later ones take the road it chose)
+            pos.zero_()
+            out = plan.scan(buf.data_ptr(), n, 0, n, 0, pos.data_ptr(), cap)
+            assert out.count == out.stored == cnt and not out.overflow, (pats, rep, out.count, cnt)
+        after = (gpu.single_launches(), gpu.tiny_dense_launches(), gpu.tiny_launches())
+        took = {"single": after[0] - before[0], "dense": after[1] - before[1], "items": (after[2] - before[2]) - (after[1] - before[1])}[road]
+        assert took >= 2, (pats, road, before, after)
+        rec = pos[: 2 * cnt].view(-1, 2)
+        st, en = rec[:, 0], rec[:, 1]
+        # order: END ascending, longest first among equal ENDs (a single literal: starts ascending) — and no duplicates
+        assert bool(torch.all((en[1:] > en[:-1]) | ((en[1:] == en[:-1]) & (st[1:] > st[:-1])))), pats
+        assert int(st.min()) >= 0 and int(en.max()) <= n
+        ln = en - st
+        seen = torch.zeros(cnt, dtype=torch.bool, device="cuda")
+        for p in pats:
+            sel = ln == len(p)
+            ss = st[sel]
+            ok = torch.ones(ss.numel(), dtype=torch.bool, device="cuda")
+            for k, c in enumerate(p):  # (byte by byte: no (records x length) gather of a billion rows)
+                ok &= buf[ss + k] == c
+            assert bool(torch.all(ok)), (pats, p)
+            seen |= sel
+            if len(p) == 1:
+                assert int(sel.sum()) == int(torch.count_nonzero(buf[:n] == p[0])), (pats, p)
+        assert bool(torch.all(seen)), pats
+        # windows against the compiled reference (records are owned by their START in a window scan: select by start)
+        for lo in (0, (3 << 30) - 70_000, n - (1 << 20)):
+            hi = min(n, lo + (1 << 20))
+            want = o.call(algo, abi.Params(pats), buf[lo:hi].cpu().numpy())[1].astype(np.int64)
+            inside = (st >= lo) & (en <= hi)
+            got = rec[inside].cpu().numpy()
+            assert np.array_equal(got - lo, want), (pats, lo)
+        plan.close()
+        del pos
