@@ -26,7 +26,7 @@ engs[0][1].generate(buf.data_ptr(), n, 0, wl["kind"], 42, wl["plant"], wl["perio
 if os.environ.get("AB_PATTERN"):
     wl["patterns"] = [os.environ["AB_PATTERN"].encode()]
 kw = dict(count_lines=True, only_match=True) if mode == "count" else dict(count_lines=True) if mode == "lines" else {}
-cap = (n // 50 if kind == 3 else n // 1500) + 4096 if mode == "pos" else 0
+cap = (n // int(os.environ.get("AB_CAP_DIV", "50" if kind == 3 else "1500"))) + 4096 if mode == "pos" else 0  # (AB_CAP_DIV: denser patterns through AB_PATTERN)
 pos = torch.empty(2 * cap, dtype=torch.int64, device="cuda") if cap else None
 plans = []
 for name, e in engs:  # the environment of a variant also holds while its plan (and tables) are built
