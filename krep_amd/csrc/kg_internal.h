@@ -21,8 +21,8 @@ hipError_t launch_literal(const LitArgs &a, uint32_t num_cu, hipStream_t st); //
 // kg_single.hip — single byte with records in one pass (counts resolved by one wave, records written a ticket later)
 uint64_t single_fused_tickets(uint64_t n_units, int shape);
 uint64_t single_fused_scratch_words(uint64_t n_tickets);
-constexpr int kFusedShapeMax = 3;
-double single_fused_max_density(int shape); // hits per byte a shape's rings are sure to hold (shape 0 / 1 / 2 / 3: ~1.2 / 5 / 10 / 20 %)
+constexpr int kFusedShapeMax = 5;
+double single_fused_max_density(int shape); // hits per byte a shape's rings are sure to hold (shapes 0..5: ~1.2 / 3.7 / 5 / 7.5 / 10 / 20 %)
 hipError_t launch_single_fused(const LitArgs &a, unsigned long long *d_agg, unsigned long long *d_pref, uint64_t n_tickets,
                                uint32_t num_cu, int shape, hipStream_t st);
 

@@ -40,9 +40,9 @@ struct krep_gpu_plan
     uint32_t ac_cap = 16;     // the same for the multi-pattern scan (16 KiB units)
     bool fused1_ok = true;    // single byte with records: the one-pass kernel (kg_single.hip) until a scan proves too dense for it
     bool fusedk_on = false;   // a 2..8-byte literal with records: the same kernel's MULTI instantiations, switched on by a two-pass scan that
-    bool fusedk_never = false; // ... counted a density its staging slots do not hold (lit_pass); never again once a ring overflowed beyond shape 3
+    bool fusedk_never = false; // ... counted a density its staging slots do not hold (lit_pass); never again once a ring overflowed beyond the last shape
     int fusedk_shape = 0;
-    int fused1_shape = 0;     // ... its ticket / ring shape (0: <= ~1.2 % hits, 1: <= ~5 %, 2: <= ~10 %), raised by the density a scan counted
+    int fused1_shape = 0;     // ... its ticket / ring shape (0..5: <= ~1.2 / 3.7 / 5 / 7.5 / 10 / 20 % hits, kg_single.hip), raised by the density a scan counted
     match_position_t *d_nl_rec = nullptr; // multi-pattern -c with a newline inside a pattern (scan_ac_newline_lines): the
     uint64_t *d_nl_ln = nullptr;          // ordered record list and the line number of every start; grow-only
     uint64_t nl_cap = 0;

@@ -207,7 +207,7 @@ static int lit_pass(krep_gpu_plan *pl, const Window &w, const LitPass &ps, hipSt
     res->anchor = a.anchor;
     // ---- single byte with records (memchr_search, BASELINE config 3): ONE pass, the records written by the scanning waves
     // at their final index (kg_single.hip) — no staging, no info words, no post-pass.  A scan too dense for the rings of its
-    // shape is counted but not recorded: the count picks the shape that holds it (up to ~10 % hits) and the scan runs again in
+    // shape is counted but not recorded: the count picks the shape that holds it (up to ~20 % hits) and the scan runs again in
     // that shape — the plan keeps it; beyond that the two-pass kernels below take this scan and the plan's later ones.
     // The same kernel takes a literal of 2..8 bytes (its MULTI instantiations) once a two-pass scan of the plan has counted a
     // density at which the staging slots of the sparse kinds overflow (`-i sh`: 35 hits per unit; ` a`: 180): pl->fusedk_on.

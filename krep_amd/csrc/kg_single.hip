@@ -31,10 +31,10 @@
 //   subset of the grid runs.  (tests/test_gpu_literal.py::test_single_byte_one_pass_with_a_starved_grid forces 1-, 2- and 3-block
 //   grids over 8 192 tickets.)
 // A ticket with more hits than the ring holds raises ctr->overflow_units (the scan still COUNTS: the resolver's running sum is
-// the total).  Four shapes (template parameters UPT = 32-KiB units per ticket, RING = 16-bit entries per wave, WPE = waves per
-// SIMD): 128-KiB tickets / 8 KiB of ring / 16 waves per CU for up to ~1.5 % hits (BASELINE config 3); 64-KiB tickets / 16 KiB /
-// 8 waves for up to ~5 %; 32-KiB tickets / 16 KiB / 8 waves for up to ~10 %; 32-KiB tickets / 32 KiB / 4 waves for up to ~20 %
-// (80 tickets per microsecond is what one counter gives: fine while the records, 16 bytes per hit, are most of the traffic).  The host picks the shape from the density the
+// the total).  Six shapes (template parameters UPT = 32-KiB units per ticket, RING = 16-bit entries per wave, WPE = waves per
+// SIMD; the table is in front of launch_shape below): from 128-KiB tickets / 8 KiB of ring / 16 waves per CU for up to ~1.2 % hits
+// (BASELINE config 3) to 32-KiB tickets / 32 KiB / 4 waves for up to ~20 % (80 tickets per microsecond is what one counter gives:
+// fine while the records, 16 bytes per hit, are most of the traffic).  The host picks the shape from the density the
 // first scan of a plan counted (kg_scan.hip, lit_pass) and falls back to the two-pass kernels beyond that.
 // SET: up to four needle bytes instead of one — a dictionary of single-byte patterns (`-e e -e t`) is this scan with a set
 // (aho_corasick_search reports such matches in text order, one per position: the records are memchr_search's).
@@ -64,7 +64,7 @@ using u64 = unsigned long long;
 constexpr u32 kUptStd = KG_S1_UPT;            // units (32 KiB each) per ticket: 128 KiB (at most 4: the flush tells units apart by three bounds)
 static_assert(kUptStd >= 1 && kUptStd <= 4, "flush() derives a record's unit from three boundaries");
 constexpr u32 kRingStd = 1024u * kUptStd;     // 16-bit entries per wave: the ticket being scanned + the one waiting
-constexpr u32 kRingDense = 8192u;             // ... of the two dense shapes (16 KiB per wave: 2 workgroups per CU)
+constexpr u32 kRingDense = 8192u;             // ... of the dense shapes (16 KiB per wave: 2 workgroups per CU; kRingMid = 12 KiB: 3)
 constexpr u32 kRingDensest = 16384u;          // ... of the densest one (32 KiB per wave: one workgroup per CU)
 constexpr u64 kReady = kTkReady;              // (the resolver itself: kg_tickets.h, shared with kg_ac_tiny.hip)
 constexpr u64 kUnitBytes1 = (u64)kRoundsBig * kSegBytes;
@@ -104,7 +104,14 @@ __global__ __launch_bounds__(kBlock, WPE) void single_fused(const LitArgs a, u64
                                                             const u64 n_tickets)
 {
     static_assert(!MULTI || !SET, "a byte set is a single-byte scan");
-    static_assert(kUpt >= 1 && kUpt <= 4 && (kRing & (kRing - 1u)) == 0u, "ticket / ring shape");
+    static_assert(kUpt >= 1 && kUpt <= 4, "ticket shape");
+    // ring positions wrap by a mask where the ring is a power of two, by one compare-and-subtract where it is not (x < 2 kRing)
+    auto rwrap = [](const u32 x) -> u32 {
+        if constexpr ((kRing & (kRing - 1u)) == 0u)
+            return x & (kRing - 1u);
+        else
+            return x >= kRing ? x - kRing : x;
+    };
     const u32 lane = s_lane();
     const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const u64 n_units = a.num_tiles * kWavesPerBlk;
@@ -154,7 +161,7 @@ __global__ __launch_bounds__(kBlock, WPE) void single_fused(const LitArgs a, u64
             if (g < pad)
                 continue;
             const u32 i = g - pad;
-            const u32 off = ring[(pend_at + i) & (kRing - 1u)];
+            const u32 off = ring[rwrap(pend_at + i)];
             const u32 unit = (i >= b1 ? 1u : 0u) + (i >= b2 ? 1u : 0u) + (i >= b3 ? 1u : 0u);
             const u64 idx = first + i;
 #ifdef KG_S1_NOSTORE // (ablation build: everything but the record stores)
@@ -312,7 +319,7 @@ __global__ __launch_bounds__(kBlock, WPE) void single_fused(const LitArgs a, u64
                     const u32 k = __builtin_ctz(rest);
                     rest &= rest - 1u;
                     if (idx < room)
-                        ring[(at + idx) & (kRing - 1u)] = (unsigned short)(rel0 + k);
+                        ring[rwrap(at + idx)] = (unsigned short)(rel0 + k);
                     ++idx;
                 }
             }
@@ -384,7 +391,7 @@ __global__ __launch_bounds__(kBlock, WPE) void single_fused(const LitArgs a, u64
             pend_c0 = c0;
             pend_c1 = c1;
             pend_c2 = c2;
-            wp = (at + cnt) & (kRing - 1u);
+            wp = rwrap(at + cnt);
         }
         else
             pend_cnt = 0;
@@ -437,24 +444,33 @@ static hipError_t launch_fused(const LitArgs &a, u64 *agg, u64 *pref, u64 n_tick
     return hipGetLastError();
 }
 
-// shape 0: 128-KiB tickets (<= ~1.2 % hits); 1: 64-KiB tickets, 16-KiB rings (<= ~5 %); 2: 32-KiB tickets, 16-KiB rings (<= ~10 %);
-// 3: 32-KiB tickets, 32-KiB rings, one workgroup per CU (<= ~20 %: by then the records are 3 bytes per byte of text)
-static u32 shape_upt(int shape) { return shape == 0 ? kUptStd : (shape == 1 ? 2u : 1u); }
+// The shapes, by the density they hold (hits per byte; half a ring per ticket with a margin for clustering):
+//   0: 128-KiB tickets,  8-KiB rings, 16 waves per CU   <= ~1.2 %   (BASELINE config 3)
+//   1:  64-KiB tickets, 12-KiB rings, 12 waves per CU   <= ~3.7 %   (round 5: 6144 entries, wrap by compare; a single byte at
+//   2:  64-KiB tickets, 16-KiB rings,  8 waves per CU   <= ~5 %      3.1-3.5 % ran 8-11 % faster than in shape 2 — the dense
+//   3:  32-KiB tickets, 12-KiB rings, 12 waves per CU   <= ~7.5 %    shapes are bound by their occupancy, not by the stores:
+//   4:  32-KiB tickets, 16-KiB rings,  8 waves per CU   <= ~10 %     profiles/r05_dense_one_pass_ablation.txt)
+//   5:  32-KiB tickets, 32-KiB rings,  4 waves per CU   <= ~20 %    (by then the records are 3 bytes per byte of text)
+constexpr u32 kRingMid = 6144u;
+static u32 shape_upt(int shape) { return shape == 0 ? kUptStd : (shape <= 2 ? 2u : 1u); }
+static u32 shape_ring(int shape) { return shape == 0 ? kRingStd : (shape == 5 ? kRingDensest : ((shape & 1) ? kRingMid : kRingDense)); }
 uint64_t single_fused_tickets(uint64_t n_units, int shape) { return (n_units + shape_upt(shape) - 1) / shape_upt(shape); }
 uint64_t single_fused_scratch_words(uint64_t n_tickets) { return 2 * n_tickets; } // counts | prefixes
-// the densest text (hits per byte) a shape's ring is sure to hold: half a ring per ticket, with a margin for clustering
+// the densest text (hits per byte) a shape's ring is sure to hold
 double single_fused_max_density(int shape)
 {
-    const double ring = shape == 0 ? kRingStd : (shape == 3 ? kRingDensest : kRingDense), bytes = (double)shape_upt(shape) * (double)kUnitBytes1;
-    return 0.4 * ring / bytes;
+    return 0.4 * (double)shape_ring(shape) / ((double)shape_upt(shape) * (double)kUnitBytes1);
 }
 
 template <bool CI, bool SET, bool MULTI = false>
 static hipError_t launch_shape(const LitArgs &a, u64 *agg, u64 *pref, u64 n_tickets, u32 num_cu, int shape, hipStream_t st)
 {
+    static_assert(kFusedShapeMax == 5, "six shapes");
     if (shape == 0) return launch_fused<CI, kUptStd, kRingStd, 4, SET, MULTI>(a, agg, pref, n_tickets, num_cu, st);
-    if (shape == 1) return launch_fused<CI, 2u, kRingDense, 2, SET, MULTI>(a, agg, pref, n_tickets, num_cu, st);
-    if (shape == 2) return launch_fused<CI, 1u, kRingDense, 2, SET, MULTI>(a, agg, pref, n_tickets, num_cu, st);
+    if (shape == 1) return launch_fused<CI, 2u, kRingMid, 3, SET, MULTI>(a, agg, pref, n_tickets, num_cu, st);
+    if (shape == 2) return launch_fused<CI, 2u, kRingDense, 2, SET, MULTI>(a, agg, pref, n_tickets, num_cu, st);
+    if (shape == 3) return launch_fused<CI, 1u, kRingMid, 3, SET, MULTI>(a, agg, pref, n_tickets, num_cu, st);
+    if (shape == 4) return launch_fused<CI, 1u, kRingDense, 2, SET, MULTI>(a, agg, pref, n_tickets, num_cu, st);
     return launch_fused<CI, 1u, kRingDensest, 1, SET, MULTI>(a, agg, pref, n_tickets, num_cu, st);
 }
 
