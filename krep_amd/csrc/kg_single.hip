@@ -99,7 +99,14 @@ __device__ __noinline__ uint4 s_load16_guarded(const uint8_t *text, u64 text_len
 // second word where the pattern is longer than four bytes); the 8 bytes behind a lane come from its right neighbour, behind the
 // round from one extra 8-byte load.  For DENSE short literals with records (`-i sh`: 35 hits per 32-KiB unit, ` a`: 180), whose
 // staging slots overflow and whose text the two-pass kernels then read twice: chosen by lit_pass from the density a scan counted.
-template <bool CI, u32 kUpt, u32 kRing, int WPE, bool SET, bool MULTI = false>
+// BDRAW (round 5, the shapes with 32-KiB tickets): ONE draw per WORKGROUP — thread 0 fetches kWavesPerBlk consecutive tickets, a
+// barrier hands wave w ticket base + w, the four waves start their tickets together.  The one counter gives ~65 draws per
+// microsecond (same-address atomics serialise in one L2 channel): a million 32-KiB tickets are 15 ms whatever the text holds.
+// The drawn tickets stay a prefix of the ticket space and a wave's tickets ascend, so the progress argument above holds as it
+// stands; a wave at the barrier holds nothing unpublished.  The resolver's own workgroup cannot use the barrier (its wave 0 never
+// gets there): its other three waves keep drawing one ticket each from the same counter — any mix of draws leaves a prefix — so a
+// device that runs a single workgroup of the grid still makes progress.
+template <bool CI, u32 kUpt, u32 kRing, int WPE, bool SET, bool MULTI = false, bool BDRAW = false>
 __global__ __launch_bounds__(kBlock, WPE) void single_fused(const LitArgs a, u64 *__restrict__ agg, u64 *__restrict__ pref,
                                                             const u64 n_tickets)
 {
@@ -126,13 +133,21 @@ __global__ __launch_bounds__(kBlock, WPE) void single_fused(const LitArgs a, u64
             r = __hip_atomic_fetch_add(&a.ctr->pad[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         resolver = s_rfl64(r) == 0ull;
     }
+    extern __shared__ __attribute__((aligned(16))) unsigned short s_ring[]; // [kWavesPerBlk][kRing] (dynamic: the densest shape asks for 128 KiB)
+    u64 *s_draw = reinterpret_cast<u64 *>(s_ring + (size_t)kWavesPerBlk * kRing); // BDRAW: [0] the workgroup's ticket base, [1] "the resolver's workgroup"
+    bool bmode = false; // BDRAW: this workgroup draws as one (uniform over the workgroup; false in the resolver's)
+    if constexpr (BDRAW)
+    {
+        if (threadIdx.x == 0)
+            s_draw[1] = resolver ? 1ull : 0ull;
+        __syncthreads();
+        bmode = s_draw[1] == 0ull;
+    }
     if (resolver)
     {
         tk_resolve(agg, pref, n_tickets, a.ctr, lane);
         return;
     }
-
-    extern __shared__ __attribute__((aligned(16))) unsigned short s_ring[]; // [kWavesPerBlk][kRing] (dynamic: the densest shape asks for 128 KiB)
     unsigned short *ring = s_ring + (size_t)wave * kRing;
     const u64 hi_match = a.own_hi < a.text_len - a.m + 1 ? a.own_hi : a.text_len - a.m + 1; // exclusive start bound
 
@@ -328,26 +343,41 @@ __global__ __launch_bounds__(kBlock, WPE) void single_fused(const LitArgs a, u64
 
     // ONE ticket counter (a.ctr->ticket): what has been drawn is always a prefix of the ticket space, and a wave's tickets
     // ascend — the two facts the progress argument in the header rests on.
+    bool blk_live = true; // BDRAW: the workgroup's last draw still lay inside the ticket space (uniform over the workgroup)
     auto draw = [&]() __attribute__((always_inline)) -> u64 {
         u64 tk = 0;
-        if (lane == 0)
-            tk = __hip_atomic_fetch_add(&a.ctr->ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        tk = s_rfl64(tk);
+        if (BDRAW && bmode)
+        {
+            __syncthreads(); // every wave has read the previous base
+            if (threadIdx.x == 0)
+                s_draw[0] = __hip_atomic_fetch_add(&a.ctr->ticket, (u64)kWavesPerBlk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            const u64 base = s_draw[0];
+            blk_live = base < n_tickets;
+            tk = base + wave;
+        }
+        else
+        {
+            if (lane == 0)
+                tk = __hip_atomic_fetch_add(&a.ctr->ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tk = s_rfl64(tk);
+        }
         return tk < n_tickets ? tk : ~0ull;
     };
     uint4 A[kCells];
     u64 t = draw();
     bool haveA = t < n_tickets && a.anchor + t * kTicketBytes + kSegBytes <= a.text_len;
     issue(A, haveA ? a.anchor + t * kTicketBytes : fb);
-    while (t < n_tickets)
+    while (bmode ? blk_live : t < n_tickets)
     {
-        const u64 tbase = a.anchor + t * kTicketBytes;
+        const bool mine = t < n_tickets; // (BDRAW: the last draw of a workgroup may leave some of its waves without a ticket)
+        const u64 tbase = a.anchor + (mine ? t : 0ull) * kTicketBytes;
         at = wp;
         room = kRing - pend_cnt; // entries this ticket may use while the previous one is still parked
         cnt = 0;
         u32 c0 = 0, c1 = 0, c2 = 0, before = 0, units_done = 0; // hits of the ticket's first three units
 #pragma unroll 1
-        for (u32 rr = 0; rr < kRoundsPerTicket; ++rr)
+        for (u32 rr = 0; rr < (mine ? kRoundsPerTicket : 0u); ++rr)
         {
             const u64 seg = tbase + (u64)rr * kSegBytes;
             if (seg >= scan_end)
@@ -374,7 +404,7 @@ __global__ __launch_bounds__(kBlock, WPE) void single_fused(const LitArgs a, u64
         if (cnt > room)
             overflowed = true; // too dense for the ring: counted, not recorded — the host re-runs the two-pass kernels
         // publish the count BEFORE waiting for anything; the ticket drawn next is behind every ticket this wave has parked
-        if (lane == 0)
+        if (lane == 0 && mine)
             __hip_atomic_store(&agg[t], (u64)cnt | kReady, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // the next ticket, and its first round on the way, before the previous ticket's records are written
         const u64 tn = draw();
@@ -405,10 +435,10 @@ __global__ __launch_bounds__(kBlock, WPE) void single_fused(const LitArgs a, u64
 
 int g_s1_force_grid = 0; // test hook: at most this many blocks (0 = auto)
 // grid = the resident blocks of the instantiation x CUs
-template <bool CI, u32 UPT, u32 RING, int WPE, bool SET, bool MULTI>
+template <bool CI, u32 UPT, u32 RING, int WPE, bool SET, bool MULTI, bool BDRAW = false>
 static hipError_t launch_fused(const LitArgs &a, u64 *agg, u64 *pref, u64 n_tickets, u32 num_cu, hipStream_t st)
 {
-    constexpr size_t kLds = (size_t)kWavesPerBlk * RING * sizeof(unsigned short);
+    constexpr size_t kLds = (size_t)kWavesPerBlk * RING * sizeof(unsigned short) + (BDRAW ? 16u : 0u);
     // per DEVICE: the granted-LDS attribute and the resident blocks per CU of this instantiation are properties of the
     // device the launch goes to — asked once per device, not once per process (multi-device searches launch from one process) and
     // not on every launch
@@ -421,13 +451,13 @@ static hipError_t launch_fused(const LitArgs &a, u64 *agg, u64 *pref, u64 n_tick
     {
         if (kLds > 64 * 1024) // more than 64 KiB of dynamic LDS has to be asked for
         {
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&single_fused<CI, UPT, RING, WPE, SET, MULTI>),
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&single_fused<CI, UPT, RING, WPE, SET, MULTI, BDRAW>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
             if (e != hipSuccess)
                 return e;
         }
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, single_fused<CI, UPT, RING, WPE, SET, MULTI>, kBlock, kLds) != hipSuccess || n < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, single_fused<CI, UPT, RING, WPE, SET, MULTI, BDRAW>, kBlock, kLds) != hipSuccess || n < 1)
         {
             (void)hipGetLastError();
             n = 1;
@@ -440,7 +470,7 @@ static hipError_t launch_fused(const LitArgs &a, u64 *agg, u64 *pref, u64 n_tick
     u32 grid = (u32)std::max<u64>(1, std::min<u64>(want, (u64)num_cu * bpc));
     if (g_s1_force_grid > 0) // test hook: a starved grid (krep_gpu_debug_force_single_grid)
         grid = std::min<u32>(grid, (u32)g_s1_force_grid);
-    hipLaunchKernelGGL((single_fused<CI, UPT, RING, WPE, SET, MULTI>), dim3(grid), dim3(kBlock), kLds, st, a, agg, pref, n_tickets);
+    hipLaunchKernelGGL((single_fused<CI, UPT, RING, WPE, SET, MULTI, BDRAW>), dim3(grid), dim3(kBlock), kLds, st, a, agg, pref, n_tickets);
     return hipGetLastError();
 }
 
@@ -449,7 +479,8 @@ static hipError_t launch_fused(const LitArgs &a, u64 *agg, u64 *pref, u64 n_tick
 //   1:  64-KiB tickets, 12-KiB rings, 12 waves per CU   <= ~3.7 %   (round 5: 6144 entries, wrap by compare; a single byte at
 //   2:  64-KiB tickets, 16-KiB rings,  8 waves per CU   <= ~5 %      3.1-3.5 % ran 8-11 % faster than in shape 2 — the dense
 //   3:  32-KiB tickets, 12-KiB rings, 12 waves per CU   <= ~7.5 %    shapes are bound by their occupancy, not by the stores:
-//   4:  32-KiB tickets, 16-KiB rings,  8 waves per CU   <= ~10 %     profiles/r05_dense_one_pass_ablation.txt)
+//   4:  32-KiB tickets, 16-KiB rings,  8 waves per CU   <= ~10 %     profiles/r05_dense_one_pass_ablation.txt); 3 and 4 draw
+//                                                                    their tickets once per workgroup (BDRAW: e t 2.32 -> 2.67 TB/s)
 //   5:  32-KiB tickets, 32-KiB rings,  4 waves per CU   <= ~20 %    (by then the records are 3 bytes per byte of text)
 constexpr u32 kRingMid = 6144u;
 static u32 shape_upt(int shape) { return shape == 0 ? kUptStd : (shape <= 2 ? 2u : 1u); }
@@ -469,9 +500,15 @@ static hipError_t launch_shape(const LitArgs &a, u64 *agg, u64 *pref, u64 n_tick
     if (shape == 0) return launch_fused<CI, kUptStd, kRingStd, 4, SET, MULTI>(a, agg, pref, n_tickets, num_cu, st);
     if (shape == 1) return launch_fused<CI, 2u, kRingMid, 3, SET, MULTI>(a, agg, pref, n_tickets, num_cu, st);
     if (shape == 2) return launch_fused<CI, 2u, kRingDense, 2, SET, MULTI>(a, agg, pref, n_tickets, num_cu, st);
-    if (shape == 3) return launch_fused<CI, 1u, kRingMid, 3, SET, MULTI>(a, agg, pref, n_tickets, num_cu, st);
-    if (shape == 4) return launch_fused<CI, 1u, kRingDense, 2, SET, MULTI>(a, agg, pref, n_tickets, num_cu, st);
-    return launch_fused<CI, 1u, kRingDensest, 1, SET, MULTI>(a, agg, pref, n_tickets, num_cu, st);
+#ifndef KG_S1_NO_BDRAW // (A/B switch)
+    constexpr bool kB = true; // 32-KiB tickets: one draw per workgroup
+#else
+    constexpr bool kB = false;
+#endif
+    if (shape == 3) return launch_fused<CI, 1u, kRingMid, 3, SET, MULTI, kB>(a, agg, pref, n_tickets, num_cu, st);
+    if (shape == 4) return launch_fused<CI, 1u, kRingDense, 2, SET, MULTI, kB>(a, agg, pref, n_tickets, num_cu, st);
+    // (not the 32-KiB-ring shape: with ONE workgroup per CU its four waves would scan and flush in lock step — measured 959 against 1000 GB/s)
+    return launch_fused<CI, 1u, kRingDensest, 1, SET, MULTI, false>(a, agg, pref, n_tickets, num_cu, st);
 }
 
 hipError_t launch_single_fused(const LitArgs &a, unsigned long long *d_agg, unsigned long long *d_pref, uint64_t n_tickets,

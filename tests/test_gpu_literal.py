@@ -333,6 +333,17 @@ def test_single_byte_one_pass_dense_shapes(gpu, oracle_engine):
                 out = plan.scan(d.data_ptr(), n, 0, n, 0, pos.data_ptr(), cap)
                 assert out.count == want[0]
                 assert np.array_equal(pos[:2 * out.count].cpu().numpy().astype(np.uint64).reshape(-1, 2), want[1]), (alpha[:4], rep)
+            # ... and on a starved grid (the shapes with 32-KiB tickets draw once per WORKGROUP behind a barrier; the resolver's own
+            # workgroup draws per wave: a single resident workgroup must still get through)
+            for blocks in (1, 2, 3):
+                gpu.force_single_grid(blocks)
+                try:
+                    pos.zero_()
+                    out = plan.scan(d.data_ptr(), n, 0, n, 0, pos.data_ptr(), cap)
+                finally:
+                    gpu.force_single_grid(0)
+                assert out.count == want[0], (alpha[:4], blocks)
+                assert np.array_equal(pos[:2 * out.count].cpu().numpy().astype(np.uint64).reshape(-1, 2), want[1]), (alpha[:4], blocks)
             plan.close()
     finally:
         gpu.force_rounds(0)
