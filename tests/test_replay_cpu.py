@@ -168,10 +168,12 @@ def test_chained_pieces_fold_equals_reference_function(lib, algo, seed):
             pieces = list(zip(cuts[:-1], cuts[1:]))
             recs = [piece_record(text, acc, lo, hi, X, hi == n, algo) for lo, hi in pieces]
             tc = abi.SeqCarry()
+            recs[-1].local_lines = 1 + 4242  # (the end piece's canonical count rides on its record: krep_gpu_replay_tail starts from it)
             for pc in recs:  # the left fold, with the product's own function
                 out = abi.SeqCarry()
                 lib.krep_gpu_debug_fold_carry(C.byref(tc), C.byref(pc), C.byref(out))
                 tc = out
+            assert tc.local_lines == 1 + 4242
             if not tc.q1:
                 cur, opn = (X // B) * B, 0
             elif tc.nl1:
