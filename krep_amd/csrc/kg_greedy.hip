@@ -43,7 +43,7 @@ __device__ __forceinline__ uint8_t g_fold(uint8_t c) { return (c >= 'A' && c <= 
 
 // What visiting element j means: is it kept, and where does the walk look next (`consume` bytes behind its start).
 // kWalkGreedy: element = occurrence; kept, consumes m.  kWalkShortO: element = first-byte candidate, classified against the text.
-struct Visit { bool keep; u32 consume; };
+struct Visit { bool keep; u64 consume; }; // (64 bits: a line jump may pass more than 4 GiB)
 __device__ __forceinline__ Visit g_visit(const WalkSpec &ws, u64 sj, u64 base, const uint8_t *__restrict__ text, u64 text_len)
 {
     const u32 m = ws.m;
@@ -75,7 +75,7 @@ __device__ __forceinline__ Visit g_visit(const WalkSpec &ws, u64 sj, u64 base, c
         while (q < text_len && text[q] != '\n')
             ++q;
         const u64 next = q < text_len ? q + 1 : text_len;
-        return Visit{true, (u32)std::min<u64>(next - p, 0xffffffffull)};
+        return Visit{true, next - p};
     }
     return Visit{ok, ok ? m : 1u}; // krep.c:4441-4446: a -w rejected match resumes one byte further
 }
