@@ -14,7 +14,8 @@
 //     multiplies (bit 8 b + w <-> position 4 w + b), 8 KiB of LDS per wave.  Once per 16-KiB unit a wave prefix of the per-lane
 //     popcounts ranks the matches, and every lane walks the lane-cells it owns — END ascending, longest first, as the automaton's
 //     output chain reports them (aho_corasick.c:383-437) — into the unit's staging slot, parked in LDS until the ticket ends;
-//   * `-c` (`LINES`): the END mask and the newline mask of the cell in position order, and the general kernel's line pass per unit;
+//   * `-c` (`LINES`, never with `KEEP` since round 5): the END mask and the newline mask of the cell in position order, consumed
+//     where they are — the carry chain of ac_line_pass (kg_ac_common.h) in the cell; nothing goes to LDS;
 //   * the emit-mode launch (`EMIT`): final records for the units whose matches did not fit their slot — or for every unit of a
 //     plan that turned out dense (ac_scan: count pass, offsets from the post-pass, this launch) — 2048 at a time through LDS so
 //     that consecutive lanes store consecutive records.
@@ -108,16 +109,14 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
             return;
         }
     }
-    // per wave, -c: END mask + newline mask per lane-cell, position order (2 + 2 KiB); records: the length words per lane-cell (8 KiB)
+    // per wave, records: the length words per lane-cell (8 KiB)
     //           + the staging slots (<= 64 words) and info words of a ticket's <= 8 units, parked until the ticket ends: a wave
     //           stores nothing while it streams (on gfx9 a store waits in the same in-order vmcnt queue as the prefetched loads)
     constexpr u32 kPark = kAcUnitsPerTicketMax * 64 + kAcUnitsPerTicketMax * 2;
-    constexpr u32 kPerWave = FUSED ? kTinyRing * 3u : (LINES ? kTinyEntries : kTinyEntries * 2 + kPark);
+    constexpr u32 kPerWave = FUSED ? kTinyRing * 3u : kTinyEntries * 2 + kPark;
     u32 *base = s_tiny + wave * kPerWave;
     u32 *park_slots = base + kTinyEntries * 2;                                                     // [unit of the ticket][64]
     u64 *park_info = reinterpret_cast<u64 *>(base + kTinyEntries * 2 + kAcUnitsPerTicketMax * 64); // [unit of the ticket]
-    unsigned short *h16 = reinterpret_cast<unsigned short *>(base);
-    unsigned short *n16 = reinterpret_cast<unsigned short *>(base + kTinyEntries / 2);
     uint2 *cw = reinterpret_cast<uint2 *>(base);
 
     const bool want_pos = (a.flags & F_POS) != 0;
@@ -245,6 +244,7 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
     // while they are in registers; nothing goes to LDS, no second pass over the unit, 3 waves per SIMD instead of 2
     constexpr bool LINL = LINES && !KEEP;
     static_assert(!EMIT || (KEEP && !LINES), "emit mode writes records");
+    static_assert(!(KEEP && LINES), "-c keeps nothing: its lines are counted in the cell");
     u32 k7f;
     asm volatile("v_mov_b32 %0, 0x7f7f7f7f" : "=v"(k7f)); // (a vector register on purpose: see the splats in the cell)
     const u32 lmax = __builtin_amdgcn_readfirstlane(td.lmax), llong = (LONG || FIVE) ? __builtin_amdgcn_readfirstlane(td.llong) : 0u;
@@ -491,12 +491,6 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
                                 else
                                 { // the length's mask in the scrambled order: 4 shifts instead of 4 multiplies
                                     F[L - 1] = (Z[0] >> 7) | (Z[1] >> 6) | (Z[2] >> 5) | (Z[3] >> 4);
-                                    if (LINES) // (the line pass wants the ENDs in position order)
-                                    {
-#pragma unroll
-                                        for (int w = 0; w < 4; ++w)
-                                            HA[w] |= Z[w];
-                                    }
                                 }
                             }
                             else
@@ -668,26 +662,11 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
                         line_cell(m16, nlm);
                     }
                     if (kp)
-                    {
-                        if (inter && LINES)
-                        { // END mask in position order: one multiply per dword
-#pragma unroll
-                            for (int w = 0; w < 4; ++w)
-                                m16 |= ac_movemask4(HA[w]) << (4 * w);
-                        }
-                        u32 nlm = NL;
-                        if (LINES && !inter)
-                            nlm &= clip(a.own_lo, a.own_hi);
+                    { // records: the lane-cell's two length words wait in LDS for the unit's record pass
                         const u32 idx = (u32)r * (kSegBytes / 16) + (u32)j * kWave + lane;
                         const u32 cwx = F[0] | (F[1] << 4), cwy = F[2] | (F[3] << 4);
                         mycnt += (u32)(__popc(cwx) + __popc(cwy));
-                        if (LINES)
-                        {
-                            h16[idx] = (unsigned short)m16;
-                            n16[idx] = (unsigned short)nlm;
-                        }
-                        else
-                            cw[idx] = make_uint2(cwx, cwy);
+                        cw[idx] = make_uint2(cwx, cwy);
                     }
                 };
                 if (fast_now)
@@ -928,11 +907,6 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
                     l_cnt += __shfl_xor(l_cnt, o);
                 wls = LS2{l_cnt + s_new, s_seen, s_seen ? s_head : s_open, s_open};
             }
-            else if (LINES) // the distinct lines of the unit that hold a match END, on this lane's own masks
-                wls = ac_line_pass(kAcRounds * kCells, [&](int rj, u32 &H, u32 &N) {
-                    H = h16[(u32)rj * kWave + lane];
-                    N = n16[(u32)rj * kWave + lane];
-                });
 
             if (chain)
                 acc_total += wcnt;
@@ -1043,9 +1017,9 @@ __global__ __launch_bounds__(kTinyBlock, KG_TINY_KEEP_WAVES_ARG) void ac_tiny_ke
 
 u32 ac_tiny_lds_bytes(bool lines, bool records)
 {
-    if (!lines && !records)
-        return 0; // a count: nothing is kept
-    return kTinyWaves * (lines ? kTinyEntries : kTinyEntries * 2 + kAcUnitsPerTicketMax * 66) * (u32)sizeof(u32);
+    if (lines || !records)
+        return 0; // a count, or -c (lines counted in the cell): nothing is kept
+    return kTinyWaves * (kTinyEntries * 2 + kAcUnitsPerTicketMax * 66) * (u32)sizeof(u32);
 }
 // resident workgroups per CU: 12 waves by registers for the counting and the emit-mode instantiations, 8 for the ones that keep
 // a unit's masks AND stream (their record / line pass runs with the next round's prefetch in registers: under the 168-register
