@@ -421,6 +421,20 @@ def test_dense_short_literals_take_the_one_pass_record_writer(gpu, oracle_engine
                     got = pos[:2 * out.count].cpu().numpy().astype(np.uint64).reshape(-1, 2)
                     assert np.array_equal(got, want[1]), (pat, kw, ti)
                     del d, pos
+                if plan_is_all_occurrence(gpu, p, n):
+                    # ownership windows with a global base on the plan that now writes in one pass: a window owns the matches
+                    # that START in it, the windows' lists concatenate to the whole list
+                    d = torch.from_numpy(dense).cuda()
+                    cap = int(fam_all[0]) + 3
+                    pos = torch.zeros(2 * cap, dtype=torch.int64, device="cuda")
+                    parts, before = [], gpu.single_launches()
+                    cuts = [0, 5, (1 << 20) + 17, (3 << 20) + 16383, n - 1, n]
+                    for lo, hi in zip(cuts[:-1], cuts[1:]):
+                        out = plan.scan(d.data_ptr(), n, lo, hi, 777, pos.data_ptr(), cap)
+                        parts.append(pos[:2 * out.stored].cpu().numpy().astype(np.uint64).reshape(-1, 2) - 777)
+                    assert np.array_equal(np.concatenate(parts), fam_all[1]), (pat, kw, "windows")
+                    assert gpu.single_launches() > before, (pat, kw, "windows on the two-pass road")
+                    del d, pos
                 plan.close()
                 if plan_is_all_occurrence(gpu, p, n):
                     # scan 0 learns, 1 and 2 take the one-pass kernel; the sparse text (3) takes it once more and switches it off,
