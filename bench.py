@@ -163,7 +163,7 @@ def cpu_baseline(wl, sample_bytes, d_buf):
         for t in ths:
             t.join()
         times.append(time.time() - t0)
-    best = min(times)
+    best, med = min(times), statistics.median(times)
     # the correctness gate of this leg: the reference's count of the sample, each match owned once, against the HIP scan of the
     # same bytes (count-only) — outside the timings above
     exact = sum(counts) - sum(overlap_only(i) for i in range(threads))
@@ -175,9 +175,11 @@ def cpu_baseline(wl, sample_bytes, d_buf):
         gp.close()
     except Exception as e:
         gpu_cnt = f"failed: {e!r}"
-    res = dict(value=round(n / best / 1e9, 3), unit="GB/s", cores=threads, kind=kind,
+    # `value` is the MEDIAN of the repetitions (on a busy 256-thread host the best of 20 sat 2.6x above the
+    # median); the best one is reported beside it
+    res = dict(value=round(n / med / 1e9, 3), unit="GB/s", cores=threads, kind=kind, best=round(n / best / 1e9, 3),
                sample=f"{n / 2**30:.1f} GiB slice of the same haystack, {threads} threads x {name}, chunk+overlap as "
-                      f"krep.c:2851-2905, best of {len(times)} (median {n / statistics.median(times) / 1e9:.1f} GB/s), "
+                      f"krep.c:2851-2905, median of {len(times)} runs (best {n / best / 1e9:.1f} GB/s), "
                       f"count={sum(counts)}",
                reference_count_owned_once=int(exact), gpu_count_same_sample=gpu_cnt, gpu_count_matches_reference=(gpu_cnt == exact))
     # The CLIs end to end on a /dev/shm copy of the sample, wall clock of the whole process (mmap + MAP_POPULATE, thread pool,
@@ -285,8 +287,9 @@ def traffic_for(name):
 # The reference's own benchmark refuses a number whose count disagrees with a second implementation
 # (/root/reference/test/benchmark_krep_vs_rg.sh:62-75: krep -c against rg -c).  Here, outside every timed region: the 8-byte
 # literal against the closed form of the synthetic generator (count AND the complete start list), the single byte against an
-# independent device-side count and offset checksum, the 1000 patterns against list properties (and, in the cpu_baseline leg,
-# against the compiled reference on the CPU sample).  `verified: false` makes bench.py exit non-zero.
+# independent device-side count and offset checksum, the 1000 patterns against the compiled reference's aho_corasick_search on four
+# 1-MiB windows, record for record (and, in the cpu_baseline leg, its count of the CPU sample).  `verified: false` makes bench.py
+# exit non-zero.
 _M64 = (1 << 64) - 1
 _GIB = 1 << 30
 
@@ -344,8 +347,13 @@ def verify_step(name, wl, eng, plan, buf, pos, out, n, text_len, shard_off, worl
         ok = (int(rec[:, 0].sum().item()) == csum and bool(torch.all(rec[1:, 0] > rec[:-1, 0]))
               and bool(torch.all(rec[:, 1] == rec[:, 0] + 1)))
         return ok, f"count {stored} == torch.nonzero count, offset checksum equal, strictly ascending"
-    # multi-pattern: a count-only scan of the same shard, the list's order (end ascending, longest first), every record's length in
-    # the dictionary's range, and a sample of records compared byte for byte with the dictionary on the host
+    # multi-pattern.  Independent of the engine (round 6, VERDICT r05 weak #2 / ADVICE r05): the COMPILED REFERENCE's
+    # aho_corasick_search (oracle/_ref, the checker) on four 1-MiB windows of this shard — start, two interior GiB-boundary
+    # neighbourhoods, end — compared record for record with the slice of the HIP list whose starts lie in the window.
+    # Self-consistency beside it (the same engine, so it cannot catch a systematic miss): a count-only scan of the shard,
+    # the list's (end, longest-first) order, every length in the dictionary's range.
+    if stored == 0:
+        return False, "no records: the synthetic dictionary workload always holds matches"
     cplan = eng.plan(abi.Params(wl["patterns"], count_lines=True, only_match=True), device=buf.device.index or 0)
     c = cplan.scan(buf.data_ptr(), text_len, 0, n, shard_off, global_len=world * n)
     cplan.close()
@@ -356,18 +364,31 @@ def verify_step(name, wl, eng, plan, buf, pos, out, n, text_len, shard_off, worl
     ln = e - st
     lens = sorted({len(x) for x in wl["patterns"]})
     in_range = bool(torch.all((ln >= lens[0]) & (ln <= lens[-1])))
-    idx = torch.randint(0, stored, (min(stored, 200000),), device=rec.device)
-    smp = rec[idx].cpu().numpy() - shard_off
-    pats = set(wl["patterns"])
-    okb = True
-    offs = torch.from_numpy(smp[:, 0].copy()).to(rec.device)
-    g = buf[(offs[:, None] + torch.arange(lens[-1], device=rec.device)[None, :]).clamp_(max=text_len - 1)].cpu().numpy()
-    for i in range(len(smp)):
-        if bytes(g[i, : smp[i, 1] - smp[i, 0]]) not in pats:
-            okb = False
-            break
-    return ordered and in_range and okb, (f"{stored} records == count-only scan, (end, longest-first) order, "
-                                          f"{len(smp)} sampled records are dictionary words")
+    if not (ordered and in_range):
+        return False, f"list order {ordered} / lengths in range {in_range}"
+    import oracle_lib as ol
+    o = ol.checker()
+    win = 1 << 20
+    spots = sorted({0, max(0, (n // 3) & ~(_GIB - 1)) + 12345 if n > 2 * _GIB else n // 3, max(0, n // 2 - win // 2), max(0, n - win)})
+    order = torch.argsort(st, stable=True)
+    st_sorted = st[order]
+    checked = 0
+    for wlo in spots:
+        whi = min(n, wlo + win)
+        b0, b1 = max(0, wlo - lens[-1]), min(text_len, whi + lens[-1])
+        host = buf[b0:b1].cpu().numpy()
+        _, wpos = o.call(abi.RA_AHO_CORASICK, abi.Params(wl["patterns"]), host)
+        wpos = wpos.astype(np.int64) + b0 + shard_off
+        want = wpos[(wpos[:, 0] >= wlo + shard_off) & (wpos[:, 0] < whi + shard_off)]  # emission order kept
+        i0 = int(torch.searchsorted(st_sorted, torch.tensor([wlo + shard_off], device=rec.device)).item())
+        i1 = int(torch.searchsorted(st_sorted, torch.tensor([whi + shard_off], device=rec.device)).item())
+        got = rec[torch.sort(order[i0:i1]).values].cpu().numpy()
+        if not np.array_equal(got, want):
+            return False, f"window [{wlo}, {whi}): {len(got)} HIP records != {len(want)} of the compiled reference's aho_corasick_search"
+        checked += len(want)
+    return True, (f"{len(spots)} windows of 1 MiB: all {checked} (start, end) records == the compiled reference's aho_corasick_search "
+                  f"(oracle/_ref) in its emission order; self-consistent beside it: {stored} records == count-only scan, "
+                  f"(end, longest-first) order, lengths in the dictionary's range")
 
 # ---------------------------------------------------------------------------------------------- one workload on this rank
 def positions_capacity(name, n):
@@ -527,9 +548,13 @@ def main():
     ap.add_argument("--workload", default="literal8", choices=sorted(WORKLOADS))
     ap.add_argument("--gib", type=float, default=32.0, help="haystack GiB per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--haystack-tries", type=int, default=3,
+    # Both default to 1 since round 6: the reported number is the one a user's single allocation
+    # gets.  Physical placement moves the 8-byte literal by 2-3 % and the single byte with records by ~10 %; values > 1
+    # draw again outside every timed region, keep the fastest candidate and say so under the line's top-level `placement` key —
+    # a development aid (A/B runs on a fixed placement), not the protocol of the headline.
+    ap.add_argument("--haystack-tries", type=int, default=1,
                     help="candidate haystack allocations (physical placement moves every workload by 2-3 %%; 1 = take the first)")
-    ap.add_argument("--placement-tries", type=int, default=6,
+    ap.add_argument("--placement-tries", type=int, default=1,
                     help="candidate record buffers to draw from (1 = take the first allocation as it comes)")
     ap.add_argument("--no-extra", action="store_true", help="N = 1: do not measure the other two BASELINE workloads")
     ap.add_argument("--cpu-sample-gib", type=float, default=4.0)
@@ -671,8 +696,9 @@ def main():
             "roofline": res["roofline"],
             "verified": res["verified"], "verified_how": res["verified_how"],
         }
-        if placement:
-            line["config"]["placement"] = placement
+        # (top level and short, so that it survives a truncating reader of `config`)
+        line["placement"] = placement or {"haystack_tries": 1, "record_buffer_tries": 1,
+                                          "policy": "the first allocation of each buffer, as the driver places it"}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(wl, min(n, int(args.cpu_sample_gib * (1 << 30))), buf)

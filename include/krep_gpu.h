@@ -412,7 +412,9 @@ void krep_gpu_debug_fold_carry(const krep_gpu_seq_carry_t *in, const krep_gpu_se
  * PRNG so that any [global_off, global_off+len) slice is reproducible on any rank.
  * kind: 2 = background a-z/space/newline + planted 8-byte literal every `period` bytes (cfg 2/5),
  *       3 = background + target byte with probability 1/100 (cfg 3),
- *       4 = background + planted dictionary words (cfg 4; `plant`/`plant_len` = packed patterns). */
+ *       4 = background + planted dictionary words (cfg 4; `plant`/`plant_len` = packed patterns),
+ *       5 = word text: `period`-byte lines ('\n'-terminated) of words drawn from the packed list `plant` with p(rank) ~ 1/rank,
+ *           single blanks between them (the natural-language-like text of cfg 1 / the reference's own benchmark corpus). */
 int krep_gpu_generate(void *d_dst, size_t len, size_t global_off, int kind, uint64_t seed,
                       const void *plant, size_t plant_len, uint64_t period, void *stream);
 /* Host twin of the generator (same bytes), for parity tests and the CPU baseline. */

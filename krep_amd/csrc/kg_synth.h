@@ -7,6 +7,11 @@
 //                stride, + one occurrence straddling every GiB boundary (start = B-3)
 //   kind 3     : + the target byte plant[0] with probability 1/100 (u32 % 100 == 0)
 //   kind 4     : + one dictionary word per stride (plant = packed dictionary, see DictView)
+//   kind 5     : WORD TEXT (round 6; SURVEY.md §8d cfg 1's "ASCII lines, words from a list"; the reference's only published
+//                benchmark runs on a natural-language corpus, test/benchmark_krep_vs_rg.sh:4): lines of exactly `period` bytes
+//                (the last one '\n'), each a pure function of (seed, line index): words of the packed list `plant` drawn with a
+//                Zipf-like law (an octave of ranks uniformly, a rank inside it uniformly: p(rank) ~ 1/rank, integer arithmetic
+//                only), single blanks between them, blanks behind the last word that fits
 #pragma once
 #include <stdint.h>
 #include <stddef.h>
@@ -64,6 +69,38 @@ KG_HD bool near_gib(uint64_t s, uint64_t plen)
     return (s + 2 * plen + 3 > B) && (s < B + 2 * plen);
 }
 
+// kind 5: index of the i-th word of line k in a list of n words — octave o of ranks [2^o, 2^(o+1)) uniformly among the
+// floor(log2 n) whole octaves, a rank inside it uniformly: every octave carries the same weight, i.e. p(rank) ~ 1 / rank
+KG_HD uint32_t word_text_draw(uint64_t seed, uint64_t k, uint32_t i, uint32_t n)
+{
+    if (n < 2)
+        return 0;
+    const uint32_t octaves = 31u - (uint32_t)__builtin_clz(n); // 2^octaves <= n
+    const uint64_t r = splitmix64(seed ^ 0x7F4A7C15D1B54A33ull ^ (k * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)i * 0xC2B2AE3D27D4EB4Full));
+    const uint32_t o = (uint32_t)((r >> 40) % octaves);
+    return (1u << o) + ((uint32_t)r & ((1u << o) - 1u)) - 1u; // rank - 1
+}
+KG_HD uint8_t word_text_byte(uint64_t g, uint64_t seed, const uint8_t *plant, uint64_t period)
+{
+    const uint64_t k = g / period, j = g % period;
+    if (j == period - 1)
+        return (uint8_t)'\n';
+    DictView dv{plant};
+    const uint32_t n = dv.n();
+    uint64_t pos = 0;
+    for (uint32_t i = 0; pos <= j; ++i)
+    {
+        const uint32_t w = word_text_draw(seed, k, i, n);
+        const uint64_t wl = dv.len(w);
+        if (!wl || pos + wl > period - 1)
+            break; // the line's remainder stays blank
+        if (j < pos + wl)
+            return plant[dv.off(w) + (j - pos)];
+        pos += wl + 1; // the blank behind the word
+    }
+    return (uint8_t)' ';
+}
+
 KG_HD uint8_t synth_byte(uint64_t g, int kind, uint64_t seed, const uint8_t *plant, uint64_t plen, uint64_t period)
 {
     if (kind == 2)
@@ -99,6 +136,8 @@ KG_HD uint8_t synth_byte(uint64_t g, int kind, uint64_t seed, const uint8_t *pla
         }
         return background_byte(seed, g);
     }
+    if (kind == 5)
+        return word_text_byte(g, seed, plant, period);
     return background_byte(seed, g);
 }
 

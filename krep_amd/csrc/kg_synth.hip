@@ -40,10 +40,12 @@ extern "C" int krep_gpu_generate(void *d_dst, size_t len, size_t global_off, int
 {
     if (!len)
         return 0;
-    if ((kind == 2 || kind == 3 || kind == 4) && (!plant || !plant_len))
+    if ((kind == 2 || kind == 3 || kind == 4 || kind == 5) && (!plant || !plant_len))
         return kg::fail("generate: kind %d needs a plant", kind);
     if ((kind == 2) && period < plant_len)
         return kg::fail("generate: period < plant length");
+    if (kind == 5 && period < 2)
+        return kg::fail("generate: word text needs a line length (period) >= 2");
     hipStream_t st = (hipStream_t)stream;
     uint8_t *d_plant = nullptr;
     if (plant_len)
@@ -51,7 +53,7 @@ extern "C" int krep_gpu_generate(void *d_dst, size_t len, size_t global_off, int
         HIPCHK(hipMalloc(&d_plant, plant_len));
         HIPCHK(hipMemcpyAsync(d_plant, plant, plant_len, hipMemcpyHostToDevice, st));
     }
-    const uint64_t plen = (kind == 4) ? 0 : plant_len;
+    const uint64_t plen = (kind == 4 || kind == 5) ? 0 : plant_len;
     hipLaunchKernelGGL(synth_kernel, dim3(256 * 16), dim3(256), 0, st, (uint8_t *)d_dst, len, global_off, kind, seed, d_plant,
                        plen, period ? period : 1);
     HIPCHK(hipGetLastError());
@@ -63,7 +65,7 @@ extern "C" void krep_gpu_generate_host(void *dst, size_t len, size_t global_off,
                                        size_t plant_len, uint64_t period)
 {
     uint8_t *d = (uint8_t *)dst;
-    const uint64_t plen = (kind == 4) ? 0 : plant_len;
+    const uint64_t plen = (kind == 4 || kind == 5) ? 0 : plant_len;
     for (size_t i = 0; i < len; ++i)
         d[i] = synth_byte(global_off + i, kind, seed, (const uint8_t *)plant, plen, period ? period : 1);
 }

@@ -17,6 +17,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT, PROF = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 DOMINANT = {"literal8": "kg::lit_scan", "memchr1": "kg::single_fused", "ac1000": "kg::ac_scan_kernel"}
+# the kernels of one step besides the dominant one (launched once per step: their bytes are added per step)
+POST = {"literal8": ("kg::post_",), "memchr1": (), "ac1000": ("kg::post_",)}
 # the sources whose change makes a workload's traffic figure stale (bench.py checks the hash before it quotes the figure)
 KERNEL_SOURCES = {"literal8": ["kg_literal.hip", "kg_post.hip", "kg_common.h"], "memchr1": ["kg_single.hip", "kg_tickets.h", "kg_common.h"],
                   "ac1000": ["kg_ac.hip", "kg_ac_common.h", "kg_ac_tables.h", "kg_post.hip", "kg_common.h"]}
@@ -88,8 +90,24 @@ def main():
             for (k, c), (n, v) in sorted(agg.items()):
                 if k.startswith("kg::") or k.startswith("synth"):
                     f.write(f'"{k}",{c},{n},{v / n:.3f}\n')
-        fk = [(k, v) for (k, c), v in agg.items() if k.startswith(dom) and c == "FETCH_SIZE"]
-        wk = [(k, v) for (k, c), v in agg.items() if k.startswith(dom) and c == "WRITE_SIZE"]
+        # ONE instantiation: the one of this family with the most dispatches x bytes (round 5 matched the family prefix and so
+        # averaged lit_scan<8,...> with the lit_scan<1,...> launches of bench.py's placement probe)
+        fam = {}
+        for (k, c), v in agg.items():
+            if k.startswith(dom) and c == "FETCH_SIZE":
+                fam[k] = v[1]
+        inst = max(fam, key=fam.get) if fam else None
+        fk = [(k, v) for (k, c), v in agg.items() if k == inst and c == "FETCH_SIZE"]
+        wk = [(k, v) for (k, c), v in agg.items() if k == inst and c == "WRITE_SIZE"]
+        # the step's other kernels (post-pass): average bytes per dispatch x dispatches per dominant dispatch
+        post_f = post_w = 0.0
+        n_dom = sum(v[0] for _, v in fk) or 1
+        for (k, c), v in agg.items():
+            if any(k.startswith(p) for p in POST[w]):
+                if c == "FETCH_SIZE":
+                    post_f += v[1] / n_dom
+                elif c == "WRITE_SIZE":
+                    post_w += v[1] / n_dom
         if fk and wk:
             fetch = sum(v[1] for _, v in fk) / sum(v[0] for _, v in fk)
             write = sum(v[1] for _, v in wk) / sum(v[0] for _, v in wk)
@@ -99,7 +117,7 @@ def main():
             filt = []
             for f in glob.glob(os.path.join(OUT, f"{tag}_{w}_FETCH_SIZE_filter", "**", "*counter_collection.csv"), recursive=True):
                 filt += [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
-                         if short(r["Kernel_Name"]).startswith(dom) and r["Counter_Name"] == "FETCH_SIZE"]
+                         if short(r["Kernel_Name"]) == inst and r["Counter_Name"] == "FETCH_SIZE"]
             if filt:
                 # streamed reads (the filter-only pass) are under-reported 2x, the verify stage's gathers are exact
                 # (tools/ubench/fetch_calib.hip): traffic = 2 x filter + 1 x (full - filter) + writes
@@ -107,9 +125,12 @@ def main():
                 hbm = int((2 * ff + max(0.0, fetch - ff) + write) * 1024)
                 note = (f"; streamed part {ff:.0f} KiB (KREP_GPU_AC_NOVERIFY pass) doubled, the verify stage's gathers "
                         f"({fetch - ff:.0f} KiB) counted as reported (profiles/r03_fetch_size_calibration.txt)")
+            hbm_step = hbm + int((2 * post_f + post_w) * 1024)  # (the post-pass reads are counted double too: an upper bound)
             traffic[w] = {
-                "hbm_bytes_per_launch": hbm, "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write,
-                "algorithmic_bytes": alg, "ratio": round(hbm / alg, 4), "kernel": dom, "measured_by": tag,
+                "hbm_bytes_per_launch": hbm, "hbm_bytes_per_step_with_post_pass": hbm_step,
+                "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write, "post_pass_FETCH_SIZE_KiB": post_f, "post_pass_WRITE_SIZE_KiB": post_w,
+                "algorithmic_bytes": alg, "ratio": round(hbm / alg, 4), "ratio_with_post_pass": round(hbm_step / alg, 4),
+                "kernel": inst, "measured_by": tag,
                 "kernel_sources": KERNEL_SOURCES[w], "kernel_sources_sha": sources_sha(w),
                 "method": f"tools/profile_round.sh {tag}: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate "
                           f"passes of `python bench.py --workload {w} --steps 2 --warmup 1 --no-cpu-baseline`; "
