@@ -145,27 +145,6 @@ void krep_gpu_set_only_matching(int on);                     /* static only_matc
 void krep_gpu_set_force_no_simd(int on);                     /* static force_no_simd,   krep.c:118   */
 void krep_gpu_set_algo_override(int krep_ref_algo_override); /* static algo_override,   krep.c:120   */
 int krep_gpu_get_reference_simd(void);
-/* test hook (host only, no GPU needed): the end-of-text replay of the block-structured -c paths
- * (krep_amd/csrc/kg_replay.h) run on host memory, so that the CPU test-suite can pin it against the oracle */
-uint64_t krep_gpu_debug_replay_host(int krep_ref_algo, const void *text, size_t n, const void *pattern, uint32_t m,
-                                    int whole_word, size_t cur, int open_line);
-/* test hook: force the kernel tile shape (0 = auto, 1 = 32 KiB tiles, 4 = 128 KiB tiles) */
-void krep_gpu_debug_force_rounds(int rounds);
-/* test hook: staging records per scan unit (0 = auto); small values exercise the emit-mode re-scan */
-void krep_gpu_debug_force_stage_cap(int records);
-/* test hooks of the one-pass single-byte kernel (kg_single.hip): at most `blocks` workgroups (0 = auto) — a starved grid, as
- * on a shared or partitioned device; and how many of its scans handed over to the two-pass kernels (ring overflow on a
- * dense text, or the spin-limit safety net) since the process started */
-void krep_gpu_debug_force_single_grid(int blocks);
-uint64_t krep_gpu_debug_single_failovers(void);
-/* ... and how many launches of that kernel there were (its 2..8-byte instantiations included: a plan takes them for records of a
- * dense short literal once a two-pass scan has counted the density) */
-uint64_t krep_gpu_debug_single_launches(void);
-/* test hook: launches of the tiny-dictionary kernel (kg_ac_tiny.hip: every pattern <= 4 bytes, compared in registers) since the
- * process started; $KREP_GPU_AC_NO_TINY=1 (read when a plan is built) keeps such dictionaries on the general kernel */
-uint64_t krep_gpu_debug_tiny_launches(void);
-/* ... and those of its one-pass record writer in the DENSE flavour (16-bit ring entries, tickets sized by the counted density) */
-uint64_t krep_gpu_debug_tiny_dense_launches(void);
 /* Twin of select_search_algorithm() (krep.c:1771): the algorithm the reference build would END UP
  * executing for `params` on a text of `text_len` bytes (text_len matters: the SIMD functions fall back
  * to BMH when text_len < pattern_len, and so on). */
@@ -230,9 +209,6 @@ int krep_gpu_worthwhile_ex(const search_params_t *params, size_t text_len, int c
 int krep_gpu_cost_estimate(const search_params_t *params, size_t text_len, int cpu_threads, krep_gpu_cost_t *out); /* 0 ok */
 void krep_gpu_get_cost_rates(krep_gpu_cost_rates_t *out);
 void krep_gpu_set_cost_rates(const krep_gpu_cost_rates_t *rates); /* NULL: back to the defaults + $KREP_GPU_COST */
-/* test hook: make the next operator calls fail at a chosen point — 0 off, 1 device allocation, 2 host->device copy,
- * 3 kernel launch, 4 device->host copy of the records.  Also read from $KREP_GPU_INJECT_FAILURE. */
-void krep_gpu_debug_inject_failure(int kind);
 
 /* ------------------------------------------------------------------------------------------------
  * Operator-level entry points (search_func_t-compatible).  `text_start` is a HOST pointer, exactly
@@ -390,9 +366,6 @@ int krep_gpu_scan_device_seq(krep_gpu_plan_t *plan, const void *d_text, size_t t
 int krep_gpu_replay_tail(krep_gpu_plan_t *plan, const void *d_tail, size_t tail_len, size_t global_len, void *stream,
                          const krep_gpu_seq_carry_t *carry_true, const krep_gpu_seq_carry_t *piece, krep_gpu_seq_carry_t *carry_out,
                          uint64_t *lines);
-/* test hook: pieces the multi-shard operators scanned AGAIN because their boundary record turned out different (rescans) and
- * end pieces that only re-ran the end-of-text replay (replays), since the process started */
-void krep_gpu_debug_chain_fixups(uint64_t *rescans, uint64_t *replays);
 /* How a text of text_len bytes may be cut for `params` under the current configuration. */
 enum krep_gpu_split
 {
@@ -403,10 +376,6 @@ enum krep_gpu_split
                                   inside a pattern, multi-pattern and through simd_sse42_search / kmp_search)             */
 };
 int krep_gpu_split_mode(const search_params_t *params, size_t text_len);
-/* test hook (host only, no GPU needed): the left fold of the boundary record exactly as the library applies it — a piece's
- * own contribution (its local_* fields) onto the record of the text in front of it — so that the CPU test-suite can pin the
- * chained-pieces algebra against the oracle (tests/test_replay_cpu.py) */
-void krep_gpu_debug_fold_carry(const krep_gpu_seq_carry_t *in, const krep_gpu_seq_carry_t *piece, krep_gpu_seq_carry_t *out);
 
 /* Deterministic synthetic haystacks, generated directly in HBM by a counter-based
  * PRNG so that any [global_off, global_off+len) slice is reproducible on any rank.

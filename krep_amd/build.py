@@ -22,7 +22,7 @@ def sources():
 
 
 def _headers():
-    return glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "krep_gpu.h")]
+    return glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
 
 
 def _obj(src: str) -> str:

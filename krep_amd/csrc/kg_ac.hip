@@ -46,9 +46,14 @@ namespace kg {
 #ifndef KG_AC_LINES_ROLL_CELLS
 #define KG_AC_LINES_ROLL_CELLS 4 // cells (1 KiB each) of the next round a -c scan prefetches (A/B: krep_amd/build.py --variant x -DKG_AC_LINES_ROLL_CELLS=8)
 #endif
-template <bool CI, bool LINES, bool SHORT, int STRIDE>
+// ANCH (round 6, kg_ac_anchor.hip; only with STRIDE == 2, no short patterns, no -c): the table holds rarity-chosen ANCHOR grams
+// (2^19 bits, which leaves room for a second bitmap per wave).  A candidate's exact anchor gram names the offsets k at which
+// patterns END behind it; those ends are marked in the unit's END bitmap, and the marked ends — not the candidates — are what the
+// end-anchored verifier (ac_walk_fast) looks at, in position order: ranking, staging and emission as before.
+template <bool CI, bool LINES, bool SHORT, int STRIDE, bool ANCH = false>
 __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
 {
+    static_assert(!ANCH || (STRIDE == 2 && !LINES && !SHORT), "anchored scan: pair filter, records / counts only");
     extern __shared__ __attribute__((aligned(16))) u32 s_mem[]; // filter table | per wave: candidate bitmap (+ hit and newline bitmaps for -c)
     const u32 lane = ac_lane();
     const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -57,8 +62,9 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
     for (u32 w = threadIdx.x; w < a.filter_words; w += kAcBlock)
         s_mem[w] = a.filter[w];
     const u32 fw = (a.filter_words + 3u) & ~3u;
-    constexpr u32 kPerWave = kAcBitmapWords + (LINES ? 2u * kAcBitmapWords : 0u); // candidate | hit | newline bitmaps
-    constexpr u32 XB = LINES ? kXBitsLines : kXBitsBig; // index bits of the exact-class table
+    constexpr u32 kPerWave = kAcBitmapWords + (LINES ? 2u * kAcBitmapWords : 0u) + (ANCH ? kAcBitmapWords : 0u); // candidate | hit | newline bitmaps (ANCH: candidate | END)
+    constexpr u32 XB = (LINES || ANCH) ? kXBitsLines : kXBitsBig; // index bits of the exact-class table
+    constexpr u32 kTabMask = XB == 20 ? 0x1fffcu : 0xfffcu; // byte address of a pair-layout slot
     constexpr bool PAIR = STRIDE == 2;                  // pair-layout table, odd positions tested (see cell_body)
     constexpr bool PIPE = PAIR && !LINES;               // ... with the table reads software-pipelined over the cells of a round
     // -c owns a match by its END and records it in the unit's hit bitmap, so the end j + 2 of the unit's last candidate bit
@@ -79,7 +85,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
     u64 *park_info = reinterpret_cast<u64 *>(cbits + 256 + kAcUnitsPerTicketMax * 16); // [kAcUnitsPerTicketMax]
     u32 *bitmap = cbits + kAcBitmapWords;
     unsigned short *nlmap = reinterpret_cast<unsigned short *>(bitmap + kAcBitmapWords); // 16 bits per lane and cell
-    if (LINES)
+    if (LINES || ANCH) // (ANCH: `bitmap` is the unit's END bitmap, one bit per end position; cleared again after every unit)
         for (u32 w = lane; w < kAcBitmapWords; w += 64)
             bitmap[w] = 0u;
     const bool want_pos = (a.flags & F_POS) != 0;
@@ -204,7 +210,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                     const int w = q / 2 + 1;
                     xs[q] = (q & 1) ? t[w] : __builtin_amdgcn_alignbit(t[w], t[w - 1], 16u);
                     // (-c: a 2^19-bit table, address bit 16 = bit 3 of the class c2 dropped)
-                    dws[q] = *(lds_u32 *)(size_t)(((xs[q] >> 3) ^ (xs[q] >> 13)) & (XB == 20 ? 0x1fffcu : 0xfffcu));
+                    dws[q] = *(lds_u32 *)(size_t)(((xs[q] >> 3) ^ (xs[q] >> 13)) & kTabMask);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 u32 acc = 0;
@@ -319,7 +325,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 {
                     const int w = q / 2 + 1;
                     x[q] = (q & 1) ? t[w] : __builtin_amdgcn_alignbit(t[w], t[w - 1], 16u);
-                    v[q] = *(lds_u32 *)(size_t)(((x[q] >> 3) ^ (x[q] >> 13)) & 0x1fffcu);
+                    v[q] = *(lds_u32 *)(size_t)(((x[q] >> 3) ^ (x[q] >> 13)) & kTabMask);
                 }
             };
             auto finish = [&](const int j, const u32 (&x)[8], const u32 (&v)[8]) __attribute__((always_inline)) {
@@ -392,6 +398,254 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
         //      [256 L, 256 L + 256) of the bitmap (8 dwords); a wave scan of the popcounts gives every lane its rank
         //      range, and the lane verifying rank q finds its candidate by a binary search over those sums and a
         //      select of the t-th set bit in the owner's block ------------------------------------------------
+        // the matches of one batch (one END pair per lane: cA at pos, cB at pos + 1, depth masks or the level walk's verdict):
+        // unit-local ranks by a wave prefix, then staging slots / final records / the -c hit bitmap, longest first at one end
+        auto rank_and_emit = [&](const u64 pos, const u32 cA, const u32 cB, const u64 dmA, const u64 dmB, const bool simA, const bool simB)
+            __attribute__((always_inline)) {
+            const u32 c = cA + cB;
+            u32 incl = c;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1)
+            {
+                const u32 t = __shfl_up(incl, o);
+                if (lane >= (u32)o)
+                    incl += t;
+            }
+            const u32 rank0 = wcnt + incl - c;
+            wcnt += __shfl(incl, 63);
+#pragma unroll 1
+            for (int e = 0; e < (STRIDE == 2 ? 2 : 1); ++e)
+            {
+                const u32 ce = e ? cB : cA;
+                if (!ce)
+                    continue;
+                const u64 pe = pos + (u64)e, dme = e ? dmB : dmA;
+                const u32 re = rank0 + (e ? cA : 0u), rele = (u32)(pe - useg); // the END's bit in the unit's hit bitmap
+                const bool sime = e ? simB : simA;
+                if (LINES)
+                    atomicOr(&bitmap[rele >> 5], 1u << (rele & 31u));
+                if (do_stage || do_final)
+                {
+                    auto write = [&](u32 at, u64 s0, u32 len) {
+                        if (do_stage)
+                        {
+                            if (at < a.stage_cap)
+                                slot[at] = ((u32)(s0 + 1024u - useg) << 11) | len; // start relative to the unit (>= -1023), length <= 1024
+                        }
+                        else
+                        {
+                            const u64 g = fbase + at;
+                            if (g < a.pos_cap)
+                            {
+                                const u64 st = s0 + a.global_base, en = st + len;
+                                *reinterpret_cast<uint4 *>(a.positions + 2 * g) =
+                                    make_uint4((u32)st, (u32)(st >> 32), (u32)en, (u32)(en >> 32));
+                            }
+                        }
+                    };
+                    if (sime)
+                    {
+                        u32 at = re;
+                        for (u64 rest = dme; rest;) // longest first
+                        {
+                            const u32 d = 63u - (u32)__builtin_clzll(rest);
+                            rest &= ~(1ull << d);
+                            write(at++, pe + 1 - (u64)d, d);
+                        }
+                    }
+                    else
+                        ac_walk<CI, true, !SHORT>(a, pe, ce, [&](u32 r, u64 s2, u32 len) { write(re + r, s2, len); });
+                }
+            }
+        };
+        if constexpr (ANCH)
+        {
+            // ================= anchored: candidates -> END bitmap (stage 2), marked ends -> exact verify (stage 3) =================
+            const u64 e_lo = useg > a.end_lo ? useg : a.end_lo;
+            const u64 e_hi = useg + kAcUnitBytes < a.end_hi ? useg + kAcUnitBytes : a.end_hi;
+            auto mark = [&](u64 e) {
+                if (e >= e_lo && e < e_hi)
+                {
+                    const u32 r = (u32)(e - useg);
+                    atomicOr(&bitmap[r >> 5], 1u << (r & 31u));
+                }
+            };
+            {
+                u32 mycnt = 0;
+                {
+                    const uint4 lo = *reinterpret_cast<const uint4 *>(cbits + lane * kWPL);
+                    mycnt = (u32)(__popc(lo.x) + __popc(lo.y) + __popc(lo.z) + __popc(lo.w));
+                }
+                u32 incl = mycnt;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1)
+                {
+                    const u32 t = __shfl_up(incl, o);
+                    if (lane >= (u32)o)
+                        incl += t;
+                }
+                const bool off = (a.flags & (1u << 31)) != 0u; // (ablation hook KREP_GPU_AC_NOVERIFY: filter cost only)
+                const u32 n = off ? 0u : __shfl(incl, 63);
+                // an END lies up to 13 bytes behind the tested position that names it: the seven tested positions in front of the
+                // unit are looked at again here (their own unit dropped the ends that fall into this one)
+                const u32 n_x = (!off && useg >= 16u) ? 7u : 0u;
+                const u32 n_tot = n + n_x;
+                for (u32 b0 = 0; b0 < n_tot; b0 += 64)
+                {
+                    const u32 qi = b0 + lane;
+                    const bool live = qi < n, isx = qi >= n && qi < n_tot;
+                    u32 rel = 0;
+                    {
+                        u32 own = 0;
+#pragma unroll
+                        for (u32 step = 32; step; step >>= 1)
+                        {
+                            const u32 t = __shfl(incl, (own + step - 1u) & 63u);
+                            if (t <= qi)
+                                own += step;
+                        }
+                        own &= 63u;
+                        const u32 oincl = __shfl(incl, own), ocnt = __shfl(mycnt, own);
+                        if (live)
+                        {
+                            u32 t = qi - (oincl - ocnt);
+                            const u32 *blk = cbits + own * kWPL;
+                            u32 w = 0, word = blk[0];
+                            for (;;)
+                            {
+                                const u32 c = (u32)__popc(word);
+                                if (t < c)
+                                    break;
+                                t -= c;
+                                word = blk[++w];
+                            }
+                            for (; t; --t)
+                                word &= word - 1u;
+                            rel = 2u * (own * 128u + w * 32u + (u32)__builtin_ctz(word)); // (bit b <-> tested position 2b + 1)
+                        }
+                    }
+                    const u64 t = isx ? useg - 13u + 2u * (u64)(qi - n) : useg + rel + 1u; // the tested position (odd)
+                    if (a.flags & (1u << 30))
+                    { // (ablation hook KREP_GPU_AC_NOPROBE: the count that comes back is the number of filter candidates)
+                        wcnt += (u32)__popcll(__ballot(live));
+                        continue;
+                    }
+                    if ((live || isx) && t < a.text_len)
+                    {
+                        if (t < 16u)
+                        { // (the first bytes of the text: no window in front — every end the position could name)
+                            for (u32 k = 0; k <= kAnchMaxK + 1u; ++k)
+                                mark(t + k);
+                        }
+                        else
+                        {
+                            struct __attribute__((packed)) U64p { u64 v; };
+                            const bool hasB = t + 1 < a.text_len;
+                            const u64 q8 = reinterpret_cast<const U64p *>(a.text + (t - (hasB ? 6u : 7u)))->v;
+                            const u64 Q = hasB ? q8 : (q8 >> 8); // bytes t - 6 .. t + 1
+                            typedef __attribute__((address_space(3))) const u32 lds_u32;
+                            auto gtest = [&](u32 E) -> bool {
+                                const u32 u = ac_pair(E);
+                                return ((*(lds_u32 *)(size_t)(((u >> 3) ^ (u >> 13)) & kTabMask) >> (u & 31u)) & 1u) != 0u;
+                            };
+                            // the position's own gram again for the seven in front of the unit; then, as in the end-gram kernel: an
+                            // anchor gram ENDS at t where the window's other gram sits at t - 1, at t + 1 where this one is that other gram
+                            const bool own_ok = live || gtest((u32)(Q >> 24));
+                            const bool liveA = own_ok && gtest((u32)(Q >> 16));
+                            const bool liveB = own_ok && hasB && gtest((u32)(Q >> 32));
+                            u32 kA = (u32)(Q >> 24), kB = (u32)(Q >> 32); // the exact anchor gram: bytes t - 3 .. t | t - 2 .. t + 1
+                            if (CI)
+                            {
+                                kA = ac_fold4(kA);
+                                kB = ac_fold4(kB);
+                            }
+                            uint4 ba = make_uint4(0, 0, 0, 0), bb = ba;
+                            if (liveA)
+                                ba = a.anch[((kA * a.anch_mul) >> 9) & a.anch_mask];
+                            if (liveB)
+                                bb = a.anch[((kB * a.anch_mul) >> 9) & a.anch_mask];
+                            u32 mA = (ba.x == kA && (ba.y >> 31)) ? ba.y : (ba.z == kA && (ba.w >> 31)) ? ba.w : 0u;
+                            u32 mB = (bb.x == kB && (bb.y >> 31)) ? bb.y : (bb.z == kB && (bb.w >> 31)) ? bb.w : 0u;
+                            mA = liveA ? (mA & 0x7fffffffu) : 0u;
+                            mB = liveB ? (mB & 0x7fffffffu) : 0u;
+                            while (mA)
+                            {
+                                mark(t + (u32)__builtin_ctz(mA));
+                                mA &= mA - 1u;
+                            }
+                            while (mB)
+                            {
+                                mark(t + 1u + (u32)__builtin_ctz(mB));
+                                mB &= mB - 1u;
+                            }
+                        }
+                    }
+                }
+            }
+            if (!(a.flags & (1u << 30)))
+            {
+                // ---- stage 3: the marked ends, one per lane, through the end-anchored verifier (lane L owns END positions [256 L, 256 L + 256))
+                const uint4 lo = *reinterpret_cast<const uint4 *>(bitmap + lane * 8u), hi = *reinterpret_cast<const uint4 *>(bitmap + lane * 8u + 4u);
+                const u32 mycnt = (u32)(__popc(lo.x) + __popc(lo.y) + __popc(lo.z) + __popc(lo.w) + __popc(hi.x) + __popc(hi.y) + __popc(hi.z) + __popc(hi.w));
+                u32 incl = mycnt;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1)
+                {
+                    const u32 t = __shfl_up(incl, o);
+                    if (lane >= (u32)o)
+                        incl += t;
+                }
+                const u32 n = __shfl(incl, 63);
+                for (u32 b0 = 0; b0 < n; b0 += 64)
+                {
+                    const u32 qi = b0 + lane;
+                    const bool live = qi < n;
+                    u32 rel = 0;
+                    {
+                        u32 own = 0;
+#pragma unroll
+                        for (u32 step = 32; step; step >>= 1)
+                        {
+                            const u32 t = __shfl(incl, (own + step - 1u) & 63u);
+                            if (t <= qi)
+                                own += step;
+                        }
+                        own &= 63u;
+                        const u32 oincl = __shfl(incl, own), ocnt = __shfl(mycnt, own);
+                        if (live)
+                        {
+                            u32 t = qi - (oincl - ocnt);
+                            const u32 *blk = bitmap + own * 8u;
+                            u32 w = 0, word = blk[0];
+                            for (;;)
+                            {
+                                const u32 c = (u32)__popc(word);
+                                if (t < c)
+                                    break;
+                                t -= c;
+                                word = blk[++w];
+                            }
+                            for (; t; --t)
+                                word &= word - 1u;
+                            rel = own * 256u + w * 32u + (u32)__builtin_ctz(word);
+                        }
+                    }
+                    const u64 pos = useg + rel;
+                    u32 cA = 0;
+                    u64 dmA = 0;
+                    bool simA = false;
+                    if (live)
+                        cA = ac_walk_fast<CI, false>(a, pos, false, dmA, simA);
+                    rank_and_emit(pos, cA, 0u, dmA, 0ull, simA, false);
+                }
+                if (n) // (wave-uniform) the END bitmap is the next unit's again
+                {
+                    *reinterpret_cast<uint4 *>(bitmap + lane * 8u) = make_uint4(0u, 0u, 0u, 0u);
+                    *reinterpret_cast<uint4 *>(bitmap + lane * 8u + 4u) = make_uint4(0u, 0u, 0u, 0u);
+                }
+            }
+        }
+        else
         {
             u32 mycnt = 0;
             {
@@ -483,7 +737,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                                 // the filter's own lookup for a gram that lies in one dword (cell_body, k = 3 mod 4)
                                 typedef __attribute__((address_space(3))) const u32 lds_u32;
                                 const u32 u = ac_pair(E);
-                                return ((*(lds_u32 *)(size_t)(((u >> 3) ^ (u >> 13)) & 0x1fffcu) >> (u & 31u)) & 1u) != 0u;
+                                return ((*(lds_u32 *)(size_t)(((u >> 3) ^ (u >> 13)) & kTabMask) >> (u & 31u)) & 1u) != 0u;
                             }
                             else
                                 return true;
@@ -506,64 +760,9 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 }
                 else if (liveA)
                     cA = ac_walk_fast<CI, SHORT>(a, pos, LINES, dmA, simA);
-                const u32 c = cA + cB;
-                u32 incl = c;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1)
-                {
-                    const u32 t = __shfl_up(incl, o);
-                    if (lane >= (u32)o)
-                        incl += t;
-                }
-                const u32 rank0 = wcnt + incl - c;
-                wcnt += __shfl(incl, 63);
-#pragma unroll 1
-                for (int e = 0; e < (pair ? 2 : 1); ++e)
-                {
-                    const u32 ce = e ? cB : cA;
-                    if (!ce)
-                        continue;
-                    const u64 pe = pos + (u64)e, dme = e ? dmB : dmA;
-                    const u32 re = rank0 + (e ? cA : 0u), rele = (u32)(pe - useg); // the END's bit in the unit's hit bitmap
-                    const bool sime = e ? simB : simA;
-                    if (LINES)
-                        atomicOr(&bitmap[rele >> 5], 1u << (rele & 31u));
-                    if (do_stage || do_final)
-                    {
-                        auto write = [&](u32 at, u64 s0, u32 len) {
-                            if (do_stage)
-                            {
-                                if (at < a.stage_cap)
-                                    slot[at] = ((u32)(s0 + 1024u - useg) << 11) | len; // start relative to the unit (>= -1023), length <= 1024
-                            }
-                            else
-                            {
-                                const u64 g = fbase + at;
-                                if (g < a.pos_cap)
-                                {
-                                    const u64 st = s0 + a.global_base, en = st + len;
-                                    *reinterpret_cast<uint4 *>(a.positions + 2 * g) =
-                                        make_uint4((u32)st, (u32)(st >> 32), (u32)en, (u32)(en >> 32));
-                                }
-                            }
-                        };
-                        if (sime)
-                        {
-                            u32 at = re;
-                            for (u64 rest = dme; rest;) // longest first
-                            {
-                                const u32 d = 63u - (u32)__builtin_clzll(rest);
-                                rest &= ~(1ull << d);
-                                write(at++, pe + 1 - (u64)d, d);
-                            }
-                        }
-                        else
-                            ac_walk<CI, true, !SHORT>(a, pe, ce, [&](u32 r, u64 s2, u32 len) { write(re + r, s2, len); });
-                    }
-                }
+                rank_and_emit(pos, cA, cB, dmA, dmB, simA, simB);
             }
         }
-
         LS2 wls{0, false, false, false};
         if (LINES)
         {
@@ -625,14 +824,14 @@ int g_ac_force_stage_cap = 0; // test hook (krep_gpu_debug_force_stage_cap)
 
 bool ac_counts_lines_in_registers(const AcTables *t) { return t && t->tiny.ok && !t->tiny.five; }
 
-static u32 ac_lds_bytes(u32 filter_words, bool lines)
+static u32 ac_lds_bytes(u32 filter_words, bool lines, bool anch)
 {
-    const u32 per_wave = kAcBitmapWords + (lines ? 2u * kAcBitmapWords : 0u);
+    const u32 per_wave = kAcBitmapWords + (lines ? 2u * kAcBitmapWords : 0u) + (anch ? kAcBitmapWords : 0u);
     return (((filter_words + 3u) & ~3u) + kAcWaves * per_wave) * (u32)sizeof(u32);
 }
 
 constexpr u32 kAcMaxLds = 160u * 1024u; // LDS of a gfx950 CU: the most a launch of the scan kernel can ask for
-template <bool CI, bool LN, bool SHORT, int STRIDE>
+template <bool CI, bool LN, bool SHORT, int STRIDE, bool ANCH = false>
 static hipError_t ac_launch3(const AcArgs &a, u32 grid, u32 lds, hipStream_t st)
 {
     // more than 64 KiB of dynamic LDS has to be requested explicitly — once per instantiation and device, not on every launch
@@ -645,20 +844,26 @@ static hipError_t ac_launch3(const AcArgs &a, u32 grid, u32 lds, hipStream_t st)
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= kMaxDev || !granted[dev].load(std::memory_order_acquire))
     {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ac_scan_kernel<CI, LN, SHORT, STRIDE>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ac_scan_kernel<CI, LN, SHORT, STRIDE, ANCH>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAcMaxLds);
         if (e != hipSuccess)
             return e;
         if (dev >= 0 && dev < kMaxDev)
             granted[dev].store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((ac_scan_kernel<CI, LN, SHORT, STRIDE>), dim3(grid), dim3(kAcBlock), lds, st, a);
+    hipLaunchKernelGGL((ac_scan_kernel<CI, LN, SHORT, STRIDE, ANCH>), dim3(grid), dim3(kAcBlock), lds, st, a);
     return hipGetLastError();
 }
 template <bool CI, bool LN>
 static hipError_t ac_launch2(const AcArgs &a, u32 grid, u32 lds, hipStream_t st)
 {
     const bool shorts = a.has1 || a.has2 || a.has3;
+    if constexpr (!LN)
+        if (a.anch && a.stride == 2 && !shorts)
+        {
+            g_ac_anchored_launches.fetch_add(1, std::memory_order_relaxed);
+            return ac_launch3<CI, false, false, 2, true>(a, grid, lds, st);
+        }
     if (a.stride == 2)
         return shorts ? ac_launch3<CI, LN, true, 2>(a, grid, lds, st) : ac_launch3<CI, LN, false, 2>(a, grid, lds, st);
     return shorts ? ac_launch3<CI, LN, true, 1>(a, grid, lds, st) : ac_launch3<CI, LN, false, 1>(a, grid, lds, st);
@@ -742,6 +947,22 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
     {
         a.filter = lines ? t->d_filters19 : t->d_filters20;
         a.stride = 2;
+    }
+    // anchors (kg_ac_anchor.hip): decided once per dictionary on the first text of >= 1 MiB; every launch without in-kernel -c then
+    // filters on the anchor grams (2^19-bit table) and verifies the ends they name
+    if (t->anch_state == 0 && text_len >= (1u << 20) && own_hi - own_lo >= (1u << 19))
+    {
+        SCHK(hipSetDevice(t->device));
+        if (ac_anchor_prepare(t, d_text, text_len, own_lo, own_hi, st) == 2)
+            (void)hipGetLastError(); // (the end grams stay; a failed sample is not a failed scan)
+    }
+    if (t->anch_state == 2 && !lines && a.stride == 2 && !getenv("KREP_GPU_AC_NO_ANCHOR"))
+    {
+        a.filter = t->d_filtera19;
+        a.filter_words = (1u << kXBitsLines) / 32;
+        a.anch = t->d_anch;
+        a.anch_mask = t->anch_mask;
+        a.anch_mul = t->anch_mul;
     }
     a.s1 = t->d_s1; a.s2 = t->d_s2; a.s3 = t->d_s3;
     if (t->short_dup)
@@ -961,7 +1182,7 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
     //  other mode of such a dictionary measured faster here)
     const bool tiny = t->tiny.ok && !ww && (!t->tiny.five || (!want && !lines && !t->ci));
     const u32 waves = tiny ? (u32)kTinyWaves : (u32)kAcWaves;
-    const u32 lds = ac_lds_bytes(a.filter_words, lines);
+    const u32 lds = ac_lds_bytes(a.filter_words, lines, a.anch != nullptr && !tiny);
     const u32 per_cu = lds <= 80 * 1024 ? 2u : 1u;
     // ticket size by text size: >= ~4 tickets per resident wave before tickets grow (small host buffers keep every
     // CU busy), 8 units (128 KiB) on large texts

@@ -68,6 +68,7 @@ AcTables *ac_build(const search_params_t &sp, int device)
         t->lmin = t->lmin ? std::min<u32>(t->lmin, (u32)p.size()) : (u32)p.size();
         pats.push_back(std::move(p));
     }
+    t->pats_h = pats; // (the anchor decision of kg_ac_anchor.hip, taken when the first large text arrives)
     // ---- exact bitmaps of the short patterns (verifier) ----
     std::vector<u32> S1, S2, S3;
     for (auto &p : pats)
@@ -425,6 +426,7 @@ void ac_free(AcTables *t)
     if (t->d_copies) (void)hipFree(t->d_copies);
     if (t->d_gram4) (void)hipFree(t->d_gram4);
     if (t->d_g4x) (void)hipFree(t->d_g4x);
+    ac_anchor_free(t);
     delete t;
 }
 

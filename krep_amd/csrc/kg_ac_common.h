@@ -51,7 +51,15 @@ struct AcArgs
     // exclusive prefix the resolver wave derives from them (kg_single.hip's scheme); n_tk tickets of `upt` units
     u64 *tk_agg, *tk_pref;
     u64 n_tk;
+    // ANCHORED scan (round 6, kg_ac_anchor.hip): the filter table holds, per pattern, the class grams of ONE 5-byte window chosen
+    // by rarity in the text (its anchor, k bytes before the pattern's end) instead of always its last five bytes; a candidate's
+    // exact anchor gram selects {key, 1 << 31 | mask of the offsets k} in buckets of two (one 16-byte load), every end t + k the
+    // mask names is marked in the unit's END bitmap, and the marked ends are verified exactly by ac_walk_fast (the end-anchored
+    // verifier, unchanged): the anchor stage is a superset filter of the ENDS, nothing else.
+    const uint4 *anch;
+    u32 anch_mask, anch_mul;
 };
+constexpr u32 kAnchMaxK = 12; // an anchor gram ends at most 12 bytes before its pattern's end: an END lies within 13 bytes of the tested position
 
 // Tiny dictionaries (kg_ac_tiny.hip): every pattern 1..4 bytes (or 1..3 and ONE length of 5..8), at most kTinyPer of each length,
 // no duplicates.  The patterns

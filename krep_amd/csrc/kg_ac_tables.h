@@ -2,6 +2,7 @@
 // kg_ac.hip): class-filter tables for LDS, the chain-compressed 4-gram buckets, exact bitmaps of the 1-3-byte patterns, the
 // reversed trie's edge table, and what the scans have learnt about the dictionary's density.
 #pragma once
+#include <vector>
 #include "kg_ac_common.h"
 
 namespace kg {
@@ -35,6 +36,18 @@ struct AcTables
     uint8_t set_b[4] = {0, 0, 0, 0};
     bool set_ok = true;
     int set_shape = 0;
+    // ---- anchored scan (kg_ac_anchor.hip): decided ONCE per dictionary, on the first text of >= 1 MiB it scans, from a 4-gram
+    // class histogram of a sample of that text
+    std::vector<std::vector<uint8_t>> pats_h; // the patterns (folded under -i), kept for that decision
+    int anch_state = 0;                       // 0: not decided yet, 1: end grams stay (nothing to gain / not eligible), 2: anchored
+    u32 *d_filtera19 = nullptr;               // pair-layout class table (2^19 bits) of the anchor grams
+    uint4 *d_anch = nullptr;                  // buckets of two {exact anchor gram, 1 << 31 | offset mask}
+    u32 anch_mask = 0, anch_mul = 0;
+    double anch_rate0 = 0, anch_rate = 0;     // estimated candidates per tested position: end grams / anchor grams (diagnostic)
+    u32 anch_moved = 0;                       // patterns whose anchor is not their end
 };
+// kg_ac_anchor.hip
+int ac_anchor_prepare(AcTables *t, const uint8_t *d_text, size_t text_len, size_t own_lo, size_t own_hi, hipStream_t st);
+void ac_anchor_free(AcTables *t);
 
 } // namespace kg

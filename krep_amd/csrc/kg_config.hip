@@ -271,4 +271,8 @@ namespace kg {
 std::atomic<uint64_t> g_tiny_dense_launches{0}; // ... of its DENSE one-pass flavour
 }
 extern "C" uint64_t krep_gpu_debug_tiny_dense_launches(void) { return kg::g_tiny_dense_launches.load(); }
+namespace kg {
+std::atomic<uint64_t> g_ac_anchored_launches{0}; // launches of the multi-pattern kernel's anchored instantiation
+}
+extern "C" uint64_t krep_gpu_debug_anchored_launches(void) { return kg::g_ac_anchored_launches.load(); }
 

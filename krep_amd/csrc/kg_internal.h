@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../../include/krep_gpu.h"
+#include "../../include/krep_gpu_debug.h" // (test hooks, exported by the same library)
 #include "kg_common.h"
 
 namespace kg {
@@ -107,6 +108,7 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
 extern std::atomic<int> g_force_rounds, g_force_stage_cap;   // krep_gpu_debug_force_rounds / _stage_cap
 extern std::atomic<uint64_t> g_tiny_launches;                // launches of ac_tiny_kernel (kg_ac_tiny.hip)
 extern std::atomic<uint64_t> g_tiny_dense_launches;          // ... of its DENSE one-pass flavour
+extern std::atomic<uint64_t> g_ac_anchored_launches;         // launches of ac_scan_kernel<.., ANCH> (kg_ac.hip, kg_ac_anchor.hip)
 extern std::atomic<uint64_t> g_fused1_launches;              // launches of single_fused (kg_single.hip)
 extern std::atomic<uint64_t> g_fused1_failovers;             // one-pass single-byte scans that handed over to the two-pass kernels
 inline uint8_t lo8(uint8_t c) { return (c >= 'A' && c <= 'Z') ? (uint8_t)(c + 32) : c; } // lower_table, krep.c:125-134

@@ -19,6 +19,7 @@
 #include "kg_internal.h"
 #include "kg_plan.h"
 #include "kg_replay.h"
+#include "kg_ac_tables.h"
 
 using namespace kg;
 
@@ -200,4 +201,13 @@ extern "C" void krep_gpu_plan_destroy(krep_gpu_plan_t *pl)
     delete pl;
 }
 extern "C" int krep_gpu_plan_ref_algo(const krep_gpu_plan_t *pl) { return pl ? pl->ref_algo : KREP_RA_NONE; }
-
+extern "C" int krep_gpu_debug_anchor_info(const krep_gpu_plan_t *pl, int *state, uint32_t *moved, double *rate_end_grams, double *rate_anchors)
+{
+    if (!pl || !pl->ac)
+        return 2;
+    if (state) *state = pl->ac->anch_state;
+    if (moved) *moved = pl->ac->anch_moved;
+    if (rate_end_grams) *rate_end_grams = pl->ac->anch_rate0;
+    if (rate_anchors) *rate_anchors = pl->ac->anch_rate;
+    return 0;
+}

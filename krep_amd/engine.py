@@ -120,6 +120,10 @@ class Engine:
         L.krep_gpu_debug_chain_fixups.restype = None
         L.krep_gpu_debug_chain_fixups.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.krep_gpu_debug_tiny_dense_launches.restype = C.c_uint64
+        L.krep_gpu_debug_anchored_launches.restype = C.c_uint64
+        L.krep_gpu_debug_anchor_info.restype = C.c_int
+        L.krep_gpu_debug_anchor_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_uint32), C.POINTER(C.c_double),
+                                                 C.POINTER(C.c_double)]
         L.krep_gpu_last_shard_info.restype = None
         L.krep_gpu_last_shard_info.argtypes = [C.POINTER(abi.ShardInfo)]
         L.krep_gpu_available.restype = C.c_int
@@ -177,6 +181,9 @@ class Engine:
 
     def tiny_dense_launches(self) -> int:
         return int(self.lib.krep_gpu_debug_tiny_dense_launches())
+
+    def anchored_launches(self) -> int:
+        return int(self.lib.krep_gpu_debug_anchored_launches())
 
     def tiny_launches(self) -> int:
         return int(self.lib.krep_gpu_debug_tiny_launches())
@@ -391,6 +398,13 @@ class Plan:
         if rc:
             raise KrepGpuError("krep_gpu_scan_device failed: " + self.eng.last_error())
         return out
+
+    def anchor_info(self):
+        """(state 0 undecided / 1 end grams / 2 anchored, patterns moved, est. candidate rate end grams, ... anchors) — multi-pattern plans"""
+        st, mv, r0, r1 = C.c_int(0), C.c_uint32(0), C.c_double(0), C.c_double(0)
+        if self.eng.lib.krep_gpu_debug_anchor_info(self.h, C.byref(st), C.byref(mv), C.byref(r0), C.byref(r1)):
+            return None
+        return int(st.value), int(mv.value), float(r0.value), float(r1.value)
 
     def scan_seq(self, d_text: int, text_len: int, own_lo, own_hi, global_base=0, d_positions: int = 0, capacity: int = 0,
                  global_len=0, carry_in: "abi.SeqCarry | None" = None):

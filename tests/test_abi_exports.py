@@ -19,7 +19,8 @@ def lib():
 
 
 def declared_functions():
-    src = open(os.path.join(ROOT, "include", "krep_gpu.h")).read()
+    # every header under include/: the drop-in boundary (krep_gpu.h) and the test hooks (krep_gpu_debug.h, moved out in round 6)
+    src = "".join(open(os.path.join(ROOT, "include", f)).read() for f in sorted(os.listdir(os.path.join(ROOT, "include"))) if f.endswith(".h"))
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     names = re.findall(r"\b([a-z_][a-z0-9_]*)\s*\([^;{]*\)\s*;", src)
     return sorted({n for n in names if n.startswith("krep_gpu_") or n.startswith("search_buffer")})
@@ -30,6 +31,10 @@ def test_every_declared_symbol_is_exported(lib):
     assert len(fns) >= 30 and "search_buffer" in fns and "search_buffer_ex" in fns and "krep_gpu_literal_search" in fns
     for n in fns:
         assert hasattr(lib, n), n
+    # the boundary header itself declares no test hook any more
+    boundary = open(os.path.join(ROOT, "include", "krep_gpu.h")).read()
+    assert "krep_gpu_debug_" not in boundary
+    assert any(n.startswith("krep_gpu_debug_") for n in fns)
 
 
 def test_struct_layouts_match_reference_header():

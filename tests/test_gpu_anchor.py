@@ -1,0 +1,129 @@
+"""GPU parity of the ANCHORED multi-pattern scan (krep_amd/csrc/kg_ac_anchor.hip, ac_scan_kernel<.., ANCH>): anchor grams chosen
+by rarity in a sample of the text, the ends they name verified by the end-anchored verifier.  The anchors may only decide which
+ends are LOOKED at; count, every (start, end) record and the emission order must stay aho_corasick_search's
+(/root/reference/aho_corasick.c:328-437).  $KREP_GPU_AC_ANCHOR=1 forces anchors by plain minimum (every offset 0..12 gets used) on
+texts where they gain nothing, so that the random cases reach every corner: ends named across unit boundaries (the seven tested
+positions in front of a unit), the first 16 bytes of a text, ownership windows, -w, -i, max_count, overflowing staging slots."""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+import wordlist
+from krep_amd import abi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import krep_amd
+    e = krep_amd.load()
+    assert e.device_count() >= 1
+    return e
+
+
+@pytest.fixture()
+def forced():
+    os.environ["KREP_GPU_AC_ANCHOR"] = "1"
+    yield
+    os.environ.pop("KREP_GPU_AC_ANCHOR", None)
+
+
+def _scan_device(gpu, pats, kw, text, lo=0, hi=None, base=0):
+    """One plan, device-resident: -> (ScanOut, records ndarray, plan.anchor_info())."""
+    import torch
+    n = len(text)
+    buf = torch.from_numpy(np.ascontiguousarray(text)).cuda()
+    cap = max(4096, n // 2)
+    pos = torch.empty(2 * cap, dtype=torch.int64, device="cuda")
+    plan = gpu.plan(abi.Params(pats, **kw))
+    out = plan.scan(buf.data_ptr(), n, lo, n if hi is None else hi, base, pos.data_ptr(), cap, global_len=base + n)
+    # a second scan of the same plan (the decision was taken by the first one) must give the same list
+    rec = pos[: 2 * out.stored].view(-1, 2).cpu().numpy().copy()
+    out2 = plan.scan(buf.data_ptr(), n, lo, n if hi is None else hi, base, pos.data_ptr(), cap, global_len=base + n)
+    assert out2.count == out.count and np.array_equal(pos[: 2 * out2.stored].view(-1, 2).cpu().numpy(), rec)
+    info = plan.anchor_info()
+    plan.close()
+    return out, rec, info
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_forced_anchors_on_random_texts(gpu, oracle_engine, forced, seed):
+    rng = np.random.RandomState(9100 + seed)
+    before = gpu.anchored_launches()
+    used = 0
+    for it in range(6):
+        alpha = [b"ab", b"abc\n", b"abcdefgh \n", bytes(range(97, 123)) + b"  \n", b"abAB -\n"][(seed + it) % 5]
+        n = (1 << 20) + [0, 1, 15, 16, 17, 8191, 16384, 16385, 40000, 123457][rng.randint(0, 10)]
+        text = cases.rand_text(rng, n, alpha)
+        k = [2, 5, 9, 40, 300][rng.randint(0, 5)]
+        lens = [[4, 5, 6], [4, 5, 8, 16], [5, 9, 13, 16, 17], [6, 7, 30, 64], [4, 4, 4, 12]][rng.randint(0, 5)]
+        pats = [cases.pick_pattern(rng, text, lens[rng.randint(0, len(lens))], alpha) for _ in range(k)]
+        if rng.rand() < 0.3:
+            pats.append(pats[0])  # a duplicate pattern is reported once per copy (aho_corasick.c:383-437)
+        # matches that END inside the first 16 bytes and straddle the 16-KiB units
+        for s in (0, 3, 16384 - 5, 16384 - 2, 32768 - 9, 3 * 16384 - 1, n - len(pats[0])):
+            p = np.frombuffer(pats[rng.randint(0, len(pats))], dtype=np.uint8)
+            if 0 <= s and s + p.size <= n:
+                text[s:s + p.size] = p
+        kw = dict(case_sensitive=bool(rng.rand() < 0.6), whole_word=bool(rng.rand() < 0.25),
+                  max_count=[abi.SIZE_MAX, abi.SIZE_MAX, abi.SIZE_MAX, 1, 77][rng.randint(0, 5)])
+        mode = ["pos", "pos", "count", "lines"][rng.randint(0, 4)]
+        if mode == "count":
+            kw.update(count_lines=True, only_match=True)
+        elif mode == "lines":
+            if any(b"\n" in p for p in pats):
+                continue
+            kw.update(count_lines=True)
+        want = oracle_engine.call(abi.RA_AHO_CORASICK, abi.Params(pats, **kw), text)
+        got = gpu.search(abi.Params(pats, **kw), text)
+        assert got[0] == want[0], (seed, it, pats[:4], kw, got[0], want[0])
+        assert np.array_equal(got[1], want[1]), (seed, it, pats[:4], kw, got[1][:6], want[1][:6])
+        used += 1
+    assert used and gpu.anchored_launches() > before  # the anchored instantiation is what ran
+
+
+def test_forced_anchors_in_ownership_windows_and_small_slots(gpu, oracle_engine, forced):
+    """Device windows (start ownership, global base beyond 2^32) cut at and around unit boundaries, with 16-entry staging slots
+    overflowing into the emit-mode re-scan."""
+    rng = np.random.RandomState(77)
+    n = (2 << 20) + 333
+    alpha = b"abcd \n"
+    text = cases.rand_text(rng, n, alpha)
+    pats = sorted({cases.pick_pattern(rng, text, [4, 5, 6, 7, 9, 12][rng.randint(0, 6)], alpha) for _ in range(60)})
+    _, want = oracle_engine.call(abi.RA_AHO_CORASICK, abi.Params(pats), text)
+    want = want.astype(np.int64)
+    base = (5 << 32) + 12345
+    for lo, hi in ((0, n), (16384, 5 * 16384), (16384 - 7, 16384 + 9), (100001, 1900003), (n - 20000, n), (3, 40)):
+        out, rec, info = _scan_device(gpu, pats, {}, text, lo, hi, base)
+        assert info is not None and info[0] == 2, info  # anchored
+        sel = want[(want[:, 0] >= lo) & (want[:, 0] < hi)] + base
+        assert out.count == len(sel) and np.array_equal(rec, sel), (lo, hi, len(rec), len(sel))
+    gpu.force_stage_cap(2)
+    try:
+        out, rec, _ = _scan_device(gpu, pats, {}, text, 0, n, 0)
+        assert np.array_equal(rec, want)
+    finally:
+        gpu.force_stage_cap(0)
+
+
+def test_decision_keeps_end_grams_on_iid_text_and_anchors_word_text(gpu, oracle_engine):
+    """Not forced: BASELINE config 4's shape (random patterns on i.i.d. letters) keeps the round-5 kernel — no pattern moves off
+    its end; a word dictionary on word text moves most of its patterns and estimates several times fewer candidates."""
+    rng = np.random.RandomState(5)
+    az = bytes(range(97, 123))
+    pats = [cases.rand_text(rng, rng.randint(4, 17), az).tobytes() for _ in range(1000)]
+    text = cases.rand_text(rng, 2 << 20, az + b"  \n")
+    out, rec, info = _scan_device(gpu, pats, {}, text)
+    assert info[0] == 1 and info[1] == 0, info
+    _, want = oracle_engine.call(abi.RA_AHO_CORASICK, abi.Params(pats), text)
+    assert np.array_equal(rec, want.astype(np.int64))
+    w = wordlist.word_list()
+    wtext = gpu.generate_host(3 << 20, 0, 5, 20260930, wordlist.pack(w), 80)
+    wp = wordlist.dictionary(w, "rare")
+    out, rec, info = _scan_device(gpu, wp, {}, wtext)
+    assert info[0] == 2 and info[1] > 500 and info[3] < 0.5 * info[2], info
+    _, want = oracle_engine.call(abi.RA_AHO_CORASICK, abi.Params(wp), wtext)
+    assert np.array_equal(rec, want.astype(np.int64))

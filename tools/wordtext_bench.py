@@ -38,6 +38,8 @@ def timed(pats, kw, want_pos, env=None):
                 first = out.kernel_ms
             else:
                 ts.append(out.kernel_ms)
+        global last_info
+        last_info = plan.anchor_info() if len(pats) > 1 else None
         plan.close()
     finally:
         for k in (env or {}):
@@ -70,6 +72,7 @@ def check_windows(pats, out):
 
 
 rows = []
+last_info = None
 texts = (("word text (kind 5)", lambda: e.generate(buf.data_ptr(), n, 0, 5, SEED, blob, LINE)),
          ("i.i.d. letters (kind 2)", lambda: e.generate(buf.data_ptr(), n, 0, 2, SEED, b"Sherlock", 10000)))
 dicts = [(k, wordlist.dictionary(W, k)) for k in ("rare", "uniform", "common")] + [("BASELINE cfg 4 (random 4-16 B)", bench.ac_patterns())]
@@ -96,9 +99,11 @@ for tname, gen in texts:
             t_f, _, _ = timed(pats, dict(count_lines=True, only_match=True), False, env={"KREP_GPU_AC_NOVERIFY": "1"})
             t_p, f_p, op = timed(pats, {}, True)
             t_l, _, ol_ = timed(pats, dict(count_lines=True), False)
+            info = last_info
             chk = check_windows(pats, op)
+            chk += f"  anchors: state {info[0]}, {info[1]} patterns moved, est. candidates/tested position {100 * info[2]:.3f} % -> {100 * info[3]:.3f} %" if info else ""
             print(f"1000 words, {name:32s} {oc.count:12d} matches  {ocand.count:12d} candidates ({ocand.count / n * 100:.3f} % of bytes)  "
-                  f"filter alone {n / t_f / 1e6:6.0f}  count {n / t_c / 1e6:6.0f}  offsets {n / t_p / 1e6:6.0f} GB/s ({t_p:.2f} ms = {n / t_p / 8e6:.3f} of 8 TB/s, first {f_p:.2f})  "
+                  f"filter alone {n / t_f / 1e6:6.0f}  count {n / t_c / 1e6:6.0f}  offsets {n / t_p / 1e6:6.0f} GB/s ({t_p:.2f} ms = {n / t_p / 8e9:.3f} of 8 TB/s, first {f_p:.2f})  "
                   f"-c {n / t_l / 1e6:6.0f} ({ol_.count} lines)  {chk}", flush=True)
         except Exception as ex:
             print(f"1000 words, {name:32s} failed: {ex!r}", flush=True)
