@@ -46,10 +46,11 @@ namespace kg {
 #ifndef KG_AC_LINES_ROLL_CELLS
 #define KG_AC_LINES_ROLL_CELLS 4 // cells (1 KiB each) of the next round a -c scan prefetches (A/B: krep_amd/build.py --variant x -DKG_AC_LINES_ROLL_CELLS=8)
 #endif
-// ANCH (round 6, kg_ac_anchor.hip; only with STRIDE == 2, no short patterns, no -c): the table holds rarity-chosen ANCHOR grams
-// (2^19 bits, which leaves room for a second bitmap per wave).  A candidate's exact anchor gram names the offsets k at which
-// patterns END behind it; those ends are marked in the unit's END bitmap, and the marked ends — not the candidates — are what the
-// end-anchored verifier (ac_walk_fast) looks at, in position order: ranking, staging and emission as before.
+// ANCH (round 6, kg_ac_anchor.hip; only with STRIDE == 2, no short patterns, no -c): the table holds rarity-chosen ANCHOR grams.
+// A candidate's exact anchor gram names the offsets k at which patterns END behind it; those ends are marked in a second bitmap
+// of the unit — same layout as the candidate bitmap: bit b <-> the END pair (2b + 1, 2b + 2), in the KiB that otherwise parks a
+// ticket's stores — and the marked pairs, not the candidates, are what the end-anchored verifier looks at, in position order:
+// ranking, staging and emission as before.
 template <bool CI, bool LINES, bool SHORT, int STRIDE, bool ANCH = false>
 __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
 {
@@ -62,8 +63,8 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
     for (u32 w = threadIdx.x; w < a.filter_words; w += kAcBlock)
         s_mem[w] = a.filter[w];
     const u32 fw = (a.filter_words + 3u) & ~3u;
-    constexpr u32 kPerWave = kAcBitmapWords + (LINES ? 2u * kAcBitmapWords : 0u) + (ANCH ? kAcBitmapWords : 0u); // candidate | hit | newline bitmaps (ANCH: candidate | END)
-    constexpr u32 XB = (LINES || ANCH) ? kXBitsLines : kXBitsBig; // index bits of the exact-class table
+    constexpr u32 kPerWave = kAcBitmapWords + (LINES ? 2u * kAcBitmapWords : 0u); // candidate | hit | newline bitmaps
+    constexpr u32 XB = LINES ? kXBitsLines : kXBitsBig; // index bits of the exact-class table
     constexpr u32 kTabMask = XB == 20 ? 0x1fffcu : 0xfffcu; // byte address of a pair-layout slot
     constexpr bool PAIR = STRIDE == 2;                  // pair-layout table, odd positions tested (see cell_body)
     constexpr bool PIPE = PAIR && !LINES;               // ... with the table reads software-pipelined over the cells of a round
@@ -85,9 +86,12 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
     u64 *park_info = reinterpret_cast<u64 *>(cbits + 256 + kAcUnitsPerTicketMax * 16); // [kAcUnitsPerTicketMax]
     u32 *bitmap = cbits + kAcBitmapWords;
     unsigned short *nlmap = reinterpret_cast<unsigned short *>(bitmap + kAcBitmapWords); // 16 bits per lane and cell
-    if (LINES || ANCH) // (ANCH: `bitmap` is the unit's END bitmap, one bit per end position; cleared again after every unit)
+    if (LINES)
         for (u32 w = lane; w < kAcBitmapWords; w += 64)
             bitmap[w] = 0u;
+    u32 *ebits = cbits + 256; // ANCH: the unit's END-pair bitmap (1 KiB, the park area: an anchored scan parks nothing)
+    if (ANCH)
+        *reinterpret_cast<uint4 *>(ebits + lane * 4u) = make_uint4(0u, 0u, 0u, 0u);
     const bool want_pos = (a.flags & F_POS) != 0;
     const bool chain = want_pos || LINES;
     const bool emit_final = a.emit_mode != 0;
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
         if (emit_final && (u32)(a.unitinfo[unit] & kUiCountMask) <= a.stage_cap)
             continue;
 
-        const bool parked = PIPE && !emit_final && chain && a.stage_cap == 16u && a.upt <= kAcUnitsPerTicketMax;
+        const bool parked = PIPE && !ANCH && !emit_final && chain && a.stage_cap == 16u && a.upt <= kAcUnitsPerTicketMax;
         u32 *slot = parked ? park_slots + (u32)(unit - u_begin) * 16u
                            : reinterpret_cast<u32 *>(a.stage) + unit * (u64)a.stage_cap; // 32-bit staged words, see write() below
         const bool do_final = emit_final && want_pos;
@@ -460,200 +464,137 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
         };
         if constexpr (ANCH)
         {
-            // ================= anchored: candidates -> END bitmap (stage 2), marked ends -> exact verify (stage 3) =================
-            const u64 e_lo = useg > a.end_lo ? useg : a.end_lo;
-            const u64 e_hi = useg + kAcUnitBytes < a.end_hi ? useg + kAcUnitBytes : a.end_hi;
+            // ================= anchored, stage 2: candidates -> END-pair bitmap =================
+            // the unit verifies the ends useg + 1 .. useg + 16384 (bit b <-> the pair 2b + 1, 2b + 2), as the end-gram kernel does
             auto mark = [&](u64 e) {
-                if (e >= e_lo && e < e_hi)
+                if (e > useg && e <= useg + kAcUnitBytes)
                 {
-                    const u32 r = (u32)(e - useg);
-                    atomicOr(&bitmap[r >> 5], 1u << (r & 31u));
+                    const u32 b = (u32)(e - useg - 1u) >> 1;
+                    atomicOr(&ebits[b >> 5], 1u << (b & 31u));
                 }
             };
-            {
-                u32 mycnt = 0;
-                {
-                    const uint4 lo = *reinterpret_cast<const uint4 *>(cbits + lane * kWPL);
-                    mycnt = (u32)(__popc(lo.x) + __popc(lo.y) + __popc(lo.z) + __popc(lo.w));
-                }
-                u32 incl = mycnt;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1)
-                {
-                    const u32 t = __shfl_up(incl, o);
-                    if (lane >= (u32)o)
-                        incl += t;
-                }
-                const bool off = (a.flags & (1u << 31)) != 0u; // (ablation hook KREP_GPU_AC_NOVERIFY: filter cost only)
-                const u32 n = off ? 0u : __shfl(incl, 63);
-                // an END lies up to 13 bytes behind the tested position that names it: the seven tested positions in front of the
-                // unit are looked at again here (their own unit dropped the ends that fall into this one)
-                const u32 n_x = (!off && useg >= 16u) ? 7u : 0u;
-                const u32 n_tot = n + n_x;
-                for (u32 b0 = 0; b0 < n_tot; b0 += 64)
-                {
-                    const u32 qi = b0 + lane;
-                    const bool live = qi < n, isx = qi >= n && qi < n_tot;
-                    u32 rel = 0;
-                    {
-                        u32 own = 0;
-#pragma unroll
-                        for (u32 step = 32; step; step >>= 1)
-                        {
-                            const u32 t = __shfl(incl, (own + step - 1u) & 63u);
-                            if (t <= qi)
-                                own += step;
-                        }
-                        own &= 63u;
-                        const u32 oincl = __shfl(incl, own), ocnt = __shfl(mycnt, own);
-                        if (live)
-                        {
-                            u32 t = qi - (oincl - ocnt);
-                            const u32 *blk = cbits + own * kWPL;
-                            u32 w = 0, word = blk[0];
-                            for (;;)
-                            {
-                                const u32 c = (u32)__popc(word);
-                                if (t < c)
-                                    break;
-                                t -= c;
-                                word = blk[++w];
-                            }
-                            for (; t; --t)
-                                word &= word - 1u;
-                            rel = 2u * (own * 128u + w * 32u + (u32)__builtin_ctz(word)); // (bit b <-> tested position 2b + 1)
-                        }
-                    }
-                    const u64 t = isx ? useg - 13u + 2u * (u64)(qi - n) : useg + rel + 1u; // the tested position (odd)
-                    if (a.flags & (1u << 30))
-                    { // (ablation hook KREP_GPU_AC_NOPROBE: the count that comes back is the number of filter candidates)
-                        wcnt += (u32)__popcll(__ballot(live));
-                        continue;
-                    }
-                    if ((live || isx) && t < a.text_len)
-                    {
-                        if (t < 16u)
-                        { // (the first bytes of the text: no window in front — every end the position could name)
-                            for (u32 k = 0; k <= kAnchMaxK + 1u; ++k)
-                                mark(t + k);
-                        }
-                        else
-                        {
-                            struct __attribute__((packed)) U64p { u64 v; };
-                            const bool hasB = t + 1 < a.text_len;
-                            const u64 q8 = reinterpret_cast<const U64p *>(a.text + (t - (hasB ? 6u : 7u)))->v;
-                            const u64 Q = hasB ? q8 : (q8 >> 8); // bytes t - 6 .. t + 1
-                            typedef __attribute__((address_space(3))) const u32 lds_u32;
-                            auto gtest = [&](u32 E) -> bool {
-                                const u32 u = ac_pair(E);
-                                return ((*(lds_u32 *)(size_t)(((u >> 3) ^ (u >> 13)) & kTabMask) >> (u & 31u)) & 1u) != 0u;
-                            };
-                            // the position's own gram again for the seven in front of the unit; then, as in the end-gram kernel: an
-                            // anchor gram ENDS at t where the window's other gram sits at t - 1, at t + 1 where this one is that other gram
-                            const bool own_ok = live || gtest((u32)(Q >> 24));
-                            const bool liveA = own_ok && gtest((u32)(Q >> 16));
-                            const bool liveB = own_ok && hasB && gtest((u32)(Q >> 32));
-                            u32 kA = (u32)(Q >> 24), kB = (u32)(Q >> 32); // the exact anchor gram: bytes t - 3 .. t | t - 2 .. t + 1
-                            if (CI)
-                            {
-                                kA = ac_fold4(kA);
-                                kB = ac_fold4(kB);
-                            }
-                            uint4 ba = make_uint4(0, 0, 0, 0), bb = ba;
-                            if (liveA)
-                                ba = a.anch[((kA * a.anch_mul) >> 9) & a.anch_mask];
-                            if (liveB)
-                                bb = a.anch[((kB * a.anch_mul) >> 9) & a.anch_mask];
-                            u32 mA = (ba.x == kA && (ba.y >> 31)) ? ba.y : (ba.z == kA && (ba.w >> 31)) ? ba.w : 0u;
-                            u32 mB = (bb.x == kB && (bb.y >> 31)) ? bb.y : (bb.z == kB && (bb.w >> 31)) ? bb.w : 0u;
-                            mA = liveA ? (mA & 0x7fffffffu) : 0u;
-                            mB = liveB ? (mB & 0x7fffffffu) : 0u;
-                            while (mA)
-                            {
-                                mark(t + (u32)__builtin_ctz(mA));
-                                mA &= mA - 1u;
-                            }
-                            while (mB)
-                            {
-                                mark(t + 1u + (u32)__builtin_ctz(mB));
-                                mB &= mB - 1u;
-                            }
-                        }
-                    }
-                }
-            }
-            if (!(a.flags & (1u << 30)))
-            {
-                // ---- stage 3: the marked ends, one per lane, through the end-anchored verifier (lane L owns END positions [256 L, 256 L + 256))
-                const uint4 lo = *reinterpret_cast<const uint4 *>(bitmap + lane * 8u), hi = *reinterpret_cast<const uint4 *>(bitmap + lane * 8u + 4u);
-                const u32 mycnt = (u32)(__popc(lo.x) + __popc(lo.y) + __popc(lo.z) + __popc(lo.w) + __popc(hi.x) + __popc(hi.y) + __popc(hi.z) + __popc(hi.w));
-                u32 incl = mycnt;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1)
-                {
-                    const u32 t = __shfl_up(incl, o);
-                    if (lane >= (u32)o)
-                        incl += t;
-                }
-                const u32 n = __shfl(incl, 63);
-                for (u32 b0 = 0; b0 < n; b0 += 64)
-                {
-                    const u32 qi = b0 + lane;
-                    const bool live = qi < n;
-                    u32 rel = 0;
-                    {
-                        u32 own = 0;
-#pragma unroll
-                        for (u32 step = 32; step; step >>= 1)
-                        {
-                            const u32 t = __shfl(incl, (own + step - 1u) & 63u);
-                            if (t <= qi)
-                                own += step;
-                        }
-                        own &= 63u;
-                        const u32 oincl = __shfl(incl, own), ocnt = __shfl(mycnt, own);
-                        if (live)
-                        {
-                            u32 t = qi - (oincl - ocnt);
-                            const u32 *blk = bitmap + own * 8u;
-                            u32 w = 0, word = blk[0];
-                            for (;;)
-                            {
-                                const u32 c = (u32)__popc(word);
-                                if (t < c)
-                                    break;
-                                t -= c;
-                                word = blk[++w];
-                            }
-                            for (; t; --t)
-                                word &= word - 1u;
-                            rel = own * 256u + w * 32u + (u32)__builtin_ctz(word);
-                        }
-                    }
-                    const u64 pos = useg + rel;
-                    u32 cA = 0;
-                    u64 dmA = 0;
-                    bool simA = false;
-                    if (live)
-                        cA = ac_walk_fast<CI, false>(a, pos, false, dmA, simA);
-                    rank_and_emit(pos, cA, 0u, dmA, 0ull, simA, false);
-                }
-                if (n) // (wave-uniform) the END bitmap is the next unit's again
-                {
-                    *reinterpret_cast<uint4 *>(bitmap + lane * 8u) = make_uint4(0u, 0u, 0u, 0u);
-                    *reinterpret_cast<uint4 *>(bitmap + lane * 8u + 4u) = make_uint4(0u, 0u, 0u, 0u);
-                }
-            }
-        }
-        else
-        {
             u32 mycnt = 0;
             {
                 const uint4 lo = *reinterpret_cast<const uint4 *>(cbits + lane * kWPL);
                 mycnt = (u32)(__popc(lo.x) + __popc(lo.y) + __popc(lo.z) + __popc(lo.w));
+            }
+            u32 incl = mycnt;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1)
+            {
+                const u32 t = __shfl_up(incl, o);
+                if (lane >= (u32)o)
+                    incl += t;
+            }
+            const bool off = (a.flags & (1u << 31)) != 0u; // (ablation hook KREP_GPU_AC_NOVERIFY: filter cost only)
+            const u32 n = off ? 0u : __shfl(incl, 63);
+            // an END lies up to 13 bytes behind the tested position that names it: the six tested positions in front of the unit
+            // whose ends can fall into it are looked at again here (their own unit drops the ends beyond its last pair)
+            const u32 n_x = (!off && useg >= 16u) ? 6u : 0u;
+            const u32 n_tot = n + n_x;
+            for (u32 b0 = 0; b0 < n_tot; b0 += 64)
+            {
+                const u32 qi = b0 + lane;
+                const bool live = qi < n, isx = qi >= n && qi < n_tot;
+                u32 rel = 0;
+                {
+                    u32 own = 0;
+#pragma unroll
+                    for (u32 step = 32; step; step >>= 1)
+                    {
+                        const u32 t = __shfl(incl, (own + step - 1u) & 63u);
+                        if (t <= qi)
+                            own += step;
+                    }
+                    own &= 63u;
+                    const u32 oincl = __shfl(incl, own), ocnt = __shfl(mycnt, own);
+                    if (live)
+                    {
+                        u32 t = qi - (oincl - ocnt);
+                        const u32 *blk = cbits + own * kWPL;
+                        u32 w = 0, word = blk[0];
+                        for (;;)
+                        {
+                            const u32 c = (u32)__popc(word);
+                            if (t < c)
+                                break;
+                            t -= c;
+                            word = blk[++w];
+                        }
+                        for (; t; --t)
+                            word &= word - 1u;
+                        rel = 2u * (own * 128u + w * 32u + (u32)__builtin_ctz(word)); // (bit b <-> tested position 2b + 1)
+                    }
+                }
+                const u64 t = isx ? useg - 11u + 2u * (u64)(qi - n) : useg + rel + 1u; // the tested position (odd)
+                if (a.flags & (1u << 30))
+                { // (ablation hook KREP_GPU_AC_NOPROBE: the count that comes back is the number of filter candidates)
+                    wcnt += (u32)__popcll(__ballot(live));
+                    continue;
+                }
+                if ((live || isx) && t < a.text_len)
+                {
+                    if (t < 16u)
+                    { // (the first bytes of the text: no window in front — every end the position could name)
+                        for (u32 k = 0; k <= kAnchMaxK + 1u; ++k)
+                            mark(t + k);
+                    }
+                    else
+                    {
+                        struct __attribute__((packed)) U64p { u64 v; };
+                        const bool hasB = t + 1 < a.text_len;
+                        const u64 q8 = reinterpret_cast<const U64p *>(a.text + (t - (hasB ? 6u : 7u)))->v;
+                        const u64 Q = hasB ? q8 : (q8 >> 8); // bytes t - 6 .. t + 1
+                        typedef __attribute__((address_space(3))) const u32 lds_u32;
+                        auto gtest = [&](u32 E) -> bool {
+                            const u32 u = ac_pair(E);
+                            return ((*(lds_u32 *)(size_t)(((u >> 3) ^ (u >> 13)) & kTabMask) >> (u & 31u)) & 1u) != 0u;
+                        };
+                        // the position's own gram again for the six in front of the unit; then, as in the end-gram kernel: an anchor
+                        // gram ENDS at t where the window's other gram sits at t - 1, at t + 1 where this one is that other gram
+                        const bool own_ok = live || gtest((u32)(Q >> 24));
+                        const bool liveA = own_ok && gtest((u32)(Q >> 16));
+                        const bool liveB = own_ok && hasB && gtest((u32)(Q >> 32));
+                        u32 kA = (u32)(Q >> 24), kB = (u32)(Q >> 32); // the exact anchor gram: bytes t - 3 .. t | t - 2 .. t + 1
+                        if (CI)
+                        {
+                            kA = ac_fold4(kA);
+                            kB = ac_fold4(kB);
+                        }
+                        uint4 ba = make_uint4(0, 0, 0, 0), bb = ba;
+                        if (liveA)
+                            ba = a.anch[((kA * a.anch_mul) >> 9) & a.anch_mask];
+                        if (liveB)
+                            bb = a.anch[((kB * a.anch_mul) >> 9) & a.anch_mask];
+                        u32 mA = (ba.x == kA && (ba.y >> 31)) ? ba.y : (ba.z == kA && (ba.w >> 31)) ? ba.w : 0u;
+                        u32 mB = (bb.x == kB && (bb.y >> 31)) ? bb.y : (bb.z == kB && (bb.w >> 31)) ? bb.w : 0u;
+                        mA = liveA ? (mA & 0x7fffffffu) : 0u;
+                        mB = liveB ? (mB & 0x7fffffffu) : 0u;
+                        while (mA)
+                        {
+                            mark(t + (u32)__builtin_ctz(mA));
+                            mA &= mA - 1u;
+                        }
+                        while (mB)
+                        {
+                            mark(t + 1u + (u32)__builtin_ctz(mB));
+                            mB &= mB - 1u;
+                        }
+                    }
+                }
+            }
+        }
+        // (ANCH: what follows is stage 3 — the same verify, over the END-pair bitmap instead of the candidate bitmap)
+        const u32 *vbits = ANCH ? ebits : cbits;
+        if (!(ANCH && (a.flags & (1u << 30))))
+        {
+            u32 mycnt = 0;
+            {
+                const uint4 lo = *reinterpret_cast<const uint4 *>(vbits + lane * kWPL);
+                mycnt = (u32)(__popc(lo.x) + __popc(lo.y) + __popc(lo.z) + __popc(lo.w));
                 if (!PIPE)
                 {
-                    const uint4 hi = *reinterpret_cast<const uint4 *>(cbits + lane * kWPL + 4u);
+                    const uint4 hi = *reinterpret_cast<const uint4 *>(vbits + lane * kWPL + 4u);
                     mycnt += (u32)(__popc(hi.x) + __popc(hi.y) + __popc(hi.z) + __popc(hi.w));
                 }
             }
@@ -689,7 +630,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                     if (live)
                     {
                         u32 t = qi - (oincl - ocnt); // my candidate is the t-th set bit of the owner's block
-                        const u32 *blk = cbits + own * kWPL;
+                        const u32 *blk = vbits + own * kWPL;
                         u32 w = 0, word = blk[0];
                         for (;;)
                         {
@@ -721,7 +662,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                     bool slA = false, slB = false;
                     u32 mA = 0, mB = 0;
 #ifndef KG_AC_NO_BTEST // (A/B switches of krep_amd/build.py --variant)
-                    constexpr bool kGram = PAIR && XB == 20; // the probe asks the class table about both ends (kg_ac_common.h)
+                    constexpr bool kGram = PAIR && XB == 20 && !ANCH; // the probe asks the class table about both ends (kg_ac_common.h; ANCH: the table holds anchor grams, not end grams)
 #else
                     constexpr bool kGram = false;
 #endif
@@ -762,6 +703,8 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                     cA = ac_walk_fast<CI, SHORT>(a, pos, LINES, dmA, simA);
                 rank_and_emit(pos, cA, cB, dmA, dmB, simA, simB);
             }
+            if (ANCH && n) // (wave-uniform) the END-pair bitmap is the next unit's again
+                *reinterpret_cast<uint4 *>(ebits + lane * 4u) = make_uint4(0u, 0u, 0u, 0u);
         }
         LS2 wls{0, false, false, false};
         if (LINES)
@@ -795,7 +738,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
             }
         }
       }
-      if (PIPE && !emit_final && chain && a.stage_cap == 16u && a.upt <= kAcUnitsPerTicketMax)
+      if (PIPE && !ANCH && !emit_final && chain && a.stage_cap == 16u && a.upt <= kAcUnitsPerTicketMax)
       {
         // the ticket's parked info words and slots (consecutive units: one contiguous 64-byte-per-unit region), two stores
         const u32 nun = (u32)(u_end - u_begin);
@@ -824,9 +767,9 @@ int g_ac_force_stage_cap = 0; // test hook (krep_gpu_debug_force_stage_cap)
 
 bool ac_counts_lines_in_registers(const AcTables *t) { return t && t->tiny.ok && !t->tiny.five; }
 
-static u32 ac_lds_bytes(u32 filter_words, bool lines, bool anch)
+static u32 ac_lds_bytes(u32 filter_words, bool lines)
 {
-    const u32 per_wave = kAcBitmapWords + (lines ? 2u * kAcBitmapWords : 0u) + (anch ? kAcBitmapWords : 0u);
+    const u32 per_wave = kAcBitmapWords + (lines ? 2u * kAcBitmapWords : 0u);
     return (((filter_words + 3u) & ~3u) + kAcWaves * per_wave) * (u32)sizeof(u32);
 }
 
@@ -930,7 +873,9 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
         a.own_lo = 0;
         a.own_hi = text_len;
     }
-    a.anchor = own_lo & ~(u64)15;
+    // (END-owned records: a unit verifies the ends behind its first byte, so the end AT own_lo belongs to the unit in front —
+    //  which has to exist; round 6)
+    a.anchor = ((own_by_end && !lines && own_lo) ? own_lo - 1 : own_lo) & ~(u64)15;
     const u64 unit_bytes = (u64)kAcUnitBytes;
     a.num_tiles = (a.end_hi - a.anchor + unit_bytes - 1) / unit_bytes;
     a.flags = (t->ci ? F_CI : 0) | (ww ? F_WW : 0) | (lines ? F_LINES : 0);
@@ -949,7 +894,7 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
         a.stride = 2;
     }
     // anchors (kg_ac_anchor.hip): decided once per dictionary on the first text of >= 1 MiB; every launch without in-kernel -c then
-    // filters on the anchor grams (2^19-bit table) and verifies the ends they name
+    // filters on the anchor grams and verifies the ends they name
     if (t->anch_state == 0 && text_len >= (1u << 20) && own_hi - own_lo >= (1u << 19))
     {
         SCHK(hipSetDevice(t->device));
@@ -958,8 +903,7 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
     }
     if (t->anch_state == 2 && !lines && a.stride == 2 && !getenv("KREP_GPU_AC_NO_ANCHOR"))
     {
-        a.filter = t->d_filtera19;
-        a.filter_words = (1u << kXBitsLines) / 32;
+        a.filter = t->d_filtera20;
         a.anch = t->d_anch;
         a.anch_mask = t->anch_mask;
         a.anch_mul = t->anch_mul;
@@ -1182,7 +1126,7 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
     //  other mode of such a dictionary measured faster here)
     const bool tiny = t->tiny.ok && !ww && (!t->tiny.five || (!want && !lines && !t->ci));
     const u32 waves = tiny ? (u32)kTinyWaves : (u32)kAcWaves;
-    const u32 lds = ac_lds_bytes(a.filter_words, lines, a.anch != nullptr && !tiny);
+    const u32 lds = ac_lds_bytes(a.filter_words, lines);
     const u32 per_cu = lds <= 80 * 1024 ? 2u : 1u;
     // ticket size by text size: >= ~4 tickets per resident wave before tickets grow (small host buffers keep every
     // CU busy), 8 units (128 KiB) on large texts

@@ -11,9 +11,10 @@
 // on the device (2^20 bins, the filter's own index space).  Per pattern the 5-byte window P[L-5-k .. L-k) whose two class grams are
 // rarest in the sample becomes its ANCHOR (k <= 12 bytes before its end; a pattern moves off its end only for a 4x rarer window,
 // so a dictionary on i.i.d. text keeps k = 0 everywhere and the round-5 kernel, bit for bit).  When the estimated candidate rate
-// drops enough, the dictionary gets a second filter table (pair layout, 2^19 bits) and a table {exact anchor gram -> mask of offsets
-// k}; the scan kernel's ANCH instantiation marks the ENDS t + k its candidates name and verifies the marked ends with the
-// end-anchored verifier it always had.  The anchors only decide WHICH ends are looked at: a superset filter, results unchanged.
+// drops enough, EVERY pattern takes its rarest window and the dictionary gets a second filter table (pair layout, 2^20 bits) and a
+// table {exact anchor gram -> mask of offsets k}; the scan kernel's ANCH instantiation marks the END pairs its candidates name and
+// verifies the marked pairs with the end-anchored verifier it always had.  The anchors only decide WHICH ends are looked at: a
+// superset filter, results unchanged.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -46,9 +47,9 @@ static inline u32 cls4_of(const uint8_t *g) { return ((u32)g[0] & 31u) | (((u32)
 
 void ac_anchor_free(AcTables *t)
 {
-    if (t->d_filtera19) (void)hipFree(t->d_filtera19);
+    if (t->d_filtera20) (void)hipFree(t->d_filtera20);
     if (t->d_anch) (void)hipFree(t->d_anch);
-    t->d_filtera19 = nullptr;
+    t->d_filtera20 = nullptr;
     t->d_anch = nullptr;
 }
 
@@ -95,7 +96,7 @@ int ac_anchor_prepare(AcTables *t, const uint8_t *d_text, size_t text_len, size_
             s += hist[known | c0];
         return s;
     };
-    std::vector<u32> ks(t->pats_h.size(), 0);
+    std::vector<u32> ks(t->pats_h.size(), 0), kfree(t->pats_h.size(), 0);
     u32 moved = 0;
     for (size_t i = 0; i < t->pats_h.size(); ++i)
     {
@@ -117,9 +118,10 @@ int ac_anchor_prepare(AcTables *t, const uint8_t *d_text, size_t text_len, size_
                 bk = k;
             }
         }
+        kfree[i] = (u32)bk; // the plain minimum
         if (bk && (force || best * 4 < c0))
         {
-            ks[i] = (u32)bk;
+            ks[i] = (u32)bk; // ... and the moves no sampling noise explains (what the DECISION rests on)
             ++moved;
         }
     }
@@ -127,8 +129,9 @@ int ac_anchor_prepare(AcTables *t, const uint8_t *d_text, size_t text_len, size_
     if (!moved)
         return 0;
     // ---- the two tables ----
-    std::vector<u32> T19((1u << kXBitsLines) / 32, 0), T20(kHistBins / 32, 0), E20(kHistBins / 32, 0);
-    auto expand = [&](std::vector<u32> &plain20, std::vector<u32> *pair19, const uint8_t *g, size_t known) {
+    std::vector<u32> T20(kHistBins / 32, 0), E20(kHistBins / 32, 0);
+    std::unordered_map<u32, u32> keys; // exact anchor gram (text order, first byte lowest) -> offset mask
+    auto expand = [&](std::vector<u32> &tab, bool pair, const uint8_t *g, size_t known) {
         u32 fixed = 0;
         for (size_t q = 0; q < known; ++q)
             fixed |= ((u32)g[q] & 31u) << (5 * (4 - known + q));
@@ -136,54 +139,75 @@ int ac_anchor_prepare(AcTables *t, const uint8_t *d_text, size_t text_len, size_
         for (u32 f = 0; f < nfree; ++f)
         {
             const u32 x = fixed | f;
-            plain20[x >> 5] |= 1u << (x & 31);
-            if (pair19)
+            if (pair)
             {
                 u32 dw, bit;
                 ac_pair_slot(x, dw, bit);
-                (*pair19)[dw & ((1u << (kXBitsLines - 5)) - 1u)] |= 1u << bit; // the kernel masks the byte address with 0xfffc
+                tab[dw] |= 1u << bit;
             }
+            else
+                tab[x >> 5] |= 1u << (x & 31);
         }
     };
-    std::unordered_map<u32, u32> keys; // exact anchor gram (text order, first byte lowest) -> offset mask
+    auto build = [&](const std::vector<u32> &kk) {
+        std::fill(T20.begin(), T20.end(), 0u);
+        keys.clear();
+        for (size_t i = 0; i < t->pats_h.size(); ++i)
+        {
+            const auto &p = t->pats_h[i];
+            const size_t L = p.size(), k = kk[i];
+            expand(T20, true, p.data() + (L - 4 - k), 4);
+            if (L - k >= 5)
+                expand(T20, true, p.data() + (L - 5 - k), 4);
+            else
+                expand(T20, true, p.data(), 3);
+            const uint8_t *g = p.data() + (L - 4 - k);
+            keys[(u32)g[0] | ((u32)g[1] << 8) | ((u32)g[2] << 16) | ((u32)g[3] << 24)] |= 1u << k;
+        }
+    };
+    // estimated candidates per tested position of a pair-layout table: the sample's grams that it holds
+    auto rate_of = [&](const std::vector<u32> &tab, bool pair) -> double {
+        u64 hits = 0;
+        for (u32 x = 0; x < kHistBins; ++x)
+        {
+            if (!hist[x])
+                continue;
+            u32 dw = x >> 5, bit = x & 31;
+            if (pair)
+                ac_pair_slot(x, dw, bit);
+            if ((tab[dw] >> bit) & 1u)
+                hits += hist[x];
+        }
+        return (double)hits / nsamp;
+    };
     for (size_t i = 0; i < t->pats_h.size(); ++i)
     {
         const auto &p = t->pats_h[i];
-        const size_t L = p.size(), k = ks[i];
-        expand(T20, &T19, p.data() + (L - 4 - k), 4);
-        if (L - k >= 5)
-            expand(T20, &T19, p.data() + (L - 5 - k), 4);
-        else
-            expand(T20, &T19, p.data(), 3);
-        expand(E20, nullptr, p.data() + (L - 4), 4);
+        const size_t L = p.size();
+        expand(E20, false, p.data() + (L - 4), 4);
         if (L >= 5)
-            expand(E20, nullptr, p.data() + (L - 5), 4);
+            expand(E20, false, p.data() + (L - 5), 4);
         else
-            expand(E20, nullptr, p.data(), 3);
-        const uint8_t *g = p.data() + (L - 4 - k);
-        keys[(u32)g[0] | ((u32)g[1] << 8) | ((u32)g[2] << 16) | ((u32)g[3] << 24)] |= 1u << k;
+            expand(E20, false, p.data(), 3);
     }
-    // estimated candidates per tested position: the end grams in the 2^20 table the round-5 kernel uses against the anchor grams in
-    // the 2^19 table (whose dropped index bit merges pairs of slots) the anchored kernel uses
-    u64 hits0 = 0, hits1 = 0;
-    for (u32 x = 0; x < kHistBins; ++x)
+    build(ks);
+    t->anch_rate0 = rate_of(E20, false);
+    t->anch_rate = rate_of(T20, true);
+    // worth a second stage: at least a third fewer candidates with the noise-proof moves alone, and a rate that matters to begin with
+    const bool go = force || (t->anch_rate0 > 0.008 && t->anch_rate < 0.66 * t->anch_rate0);
+    if (go && !force)
     {
-        if (!hist[x])
-            continue;
-        if ((E20[x >> 5] >> (x & 31)) & 1u)
-            hits0 += hist[x];
-        u32 dw, bit;
-        ac_pair_slot(x, dw, bit);
-        if ((T19[dw & ((1u << (kXBitsLines - 5)) - 1u)] >> bit) & 1u)
-            hits1 += hist[x];
+        // ... then every pattern takes its rarest window (a choice among windows the sample hardly holds costs nothing if it is noise)
+        build(kfree);
+        t->anch_rate = rate_of(T20, true);
+        t->anch_moved = 0;
+        for (u32 k : kfree)
+            t->anch_moved += k ? 1u : 0u;
     }
-    t->anch_rate0 = (double)hits0 / nsamp;
-    t->anch_rate = (double)hits1 / nsamp;
     if (getenv("KREP_GPU_DEBUG"))
-        fprintf(stderr, "krep-gpu: anchors: %u of %zu patterns moved off their end; candidates per tested position %.4f %% (end grams) -> %.4f %% (anchors), %zu anchor grams\n",
-                moved, t->pats_h.size(), 100.0 * t->anch_rate0, 100.0 * t->anch_rate, keys.size());
-    // worth a second stage and the smaller table: at least a third fewer candidates, and a rate that matters to begin with
-    if (!force && !(t->anch_rate0 > 0.008 && t->anch_rate < 0.66 * t->anch_rate0))
+        fprintf(stderr, "krep-gpu: anchors: %u of %zu patterns off their end (%u beyond sampling noise); candidates per tested position %.4f %% (end grams) -> %.4f %% (anchors), %zu anchor grams: %s\n",
+                t->anch_moved, t->pats_h.size(), moved, 100.0 * t->anch_rate0, 100.0 * t->anch_rate, keys.size(), go ? "anchored" : "end grams kept");
+    if (!go)
         return 0;
     // buckets of two {key, 1 << 31 | mask}: no bucket overfull, one 16-byte load per probe
     static const u32 muls[] = {0x9E3779B1u, 0x85EBCA6Bu, 0xC2B2AE35u, 0x27D4EB2Fu, 0x165667B1u, 0xD3A2646Cu};
@@ -228,8 +252,8 @@ int ac_anchor_prepare(AcTables *t, const uint8_t *d_text, size_t text_len, size_
     }
     if (!nb_used)
         return 0;
-    if (hipMalloc(&t->d_filtera19, T19.size() * sizeof(u32)) != hipSuccess || hipMalloc(&t->d_anch, bk.size() * sizeof(uint4)) != hipSuccess ||
-        hipMemcpyAsync(t->d_filtera19, T19.data(), T19.size() * sizeof(u32), hipMemcpyHostToDevice, st) != hipSuccess ||
+    if (hipMalloc(&t->d_filtera20, T20.size() * sizeof(u32)) != hipSuccess || hipMalloc(&t->d_anch, bk.size() * sizeof(uint4)) != hipSuccess ||
+        hipMemcpyAsync(t->d_filtera20, T20.data(), T20.size() * sizeof(u32), hipMemcpyHostToDevice, st) != hipSuccess ||
         hipMemcpyAsync(t->d_anch, bk.data(), bk.size() * sizeof(uint4), hipMemcpyHostToDevice, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess)
     {

@@ -40,7 +40,7 @@ struct AcTables
     // class histogram of a sample of that text
     std::vector<std::vector<uint8_t>> pats_h; // the patterns (folded under -i), kept for that decision
     int anch_state = 0;                       // 0: not decided yet, 1: end grams stay (nothing to gain / not eligible), 2: anchored
-    u32 *d_filtera19 = nullptr;               // pair-layout class table (2^19 bits) of the anchor grams
+    u32 *d_filtera20 = nullptr;               // pair-layout class table (2^20 bits) of the anchor grams
     uint4 *d_anch = nullptr;                  // buckets of two {exact anchor gram, 1 << 31 | offset mask}
     u32 anch_mask = 0, anch_mul = 0;
     double anch_rate0 = 0, anch_rate = 0;     // estimated candidates per tested position: end grams / anchor grams (diagnostic)

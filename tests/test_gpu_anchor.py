@@ -127,3 +127,33 @@ def test_decision_keeps_end_grams_on_iid_text_and_anchors_word_text(gpu, oracle_
     assert info[0] == 2 and info[1] > 500 and info[3] < 0.5 * info[2], info
     _, want = oracle_engine.call(abi.RA_AHO_CORASICK, abi.Params(wp), wtext)
     assert np.array_equal(rec, want.astype(np.int64))
+
+
+def test_end_owned_window_that_starts_on_a_16_byte_boundary(gpu, oracle_engine):
+    """Multi-pattern -c on the record-list road owns a match by its END.  A window whose first owned byte is 16-byte aligned starts
+    a scan unit there, and a unit verifies the ends BEHIND its first byte (its first byte is the last end of the unit in front):
+    the match whose last byte is exactly the window's first one needs the unit in front of the window to be scanned as well
+    (found in round 6 while the END bitmaps of the anchored scan were laid out; the round-5 kernel lost that match)."""
+    import torch
+    rng = np.random.RandomState(31)
+    n = 40 << 20
+    text = cases.rand_text(rng, n, bytes(range(97, 123)) + b"  \n")
+    pats = [b"QWERTY", b"ZXCVB", b"ASDFGHJK", b"POIUY"]
+    cuts = [16 << 20, (33 << 20) + 16, 35 << 20]
+    for c in cuts:  # a pattern whose LAST byte is the first byte of the window [c, ...), alone on its line
+        p = np.frombuffer(pats[c % len(pats)], dtype=np.uint8)
+        text[c - 40:c + 40] = ord("x")
+        text[c - 41] = text[c + 40] = 10
+        text[c - p.size + 1:c + 1] = p
+    d = torch.from_numpy(text).cuda()
+    kwc = dict(count_lines=True)
+    want = oracle_engine.call(abi.RA_AHO_CORASICK, abi.Params(pats, **kwc), text)[0]
+    assert want >= 3
+    plan = gpu.plan(abi.Params(pats, **kwc))
+    whole = plan.scan(d.data_ptr(), n)
+    assert whole.count == want
+    edges = [0] + cuts + [n]
+    outs = [plan.scan(d.data_ptr(), n, lo, hi) for lo, hi in zip(edges[:-1], edges[1:])]
+    assert sum(o.total_matches for o in outs) == whole.total_matches
+    assert gpu.lib.krep_gpu_combine_line_counts((abi.ScanOut * len(outs))(*outs), len(outs)) == want
+    plan.close()
