@@ -492,47 +492,74 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
             // whose ends can fall into it are looked at again here (their own unit drops the ends beyond its last pair)
             const u32 n_x = (!off && useg >= 16u) ? 6u : 0u;
             const u32 n_tot = n + n_x;
+            // the candidates of a batch: lane -> tested position (binary search over the owners' prefix sums, then the t-th set bit)
+            auto locate = [&](const u32 b0, u64 &t, bool &live, bool &valid) {
+                const u32 qi = b0 + lane;
+                live = qi < n;
+                const bool isx = qi >= n && qi < n_tot;
+                u32 rel = 0, own = 0;
+#pragma unroll
+                for (u32 step = 32; step; step >>= 1)
+                {
+                    const u32 x = __shfl(incl, (own + step - 1u) & 63u);
+                    if (x <= qi)
+                        own += step;
+                }
+                own &= 63u;
+                const u32 oincl = __shfl(incl, own), ocnt = __shfl(mycnt, own);
+                if (live)
+                {
+                    u32 x = qi - (oincl - ocnt);
+                    const u32 *blk = cbits + own * kWPL;
+                    u32 w = 0, word = blk[0];
+                    for (;;)
+                    {
+                        const u32 c = (u32)__popc(word);
+                        if (x < c)
+                            break;
+                        x -= c;
+                        word = blk[++w];
+                    }
+                    for (; x; --x)
+                        word &= word - 1u;
+                    rel = 2u * (own * 128u + w * 32u + (u32)__builtin_ctz(word)); // (bit b <-> tested position 2b + 1)
+                }
+                t = isx ? useg - 11u + 2u * (u64)(qi - n) : useg + rel + 1u; // the tested position (odd)
+                valid = (live || isx) && t < a.text_len;
+            };
+            // its eight bytes t - 6 .. t + 1 (without the last one where the text ends: one byte lower, shifted back)
+            auto fetch = [&](const u64 t, const bool valid) -> u64 {
+                struct __attribute__((packed)) U64p { u64 v; };
+                if (!valid || t < 16u)
+                    return 0ull;
+                const bool hasB = t + 1 < a.text_len;
+                const u64 q8 = reinterpret_cast<const U64p *>(a.text + (t - (hasB ? 6u : 7u)))->v;
+                return hasB ? q8 : (q8 >> 8);
+            };
+            // Two dependent round trips per batch (window, then bucket) and, on a text where most candidates reach their bucket, three
+            // or four batches per unit: the NEXT batch's windows are requested before this batch's buckets, so a batch waits once
+            u64 tN = 0, QN = 0;
+            bool liveN = false, validN = false;
+            if (n_tot)
+            {
+                locate(0u, tN, liveN, validN);
+                QN = fetch(tN, validN);
+            }
             for (u32 b0 = 0; b0 < n_tot; b0 += 64)
             {
-                const u32 qi = b0 + lane;
-                const bool live = qi < n, isx = qi >= n && qi < n_tot;
-                u32 rel = 0;
+                const u64 t = tN, Q = QN;
+                const bool live = liveN, valid = validN;
+                if (b0 + 64u < n_tot)
                 {
-                    u32 own = 0;
-#pragma unroll
-                    for (u32 step = 32; step; step >>= 1)
-                    {
-                        const u32 t = __shfl(incl, (own + step - 1u) & 63u);
-                        if (t <= qi)
-                            own += step;
-                    }
-                    own &= 63u;
-                    const u32 oincl = __shfl(incl, own), ocnt = __shfl(mycnt, own);
-                    if (live)
-                    {
-                        u32 t = qi - (oincl - ocnt);
-                        const u32 *blk = cbits + own * kWPL;
-                        u32 w = 0, word = blk[0];
-                        for (;;)
-                        {
-                            const u32 c = (u32)__popc(word);
-                            if (t < c)
-                                break;
-                            t -= c;
-                            word = blk[++w];
-                        }
-                        for (; t; --t)
-                            word &= word - 1u;
-                        rel = 2u * (own * 128u + w * 32u + (u32)__builtin_ctz(word)); // (bit b <-> tested position 2b + 1)
-                    }
+                    locate(b0 + 64u, tN, liveN, validN);
+                    QN = fetch(tN, validN);
                 }
-                const u64 t = isx ? useg - 11u + 2u * (u64)(qi - n) : useg + rel + 1u; // the tested position (odd)
                 if (a.flags & (1u << 30))
                 { // (ablation hook KREP_GPU_AC_NOPROBE: the count that comes back is the number of filter candidates)
                     wcnt += (u32)__popcll(__ballot(live));
                     continue;
                 }
-                if ((live || isx) && t < a.text_len)
+                if (valid)
                 {
                     if (t < 16u)
                     { // (the first bytes of the text: no window in front — every end the position could name)
@@ -541,10 +568,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                     }
                     else
                     {
-                        struct __attribute__((packed)) U64p { u64 v; };
                         const bool hasB = t + 1 < a.text_len;
-                        const u64 q8 = reinterpret_cast<const U64p *>(a.text + (t - (hasB ? 6u : 7u)))->v;
-                        const u64 Q = hasB ? q8 : (q8 >> 8); // bytes t - 6 .. t + 1
                         typedef __attribute__((address_space(3))) const u32 lds_u32;
                         auto gtest = [&](u32 E) -> bool {
                             const u32 u = ac_pair(E);
@@ -561,15 +585,33 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                             kA = ac_fold4(kA);
                             kB = ac_fold4(kB);
                         }
-                        uint4 ba = make_uint4(0, 0, 0, 0), bb = ba;
+                        // buckets of two 16-byte entries {exact anchor gram, 1 << 31 | offset mask, the three bytes in front of the
+                        // 5-byte window, their byte mask}: seven exact bytes decide, all of them in the window already fetched
+                        u32 cxA = (u32)Q & 0xffffffu, cxB = (u32)(Q >> 8) & 0xffffffu; // bytes a - 6 .. a - 4 of either parity
+                        if (CI)
+                        {
+                            cxA = ac_fold4(cxA);
+                            cxB = ac_fold4(cxB);
+                        }
+                        uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0, b0_ = a0, b1_ = a0;
                         if (liveA)
-                            ba = a.anch[((kA * a.anch_mul) >> 9) & a.anch_mask];
+                        {
+                            const uint4 *bk = a.anch + 2u * (size_t)(((kA * a.anch_mul) >> 9) & a.anch_mask);
+                            a0 = bk[0];
+                            a1 = bk[1];
+                        }
                         if (liveB)
-                            bb = a.anch[((kB * a.anch_mul) >> 9) & a.anch_mask];
-                        u32 mA = (ba.x == kA && (ba.y >> 31)) ? ba.y : (ba.z == kA && (ba.w >> 31)) ? ba.w : 0u;
-                        u32 mB = (bb.x == kB && (bb.y >> 31)) ? bb.y : (bb.z == kB && (bb.w >> 31)) ? bb.w : 0u;
-                        mA = liveA ? (mA & 0x7fffffffu) : 0u;
-                        mB = liveB ? (mB & 0x7fffffffu) : 0u;
+                        {
+                            const uint4 *bk = a.anch + 2u * (size_t)(((kB * a.anch_mul) >> 9) & a.anch_mask);
+                            b0_ = bk[0];
+                            b1_ = bk[1];
+                        }
+                        auto pick = [](const uint4 &e0, const uint4 &e1, u32 key, u32 cx) -> u32 {
+                            const uint4 &e = (e0.x == key && (e0.y >> 31)) ? e0 : e1;
+                            return (e.x == key && (e.y >> 31) && ((cx ^ e.z) & e.w) == 0u) ? (e.y & 0x7fffffffu) : 0u;
+                        };
+                        u32 mA = liveA ? pick(a0, a1, kA, cxA) : 0u;
+                        u32 mB = liveB ? pick(b0_, b1_, kB, cxB) : 0u;
                         while (mA)
                         {
                             mark(t + (u32)__builtin_ctz(mA));
@@ -586,7 +628,17 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
         }
         // (ANCH: what follows is stage 3 — the same verify, over the END-pair bitmap instead of the candidate bitmap)
         const u32 *vbits = ANCH ? ebits : cbits;
-        if (!(ANCH && (a.flags & (1u << 30))))
+        if (ANCH && (a.flags & (1u << 28))) // (ablation hook KREP_GPU_AC_NOSTAGE3: the anchor stage alone; the count is the number of marked END pairs)
+        {
+            const uint4 m = *reinterpret_cast<const uint4 *>(ebits + lane * 4u);
+            u32 c = (u32)(__popc(m.x) + __popc(m.y) + __popc(m.z) + __popc(m.w));
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1)
+                c += __shfl_xor(c, o);
+            wcnt += c;
+            *reinterpret_cast<uint4 *>(ebits + lane * 4u) = make_uint4(0u, 0u, 0u, 0u);
+        }
+        else if (!(ANCH && (a.flags & (1u << 30))))
         {
             u32 mycnt = 0;
             {
@@ -881,6 +933,8 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
     a.flags = (t->ci ? F_CI : 0) | (ww ? F_WW : 0) | (lines ? F_LINES : 0);
     if (getenv("KREP_GPU_AC_NOVERIFY")) // measurement hook: filter cost only (wrong results by design)
         a.flags |= 1u << 31;
+    if (getenv("KREP_GPU_AC_NOSTAGE3")) // measurement hook (anchored scan): candidates -> END pairs, no verify; a count-only scan returns the number of marked pairs
+        a.flags |= 1u << 28;
     if (getenv("KREP_GPU_AC_NOPROBE")) // measurement hook: filter + candidate enumeration, no probes: a count-only scan returns the number of candidates
         a.flags |= 1u << 30;
     a.lmax = t->lmax;

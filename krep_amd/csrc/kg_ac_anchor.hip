@@ -130,7 +130,8 @@ int ac_anchor_prepare(AcTables *t, const uint8_t *d_text, size_t text_len, size_
         return 0;
     // ---- the two tables ----
     std::vector<u32> T20(kHistBins / 32, 0), E20(kHistBins / 32, 0);
-    std::unordered_map<u32, u32> keys; // exact anchor gram (text order, first byte lowest) -> offset mask
+    struct Anchor { u32 kmask = 0, ctx = 0, cmask = 0xffffffu; bool first = true; };
+    std::unordered_map<u32, Anchor> keys; // exact anchor gram (text order, first byte lowest) -> offset mask + the bytes in front
     auto expand = [&](std::vector<u32> &tab, bool pair, const uint8_t *g, size_t known) {
         u32 fixed = 0;
         for (size_t q = 0; q < known; ++q)
@@ -162,7 +163,35 @@ int ac_anchor_prepare(AcTables *t, const uint8_t *d_text, size_t text_len, size_
             else
                 expand(T20, true, p.data(), 3);
             const uint8_t *g = p.data() + (L - 4 - k);
-            keys[(u32)g[0] | ((u32)g[1] << 8) | ((u32)g[2] << 16) | ((u32)g[3] << 24)] |= 1u << k;
+            Anchor &an = keys[(u32)g[0] | ((u32)g[1] << 8) | ((u32)g[2] << 16) | ((u32)g[3] << 24)];
+            an.kmask |= 1u << k;
+            // the three bytes in front of the 5-byte window (text order: a - 6 lowest), as far as the pattern reaches; several
+            // patterns on one gram keep the bytes they agree on
+            u32 cx = 0, cm = 0;
+            for (int j = 0; j < 3; ++j) // byte a - 4 - j... stored at byte 2 - j
+            {
+                const long q = (long)L - 5 - (long)k - j;
+                if (q >= 0)
+                {
+                    cx |= (u32)p[(size_t)q] << (8 * (2 - j));
+                    cm |= 0xffu << (8 * (2 - j));
+                }
+            }
+            if (an.first)
+            {
+                an.ctx = cx;
+                an.cmask = cm;
+                an.first = false;
+            }
+            else
+            {
+                u32 keep = an.cmask & cm;
+                for (int b = 0; b < 3; ++b)
+                    if (((an.ctx ^ cx) >> (8 * b)) & 0xffu)
+                        keep &= ~(0xffu << (8 * b));
+                an.cmask = keep;
+                an.ctx &= keep;
+            }
         }
     };
     // estimated candidates per tested position of a pair-layout table: the sample's grams that it holds
@@ -209,7 +238,7 @@ int ac_anchor_prepare(AcTables *t, const uint8_t *d_text, size_t text_len, size_
                 t->anch_moved, t->pats_h.size(), moved, 100.0 * t->anch_rate0, 100.0 * t->anch_rate, keys.size(), go ? "anchored" : "end grams kept");
     if (!go)
         return 0;
-    // buckets of two {key, 1 << 31 | mask}: no bucket overfull, one 16-byte load per probe
+    // buckets of two 16-byte entries {key, 1 << 31 | offset mask, bytes in front, their mask}: no bucket overfull, one 32-byte probe
     static const u32 muls[] = {0x9E3779B1u, 0x85EBCA6Bu, 0xC2B2AE35u, 0x27D4EB2Fu, 0x165667B1u, 0xD3A2646Cu};
     std::vector<uint4> bk;
     u32 nb_used = 0, mul_used = 0;
@@ -229,21 +258,12 @@ int ac_anchor_prepare(AcTables *t, const uint8_t *d_text, size_t text_len, size_
                 }
             if (!fits)
                 continue;
-            bk.assign(nb, make_uint4(0u, 0u, 0u, 0u));
+            bk.assign(2 * (size_t)nb, make_uint4(0u, 0u, 0u, 0u));
             std::fill(fill.begin(), fill.end(), 0);
             for (auto &kv : keys)
             {
                 const u32 b = ((kv.first * mul) >> 9) & (nb - 1);
-                if (fill[b]++ == 0)
-                {
-                    bk[b].x = kv.first;
-                    bk[b].y = kv.second | 0x80000000u;
-                }
-                else
-                {
-                    bk[b].z = kv.first;
-                    bk[b].w = kv.second | 0x80000000u;
-                }
+                bk[2 * (size_t)b + fill[b]++] = make_uint4(kv.first, kv.second.kmask | 0x80000000u, kv.second.ctx & kv.second.cmask, kv.second.cmask);
             }
             nb_used = nb;
             mul_used = mul;

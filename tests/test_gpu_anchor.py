@@ -31,21 +31,35 @@ def forced():
     os.environ.pop("KREP_GPU_AC_ANCHOR", None)
 
 
-def _scan_device(gpu, pats, kw, text, lo=0, hi=None, base=0):
-    """One plan, device-resident: -> (ScanOut, records ndarray, plan.anchor_info())."""
-    import torch
-    n = len(text)
-    buf = torch.from_numpy(np.ascontiguousarray(text)).cuda()
-    cap = max(4096, n // 2)
-    pos = torch.empty(2 * cap, dtype=torch.int64, device="cuda")
-    plan = gpu.plan(abi.Params(pats, **kw))
-    out = plan.scan(buf.data_ptr(), n, lo, n if hi is None else hi, base, pos.data_ptr(), cap, global_len=base + n)
-    # a second scan of the same plan (the decision was taken by the first one) must give the same list
-    rec = pos[: 2 * out.stored].view(-1, 2).cpu().numpy().copy()
-    out2 = plan.scan(buf.data_ptr(), n, lo, n if hi is None else hi, base, pos.data_ptr(), cap, global_len=base + n)
-    assert out2.count == out.count and np.array_equal(pos[: 2 * out2.stored].view(-1, 2).cpu().numpy(), rec)
-    info = plan.anchor_info()
-    plan.close()
+class _DevicePlan:
+    """One plan and one device copy of a text; scan(lo, hi, base) -> (ScanOut, records ndarray)."""
+
+    def __init__(self, gpu, pats, kw, text):
+        import torch
+        self.n = len(text)
+        self.buf = torch.from_numpy(np.ascontiguousarray(text)).cuda()
+        self.cap = max(4096, self.n // 2)
+        self.pos = torch.empty(2 * self.cap, dtype=torch.int64, device="cuda")
+        self.plan = gpu.plan(abi.Params(pats, **kw))
+
+    def scan(self, lo=0, hi=None, base=0):
+        n = self.n
+        out = self.plan.scan(self.buf.data_ptr(), n, lo, n if hi is None else hi, base, self.pos.data_ptr(), self.cap, global_len=base + n)
+        rec = self.pos[: 2 * out.stored].view(-1, 2).cpu().numpy().copy()
+        return out, rec
+
+    def close(self):
+        self.plan.close()
+
+
+def _scan_device(gpu, pats, kw, text):
+    """whole text, twice (the anchor decision is taken by the first scan) -> (ScanOut, records, plan.anchor_info())"""
+    d = _DevicePlan(gpu, pats, kw, text)
+    out, rec = d.scan()
+    out2, rec2 = d.scan()
+    assert out2.count == out.count and np.array_equal(rec2, rec)
+    info = d.plan.anchor_info()
+    d.close()
     return out, rec, info
 
 
@@ -96,17 +110,20 @@ def test_forced_anchors_in_ownership_windows_and_small_slots(gpu, oracle_engine,
     _, want = oracle_engine.call(abi.RA_AHO_CORASICK, abi.Params(pats), text)
     want = want.astype(np.int64)
     base = (5 << 32) + 12345
-    for lo, hi in ((0, n), (16384, 5 * 16384), (16384 - 7, 16384 + 9), (100001, 1900003), (n - 20000, n), (3, 40)):
-        out, rec, info = _scan_device(gpu, pats, {}, text, lo, hi, base)
-        assert info is not None and info[0] == 2, info  # anchored
+    d = _DevicePlan(gpu, pats, {}, text)
+    for lo, hi in ((0, n), (16384, 5 * 16384), (16384 - 7, 16384 + 9), (100001, 1900003), (n - 20000, n), (3, 40), (16, 48), (32768, 32768 + 16)):
+        out, rec = d.scan(lo, hi, base)
+        info = d.plan.anchor_info()
+        assert info is not None and info[0] == 2, info  # anchored (decided by the first, whole-text scan)
         sel = want[(want[:, 0] >= lo) & (want[:, 0] < hi)] + base
         assert out.count == len(sel) and np.array_equal(rec, sel), (lo, hi, len(rec), len(sel))
     gpu.force_stage_cap(2)
     try:
-        out, rec, _ = _scan_device(gpu, pats, {}, text, 0, n, 0)
+        out, rec = d.scan()
         assert np.array_equal(rec, want)
     finally:
         gpu.force_stage_cap(0)
+        d.close()
 
 
 def test_decision_keeps_end_grams_on_iid_text_and_anchors_word_text(gpu, oracle_engine):

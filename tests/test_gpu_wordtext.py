@@ -52,7 +52,8 @@ def test_word_dictionaries_on_word_text(gpu, oracle_engine, words, kind):
     assert len(pats) == 1000
     before = gpu.anchored_launches()
     _check_ac(gpu, oracle_engine, text, pats, dict())
-    assert gpu.anchored_launches() > before  # word dictionaries on word text take the anchored instantiation (kg_ac_anchor.hip)
+    if kind != "common":  # (a dictionary of FREQUENT words: its rarest windows are common too, the estimate keeps the end grams)
+        assert gpu.anchored_launches() > before  # word dictionaries on word text take the anchored instantiation (kg_ac_anchor.hip)
     _check_ac(gpu, oracle_engine, text, pats, dict(count_lines=True))
     _check_ac(gpu, oracle_engine, text, pats, dict(count_lines=True, only_match=True))
     _check_ac(gpu, oracle_engine, text, pats, dict(whole_word=True))
