@@ -228,7 +228,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
 #pragma unroll
                     for (int q = 0; q < 8; ++q)
                     {
-                        const u32 rot = dws[q] >> (xs[q] & 15u);
+                        const u32 rot = __builtin_amdgcn_alignbit(dws[q], dws[q], xs[q]);
                         S8 |= (rot & 1u) << q;
                         L8 |= ((rot >> 16) & 1u) << q;
                     }
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
             auto finish = [&](const int j, const u32 (&x)[8], const u32 (&v)[8]) __attribute__((always_inline)) {
                 if constexpr (ANCH)
                 {
-                    // two planes in one table word (kg_ac_anchor.hip): shifted right by the class c0 & 15, bit 0 is the SINGLE plane
+                    // two planes in one table word (kg_ac_anchor.hip): rotated right by the class c0, bit 0 is the SINGLE plane
                     // (a gram that makes a candidate by itself: patterns too short for a second gram) and bit 16 the PAIR plane
                     // (a candidate needs the pair plane's bit of the tested position two bytes back as well: six or seven
                     // bytes of a pattern instead of four or five)
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
 #pragma unroll
                     for (int q = 0; q < 8; ++q)
                     {
-                        const u32 rot = v[q] >> (x[q] & 15u);
+                        const u32 rot = __builtin_amdgcn_alignbit(v[q], v[q], x[q]);
                         accS = __builtin_amdgcn_alignbit(rot, accS, 1u);
                         accL = __builtin_amdgcn_alignbit(rot >> 16, accL, 1u);
                     }
@@ -620,7 +620,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                         auto gtest = [&](u32 E) -> bool { // (either plane)
                             const u32 u = ac_pair(E);
                             const u32 w = *(lds_u32 *)(size_t)(((u >> 3) ^ (u >> 13)) & kTabMask);
-                            return ((w >> (u & 15u)) & 0x00010001u) != 0u;
+                            return (__builtin_amdgcn_alignbit(w, w, u) & 0x00010001u) != 0u;
                         };
                         // the position's own gram again for the six in front of the unit; then, as in the end-gram kernel: an anchor
                         // gram ENDS at t where the window's other gram sits at t - 1, at t + 1 where this one is that other gram

@@ -146,9 +146,8 @@ int ac_anchor_prepare(AcTables *t, const uint8_t *d_text, size_t text_len, size_
     std::vector<u32> T20(kHistBins / 32, 0), E20(kHistBins / 32, 0);
     struct Anchor { u32 kmask = 0, ctx = 0, cmask = 0xffffffu; bool first = true; };
     std::unordered_map<u32, Anchor> keys; // exact anchor gram (text order, first byte lowest) -> offset mask + the bytes in front
-    // plane: 0 = single, 16 = pair; the kernel shifts a table word right by c0 & 15 and reads bit 0 / bit 16: sixteen bits per plane,
-    // the classes c0 and c0 ^ 16 of ONE plane share a bit (a rotation by c0 let a pair-plane gram `elch` act as the single-plane
-    // gram `ulch`: four times the candidates, measured)
+    // plane: 0 = single, 16 = pair; the kernel rotates a table word right by c0 and reads bit 0 / bit 16, so the single plane's bit
+    // of class c0 is bit c0 and the pair plane's bit (c0 + 16) mod 32 (a single-plane class and the pair-plane class 16 away share one)
     auto expand = [&](std::vector<u32> &tab, int plane, const uint8_t *g, size_t known) {
         u32 fixed = 0;
         for (size_t q = 0; q < known; ++q)
@@ -161,7 +160,7 @@ int ac_anchor_prepare(AcTables *t, const uint8_t *d_text, size_t text_len, size_
             {
                 u32 dw, bit;
                 ac_pair_slot(x, dw, bit);
-                tab[dw] |= 1u << ((bit & 15u) + (u32)plane);
+                tab[dw] |= 1u << ((bit + (u32)plane) & 31u);
             }
             else
                 tab[x >> 5] |= 1u << (x & 31);
