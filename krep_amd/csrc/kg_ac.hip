@@ -118,15 +118,11 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
       uint4 d[kCells];
       bool have = false; // d[] holds (or is receiving) the round about to be processed (uniform)
       u32 carry = 0;     // the 4 bytes in front of that round (valid when have)
-      u32 pairL_carry = 0x80u; // ANCH: the pair plane's 8 bits of lane 63 of the cell in front (a ticket starts with "set": superset)
       for (u64 unit = u_begin; unit < u_end; ++unit)
       {
         const u64 useg = a.anchor + unit * (u64)kAcUnitBytes; // the unit = kAcRounds load rounds of 8 KiB
         if (emit_final && (u32)(a.unitinfo[unit] & kUiCountMask) <= a.stage_cap)
-        {
-            pairL_carry = 0x80u; // (the next unit scanned is not behind the last one)
             continue;
-        }
 
         const bool parked = PIPE && !ANCH && !emit_final && chain && a.stage_cap == 16u && a.upt <= kAcUnitsPerTicketMax;
         u32 *slot = parked ? park_slots + (u32)(unit - u_begin) * 16u
@@ -222,28 +218,9 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 u32 acc = 0;
-                if constexpr (ANCH)
-                { // (the two planes of finish() below, for the cells at the ragged end of a text; every position in front of a lane's first: assumed set)
-                    u32 S8 = 0, L8 = 0;
-#pragma unroll
-                    for (int q = 0; q < 8; ++q)
-                    {
-                        const u32 rot = __builtin_amdgcn_alignbit(dws[q], dws[q], xs[q]);
-                        S8 |= (rot & 1u) << q;
-                        L8 |= ((rot >> 16) & 1u) << q;
-                    }
-                    const u32 c8 = S8 | (L8 & ((L8 << 1) | 1u));
-#pragma unroll
-                    for (int q = 0; q < 8; ++q)
-                        acc |= ((c8 >> q) & 1u) << (16 + 2 * q);
-                    pairL_carry = 0x80u;
-                }
-                else
-                {
 #pragma unroll
                 for (int q = 0; q < 8; ++q)
                     acc = __builtin_amdgcn_alignbit(dws[q] >> (xs[q] & 31u), acc, 2u);
-                }
                 cand = (acc >> 16) & 0x5555u; // bit 2q <-> tested position 2q + 1 (the verify stage adds the 1)
             }
             else
@@ -356,35 +333,11 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 }
             };
             auto finish = [&](const int j, const u32 (&x)[8], const u32 (&v)[8]) __attribute__((always_inline)) {
-                if constexpr (ANCH)
-                {
-                    // two planes in one table word (kg_ac_anchor.hip): rotated right by the class c0, bit 0 is the SINGLE plane
-                    // (a gram that makes a candidate by itself: patterns too short for a second gram) and bit 16 the PAIR plane
-                    // (a candidate needs the pair plane's bit of the tested position two bytes back as well: six or seven
-                    // bytes of a pattern instead of four or five)
-                    u32 accS = 0, accL = 0;
-#pragma unroll
-                    for (int q = 0; q < 8; ++q)
-                    {
-                        const u32 rot = __builtin_amdgcn_alignbit(v[q], v[q], x[q]);
-                        accS = __builtin_amdgcn_alignbit(rot, accS, 1u);
-                        accL = __builtin_amdgcn_alignbit(rot >> 16, accL, 1u);
-                    }
-                    const u32 L8 = accL >> 24; // bit q <-> tested position 2q + 1
-                    // the tested position in front of the lane's first one: the left neighbour's last (lane 0: the previous cell's
-                    // lane 63; unknown at the start of a ticket: assumed set)
-                    const u32 prev = (u32)__builtin_amdgcn_update_dpp((int)pairL_carry, (int)L8, 0x138 /* wave_shr:1 */, 0xf, 0xf, false) >> 7;
-                    pairL_carry = __builtin_amdgcn_readlane(L8, 63);
-                    cbits8[(u32)r * (kSegBytes / 16) + (u32)j * kWave + lane] = (uint8_t)((accS >> 24) | (L8 & ((L8 << 1) | (prev & 1u))));
-                }
-                else
-                {
                 u32 acc = 0;
 #pragma unroll
                 for (int q = 0; q < 8; ++q)
                     acc = __builtin_amdgcn_alignbit(v[q] >> (x[q] & 31u), acc, 1u);
                 cbits8[(u32)r * (kSegBytes / 16) + (u32)j * kWave + lane] = (uint8_t)(acc >> 24); // bit q <-> tested position 2q + 1
-                }
             };
             issue(0, xs[0], dw[0]);
 #pragma unroll
@@ -617,10 +570,9 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                     {
                         const bool hasB = t + 1 < a.text_len;
                         typedef __attribute__((address_space(3))) const u32 lds_u32;
-                        auto gtest = [&](u32 E) -> bool { // (either plane)
+                        auto gtest = [&](u32 E) -> bool {
                             const u32 u = ac_pair(E);
-                            const u32 w = *(lds_u32 *)(size_t)(((u >> 3) ^ (u >> 13)) & kTabMask);
-                            return (__builtin_amdgcn_alignbit(w, w, u) & 0x00010001u) != 0u;
+                            return ((*(lds_u32 *)(size_t)(((u >> 3) ^ (u >> 13)) & kTabMask) >> (u & 31u)) & 1u) != 0u;
                         };
                         // the position's own gram again for the six in front of the unit; then, as in the end-gram kernel: an anchor
                         // gram ENDS at t where the window's other gram sits at t - 1, at t + 1 where this one is that other gram

@@ -96,59 +96,43 @@ int ac_anchor_prepare(AcTables *t, const uint8_t *d_text, size_t text_len, size_
             s += hist[known | c0];
         return s;
     };
-    // Two planes (kg_ac.hip finish()): a SINGLE-plane gram makes a candidate by itself — the window's grams A and B as above; a
-    // PAIR-plane gram only together with the pair-plane gram two bytes earlier, so a pattern with seven bytes in front of its
-    // anchor's end puts A, B and the grams two bytes in front of them (A2, B2) there and a candidate then holds six or seven of
-    // its bytes.  The sample cannot count 6-grams; min(count(A), count(A2)) bounds the pair from above.
-    struct Choice { u32 k = 0; bool pair = false; u64 cost = 0; };
-    auto choose = [&](const std::vector<uint8_t> &p, bool allow_move) -> Choice {
-        const int L = (int)p.size(), kmax = allow_move ? std::min<int>(L - 4, (int)kAnchMaxK) : 0;
-        Choice best;
-        best.cost = ~0ull;
-        for (int k = 0; k <= kmax; ++k)
-        {
-            const u64 cA = gram_count(p, L - k), cB = gram_count(p, L - k - 1);
-            Choice c;
-            c.k = (u32)k;
-            c.cost = cA + cB + 16;
-            if (L - k >= 7)
-            {
-                const u64 pc = std::min(cA, gram_count(p, L - k - 2)) + std::min(cB, gram_count(p, L - k - 3)) + 16;
-                if (pc <= c.cost)
-                {
-                    c.cost = pc;
-                    c.pair = true;
-                }
-            }
-            if (c.cost < best.cost)
-                best = c;
-        }
-        return best;
-    };
-    std::vector<Choice> ch0(t->pats_h.size()), ch(t->pats_h.size());
+    std::vector<u32> ks(t->pats_h.size(), 0), kfree(t->pats_h.size(), 0);
     u32 moved = 0;
-    u64 sum0 = 0, sum1 = 0;
     for (size_t i = 0; i < t->pats_h.size(); ++i)
     {
         const auto &p = t->pats_h[i];
-        if (p.size() < 4)
+        const int L = (int)p.size();
+        if (L < 4)
             return 0; // (not reached: has1..3 excluded above)
-        Choice e;
-        e.cost = gram_count(p, (int)p.size()) + gram_count(p, (int)p.size() - 1) + 16; // what the end-gram kernel pays for this pattern
-        ch0[i] = e;
-        ch[i] = choose(p, true);
-        sum0 += e.cost;
-        sum1 += ch[i].cost;
-        moved += (ch[i].k || ch[i].pair) ? 1u : 0u;
+        const int kmax = std::min<int>(L - 4, (int)kAnchMaxK);
+        u64 best = ~0ull, c0 = 0;
+        int bk = 0;
+        for (int k = 0; k <= kmax; ++k)
+        {
+            const u64 c = gram_count(p, L - k) + gram_count(p, L - k - 1) + 16;
+            if (k == 0)
+                c0 = c;
+            if (c < best)
+            {
+                best = c;
+                bk = k;
+            }
+        }
+        kfree[i] = (u32)bk; // the plain minimum
+        if (bk && (force || best * 4 < c0))
+        {
+            ks[i] = (u32)bk; // ... and the moves no sampling noise explains (what the DECISION rests on)
+            ++moved;
+        }
     }
     t->anch_moved = moved;
-    // ---- the tables ----
+    if (!moved)
+        return 0;
+    // ---- the two tables ----
     std::vector<u32> T20(kHistBins / 32, 0), E20(kHistBins / 32, 0);
     struct Anchor { u32 kmask = 0, ctx = 0, cmask = 0xffffffu; bool first = true; };
     std::unordered_map<u32, Anchor> keys; // exact anchor gram (text order, first byte lowest) -> offset mask + the bytes in front
-    // plane: 0 = single, 16 = pair; the kernel rotates a table word right by c0 and reads bit 0 / bit 16, so the single plane's bit
-    // of class c0 is bit c0 and the pair plane's bit (c0 + 16) mod 32 (a single-plane class and the pair-plane class 16 away share one)
-    auto expand = [&](std::vector<u32> &tab, int plane, const uint8_t *g, size_t known) {
+    auto expand = [&](std::vector<u32> &tab, bool pair, const uint8_t *g, size_t known) {
         u32 fixed = 0;
         for (size_t q = 0; q < known; ++q)
             fixed |= ((u32)g[q] & 31u) << (5 * (4 - known + q));
@@ -156,88 +140,102 @@ int ac_anchor_prepare(AcTables *t, const uint8_t *d_text, size_t text_len, size_
         for (u32 f = 0; f < nfree; ++f)
         {
             const u32 x = fixed | f;
-            if (plane >= 0)
+            if (pair)
             {
                 u32 dw, bit;
                 ac_pair_slot(x, dw, bit);
-                tab[dw] |= 1u << ((bit + (u32)plane) & 31u);
+                tab[dw] |= 1u << bit;
             }
             else
                 tab[x >> 5] |= 1u << (x & 31);
         }
     };
-    auto gram_at = [&](std::vector<u32> &tab, int plane, const std::vector<uint8_t> &p, long end_excl) {
-        if (end_excl >= 4)
-            expand(tab, plane, p.data() + (end_excl - 4), 4);
-        else
-            expand(tab, plane, p.data(), 3); // (end_excl == 3: one byte in front of the pattern, every class)
+    auto build = [&](const std::vector<u32> &kk) {
+        std::fill(T20.begin(), T20.end(), 0u);
+        keys.clear();
+        for (size_t i = 0; i < t->pats_h.size(); ++i)
+        {
+            const auto &p = t->pats_h[i];
+            const size_t L = p.size(), k = kk[i];
+            expand(T20, true, p.data() + (L - 4 - k), 4);
+            if (L - k >= 5)
+                expand(T20, true, p.data() + (L - 5 - k), 4);
+            else
+                expand(T20, true, p.data(), 3);
+            const uint8_t *g = p.data() + (L - 4 - k);
+            Anchor &an = keys[(u32)g[0] | ((u32)g[1] << 8) | ((u32)g[2] << 16) | ((u32)g[3] << 24)];
+            an.kmask |= 1u << k;
+            // the three bytes in front of the 5-byte window (text order: a - 6 lowest), as far as the pattern reaches; several
+            // patterns on one gram keep the bytes they agree on
+            u32 cx = 0, cm = 0;
+            for (int j = 0; j < 3; ++j) // byte a - 4 - j... stored at byte 2 - j
+            {
+                const long q = (long)L - 5 - (long)k - j;
+                if (q >= 0)
+                {
+                    cx |= (u32)p[(size_t)q] << (8 * (2 - j));
+                    cm |= 0xffu << (8 * (2 - j));
+                }
+            }
+            if (an.first)
+            {
+                an.ctx = cx;
+                an.cmask = cm;
+                an.first = false;
+            }
+            else
+            {
+                u32 keep = an.cmask & cm;
+                for (int b = 0; b < 3; ++b)
+                    if (((an.ctx ^ cx) >> (8 * b)) & 0xffu)
+                        keep &= ~(0xffu << (8 * b));
+                an.cmask = keep;
+                an.ctx &= keep;
+            }
+        }
+    };
+    // estimated candidates per tested position of a pair-layout table: the sample's grams that it holds
+    auto rate_of = [&](const std::vector<u32> &tab, bool pair) -> double {
+        u64 hits = 0;
+        for (u32 x = 0; x < kHistBins; ++x)
+        {
+            if (!hist[x])
+                continue;
+            u32 dw = x >> 5, bit = x & 31;
+            if (pair)
+                ac_pair_slot(x, dw, bit);
+            if ((tab[dw] >> bit) & 1u)
+                hits += hist[x];
+        }
+        return (double)hits / nsamp;
     };
     for (size_t i = 0; i < t->pats_h.size(); ++i)
     {
         const auto &p = t->pats_h[i];
-        const long L = (long)p.size(), k = (long)ch[i].k;
-        const int plane = ch[i].pair ? 16 : 0;
-        gram_at(T20, plane, p, L - k);
-        gram_at(T20, plane, p, L - k - 1);
-        if (ch[i].pair)
-        {
-            gram_at(T20, 16, p, L - k - 2);
-            gram_at(T20, 16, p, L - k - 3);
-        }
-        gram_at(E20, -1, p, L);
-        gram_at(E20, -1, p, L - 1);
-        const uint8_t *g = p.data() + (L - 4 - k);
-        Anchor &an = keys[(u32)g[0] | ((u32)g[1] << 8) | ((u32)g[2] << 16) | ((u32)g[3] << 24)];
-        an.kmask |= 1u << k;
-        // the three bytes in front of the 5-byte window (text order: a - 6 lowest), as far as the pattern reaches; several
-        // patterns on one gram keep the bytes they agree on
-        u32 cx = 0, cm = 0;
-        for (int j = 0; j < 3; ++j) // byte a - 4 - j, stored at byte 2 - j
-        {
-            const long q = L - 5 - k - j;
-            if (q >= 0)
-            {
-                cx |= (u32)p[(size_t)q] << (8 * (2 - j));
-                cm |= 0xffu << (8 * (2 - j));
-            }
-        }
-        if (an.first)
-        {
-            an.ctx = cx;
-            an.cmask = cm;
-            an.first = false;
-        }
+        const size_t L = p.size();
+        expand(E20, false, p.data() + (L - 4), 4);
+        if (L >= 5)
+            expand(E20, false, p.data() + (L - 5), 4);
         else
-        {
-            u32 keep = an.cmask & cm;
-            for (int b = 0; b < 3; ++b)
-                if (((an.ctx ^ cx) >> (8 * b)) & 0xffu)
-                    keep &= ~(0xffu << (8 * b));
-            an.cmask = keep;
-            an.ctx &= keep;
-        }
+            expand(E20, false, p.data(), 3);
     }
-    // estimated candidates per tested position: the sample's grams that the end-gram table holds, against the per-pattern bounds of
-    // the chosen windows (their sum: patterns that share a gram are counted twice, a pair by the rarer of its two grams)
+    build(ks);
+    t->anch_rate0 = rate_of(E20, false);
+    t->anch_rate = rate_of(T20, true);
+    // worth a second stage: at least a third fewer candidates with the noise-proof moves alone, and a rate that matters to begin with
+    const bool go = force || (t->anch_rate0 > 0.008 && t->anch_rate < 0.66 * t->anch_rate0);
+    if (go && !force)
     {
-        u64 hits = 0;
-        for (u32 x = 0; x < kHistBins; ++x)
-            if (hist[x] && ((E20[x >> 5] >> (x & 31)) & 1u))
-                hits += hist[x];
-        t->anch_rate0 = (double)hits / nsamp;
-        t->anch_rate = (double)(sum1 - 16 * t->pats_h.size()) / nsamp;
+        // ... then every pattern takes its rarest window (a choice among windows the sample hardly holds costs nothing if it is noise)
+        build(kfree);
+        t->anch_rate = rate_of(T20, true);
+        t->anch_moved = 0;
+        for (u32 k : kfree)
+            t->anch_moved += k ? 1u : 0u;
     }
-    // worth a second stage: a rate that matters to begin with, and at most half of it left (sampling noise among grams the sample
-    // hardly holds cannot do that: the prior of 16 per pattern is in both sums)
-    const bool go = force || (t->anch_rate0 > 0.008 && (double)sum1 < 0.5 * (double)sum0);
     if (getenv("KREP_GPU_DEBUG"))
-    {
-        u32 npair = 0;
-        for (auto &c : ch)
-            npair += c.pair ? 1u : 0u;
-        fprintf(stderr, "krep-gpu: anchors: %u of %zu patterns off their end grams (%u on the pair plane); candidates per tested position %.4f %% (end grams) -> <= %.4f %% (anchors), %zu anchor grams: %s\n",
-                moved, t->pats_h.size(), npair, 100.0 * t->anch_rate0, 100.0 * t->anch_rate, keys.size(), go ? "anchored" : "end grams kept");
-    }
+        fprintf(stderr, "krep-gpu: anchors: %u of %zu patterns off their end (%u beyond sampling noise); candidates per tested position %.4f %% (end grams) -> %.4f %% (anchors), %zu anchor grams: %s\n",
+                t->anch_moved, t->pats_h.size(), moved, 100.0 * t->anch_rate0, 100.0 * t->anch_rate, keys.size(), go ? "anchored" : "end grams kept");
     if (!go)
         return 0;
     // buckets of two 16-byte entries {key, 1 << 31 | offset mask, bytes in front, their mask}: no bucket overfull, one 32-byte probe
