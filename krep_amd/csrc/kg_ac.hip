@@ -927,7 +927,7 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
     }
     // (END-owned records: a unit verifies the ends behind its first byte, so the end AT own_lo belongs to the unit in front —
     //  which has to exist; round 6)
-    a.anchor = ((own_by_end && !lines && own_lo) ? own_lo - 1 : own_lo) & ~(u64)15;
+    a.anchor = ((own_by_end && !lines && own_lo && !getenv("KREP_GPU_AC_R05_ANCHOR")) ? own_lo - 1 : own_lo) & ~(u64)15; // (the hook: the round-5 grid, for the regression test's own check)
     const u64 unit_bytes = (u64)kAcUnitBytes;
     a.num_tiles = (a.end_hi - a.anchor + unit_bytes - 1) / unit_bytes;
     a.flags = (t->ci ? F_CI : 0) | (ww ? F_WW : 0) | (lines ? F_LINES : 0);

@@ -275,4 +275,5 @@ namespace kg {
 std::atomic<uint64_t> g_ac_anchored_launches{0}; // launches of the multi-pattern kernel's anchored instantiation
 }
 extern "C" uint64_t krep_gpu_debug_anchored_launches(void) { return kg::g_ac_anchored_launches.load(); }
+extern "C" uint64_t krep_gpu_debug_literal_dma_launches(void) { return kg::g_lit_dma_launches.load(); }
 

@@ -18,6 +18,9 @@ bool inject(int kind);                   // test hook: is failure `kind` being i
 
 // kg_literal.hip
 hipError_t launch_literal(const LitArgs &a, uint32_t num_cu, hipStream_t st); // grid = resident blocks of the variant x CUs
+bool literal_dma_eligible(const LitArgs &a);                                       // kg_literal_dma.hip: 2..8-byte patterns, 32-KiB units, no -c
+hipError_t launch_literal_dma(const LitArgs &a, uint32_t num_cu, hipStream_t st);
+extern std::atomic<uint64_t> g_lit_dma_launches;                                   // launches of lit_scan_dma (test hook)
 
 // kg_single.hip — single byte with records in one pass (counts resolved by one wave, records written a ticket later)
 uint64_t single_fused_tickets(uint64_t n_units, int shape);

@@ -988,9 +988,13 @@ static hipError_t launch1(const LitArgs &a, u32 num_cu, hipStream_t st)
     return (a.flags & F_CI) ? launch2<KIND, MASKED, true>(a, num_cu, st) : launch2<KIND, MASKED, false>(a, num_cu, st);
 }
 
+bool literal_dma_eligible(const LitArgs &a);                                  // kg_literal_dma.hip
+hipError_t launch_literal_dma(const LitArgs &a, u32 num_cu, hipStream_t st);
 // a.num_tiles counts workgroup tiles of 4 x a.rounds x 8 KiB; a.rounds is 1 or kRoundsBig
 hipError_t launch_literal(const LitArgs &a, u32 num_cu, hipStream_t st)
 {
+    if (literal_dma_eligible(a)) // 2..8-byte patterns on 32-KiB units without -c: the LDS-DMA streaming kernel (kg_literal_dma.hip, round 6)
+        return launch_literal_dma(a, num_cu, st);
     if (a.m == 1)
         return launch1<1, false>(a, num_cu, st);
     if (a.m < 4)

@@ -121,6 +121,7 @@ class Engine:
         L.krep_gpu_debug_chain_fixups.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.krep_gpu_debug_tiny_dense_launches.restype = C.c_uint64
         L.krep_gpu_debug_anchored_launches.restype = C.c_uint64
+        L.krep_gpu_debug_literal_dma_launches.restype = C.c_uint64
         L.krep_gpu_debug_anchor_info.restype = C.c_int
         L.krep_gpu_debug_anchor_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_uint32), C.POINTER(C.c_double),
                                                  C.POINTER(C.c_double)]
@@ -181,6 +182,9 @@ class Engine:
 
     def tiny_dense_launches(self) -> int:
         return int(self.lib.krep_gpu_debug_tiny_dense_launches())
+
+    def literal_dma_launches(self) -> int:
+        return int(self.lib.krep_gpu_debug_literal_dma_launches())
 
     def anchored_launches(self) -> int:
         return int(self.lib.krep_gpu_debug_anchored_launches())

@@ -117,7 +117,7 @@ class OracleEngine(_Engine):
     ac_build, ac_free = "ko_ac_trie_build", "ko_ac_trie_free"
 
     def __init__(self):
-        path = os.path.join(ORACLE_DIR, "liboracle_krep.so")
+        path = os.environ.get("KREP_ORACLE_LIB") or os.path.join(ORACLE_DIR, "liboracle_krep.so")  # (tools/sanitize.py: an ASan build)
         if not os.path.exists(path):
             subprocess.run(["make", "-C", ORACLE_DIR, "liboracle_krep.so"], check=True,
                            stdout=subprocess.DEVNULL)

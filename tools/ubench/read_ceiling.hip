@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstdint>
+#include <cstring>
 #include <vector>
 #include <algorithm>
 
@@ -227,6 +228,85 @@ __global__ __launch_bounds__(256, 4) void rd_static(const uint8_t *__restrict__ 
         atomicAdd((unsigned long long *)(out + 2), hits);
 }
 
+
+// LDS-DMA streaming WITH the literal8 compare (round 6): every wave owns NBUF buffers of KB KiB; the DMA of round
+// g + NBUF - 1 is issued before round g is consumed (counted vmcnt), the consumer reads its 16 bytes per lane with ds_read_b128 and
+// the 8 bytes behind them with ds_read_b64 (the neighbour's bytes: no shuffle).  Static interleaved deal of R-round units.
+template <int KB, int NBUF, int AUX, int R>
+__global__ __launch_bounds__(256) void rd_ldsdma_cmp(const uint8_t *__restrict__ p, size_t n, uint32_t *out, unsigned long long *,
+                                                     uint32_t p0, uint32_t p1)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint8_t *mine = smem + wave * (NBUF * KB * 1024 + 16);
+    const size_t round_bytes = (size_t)KB * 1024, unit_bytes = round_bytes * R, n_units = n / unit_bytes;
+    const size_t stride = (size_t)gridDim.x * 4, first = (size_t)blockIdx.x * 4 + wave;
+    const size_t my_units = first < n_units ? (n_units - first + stride - 1) / stride : 0, G = my_units * R;
+    auto src_of = [&](size_t g) -> const uint8_t * { return p + (first + (g / R) * stride) * unit_bytes + (g % R) * round_bytes + lane * 16; };
+    auto issue = [&](size_t g) {
+        const uint8_t *src = src_of(g);
+        uint8_t *dst = mine + (g % NBUF) * round_bytes;
+#pragma unroll
+        for (int j = 0; j < KB; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + j * 1024),
+                                             (__attribute__((address_space(3))) void *)(dst + j * 1024), 16, 0, AUX);
+    };
+    unsigned long long hits = 0;
+    for (size_t g = 0; g < (size_t)(NBUF - 1) && g < G; ++g)
+        issue(g);
+    for (size_t g = 0; g < G; ++g)
+    {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (the buffer about to be refilled has been read)
+        if (g + NBUF - 1 < G)
+        {
+            issue(g + NBUF - 1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 1) * KB) : "memory");
+        }
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint8_t *b = mine + (g % NBUF) * round_bytes + lane * 16;
+        // all LDS reads of the round first (one LDS latency per round, not per cell)
+        u32x4 vv[KB];
+        uint2 nn[KB];
+#pragma unroll
+        for (int j = 0; j < KB; ++j)
+        {
+            vv[j] = *reinterpret_cast<const u32x4 *>(b + j * 1024);
+            nn[j] = *reinterpret_cast<const uint2 *>(b + j * 1024 + 16); // (the round's last 8 positions see the next buffer: ubench)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < KB; ++j)
+        {
+            const u32x4 v = vv[j];
+            const uint2 nx = nn[j];
+            uint32_t D[6] = {v.x, v.y, v.z, v.w, nx.x, nx.y};
+            unsigned long long any = 0;
+            uint32_t A0[16];
+            bool c[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+            {
+                A0[k] = (k & 3) == 0 ? D[k >> 2] : __builtin_amdgcn_alignbyte(D[(k >> 2) + 1], D[k >> 2], (uint32_t)(k & 3));
+                c[k] = A0[k] == p0;
+                any |= __ballot(c[k]);
+            }
+            if (any)
+            {
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                {
+                    const uint32_t a4 = k < 12 ? A0[k + 4] : __builtin_amdgcn_alignbyte(D[(k >> 2) + 2], D[(k >> 2) + 1], (uint32_t)(k & 3));
+                    if (c[k] && a4 == p1)
+                        hits += 1;
+                }
+            }
+        }
+    }
+    if (hits)
+        atomicAdd((unsigned long long *)(out + 2), hits);
+}
+
 __global__ void fill(uint32_t *p, size_t nwords)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (size_t)gridDim.x * blockDim.x)
@@ -292,6 +372,40 @@ int main(int argc, char **argv)
         CHK(hipGetLastError());                                                                                      \
         printf("%-44s blocks/CU=%d  %7.3f ms  %7.1f GB/s  (%.3f of 8 TB/s)\n", name, bpc, ms, n / ms / 1e6, n / ms / 1e6 / 8000.0); \
         fflush(stdout);                                                                                               \
+    }
+
+#define RUNL(name, kern, bpc, lds)                                                                                   \
+    {                                                                                                                 \
+        if (lds > 65536) CHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+        double ms = time_it([&] {                                                                                     \
+            hipLaunchKernelGGL(kern, dim3(cu * bpc), dim3(256), lds, 0, buf, n, out, ticket, 0x72656853u, 0x6b636f6cu); \
+        });                                                                                                           \
+        CHK(hipGetLastError());                                                                                      \
+        printf("%-52s blocks/CU=%d  %7.3f ms  %7.1f GB/s  (%.3f of 8 TB/s)\n", name, bpc, ms, n / ms / 1e6, n / ms / 1e6 / 8000.0); \
+        fflush(stdout);                                                                                               \
+    }
+    if (argc > 2 && !strcmp(argv[2], "ldsdma"))
+    {
+        // round 6: LDS-DMA streaming with the literal8 compare against the register-load variants with the same compare
+        RUNS("static R=4, literal8 compare, ROLLING PREFETCH", (rd_static<4, true>), 4);
+        RUNS("static R=4, literal8 compare, no prefetch", (rd_static<4, false>), 4);
+        RUN("regs  8 x dwordx4, nontemporal (bare reader)", (rd_regs<8, true>), 2, 0);
+        RUN("lds-dma  8 KiB/wave, nt (bare reader)", (rd_ldsdma<8, 2>), 1, 4 * 8 * 1024);
+        for (int bpc : {1, 2})
+        {
+            RUNL("lds-dma + literal8 compare, 2 x 8 KiB per wave, nt", (rd_ldsdma_cmp<8, 2, 2, 4>), bpc, 4 * (2 * 8 * 1024 + 16));
+            RUNL("lds-dma + literal8 compare, 2 x 8 KiB per wave, default", (rd_ldsdma_cmp<8, 2, 0, 4>), bpc, 4 * (2 * 8 * 1024 + 16));
+        }
+        RUNL("lds-dma + literal8 compare, 3 x 8 KiB per wave, nt", (rd_ldsdma_cmp<8, 3, 2, 4>), 1, 4 * (3 * 8 * 1024 + 16));
+        RUNL("lds-dma + literal8 compare, 4 x 8 KiB per wave, nt", (rd_ldsdma_cmp<8, 4, 2, 4>), 1, 4 * (4 * 8 * 1024 + 16));
+        for (int bpc : {1, 2, 4})
+        {
+            RUNL("lds-dma + literal8 compare, 2 x 4 KiB per wave, nt", (rd_ldsdma_cmp<4, 2, 2, 8>), bpc, 4 * (2 * 4 * 1024 + 16));
+            RUNL("lds-dma + literal8 compare, 4 x 4 KiB per wave, nt", (rd_ldsdma_cmp<4, 4, 2, 8>), bpc > 2 ? 2 : bpc, 4 * (4 * 4 * 1024 + 16));
+        }
+        RUNL("lds-dma + literal8 compare, 4 x 2 KiB per wave, nt", (rd_ldsdma_cmp<2, 4, 2, 16>), 4, 4 * (4 * 2 * 1024 + 16));
+        RUNL("lds-dma + literal8 compare, 8 x 2 KiB per wave, nt", (rd_ldsdma_cmp<2, 8, 2, 16>), 2, 4 * (8 * 2 * 1024 + 16));
+        return 0;
     }
     for (int bpc : {4})
     {
