@@ -446,8 +446,7 @@ static hipError_t dma_launch2(const LitArgs &a, u32 num_cu, hipStream_t st)
 // does this launch take the LDS-DMA kernel?  2..8-byte patterns, 32-KiB units, no -c, not the emit-mode re-scan
 bool literal_dma_eligible(const LitArgs &a)
 {
-    static const bool off = getenv("KREP_GPU_LIT_NO_DMA") != nullptr;
-    return !off && a.m >= 2 && a.m <= 8 && a.rounds == (u32)kRoundsBig && !(a.flags & F_LINES) && !a.emit_mode &&
+    return !getenv("KREP_GPU_LIT_NO_DMA") && a.m >= 2 && a.m <= 8 && a.rounds == (u32)kRoundsBig && !(a.flags & F_LINES) && !a.emit_mode &&
            (a.upt == 0 || a.upt == 8 || a.upt == 4 || a.upt == 2 || a.upt == 1) && a.text_len >= 4u * kSegBytes;
 }
 hipError_t launch_literal_dma(const LitArgs &a, u32 num_cu, hipStream_t st)

@@ -1,0 +1,38 @@
+"""A/B of the LDS-DMA literal kernel (kg_literal_dma.hip) against the register-load kernel (kg_literal.hip) IN ONE PROCESS on the
+same HBM buffers: $KREP_GPU_LIT_NO_DMA is read per launch.   usage: python tools/lit_dma_ab.py <gib> [reps]"""
+import os, sys, statistics
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import krep_amd
+from krep_amd import abi
+
+gib = float(sys.argv[1]) if len(sys.argv) > 1 else 32.0
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 7
+n = int(gib * (1 << 30))
+e = krep_amd.load()
+buf = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+cap = n // 2000 + 4096
+pos = torch.empty(2 * cap, dtype=torch.int64, device="cuda")
+base = b"Sherlock Holmes"
+print(f"# {gib:g} GiB, median of {reps} launches each, alternating in one process; ms (GB/s)   [dma = kg_literal_dma.hip, regs = kg_literal.hip]")
+for m, kw, label in ((8, {}, "m=8 offsets"), (8, dict(count_lines=True, only_match=True), "m=8 count"), (8, dict(case_sensitive=False), "m=8 -i offsets"),
+                     (8, dict(whole_word=True), "m=8 -w offsets"), (5, {}, "m=5 offsets"), (4, {}, "m=4 offsets"), (3, {}, "m=3 offsets"), (2, {}, "m=2 offsets")):
+    pat = base[:m]
+    e.generate(buf.data_ptr(), n, 0, 2, 42, pat, 10000)
+    torch.cuda.synchronize()
+    want_pos = "count" not in label
+    plan = e.plan(abi.Params([pat], **kw))
+    t = {"dma": [], "regs": []}
+    cnt = {}
+    for rep in range(reps + 1):
+        for which in ("dma", "regs"):
+            if which == "regs":
+                os.environ["KREP_GPU_LIT_NO_DMA"] = "1"
+            out = plan.scan(buf.data_ptr(), n, 0, n, 0, pos.data_ptr() if want_pos else 0, cap if want_pos else 0, time_it=True)
+            os.environ.pop("KREP_GPU_LIT_NO_DMA", None)
+            cnt[which] = (out.count, int(pos[: 2 * min(out.stored, 1000)].sum().item()) if want_pos else 0)
+            if rep:
+                t[which].append(out.kernel_ms)
+    plan.close()
+    a, b = statistics.median(t["dma"]), statistics.median(t["regs"])
+    print(f"{label:16s} dma {a:6.3f} ({n / a / 1e6:6.0f})   regs {b:6.3f} ({n / b / 1e6:6.0f})   count {cnt['dma'][0]}   same result: {cnt['dma'] == cnt['regs']}   dma launches so far {e.literal_dma_launches()}", flush=True)
