@@ -31,7 +31,7 @@ namespace {
 constexpr u32 kDmaPark = 80;                 // parked units per wave (info word + 16 staged offsets each)
 constexpr u32 kDmaRing = 2u * kSegBytes;     // two rounds
 constexpr u32 kDmaTail = 256u;               // the DMA piece behind a ticket (4 B per lane)
-constexpr u32 kDmaWaveLds = kDmaRing + kDmaTail + kDmaPark * 8u + kDmaPark * 32u + kDmaPark * 4u; // 20160 B: two workgroups per CU
+constexpr u32 kDmaWaveLds = kDmaRing + kDmaTail; // dynamic LDS per wave; + 44 B per parked unit in static arrays: 20160 B per wave, two workgroups per CU
 
 __device__ __forceinline__ u32 d_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 __device__ __forceinline__ u32 d_mbcnt(u64 m) { return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)); }
@@ -65,14 +65,21 @@ __device__ __noinline__ W6d d_window_guarded(const uint8_t *text, u64 text_len, 
 template <int KIND, bool MASKED, bool CI>
 __global__ __launch_bounds__(kBlock, 2) void lit_scan_dma(const LitArgs a)
 {
+    // The ring is the ONLY thing in the dynamic LDS block and is read through inline ds_read (below): the compiler orders every LDS
+    // access that may alias an LDS-DMA destination behind s_waitcnt vmcnt(0) — which would retire the next round's DMA before this
+    // round is looked at (measured: 6.3 ms where the register kernel takes 5.3).  The parked stores live in static arrays of their own.
     extern __shared__ __attribute__((aligned(16))) uint8_t d_smem[];
+    __shared__ u64 s_info_all[kWavesPerBlk][kDmaPark];
+    __shared__ __attribute__((aligned(16))) unsigned short s_slots_all[kWavesPerBlk][kDmaPark * 16u];
+    __shared__ u32 s_unit_all[kWavesPerBlk][kDmaPark];
     const u32 lane = d_lane();
     const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint8_t *ring = d_smem + wave * kDmaWaveLds;
     uint8_t *tailb = ring + kDmaRing;
-    u64 *s_info = reinterpret_cast<u64 *>(tailb + kDmaTail);
-    unsigned short *s_slots = reinterpret_cast<unsigned short *>(s_info + kDmaPark);
-    u32 *s_unit = reinterpret_cast<u32 *>(s_slots + kDmaPark * 16u);
+    u64 *s_info = s_info_all[wave];
+    unsigned short *s_slots = s_slots_all[wave];
+    u32 *s_unit = s_unit_all[wave];
+    const u32 ring_lds = (u32)(size_t)(__attribute__((address_space(3))) uint8_t *)ring; // LDS byte address of the wave's ring
 
     const bool want_pos = (a.flags & F_POS) != 0;
     const bool ww = (a.flags & F_WW) != 0;
@@ -255,12 +262,28 @@ __global__ __launch_bounds__(kBlock, 2) void lit_scan_dma(const LitArgs a)
             uint2 nn[kCells];
             if (dma_cur)
             {
-                const uint8_t *b = ring + (g & 1u) * kSegBytes + lane * 16u;
+                typedef u32 v4 __attribute__((ext_vector_type(4)));
+                typedef u32 v2 __attribute__((ext_vector_type(2)));
+                const u32 addr = ring_lds + (g & 1u) * kSegBytes + lane * 16u;
+                v4 x[kCells];
+                v2 y[kCells];
 #pragma unroll
                 for (int j = 0; j < kCells; ++j)
                 {
-                    vv[j] = *reinterpret_cast<const uint4 *>(b + j * kCellBytes);
-                    nn[j] = *reinterpret_cast<const uint2 *>(b + j * kCellBytes + 16); // (lane 63 of the last cell: not this round's bytes — masked below)
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x[j]) : "v"(addr), "n"(j * (int)kCellBytes));
+                    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(y[j]) : "v"(addr), "n"(j * (int)kCellBytes + 16)); // (lane 63 of the last cell: not this round's bytes — masked below)
+                }
+                // (the wait names every destination: nothing that uses one can be scheduled in front of it)
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(y[0]), "+v"(y[1]),
+                               "+v"(y[2]), "+v"(y[3]), "+v"(y[4]), "+v"(y[5]), "+v"(y[6]), "+v"(y[7])
+                             :
+                             : "memory");
+#pragma unroll
+                for (int j = 0; j < kCells; ++j)
+                {
+                    vv[j] = make_uint4(x[j].x, x[j].y, x[j].z, x[j].w);
+                    nn[j] = make_uint2(y[j].x, y[j].y);
                 }
             }
             else
@@ -384,7 +407,10 @@ __global__ __launch_bounds__(kBlock, 2) void lit_scan_dma(const LitArgs a)
                     u32 n0 = 0, n1 = 0;
                     if (tail_ok)
                     { // (the piece was issued in front of the next ticket's first round: the wait above covered it)
-                        const uint2 t = *reinterpret_cast<const uint2 *>(tailb);
+                        typedef u32 v2 __attribute__((ext_vector_type(2)));
+                        v2 t;
+                        const u32 taddr = ring_lds + kDmaRing;
+                        asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(t) : "v"(taddr) : "memory");
                         n0 = __builtin_amdgcn_readfirstlane(t.x);
                         n1 = __builtin_amdgcn_readfirstlane(t.y);
                     }
@@ -417,7 +443,7 @@ std::atomic<uint64_t> g_lit_dma_launches{0};
 template <int KIND, bool MASKED, bool CI>
 static hipError_t dma_launch3(const LitArgs &a, u32 num_cu, hipStream_t st)
 {
-    constexpr u32 lds = kWavesPerBlk * kDmaWaveLds;
+    constexpr u32 lds = kWavesPerBlk * kDmaWaveLds; // dynamic part (the rings); the parked stores are static
     constexpr int kMaxDev = 64;
     static std::atomic<bool> granted[kMaxDev];
     int dev = 0;
