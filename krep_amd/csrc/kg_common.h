@@ -84,6 +84,9 @@ struct LitArgs {
     const uint64_t *offsets;      // [units] exclusive global index of each unit's first match (emit mode)
     uint64_t *positions;          // match_position_t records (2 x u64) or nullptr
     uint64_t pos_cap;             // min(capacity, max_count)
+    uint32_t prefilter;           // kg_literal_dma.hip: the pattern's first byte in every byte lane (| 0x20 under F_CI) when that byte is
+                                  //   rare in text — a cell none of whose bytes equals it is skipped after one zero-byte test per dword
+                                  //   (0: no prefilter, all 16 windows are compared)
 };
 
 } // namespace kg

@@ -200,6 +200,13 @@ __global__ __launch_bounds__(kBlock, 2) void lit_scan_dma(const LitArgs a)
     // the start positions of a round whose window crosses its end: lanes 0..7 hold position seg_prev + 8184 + lane; c0, c1 = the
     // round's last 8 bytes, n0, n1 = the 8 bytes behind it
     auto boundary = [&](u64 seg_prev, u64 unit, u32 r_prev, u32 c0, u32 c1, u32 n0, u32 n1) __attribute__((always_inline)) {
+        {
+            // on the scalar unit: does one of the round's last 8 bytes equal the pattern's first byte at all?
+            const u32 f = 0x01010101u * ((CI ? (a.p0 | 0x20u) : a.p0) & 0xffu);
+            const u32 y0 = (CI ? (c0 | 0x20202020u) : c0) ^ f, y1 = (CI ? (c1 | 0x20202020u) : c1) ^ f;
+            if (((((y0 - 0x01010101u) & ~y0) | ((y1 - 0x01010101u) & ~y1)) & 0x80808080u) == 0u)
+                return;
+        }
         const u32 q = lane & 7u, sh = q & 3u;
         const bool up = (q >> 2) != 0u;
         const u32 lo = up ? c1 : c0, mid = up ? n0 : c1, hi = up ? n1 : n0;
@@ -324,6 +331,18 @@ __global__ __launch_bounds__(kBlock, 2) void lit_scan_dma(const LitArgs a)
                     return ((k & 3) == 0) ? Dq[k >> 2] : __builtin_amdgcn_alignbyte(Dq[(k >> 2) + 1], Dq[k >> 2], (u32)(k & 3));
                 };
                 const u32 p0q = CI ? (a.p0 | 0x20202020u) : a.p0;
+                if (a.prefilter) // (uniform) a rare first byte: one zero-byte test per dword says whether the cell can start a match at all
+                {
+                    u32 z = 0;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w)
+                    {
+                        const u32 y = Dq[w] ^ a.prefilter;
+                        z |= (y - 0x01010101u) & ~y;
+                    }
+                    if (!__ballot((z & 0x80808080u) != 0u))
+                        continue;
+                }
                 bool c[16];
                 u64 any = 0;
 #pragma unroll
@@ -338,7 +357,8 @@ __global__ __launch_bounds__(kBlock, 2) void lit_scan_dma(const LitArgs a)
                 u32 m16 = 0;
 #pragma unroll
                 for (int k = 0; k < 16; ++k)
-                    m16 |= (c[k] && exact(A(k), A(k + 4))) ? (1u << k) : 0u;
+                    if (__ballot(c[k])) // (uniform: the exact compare only at the start positions some lane's first word matched at)
+                        m16 |= (c[k] && exact(A(k), A(k + 4))) ? (1u << k) : 0u;
                 // lane 63 of a DMA round's last cell does not have the bytes behind the round: its crossing positions are deferred
                 if (dma_cur && j == kCells - 1 && lane == 63u)
                     m16 &= (1u << (17u - a.m)) - 1u;

@@ -168,6 +168,17 @@ static int lit_pass(krep_gpu_plan *pl, const Window &w, const LitPass &ps, hipSt
         a.l0 = pl->l0; a.l1 = pl->l1;
         a.p2 = pl->p2; a.p3 = pl->p3; a.k2 = pl->k2; a.k3 = pl->k3; a.l2 = pl->l2; a.l3 = pl->l3;
     }
+    {
+        // kg_literal_dma.hip's prefilter: only for a first byte that text rarely holds (the blank and the dozen most frequent letters
+        // of running text, either case, would pass nearly every 16-byte lane: the test would be paid for nothing)
+        // (case-sensitive: the lower-case ones only — a capital first letter is rare)
+        const uint32_t b0 = (a.p0 & 0xffu) | (pl->cs ? 0u : 0x20u);
+        static const char common[] = "etaoinshrdlu";
+        bool rare = b0 != ' ' && b0 != '\n';
+        for (const char *q = common; *q; ++q)
+            rare = rare && b0 != (uint32_t)*q;
+        a.prefilter = (rare && !ps.first_byte && !getenv("KREP_GPU_LIT_NO_PREFILTER")) ? 0x01010101u * b0 : 0u;
+    }
     a.pat = pl->d_pat;
     a.pat_chunks = pl->d_pat_chunks;
     a.n_chunks = ps.first_byte ? 0 : pl->n_chunks;
