@@ -492,7 +492,9 @@ static hipError_t dma_launch2(const LitArgs &a, u32 num_cu, hipStream_t st)
 // does this launch take the LDS-DMA kernel?  2..8-byte patterns, 32-KiB units, no -c, not the emit-mode re-scan
 bool literal_dma_eligible(const LitArgs &a)
 {
-    return !getenv("KREP_GPU_LIT_NO_DMA") && a.m >= 2 && a.m <= 8 && a.rounds == (u32)kRoundsBig && !(a.flags & F_LINES) && !a.emit_mode &&
+    // (and only with the rare-first-byte prefilter: without it the compare's VALU work is not hidden at two waves per SIMD —
+    //  `-i sherlock`: 6.26 ms against 5.21 ms for the register kernel, which keeps such patterns)
+    return !getenv("KREP_GPU_LIT_NO_DMA") && a.prefilter != 0u && a.m >= 2 && a.m <= 8 && a.rounds == (u32)kRoundsBig && !(a.flags & F_LINES) && !a.emit_mode &&
            (a.upt == 0 || a.upt == 8 || a.upt == 4 || a.upt == 2 || a.upt == 1) && a.text_len >= 4u * kSegBytes;
 }
 hipError_t launch_literal_dma(const LitArgs &a, u32 num_cu, hipStream_t st)

@@ -14,7 +14,7 @@ buf = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
 cap = n // 2000 + 4096
 pos = torch.empty(2 * cap, dtype=torch.int64, device="cuda")
 base = b"Sherlock Holmes"
-print(f"# {gib:g} GiB, median of {reps} launches each, alternating in one process; ms (GB/s)   [dma = kg_literal_dma.hip, regs = kg_literal.hip]")
+print(f"# {gib:g} GiB, median of {reps} launches each, alternating in one process; ms (GB/s)   [dma = kg_literal_dma.hip (where eligible), regs = kg_literal.hip, +pf = with the rare-first-byte prefilter]")
 for m, kw, label in ((8, {}, "m=8 offsets"), (8, dict(count_lines=True, only_match=True), "m=8 count"), (8, dict(case_sensitive=False), "m=8 -i offsets"),
                      (8, dict(whole_word=True), "m=8 -w offsets"), (5, {}, "m=5 offsets"), (4, {}, "m=4 offsets"), (3, {}, "m=3 offsets"), (2, {}, "m=2 offsets")):
     pat = base[:m]
@@ -22,17 +22,19 @@ for m, kw, label in ((8, {}, "m=8 offsets"), (8, dict(count_lines=True, only_mat
     torch.cuda.synchronize()
     want_pos = "count" not in label
     plan = e.plan(abi.Params([pat], **kw))
-    t = {"dma": [], "regs": []}
+    ENV = {"dma": {}, "regs+pf": {"KREP_GPU_LIT_NO_DMA": "1"}, "regs": {"KREP_GPU_LIT_NO_DMA": "1", "KREP_GPU_LIT_NO_PREFILTER": "1"}}
+    t = {k: [] for k in ENV}
     cnt = {}
     for rep in range(reps + 1):
-        for which in ("dma", "regs"):
-            if which == "regs":
-                os.environ["KREP_GPU_LIT_NO_DMA"] = "1"
+        for which, env in ENV.items():
+            os.environ.update(env)
             out = plan.scan(buf.data_ptr(), n, 0, n, 0, pos.data_ptr() if want_pos else 0, cap if want_pos else 0, time_it=True)
-            os.environ.pop("KREP_GPU_LIT_NO_DMA", None)
+            for k in env:
+                os.environ.pop(k, None)
             cnt[which] = (out.count, int(pos[: 2 * min(out.stored, 1000)].sum().item()) if want_pos else 0)
             if rep:
                 t[which].append(out.kernel_ms)
     plan.close()
-    a, b = statistics.median(t["dma"]), statistics.median(t["regs"])
-    print(f"{label:16s} dma {a:6.3f} ({n / a / 1e6:6.0f})   regs {b:6.3f} ({n / b / 1e6:6.0f})   count {cnt['dma'][0]}   same result: {cnt['dma'] == cnt['regs']}   dma launches so far {e.literal_dma_launches()}", flush=True)
+    med = {k: statistics.median(v) for k, v in t.items()}
+    print(f"{label:16s} " + "   ".join(f"{k} {v:6.3f} ({n / v / 1e6:5.0f})" for k, v in med.items()) +
+          f"   count {cnt['dma'][0]}   same result: {len(set(cnt.values())) == 1}   dma launches so far {e.literal_dma_launches()}", flush=True)
