@@ -539,20 +539,6 @@ __global__ __launch_bounds__(kBlock, (KIND == 1 && LINES && R == 4) ? KG_LIT1_LI
                     u32 A0[16];
                     bool c[16];
                     u64 any = 0;
-                    bool skip = false;
-                    if (a.prefilter && fast) // (uniform; round 6) a rare first byte: one zero-byte test per dword says whether the cell can start a match
-                    {
-                        u32 z = 0;
-#pragma unroll
-                        for (int w = 0; w < 4; ++w)
-                        {
-                            const u32 y = Dq[w] ^ a.prefilter;
-                            z |= (y - 0x01010101u) & ~y;
-                        }
-                        skip = !__ballot((z & 0x80808080u) != 0u);
-                    }
-                    if (!skip)
-                    {
 #pragma unroll
                     for (int k = 0; k < 16; ++k)
                     {
@@ -583,7 +569,6 @@ __global__ __launch_bounds__(kBlock, (KIND == 1 && LINES && R == 4) ? KG_LIT1_LI
                             }
                             m16 |= h ? (1u << k) : 0u;
                         }
-                    }
                     }
                 }
 

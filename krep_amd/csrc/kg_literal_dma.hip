@@ -495,7 +495,9 @@ bool literal_dma_eligible(const LitArgs &a)
     // (and only with the rare-first-byte prefilter: without it the compare's VALU work is not hidden at two waves per SIMD —
     //  `-i sherlock`: 6.26 ms against 5.21 ms for the register kernel, which keeps such patterns)
     return !getenv("KREP_GPU_LIT_NO_DMA") && a.prefilter != 0u && a.m >= 2 && a.m <= 8 && a.rounds == (u32)kRoundsBig && !(a.flags & F_LINES) && !a.emit_mode &&
-           (a.upt == 0 || a.upt == 8 || a.upt == 4 || a.upt == 2 || a.upt == 1) && a.text_len >= 4u * kSegBytes;
+           (a.upt >= 4 || getenv("KREP_GPU_LIT_DMA_ALL")) && a.text_len >= 4u * kSegBytes;
+    // (tickets of >= 4 units — texts from ~24 GiB — : with one-unit tickets / the static deal of smaller texts every fourth round ends
+    //  a ticket, and the register kernel is as fast or faster: 8 GiB 1.42 against 1.36 ms.  $KREP_GPU_LIT_DMA_ALL: the tests' switch.)
 }
 hipError_t launch_literal_dma(const LitArgs &a, u32 num_cu, hipStream_t st)
 {
