@@ -234,3 +234,52 @@ def test_bench_two_ranks_over_rccl_when_two_devices_exist(gpu):
     rec = json.loads(line)
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
     assert "RCCL" in rec["config"]["parallelism"], rec["config"]
+
+
+@pytest.mark.parametrize("name", ["literal8", "memchr1", "ac1000"])
+def test_eight_rank_windows_as_bench_issues_them(gpu, name):
+    """The product's rank path at G = 8 on ONE device: eight shards of 1 GiB, each generated in a buffer of its
+    own at global offset rank * n with a 64-byte halo and scanned with krep_gpu_scan_device_ex() exactly as bench.py's ranks do
+    (text_len n + halo, n for the last; own [0, n); global_base = rank * n; global_len = 8 n).  The eight record lists, concatenated
+    in rank order, must be the single-window list of the whole 8-GiB text — so the first SCALE run cannot fail on arithmetic.
+    (The reference's counterpart: search_file()'s chunk loop, krep.c:2851-2905.)"""
+    import torch
+    import bench
+    G, n, halo = 8, 1 << 30, 64
+    free, _ = torch.cuda.mem_get_info()
+    if free < G * n + 2 * n + (8 << 30):
+        pytest.skip("not enough free HBM")
+    wl = bench.workload(name)
+    cap1 = bench.positions_capacity(name, n)
+    whole = torch.empty(G * n + 64, dtype=torch.uint8, device="cuda")
+    gpu.generate(whole.data_ptr(), G * n, 0, wl["kind"], bench.SEED, wl["plant"], wl["period"])
+    pos_w = torch.empty(2 * G * cap1, dtype=torch.int64, device="cuda")
+    plan = gpu.plan(abi.Params(wl["patterns"], **wl["kw"]))
+    ow = plan.scan(whole.data_ptr(), G * n, 0, G * n, 0, pos_w.data_ptr(), G * cap1)
+    assert not ow.overflow and ow.stored == ow.count
+    want = pos_w[: 2 * ow.stored].view(-1, 2)
+    shard = torch.empty(n + halo, dtype=torch.uint8, device="cuda")
+    pos = torch.empty(2 * cap1, dtype=torch.int64, device="cuda")
+    got, total = [], 0
+    for rank in range(G):
+        gpu.generate(shard.data_ptr(), n + halo, rank * n, wl["kind"], bench.SEED, wl["plant"], wl["period"])
+        # (the generator is a pure function of the global byte index: the shard's bytes are the whole text's)
+        assert torch.equal(shard[: n + (halo if rank < G - 1 else 0)], whole[rank * n: rank * n + n + (halo if rank < G - 1 else 0)])
+        text_len = n if rank == G - 1 else n + halo
+        o = plan.scan(shard.data_ptr(), text_len, 0, n, rank * n, pos.data_ptr(), cap1, global_len=G * n)
+        assert not o.overflow and o.stored == o.count
+        got.append(pos[: 2 * o.stored].view(-1, 2).clone())
+        total += o.count
+    assert total == ow.count, (name, total, ow.count)
+    cat = torch.cat(got)
+    if name == "ac1000":
+        # emission order is (end, longest first) inside a shard and a match is owned by its START: at a cut a longer match of the
+        # left shard can end behind the first ends of the right one — compare as multisets, and the order inside every shard
+        key = lambda a: a[torch.argsort(a[:, 0] * 64 + (a[:, 1] - a[:, 0]), stable=True)]
+        assert torch.equal(key(cat), key(want))
+        for a in got:
+            e, s = a[:, 1], a[:, 0]
+            assert bool(torch.all((e[1:] > e[:-1]) | ((e[1:] == e[:-1]) & (s[1:] >= s[:-1]))))
+    else:
+        assert torch.equal(cat, want)
+    plan.close()
