@@ -38,6 +38,7 @@ struct krep_gpu_plan
     uint32_t sparse_cap = 16; // staging entries per 32 KiB unit of the sparse literal kinds: 16, raised to 64 after a scan whose
                               // units overflowed (see lit_pass); one 32-byte slot per unit keeps the store stream dense
     uint32_t ac_cap = 16;     // the same for the multi-pattern scan (16 KiB units)
+    bool first_look_done = false; // lit_pass: the density of the plan's first large text has been sampled (road / ring shape / slot from it)
     bool fused1_ok = true;    // single byte with records: the one-pass kernel (kg_single.hip) until a scan proves too dense for it
     bool fusedk_on = false;   // a 2..8-byte literal with records: the same kernel's MULTI instantiations, switched on by a two-pass scan that
     bool fusedk_never = false; // ... counted a density its staging slots do not hold (lit_pass); never again once a ring overflowed beyond the last shape

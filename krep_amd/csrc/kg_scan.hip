@@ -222,6 +222,64 @@ static int lit_pass(krep_gpu_plan *pl, const Window &w, const LitPass &ps, hipSt
     // that shape — the plan keeps it; beyond that the two-pass kernels below take this scan and the plan's later ones.
     // The same kernel takes a literal of 2..8 bytes (its MULTI instantiations) once a two-pass scan of the plan has counted a
     // density at which the staging slots of the sparse kinds overflow (`-i sh`: 35 hits per unit; ` a`: 180): pl->fusedk_on.
+    // ---- the FIRST records scan of a plan on a large text: one cheap look before the full launch (round 6).  A plan
+    // used to learn the density of its text from whole scans — the two-pass road first, the one-pass writers and their ring shape
+    // from the third or fourth scan on (`-i Sh`: 4222 / 4886 / 5026 / 5097 GB/s in four consecutive scans), which a CLI process,
+    // making ONE scan, never reached.  Four 1-MiB windows are counted (~60 us next to >= 160 us of scan) and the road, the ring shape
+    // and the staging slot are chosen from that; every later scan re-evaluates them as before.
+    if (ps.sink == LitPass::RECORDS && !pl->first_look_done && a.rounds == kRoundsBig && fsc == 0 && !ps.first_byte && !ps.lines &&
+        ps.excl_lo == ps.excl_hi && hi_match - a.anchor >= (1ull << 30) && !getenv("KREP_GPU_NO_FIRST_LOOK"))
+    {
+        pl->first_look_done = true;
+        const uint64_t span = hi_match - a.anchor, win = 1ull << 20, tile_bytes = (uint64_t)kRoundsBig * kSegBytes * kWavesPerBlk;
+        HIPCHK(hipMemsetAsync(pl->d_ctr, 0, sizeof(Counters), st));
+        uint64_t looked = 0;
+        for (int q = 0; q < 4; ++q)
+        {
+            LitArgs sm = a;
+            sm.flags &= ~(uint32_t)(F_POS | F_LINES);
+            sm.stage_cap = 0;
+            sm.upt = 0;
+            sm.emit_mode = 0;
+            sm.own_lo = (a.anchor + span / 8 * (2 * q + 1)) & ~(uint64_t)15;
+            sm.own_hi = std::min<uint64_t>(hi_match, sm.own_lo + win);
+            sm.anchor = sm.own_lo;
+            sm.num_tiles = (sm.own_hi - sm.anchor + tile_bytes - 1) / tile_bytes;
+            looked += sm.own_hi - sm.own_lo;
+            HIPCHK(launch_literal(sm, grid, st));
+        }
+        HIPCHK(hipMemcpyAsync(pl->h_ctr, pl->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        const double density = looked ? (double)pl->h_ctr->total / (double)looked : 0.0, per_unit = density * 32768.0;
+        if (m_scan == 1)
+        {
+            if (density > single_fused_max_density(kFusedShapeMax))
+                pl->fused1_ok = false;
+            else
+            {
+                int shape = 0;
+                while (shape < kFusedShapeMax && 1.15 * density > single_fused_max_density(shape))
+                    ++shape;
+                pl->fused1_shape = shape;
+            }
+        }
+        else if (m_scan <= 8 && !ps.ww && !pl->fusedk_never && per_unit >= fusedk_min_hits_per_unit() &&
+                 density <= single_fused_max_density(kFusedShapeMax))
+        {
+            int shape = 0;
+            while (shape < kFusedShapeMax && 1.15 * density > single_fused_max_density(shape))
+                ++shape;
+            pl->fusedk_on = true;
+            pl->fusedk_shape = shape;
+        }
+        else if (per_unit > 6.0) // the staging road with slots that hold what a unit holds (what a whole scan used to find out)
+            pl->sparse_cap = std::max<uint32_t>(pl->sparse_cap, per_unit > 100.0 ? 256u : per_unit > 40.0 ? 128u : 64u);
+        if (getenv("KREP_GPU_DEBUG"))
+            fprintf(stderr, "krep-gpu: first look: %.2f hits per 32-KiB unit in %llu sampled bytes -> one-pass %d (shape %d / %d), staging slot %u\n", per_unit,
+                    (unsigned long long)looked, (int)(m_scan == 1 ? pl->fused1_ok : pl->fusedk_on), pl->fused1_shape, pl->fusedk_shape, pl->sparse_cap);
+        if ((a.flags & F_POS) && !fsc)
+            a.stage_cap = a.rounds == kRoundsBig ? (m_scan == 1 ? 512u : pl->sparse_cap) : a.stage_cap;
+    }
     const bool fusedk = m_scan >= 2 && m_scan <= 8 && pl->fusedk_on;
     if ((m_scan == 1 ? pl->fused1_ok : fusedk) && ps.sink == LitPass::RECORDS && !ps.ww && !ps.lines && !ps.first_byte &&
         a.rounds == kRoundsBig && fsc == 0 && ps.excl_lo == ps.excl_hi && w.text_len >= 2 * (size_t)kSegBytes &&
