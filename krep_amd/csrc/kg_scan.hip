@@ -225,23 +225,23 @@ static int lit_pass(krep_gpu_plan *pl, const Window &w, const LitPass &ps, hipSt
     // ---- the FIRST records scan of a plan on a large text: one cheap look before the full launch (round 6).  A plan
     // used to learn the density of its text from whole scans — the two-pass road first, the one-pass writers and their ring shape
     // from the third or fourth scan on (`-i Sh`: 4222 / 4886 / 5026 / 5097 GB/s in four consecutive scans), which a CLI process,
-    // making ONE scan, never reached.  Four 1-MiB windows are counted (~60 us next to >= 160 us of scan) and the road, the ring shape
+    // making ONE scan, never reached.  Two 2-MiB windows are counted (~0.1 ms next to >= 0.16 ms of scan) and the road, the ring shape
     // and the staging slot are chosen from that; every later scan re-evaluates them as before.
     if (ps.sink == LitPass::RECORDS && !pl->first_look_done && a.rounds == kRoundsBig && fsc == 0 && !ps.first_byte && !ps.lines &&
         ps.excl_lo == ps.excl_hi && hi_match - a.anchor >= (1ull << 30) && !getenv("KREP_GPU_NO_FIRST_LOOK"))
     {
         pl->first_look_done = true;
-        const uint64_t span = hi_match - a.anchor, win = 1ull << 20, tile_bytes = (uint64_t)kRoundsBig * kSegBytes * kWavesPerBlk;
+        const uint64_t span = hi_match - a.anchor, win = 2ull << 20, tile_bytes = (uint64_t)kRoundsBig * kSegBytes * kWavesPerBlk;
         HIPCHK(hipMemsetAsync(pl->d_ctr, 0, sizeof(Counters), st));
         uint64_t looked = 0;
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < 2; ++q)
         {
             LitArgs sm = a;
             sm.flags &= ~(uint32_t)(F_POS | F_LINES);
             sm.stage_cap = 0;
             sm.upt = 0;
             sm.emit_mode = 0;
-            sm.own_lo = (a.anchor + span / 8 * (2 * q + 1)) & ~(uint64_t)15;
+            sm.own_lo = (a.anchor + span / 4 * (2 * q + 1)) & ~(uint64_t)15;
             sm.own_hi = std::min<uint64_t>(hi_match, sm.own_lo + win);
             sm.anchor = sm.own_lo;
             sm.num_tiles = (sm.own_hi - sm.anchor + tile_bytes - 1) / tile_bytes;
@@ -258,7 +258,7 @@ static int lit_pass(krep_gpu_plan *pl, const Window &w, const LitPass &ps, hipSt
             else
             {
                 int shape = 0;
-                while (shape < kFusedShapeMax && 1.15 * density > single_fused_max_density(shape))
+                while (shape < kFusedShapeMax && 1.05 * density > single_fused_max_density(shape))
                     ++shape;
                 pl->fused1_shape = shape;
             }
@@ -267,7 +267,7 @@ static int lit_pass(krep_gpu_plan *pl, const Window &w, const LitPass &ps, hipSt
                  density <= single_fused_max_density(kFusedShapeMax))
         {
             int shape = 0;
-            while (shape < kFusedShapeMax && 1.15 * density > single_fused_max_density(shape))
+            while (shape < kFusedShapeMax && 1.05 * density > single_fused_max_density(shape))
                 ++shape;
             pl->fusedk_on = true;
             pl->fusedk_shape = shape;
