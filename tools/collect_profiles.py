@@ -20,7 +20,7 @@ DOMINANT = {"literal8": "kg::lit_scan", "memchr1": "kg::single_fused", "ac1000":
 # the kernels of one step besides the dominant one (launched once per step: their bytes are added per step)
 POST = {"literal8": ("kg::post_",), "memchr1": (), "ac1000": ("kg::post_",)}
 # the sources whose change makes a workload's traffic figure stale (bench.py checks the hash before it quotes the figure)
-KERNEL_SOURCES = {"literal8": ["kg_literal.hip", "kg_post.hip", "kg_common.h"], "memchr1": ["kg_single.hip", "kg_tickets.h", "kg_common.h"],
+KERNEL_SOURCES = {"literal8": ["kg_literal_dma.hip", "kg_literal.hip", "kg_post.hip", "kg_common.h"], "memchr1": ["kg_single.hip", "kg_tickets.h", "kg_common.h"],
                   "ac1000": ["kg_ac.hip", "kg_ac_common.h", "kg_ac_tables.h", "kg_post.hip", "kg_common.h"]}
 
 
