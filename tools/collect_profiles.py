@@ -75,6 +75,20 @@ def main():
         kt = glob.glob(os.path.join(OUT, f"{tag}_{w}_kt", "**", "*kernel_trace.csv"), recursive=True)
         if kt:
             steady_stats(kt[0], os.path.join(PROF, f"{tag}_{w}_kernel_steady.csv"))
+            # the bench line printed BY THE TRACED PROCESS (round 6): its hipEvent kernel_ms and the trace's per-kernel averages are
+            # one process, one placement draw — the pair to recompute the roofline fraction from (the plain <tag>_<w>_bench.json is
+            # another process and draws its own placement, 1-2 % apart)
+            ktlog = os.path.join(OUT, f"{tag}_{w}_kt.log")
+            tl = [l for l in open(ktlog) if l.startswith("{")] if os.path.exists(ktlog) else []
+            if tl:
+                open(os.path.join(PROF, f"{tag}_{w}_bench_under_trace.json"), "w").write(tl[-1])
+                tr = json.loads(tl[-1])["roofline"]
+                step_ns = 0.0
+                for row in csv.DictReader(open(os.path.join(PROF, f"{tag}_{w}_kernel_steady.csv"))):
+                    if row["kernel"].startswith(dom) and int(row["calls"]) >= 10 or any(row["kernel"].startswith(p) for p in POST[w]):
+                        step_ns += float(row["avg_ns_steady"])
+                print(f"{w}: traced process: hipEvent kernel_ms {tr['kernel_ms']:.4f} (frac {tr['frac']:.4f}) vs kernel-trace steady sum {step_ns / 1e6:.4f} ms "
+                      f"({(tr['kernel_ms'] * 1e6 / step_ns - 1) * 100:+.2f} %)")
         agg = {}
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
             for f in glob.glob(os.path.join(OUT, f"{tag}_{w}_{c}", "**", "*counter_collection.csv"), recursive=True):
