@@ -51,7 +51,10 @@ namespace kg {
 // of the unit — same layout as the candidate bitmap: bit b <-> the END pair (2b + 1, 2b + 2), in the KiB that otherwise parks a
 // ticket's stores — and the marked pairs, not the candidates, are what the end-anchored verifier looks at, in position order:
 // ranking, staging and emission as before.
-template <bool CI, bool LINES, bool SHORT, int STRIDE, bool ANCH = false>
+// ANCH == 2: the filter's index holds FIVE classes — the class of the byte in front of the 4-gram goes into the five unused bits
+// (10..14) of the pair register before the slot address is formed, two VALU per tested position — for dictionaries (almost)
+// without patterns of 4 or 5 bytes: a 5-gram window of a word is several times rarer than its rarest 4-gram (kg_ac_anchor.hip).
+template <bool CI, bool LINES, bool SHORT, int STRIDE, int ANCH = 0>
 __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
 {
     static_assert(!ANCH || (STRIDE == 2 && !LINES && !SHORT), "anchored scan: pair filter, records / counts only");
@@ -213,6 +216,8 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 {
                     const int w = q / 2 + 1;
                     xs[q] = (q & 1) ? t[w] : __builtin_amdgcn_alignbit(t[w], t[w - 1], 16u);
+                    if constexpr (ANCH == 2)
+                        xs[q] = __builtin_amdgcn_ubfe(t[(2 * q + 1) / 4], ((2 * q + 1) % 4 == 1) ? 5u : 21u, 5u) << 10 | xs[q];
                     // (-c: a 2^19-bit table, address bit 16 = bit 3 of the class c2 dropped)
                     dws[q] = *(lds_u32 *)(size_t)(((xs[q] >> 3) ^ (xs[q] >> 13)) & kTabMask);
                 }
@@ -329,6 +334,8 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 {
                     const int w = q / 2 + 1;
                     x[q] = (q & 1) ? t[w] : __builtin_amdgcn_alignbit(t[w], t[w - 1], 16u);
+                    if constexpr (ANCH == 2) // the class of the byte in front of the gram (byte 2q - 3 of the lane): bits 10..14
+                        x[q] = __builtin_amdgcn_ubfe(t[(2 * q + 1) / 4], ((2 * q + 1) % 4 == 1) ? 5u : 21u, 5u) << 10 | x[q];
                     v[q] = *(lds_u32 *)(size_t)(((x[q] >> 3) ^ (x[q] >> 13)) & kTabMask);
                 }
             };
@@ -570,15 +577,20 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                     {
                         const bool hasB = t + 1 < a.text_len;
                         typedef __attribute__((address_space(3))) const u32 lds_u32;
-                        auto gtest = [&](u32 E) -> bool {
-                            const u32 u = ac_pair(E);
+                        // the table's answer for the gram whose LAST byte is byte `last` of the window (ANCH == 2: with the class of the
+                        // byte in front of the gram, byte last - 4)
+                        auto gtest = [&](const int last) -> bool {
+                            u32 u = ac_pair((u32)(Q >> (8 * (last - 3))));
+                            if constexpr (ANCH == 2)
+                                u |= ((u32)(Q >> (8 * (last - 4))) & 31u) << 10;
                             return ((*(lds_u32 *)(size_t)(((u >> 3) ^ (u >> 13)) & kTabMask) >> (u & 31u)) & 1u) != 0u;
                         };
                         // the position's own gram again for the six in front of the unit; then, as in the end-gram kernel: an anchor
                         // gram ENDS at t where the window's other gram sits at t - 1, at t + 1 where this one is that other gram
-                        const bool own_ok = live || gtest((u32)(Q >> 24));
-                        const bool liveA = own_ok && gtest((u32)(Q >> 16));
-                        const bool liveB = own_ok && hasB && gtest((u32)(Q >> 32));
+                        // (window bytes 0..7 = text bytes t - 6 .. t + 1)
+                        const bool own_ok = live || gtest(6);
+                        const bool liveA = own_ok && gtest(5);
+                        const bool liveB = own_ok && hasB && gtest(7);
                         u32 kA = (u32)(Q >> 24), kB = (u32)(Q >> 32); // the exact anchor gram: bytes t - 3 .. t | t - 2 .. t + 1
                         if (CI)
                         {
@@ -826,7 +838,7 @@ static u32 ac_lds_bytes(u32 filter_words, bool lines)
 }
 
 constexpr u32 kAcMaxLds = 160u * 1024u; // LDS of a gfx950 CU: the most a launch of the scan kernel can ask for
-template <bool CI, bool LN, bool SHORT, int STRIDE, bool ANCH = false>
+template <bool CI, bool LN, bool SHORT, int STRIDE, int ANCH = 0>
 static hipError_t ac_launch3(const AcArgs &a, u32 grid, u32 lds, hipStream_t st)
 {
     // more than 64 KiB of dynamic LDS has to be requested explicitly — once per instantiation and device, not on every launch
@@ -857,7 +869,7 @@ static hipError_t ac_launch2(const AcArgs &a, u32 grid, u32 lds, hipStream_t st)
         if (a.anch && a.stride == 2 && !shorts)
         {
             g_ac_anchored_launches.fetch_add(1, std::memory_order_relaxed);
-            return ac_launch3<CI, false, false, 2, true>(a, grid, lds, st);
+            return a.anch_five ? ac_launch3<CI, false, false, 2, 2>(a, grid, lds, st) : ac_launch3<CI, false, false, 2, 1>(a, grid, lds, st);
         }
     if (a.stride == 2)
         return shorts ? ac_launch3<CI, LN, true, 2>(a, grid, lds, st) : ac_launch3<CI, LN, false, 2>(a, grid, lds, st);
@@ -961,6 +973,7 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
         a.anch = t->d_anch;
         a.anch_mask = t->anch_mask;
         a.anch_mul = t->anch_mul;
+        a.anch_five = t->anch_five;
     }
     a.s1 = t->d_s1; a.s2 = t->d_s2; a.s3 = t->d_s3;
     if (t->short_dup)

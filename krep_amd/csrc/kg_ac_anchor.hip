@@ -43,6 +43,30 @@ __global__ __launch_bounds__(256) void ac_gram_hist_kernel(const uint8_t *text, 
         atomicAdd(&hist[ac_cls4(reinterpret_cast<const U32p *>(text + base + p)->v)], 1u);
 }
 
+// how often do the given five-class grams (sorted keys, c(b0) | c(b1) << 5 | ... | c(b4) << 20) occur in the same sample?
+__global__ __launch_bounds__(256) void ac_gram5_count_kernel(const uint8_t *text, u64 lo, u64 span, u32 nchunks, u32 chunk_bytes, const u32 *keys,
+                                                             u32 nkeys, u32 *counts)
+{
+    const u64 c = blockIdx.x;
+    const u64 base = lo + (nchunks > 1 ? (span - chunk_bytes) / (nchunks - 1) * c : 0ull);
+    struct __attribute__((packed)) U32p { u32 v; };
+    for (u32 p = threadIdx.x; p + 5u <= chunk_bytes; p += blockDim.x)
+    {
+        const u32 key = ac_cls4(reinterpret_cast<const U32p *>(text + base + p)->v) | (((u32)text[base + p + 4] & 31u) << 20);
+        u32 a = 0, b = nkeys; // lower bound
+        while (a < b)
+        {
+            const u32 m = (a + b) >> 1;
+            if (keys[m] < key)
+                a = m + 1;
+            else
+                b = m;
+        }
+        if (a < nkeys && keys[a] == key)
+            atomicAdd(&counts[a], 1u);
+    }
+}
+
 static inline u32 cls4_of(const uint8_t *g) { return ((u32)g[0] & 31u) | (((u32)g[1] & 31u) << 5) | (((u32)g[2] & 31u) << 10) | (((u32)g[3] & 31u) << 15); }
 
 void ac_anchor_free(AcTables *t)
@@ -150,18 +174,42 @@ int ac_anchor_prepare(AcTables *t, const uint8_t *d_text, size_t text_len, size_
                 tab[x >> 5] |= 1u << (x & 31);
         }
     };
-    auto build = [&](const std::vector<u32> &kk) {
+    // five-class entries (ANCH == 2): the gram that ends in front of `end_excl` with the class of the byte in front of IT; classes the
+    // pattern does not reach are free (32 or 1024 slots)
+    auto expand5 = [&](std::vector<u32> &tab, const std::vector<uint8_t> &p, long end_excl) {
+        const long have = std::min<long>(5, end_excl); // known bytes: the last `have` of the five
+        u32 fixed = 0; // c(e) | c0 << 5 | c1 << 10 | c2 << 15 | c3 << 20 over the five bytes in text order
+        for (long q = 0; q < have; ++q)
+            fixed |= ((u32)p[(size_t)(end_excl - have + q)] & 31u) << (5 * (5 - have + q));
+        const u32 nfree = 1u << (5 * (5 - have));
+        for (u32 f = 0; f < nfree; ++f)
+        {
+            const u32 y = fixed | f, e = y & 31u, x = y >> 5;
+            u32 dw, bit;
+            ac_pair_slot5(x, e, dw, bit);
+            tab[dw] |= 1u << bit;
+        }
+    };
+    auto build = [&](const std::vector<u32> &kk, bool five) {
         std::fill(T20.begin(), T20.end(), 0u);
         keys.clear();
         for (size_t i = 0; i < t->pats_h.size(); ++i)
         {
             const auto &p = t->pats_h[i];
             const size_t L = p.size(), k = kk[i];
+            if (five)
+            {
+                expand5(T20, p, (long)(L - k));
+                expand5(T20, p, (long)(L - k) - 1);
+            }
+            else
+            {
             expand(T20, true, p.data() + (L - 4 - k), 4);
             if (L - k >= 5)
                 expand(T20, true, p.data() + (L - 5 - k), 4);
             else
                 expand(T20, true, p.data(), 3);
+            }
             const uint8_t *g = p.data() + (L - 4 - k);
             Anchor &an = keys[(u32)g[0] | ((u32)g[1] << 8) | ((u32)g[2] << 16) | ((u32)g[3] << 24)];
             an.kmask |= 1u << k;
@@ -219,7 +267,7 @@ int ac_anchor_prepare(AcTables *t, const uint8_t *d_text, size_t text_len, size_
         else
             expand(E20, false, p.data(), 3);
     }
-    build(ks);
+    build(ks, false);
     t->anch_rate0 = rate_of(E20, false);
     t->anch_rate = rate_of(T20, true);
     // worth a second stage: at least a third fewer candidates with the noise-proof moves alone, and a rate that matters to begin with
@@ -227,7 +275,7 @@ int ac_anchor_prepare(AcTables *t, const uint8_t *d_text, size_t text_len, size_
     if (go && !force)
     {
         // ... then every pattern takes its rarest window (a choice among windows the sample hardly holds costs nothing if it is noise)
-        build(kfree);
+        build(kfree, false);
         t->anch_rate = rate_of(T20, true);
         t->anch_moved = 0;
         for (u32 k : kfree)
@@ -238,6 +286,91 @@ int ac_anchor_prepare(AcTables *t, const uint8_t *d_text, size_t text_len, size_
                 t->anch_moved, t->pats_h.size(), moved, 100.0 * t->anch_rate0, 100.0 * t->anch_rate, keys.size(), go ? "anchored" : "end grams kept");
     if (!go)
         return 0;
+    // ---- five classes per lookup?  A 6-byte window of a word is several times rarer than its rarest 5-byte one (word text, 1000 rare
+    // words: 0.37 % against 2.6 % of the tested positions), at two more VALU per tested position.  Windows that reach in front of a
+    // pattern leave classes free (a 4-byte pattern: 32 + 1024 slots), so this is for dictionaries (almost) without 4- and 5-byte patterns.
+    if (!getenv("KREP_GPU_AC_NO_ANCHOR5"))
+    {
+        auto key5 = [](const uint8_t *g) -> u32 {
+            return ((u32)g[0] & 31u) | (((u32)g[1] & 31u) << 5) | (((u32)g[2] & 31u) << 10) | (((u32)g[3] & 31u) << 15) | (((u32)g[4] & 31u) << 20);
+        };
+        std::vector<u32> K;
+        for (auto &p : t->pats_h)
+        {
+            const long L = (long)p.size(), kmax = std::min<long>(L - 4, (long)kAnchMaxK);
+            for (long k = 0; k <= kmax; ++k)
+                for (long end : {L - k, L - k - 1})
+                    if (end >= 5)
+                        K.push_back(key5(p.data() + (end - 5)));
+        }
+        std::sort(K.begin(), K.end());
+        K.erase(std::unique(K.begin(), K.end()), K.end());
+        std::vector<u32> cnt5(K.size(), 0);
+        u32 *d_k = nullptr, *d_c = nullptr;
+        bool ok5 = !K.empty() && hipMalloc(&d_k, K.size() * sizeof(u32)) == hipSuccess && hipMalloc(&d_c, K.size() * sizeof(u32)) == hipSuccess &&
+                   hipMemcpyAsync(d_k, K.data(), K.size() * sizeof(u32), hipMemcpyHostToDevice, st) == hipSuccess &&
+                   hipMemsetAsync(d_c, 0, K.size() * sizeof(u32), st) == hipSuccess;
+        if (ok5)
+        {
+            hipLaunchKernelGGL(ac_gram5_count_kernel, dim3(nchunks), dim3(256), 0, st, d_text, (u64)own_lo, span, nchunks, chunk, d_k, (u32)K.size(), d_c);
+            ok5 = hipGetLastError() == hipSuccess && hipMemcpyAsync(cnt5.data(), d_c, K.size() * sizeof(u32), hipMemcpyDeviceToHost, st) == hipSuccess &&
+                  hipStreamSynchronize(st) == hipSuccess;
+        }
+        if (d_k) (void)hipFree(d_k);
+        if (d_c) (void)hipFree(d_c);
+        if (!ok5)
+            (void)hipGetLastError();
+        else
+        {
+            auto count5 = [&](const std::vector<uint8_t> &p, long end_excl) -> u64 { // the gram in front of end_excl with the byte in front of it
+                if (end_excl >= 5)
+                {
+                    const u32 key = key5(p.data() + (end_excl - 5));
+                    return cnt5[(size_t)(std::lower_bound(K.begin(), K.end(), key) - K.begin())];
+                }
+                return gram_count(p, (int)end_excl); // the byte(s) in front lie outside the pattern: any class — the 4- (3-) gram's own count
+            };
+            std::vector<u32> k5(t->pats_h.size(), 0);
+            u64 sum5 = 0;
+            for (size_t i = 0; i < t->pats_h.size(); ++i)
+            {
+                const auto &p = t->pats_h[i];
+                const long L = (long)p.size(), kmax = std::min<long>(L - 4, (long)kAnchMaxK);
+                u64 best = ~0ull;
+                for (long k = 0; k <= kmax; ++k)
+                {
+                    const u64 c = count5(p, L - k) + count5(p, L - k - 1);
+                    if (c < best)
+                    {
+                        best = c;
+                        k5[i] = (u32)k;
+                    }
+                }
+                sum5 += best;
+            }
+            const double rate4 = t->anch_rate;
+            build(k5, true);
+            u64 slots = 0;
+            for (u32 w : T20)
+                slots += (u64)__builtin_popcount(w);
+            // what the sample holds of the chosen windows + what a random 5-gram finds set by chance
+            const double rate5 = (double)sum5 / nsamp + (double)slots / (double)kHistBins;
+            const bool five = slots <= 16384 && rate5 < 0.6 * rate4;
+            if (getenv("KREP_GPU_DEBUG"))
+                fprintf(stderr, "krep-gpu: anchors, five classes: %zu windows counted, %llu table slots, candidates per tested position %.4f %% (four classes: %.4f %%): %s\n",
+                        K.size(), (unsigned long long)slots, 100.0 * rate5, 100.0 * rate4, five ? "taken" : "not taken");
+            if (five || getenv("KREP_GPU_AC_ANCHOR5"))
+            {
+                t->anch_five = 1;
+                t->anch_rate = rate5;
+                t->anch_moved = 0;
+                for (u32 k : k5)
+                    t->anch_moved += k ? 1u : 0u;
+            }
+            else
+                build(force ? ks : kfree, false); // (back to the four-class tables)
+        }
+    }
     // buckets of two 16-byte entries {key, 1 << 31 | offset mask, bytes in front, their mask}: no bucket overfull, one 32-byte probe
     static const u32 muls[] = {0x9E3779B1u, 0x85EBCA6Bu, 0xC2B2AE35u, 0x27D4EB2Fu, 0x165667B1u, 0xD3A2646Cu};
     std::vector<uint4> bk;

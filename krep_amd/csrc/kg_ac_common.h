@@ -58,6 +58,7 @@ struct AcArgs
     // verifier, unchanged): the anchor stage is a superset filter of the ENDS, nothing else.
     const uint4 *anch;
     u32 anch_mask, anch_mul;
+    u32 anch_five; // the table is indexed with FIVE classes (ac_scan_kernel<.., ANCH = 2>)
 };
 constexpr u32 kAnchMaxK = 12; // an anchor gram ends at most 12 bytes before its pattern's end: an END lies within 13 bytes of the tested position
 
@@ -651,6 +652,15 @@ __host__ __device__ __forceinline__ void ac_pair_slot(u32 x, u32 &dword, u32 &bi
     const u32 c1 = (x >> 5) & 31u, c2 = (x >> 10) & 31u, c3 = (x >> 15) & 31u;
     bit = x & 31u;
     dword = (c1 ^ ((c2 & 15u) << 1)) | ((c2 >> 4) << 5) | (c3 << 6) | ((c2 & 15u) << 11);
+}
+// The same with the class e of the byte in FRONT of the gram in the pair register's unused bits 10..14 (five-class index of the
+// anchored scan, ANCH == 2): slot = what the kernel computes from u = c0 | c1 << 5 | e << 10 | c2 << 16 | c3 << 21.  e == 0 gives
+// ac_pair_slot's slot.
+__host__ __device__ __forceinline__ void ac_pair_slot5(u32 x, u32 e, u32 &dword, u32 &bit)
+{
+    const u32 u = (x & 0x3ffu) | ((e & 31u) << 10) | (((x >> 10) & 0x3ffu) << 16);
+    bit = u & 31u;
+    dword = (((u >> 3) ^ (u >> 13)) & 0x1fffcu) >> 2;
 }
 
 } // namespace kg

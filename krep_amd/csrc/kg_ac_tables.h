@@ -43,6 +43,7 @@ struct AcTables
     u32 *d_filtera20 = nullptr;               // pair-layout class table (2^20 bits) of the anchor grams
     uint4 *d_anch = nullptr;                  // buckets of two {exact anchor gram, 1 << 31 | offset mask}
     u32 anch_mask = 0, anch_mul = 0;
+    u32 anch_five = 0;                        // the anchor table is indexed with five classes (6-byte windows)
     double anch_rate0 = 0, anch_rate = 0;     // estimated candidates per tested position: end grams / anchor grams (diagnostic)
     u32 anch_moved = 0;                       // patterns whose anchor is not their end
 };

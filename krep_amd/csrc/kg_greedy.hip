@@ -71,7 +71,17 @@ __device__ __forceinline__ Visit g_visit(const WalkSpec &ws, u64 sj, u64 base, c
     {
         // -c: the line is counted and the scan continues at the start of the next line (krep.c:4460-4468: find_line_end from the
         // line's start = the first '\n' at or behind the match start — there is none between the two)
+        // (eight bytes per step until a word holds the '\n': every candidate of the list pays this walk in g_next's parallel form,
+        //  visited or not, and a text with very long lines made it a byte loop per candidate — ADVICE r05)
         u64 q = p;
+        struct __attribute__((packed)) U64p { u64 v; };
+        while (q + 8 <= text_len)
+        {
+            const u64 y = reinterpret_cast<const U64p *>(text + q)->v ^ 0x0a0a0a0a0a0a0a0aull;
+            if ((y - 0x0101010101010101ull) & ~y & 0x8080808080808080ull)
+                break;
+            q += 8;
+        }
         while (q < text_len && text[q] != '\n')
             ++q;
         const u64 next = q < text_len ? q + 1 : text_len;

@@ -431,6 +431,9 @@ static int lit_pass(krep_gpu_plan *pl, const Window &w, const LitPass &ps, hipSt
     if (!pl->fused1_ok && m_scan == 1 && hi_match > a.anchor &&
         (double)pl->h_ctr->total / (double)(hi_match - a.anchor) < 0.5 * single_fused_max_density(kFusedShapeMax))
         pl->fused1_ok = true; // (a later, sparser text of the same plan takes the one-pass kernel again)
+    if (pl->fusedk_never && m_scan >= 2 && m_scan <= 8 && hi_match > a.anchor &&
+        (double)pl->h_ctr->total / (double)(hi_match - a.anchor) < 0.5 * single_fused_max_density(kFusedShapeMax))
+        pl->fusedk_never = false; // (the same for the 2..8-byte instantiations: one overflowing text no longer bars them for good)
     res->summary = chain ? pl->h_ctr->summary : (res->total ? (kLnHead | kLnTail) : 0);
     return 0;
 }
@@ -598,7 +601,13 @@ static int last_accepted_before(krep_gpu_plan *pl, const Window &w, const LitRes
 
 // The end-of-text replay of a PIECE: where the reference's block loop stands when it enters the last kReplayWindow bytes follows
 // from the folded boundary record alone (global offsets, stored + 1); `text_g` is indexed with global offsets.
-static int replay_from_record(krep_gpu_plan *pl, int algo, const krep_gpu_seq_carry_t &co, const uint8_t *text_g, uint64_t G,
+// (`text_g` is a DEVICE address rebased so that it can be indexed with global offsets; the first global offset really held is text_lo.
+//  The rebasing is integer arithmetic on the address — no pointer outside an object is formed on the host)
+static const uint8_t *rebased(const void *d_held, uint64_t held_from)
+{
+    return reinterpret_cast<const uint8_t *>(reinterpret_cast<uintptr_t>(d_held) - (uintptr_t)held_from);
+}
+static int replay_from_record(krep_gpu_plan *pl, int algo, const krep_gpu_seq_carry_t &co, const uint8_t *text_g, uint64_t text_lo, uint64_t G,
                               hipStream_t st, uint64_t *extra)
 {
     *extra = 0;
@@ -611,7 +620,9 @@ static int replay_from_record(krep_gpu_plan *pl, int algo, const krep_gpu_seq_ca
         cur = co.nl1 <= X ? co.nl1 + ((X - co.nl1) / B) * B : co.nl1; // restarted at the line start behind q
     else if (algo == KREP_RA_NEON)
     {
-        cur = co.g0 + ((X - co.g0) / B) * B; // no restart on an unterminated line: the previous counted line's grid
+        // no restart on an unterminated line: the previous counted line's grid (a grid origin behind X — a text shorter than the
+        // replay window — is where the loop stands; ADVICE r05: the unsigned difference wrapped)
+        cur = co.g0 <= X ? co.g0 + ((X - co.g0) / B) * B : co.g0;
         open = 1;
     }
     else
@@ -620,6 +631,8 @@ static int replay_from_record(krep_gpu_plan *pl, int algo, const krep_gpu_seq_ca
     r.algo = algo; r.m = pl->m; r.ww = pl->ww; r.n = G; r.cur = cur; r.open = open;
     r.text = text_g;
     r.pat = pl->d_pat;
+    if (cur < G && cur + 1 < text_lo + 1) // (the replay reads global offsets >= cur - 1: they have to lie in what the caller holds)
+        return kg::fail("end-of-text replay: the loop stands at %llu, in front of the bytes held (from %llu)", (unsigned long long)cur, (unsigned long long)text_lo);
     if (cur < G && tail_run_replay(r, &pl->d_ctr->pad[0], &pl->h_ctr->pad[0], st, extra))
         return 2;
     return 0;
@@ -899,7 +912,7 @@ static int scan_literal(krep_gpu_plan *pl, int algo, const Window &w, match_posi
             if (final_piece)
             {
                 uint64_t extra = 0;
-                if (replay_from_record(pl, algo, co, w.d_text - base, G, st, &extra)) // (global offsets >= cur - 1 >= base: inside the buffer)
+                if (replay_from_record(pl, algo, co, rebased(w.d_text, base), base ? base + 1 : 0, G, st, &extra)) // (global offsets >= cur - 1 >= base: inside the buffer)
                     return 2;
                 // the lines the replay counts are new ones (it starts behind the line of q), and the line open at the piece's
                 // start can only be among them when nothing in front of the piece counted it: the canonical head bit stands
@@ -1356,7 +1369,7 @@ extern "C" int krep_gpu_replay_tail(krep_gpu_plan_t *pl, const void *d_tail, siz
     uint64_t extra = 0;
     hipStream_t st = (hipStream_t)stream;
     // (the replay reads global offsets >= cur - 1 with cur >= the block in front of the last kReplayWindow bytes: > G - 512)
-    if (replay_from_record(pl, algo, co, (const uint8_t *)d_tail - (G - tail_len), G, st, &extra))
+    if (replay_from_record(pl, algo, co, rebased(d_tail, G - tail_len), G - tail_len ? G - tail_len + 1 : 0, G, st, &extra))
         return 2;
     HIPCHK(hipStreamSynchronize(st));
     if (carry_out)

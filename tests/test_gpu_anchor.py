@@ -24,11 +24,18 @@ def gpu():
     return e
 
 
-@pytest.fixture()
-def forced():
+@pytest.fixture(params=["four classes", "five classes"])
+def forced(request):
+    """$KREP_GPU_AC_ANCHOR: anchors whatever the gain; + $KREP_GPU_AC_ANCHOR5: the five-class index (ac_scan_kernel<.., ANCH = 2>) whatever
+    the number of table slots it takes (4- and 5-byte patterns leave classes free: 32 or 1024 slots each)."""
     os.environ["KREP_GPU_AC_ANCHOR"] = "1"
-    yield
-    os.environ.pop("KREP_GPU_AC_ANCHOR", None)
+    if request.param == "five classes":
+        os.environ["KREP_GPU_AC_ANCHOR5"] = "1"
+    else:
+        os.environ["KREP_GPU_AC_NO_ANCHOR5"] = "1"
+    yield request.param
+    for k in ("KREP_GPU_AC_ANCHOR", "KREP_GPU_AC_ANCHOR5", "KREP_GPU_AC_NO_ANCHOR5"):
+        os.environ.pop(k, None)
 
 
 class _DevicePlan:

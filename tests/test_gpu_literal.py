@@ -1,5 +1,6 @@
-"""GPU parity: the HIP literal scan, called through the C-ABI, against the oracle restatement of the
-reference function that select_search_algorithm() would have executed (bit-exact count + offsets)."""
+"""GPU parity: the HIP literal scan, called through the C-ABI, against the COMPILED REFERENCE (oracle/_ref: the function
+select_search_algorithm() would have executed, called directly; the restatement oracle/krep_oracle.c only under the file-static
+only_matching) — bit-exact count + offsets."""
 import numpy as np
 import pytest
 
