@@ -51,8 +51,8 @@ namespace kg {
 // of the unit — same layout as the candidate bitmap: bit b <-> the END pair (2b + 1, 2b + 2), in the KiB that otherwise parks a
 // ticket's stores — and the marked pairs, not the candidates, are what the end-anchored verifier looks at, in position order:
 // ranking, staging and emission as before.
-// ANCH == 2: the filter's index holds FIVE classes — the class of the byte in front of the 4-gram goes into the five unused bits
-// (10..14) of the pair register before the slot address is formed, two VALU per tested position — for dictionaries (almost)
+// ANCH == 2: the filter's index holds FIVE classes — the class of the byte in front of the 4-gram is multiplied out over the class
+// fields of the pair register (ac_mix5) before the slot address is formed, three VALU per tested position — for dictionaries (almost)
 // without patterns of 4 or 5 bytes: a 5-gram window of a word is several times rarer than its rarest 4-gram (kg_ac_anchor.hip).
 template <bool CI, bool LINES, bool SHORT, int STRIDE, int ANCH = 0>
 __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                     const int w = q / 2 + 1;
                     xs[q] = (q & 1) ? t[w] : __builtin_amdgcn_alignbit(t[w], t[w - 1], 16u);
                     if constexpr (ANCH == 2)
-                        xs[q] = __builtin_amdgcn_ubfe(t[(2 * q + 1) / 4], ((2 * q + 1) % 4 == 1) ? 5u : 21u, 5u) << 10 | xs[q];
+                        xs[q] = ac_mix5(xs[q], __builtin_amdgcn_ubfe(t[(2 * q + 1) / 4], ((2 * q + 1) % 4 == 1) ? 5u : 21u, 5u));
                     // (-c: a 2^19-bit table, address bit 16 = bit 3 of the class c2 dropped)
                     dws[q] = *(lds_u32 *)(size_t)(((xs[q] >> 3) ^ (xs[q] >> 13)) & kTabMask);
                 }
@@ -334,8 +334,8 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 {
                     const int w = q / 2 + 1;
                     x[q] = (q & 1) ? t[w] : __builtin_amdgcn_alignbit(t[w], t[w - 1], 16u);
-                    if constexpr (ANCH == 2) // the class of the byte in front of the gram (byte 2q - 3 of the lane): bits 10..14
-                        x[q] = __builtin_amdgcn_ubfe(t[(2 * q + 1) / 4], ((2 * q + 1) % 4 == 1) ? 5u : 21u, 5u) << 10 | x[q];
+                    if constexpr (ANCH == 2) // the class of the byte in front of the gram (byte 2q - 3 of the lane), mixed into the class fields
+                        x[q] = ac_mix5(x[q], __builtin_amdgcn_ubfe(t[(2 * q + 1) / 4], ((2 * q + 1) % 4 == 1) ? 5u : 21u, 5u));
                     v[q] = *(lds_u32 *)(size_t)(((x[q] >> 3) ^ (x[q] >> 13)) & kTabMask);
                 }
             };
@@ -582,7 +582,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                         auto gtest = [&](const int last) -> bool {
                             u32 u = ac_pair((u32)(Q >> (8 * (last - 3))));
                             if constexpr (ANCH == 2)
-                                u |= ((u32)(Q >> (8 * (last - 4))) & 31u) << 10;
+                                u = ac_mix5(u, (u32)(Q >> (8 * (last - 4))) & 31u);
                             return ((*(lds_u32 *)(size_t)(((u >> 3) ^ (u >> 13)) & kTabMask) >> (u & 31u)) & 1u) != 0u;
                         };
                         // the position's own gram again for the six in front of the unit; then, as in the end-gram kernel: an anchor
