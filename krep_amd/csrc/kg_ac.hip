@@ -735,7 +735,37 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
 #else
                     constexpr bool kStaged = false;
 #endif
-                    if (!(a.flags & (1u << 30))) // (ablation hook KREP_GPU_AC_NOPROBE: candidate enumeration without the probes)
+                    bool exact_done = false;
+                    if constexpr (ANCH != 0)
+                        if (a.xtab && !(a.flags & F_WW) && pos >= 15u)
+                        {
+                            // stage 3 through the length-keyed exact dictionary (kg_ac_common.h ac_exact_end): no trie, no chain
+                            bool muA = false, muB = false;
+                            if (liveA)
+                                mA = ac_exact_end<CI>(a, pos, muA);
+                            if (liveB)
+                                mB = ac_exact_end<CI>(a, pos + 1u, muB);
+                            // start ownership (the same clip as ac_eval_entry's)
+                            auto clip = [&](u32 m, u64 end) -> u32 {
+                                const u64 e = end + 1;
+                                if (e <= a.own_lo)
+                                    return 0u;
+                                if (e - a.own_lo < 32)
+                                    m &= (2u << (u32)(e - a.own_lo)) - 1u;
+                                if (e > a.own_hi)
+                                    m = (e - a.own_hi < 32) ? (m & ~((2u << (u32)(e - a.own_hi)) - 1u)) : 0u;
+                                return m;
+                            };
+                            mA = clip(mA, pos);
+                            mB = clip(mB, pos + 1u);
+                            slA = muA && mA != 0u; // (a pattern the dictionary holds twice: counted and emitted by the level walk)
+                            slB = muB && mB != 0u;
+                            exact_done = true;
+                        }
+                    if (exact_done)
+                    {
+                    }
+                    else if (!(a.flags & (1u << 30))) // (ablation hook KREP_GPU_AC_NOPROBE: candidate enumeration without the probes)
                         ac_walk_probe2<CI, SHORT, kStaged>(a, pos, liveA, liveB, LINES, mA, slA, mB, slB, [&](u32 E) -> bool {
                             if constexpr (kGram)
                             {
@@ -974,6 +1004,13 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
         a.anch_mask = t->anch_mask;
         a.anch_mul = t->anch_mul;
         a.anch_five = t->anch_five;
+        if (t->d_xtab && !getenv("KREP_GPU_AC_NO_EXACT"))
+        {
+            a.xlen = t->d_xlen;
+            a.xtab = t->d_xtab;
+            a.xmask = t->xmask;
+            a.xmul = t->xmul;
+        }
     }
     a.s1 = t->d_s1; a.s2 = t->d_s2; a.s3 = t->d_s3;
     if (t->short_dup)

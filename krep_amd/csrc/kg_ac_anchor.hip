@@ -73,8 +73,12 @@ void ac_anchor_free(AcTables *t)
 {
     if (t->d_filtera20) (void)hipFree(t->d_filtera20);
     if (t->d_anch) (void)hipFree(t->d_anch);
+    if (t->d_xlen) (void)hipFree(t->d_xlen);
+    if (t->d_xtab) (void)hipFree(t->d_xtab);
     t->d_filtera20 = nullptr;
     t->d_anch = nullptr;
+    t->d_xlen = nullptr;
+    t->d_xtab = nullptr;
 }
 
 // -> 0 (anch_state settled to 1 or 2), 2 on a HIP error (anch_state 1: the scan goes on with the end grams)
@@ -416,6 +420,82 @@ int ac_anchor_prepare(AcTables *t, const uint8_t *d_text, size_t text_len, size_
     t->anch_mask = nb_used - 1;
     t->anch_mul = mul_used;
     t->anch_state = 2;
+    // ---- stage 3's exact dictionary (kg_ac_common.h ac_exact_end): for dictionaries whose patterns all have 4..16 bytes ----
+    if (t->lmin >= 4 && t->lmax <= 16)
+    {
+        struct X { u32 w[4]; u32 len, copies; };
+        std::vector<X> xs;
+        std::vector<unsigned short> xlen(65536, 0);
+        for (auto &p : t->pats_h)
+        {
+            X x{};
+            uint8_t b[16] = {0};
+            memcpy(b + (16 - p.size()), p.data(), p.size());
+            for (int w = 0; w < 4; ++w)
+                x.w[w] = (u32)b[4 * w] | ((u32)b[4 * w + 1] << 8) | ((u32)b[4 * w + 2] << 16) | ((u32)b[4 * w + 3] << 24);
+            x.len = (u32)p.size();
+            x.copies = 1;
+            bool dup = false;
+            for (auto &y : xs)
+                if (y.len == x.len && !memcmp(y.w, x.w, sizeof x.w))
+                {
+                    ++y.copies;
+                    dup = true;
+                    break;
+                }
+            if (!dup)
+                xs.push_back(x);
+            xlen[ac_xlen_slot(x.w[3])] |= (unsigned short)(1u << (x.len - 4));
+        }
+        static const u32 xmuls[] = {0x9E3779B1u, 0x7FEB352Du, 0x846CA68Bu, 0x2C1B3C6Du, 0x297A2D39u, 0xB55A4F09u};
+        std::vector<uint4> xt;
+        u32 xnb = 0, xm = 0;
+        for (u32 nb = 1024; nb <= (1u << 18) && !xnb; nb <<= 1)
+        {
+            if ((u64)nb * 2 < xs.size())
+                continue;
+            for (u32 mul : xmuls)
+            {
+                std::vector<uint8_t> fill(nb, 0);
+                bool fits = true;
+                for (auto &x : xs)
+                    if (++fill[ac_xhash(x.w[0], x.w[1], x.w[2], x.w[3], x.len, mul) & (nb - 1)] > 2)
+                    {
+                        fits = false;
+                        break;
+                    }
+                if (!fits)
+                    continue;
+                xt.assign(4 * (size_t)nb, make_uint4(0u, 0u, 0u, 0u));
+                std::fill(fill.begin(), fill.end(), 0);
+                for (auto &x : xs)
+                {
+                    const u32 b = ac_xhash(x.w[0], x.w[1], x.w[2], x.w[3], x.len, mul) & (nb - 1);
+                    const u32 way = fill[b]++;
+                    xt[4 * (size_t)b + 2 * way] = make_uint4(x.w[0], x.w[1], x.w[2], x.w[3]);
+                    xt[4 * (size_t)b + 2 * way + 1] = make_uint4(x.len, x.copies, 0u, 0u);
+                }
+                xnb = nb;
+                xm = mul;
+                break;
+            }
+        }
+        if (xnb && hipMalloc(&t->d_xlen, xlen.size() * sizeof(unsigned short)) == hipSuccess && hipMalloc(&t->d_xtab, xt.size() * sizeof(uint4)) == hipSuccess &&
+            hipMemcpyAsync(t->d_xlen, xlen.data(), xlen.size() * sizeof(unsigned short), hipMemcpyHostToDevice, st) == hipSuccess &&
+            hipMemcpyAsync(t->d_xtab, xt.data(), xt.size() * sizeof(uint4), hipMemcpyHostToDevice, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess)
+        {
+            t->xmask = xnb - 1;
+            t->xmul = xm;
+        }
+        else
+        {
+            (void)hipGetLastError();
+            if (t->d_xlen) (void)hipFree(t->d_xlen);
+            if (t->d_xtab) (void)hipFree(t->d_xtab);
+            t->d_xlen = nullptr;
+            t->d_xtab = nullptr; // (stage 3 then walks the trie as before)
+        }
+    }
     return 0;
 }
 

@@ -59,6 +59,12 @@ struct AcArgs
     const uint4 *anch;
     u32 anch_mask, anch_mul;
     u32 anch_five; // the table is indexed with FIVE classes (ac_scan_kernel<.., ANCH = 2>)
+    // stage 3 of the anchored scan for dictionaries of 4..16-byte patterns: which LENGTHS end in these four bytes (a hashed 16-bit mask per
+    // final gram), and per length an exact entry {the pattern right-aligned in 16 bytes, length, copies} in buckets of two — every pattern
+    // that ends at a marked position, longest first, without walking a trie (ac_exact_end)
+    const unsigned short *xlen; // [65536]: bit l - 4 set: a pattern of length l has a final 4-gram with this hash
+    const uint4 *xtab;          // buckets of two 32-byte entries {w0..w3}{length, copies, 0, 0}
+    u32 xmask, xmul;
 };
 constexpr u32 kAnchMaxK = 12; // an anchor gram ends at most 12 bytes before its pattern's end: an END lies within 13 bytes of the tested position
 
@@ -619,6 +625,64 @@ __device__ __forceinline__ void ac_walk_probe2(const AcArgs &a, u64 i, bool live
 #endif
     if (liveB)
         ac_eval_entry(a, foundB, TB, b0, b1, sbB, i + 1, own_by_end, dmB, slowB);
+}
+
+// ---- the length-keyed exact dictionary (stage 3 of the anchored scan, kg_ac_anchor.hip) ----
+// A word dictionary's reversed trie branches right behind its final grams (`tion`, `ness` end dozens of words each), which is exactly what
+// the chain-compressed entries cannot express: nearly every marked end took the level-by-level walk, ~12 dependent L2 round trips, and
+// stage 3 cost 7.7 ms for 12 M ends.  Here an end is answered per LENGTH: the (hashed) final gram names the lengths that can end on it, and
+// for each of them the text's last l bytes are looked up whole.  Longest first is the order of the loop.
+__host__ __device__ __forceinline__ u32 ac_xhash(u32 w0, u32 w1, u32 w2, u32 w3, u32 len, u32 mul)
+{ // (w0..w3: the 16 bytes ending at the end position, the bytes in front of the pattern zeroed)
+    u32 h = w3 * mul;
+    h = (h ^ (h >> 15)) + w2 * 0x85EBCA6Bu;
+    h = (h ^ (h >> 13)) + w1 * 0xC2B2AE35u;
+    h = (h ^ (h >> 16)) + w0 * 0x27D4EB2Fu;
+    h = (h ^ (h >> 15)) + len * 0x165667B1u;
+    return h ^ (h >> 14);
+}
+__host__ __device__ __forceinline__ u32 ac_xlen_slot(u32 last4) { return (last4 * kHashMul) >> 16; }
+// depth mask of the patterns ending at i (i >= 15) from the exact dictionary; `multi` when one of them occurs more than once in the
+// dictionary (the caller then counts and emits through the level walk, which knows the copies)
+template <bool CI>
+__device__ __forceinline__ u32 ac_exact_end(const AcArgs &a, u64 i, bool &multi)
+{
+    struct __attribute__((packed)) U32p { u32 v; };
+    const U32p *q = reinterpret_cast<const U32p *>(a.text + (i - 15));
+    u32 T[4] = {q[0].v, q[1].v, q[2].v, q[3].v};
+    if (CI)
+    {
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+            T[w] = ac_fold4(T[w]);
+    }
+    u32 lm = a.xlen[ac_xlen_slot(T[3])];
+    u32 dm = 0;
+    multi = false;
+    while (lm)
+    {
+        const u32 b = 31u - (u32)__builtin_clz(lm), len = b + 4u;
+        lm &= ~(1u << b);
+        // keep the last `len` bytes of the 16: word w holds bytes 4w .. 4w + 3, the pattern starts at byte 16 - len
+        const u32 drop = 16u - len; // leading bytes that are not the pattern's
+        u32 M[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+        {
+            const u32 lo = 4u * (u32)w; // first byte of the word
+            M[w] = drop >= lo + 4u ? 0u : drop <= lo ? T[w] : (T[w] & (0xffffffffu << (8u * (drop - lo))));
+        }
+        const uint4 *bk = a.xtab + 4u * (size_t)(ac_xhash(M[0], M[1], M[2], M[3], len, a.xmul) & a.xmask);
+        const uint4 e0 = bk[0], m0 = bk[1], e1 = bk[2], m1 = bk[3];
+        const bool h0 = m0.x == len && e0.x == M[0] && e0.y == M[1] && e0.z == M[2] && e0.w == M[3];
+        const bool h1 = m1.x == len && e1.x == M[0] && e1.y == M[1] && e1.z == M[2] && e1.w == M[3];
+        if (h0 || h1)
+        {
+            dm |= 1u << len;
+            multi = multi || (h0 ? m0.y : m1.y) != 1u;
+        }
+    }
+    return dm;
 }
 
 constexpr u32 kAcUnitsPerTicketMax = 8; // fused kernel: up to 128 KiB per wave ticket (one cold round in 16), fewer on small texts

@@ -44,6 +44,9 @@ struct AcTables
     uint4 *d_anch = nullptr;                  // buckets of two {exact anchor gram, 1 << 31 | offset mask}
     u32 anch_mask = 0, anch_mul = 0;
     u32 anch_five = 0;                        // the anchor table is indexed with five classes (6-byte windows)
+    unsigned short *d_xlen = nullptr;         // stage 3's exact dictionary (AcArgs::xlen / xtab): dictionaries of 4..16-byte patterns
+    uint4 *d_xtab = nullptr;
+    u32 xmask = 0, xmul = 0;
     double anch_rate0 = 0, anch_rate = 0;     // estimated candidates per tested position: end grams / anchor grams (diagnostic)
     u32 anch_moved = 0;                       // patterns whose anchor is not their end
 };
