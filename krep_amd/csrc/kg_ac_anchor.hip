@@ -425,7 +425,7 @@ int ac_anchor_prepare(AcTables *t, const uint8_t *d_text, size_t text_len, size_
     {
         struct X { u32 w[4]; u32 len, copies; };
         std::vector<X> xs;
-        std::vector<unsigned short> xlen(65536, 0);
+        std::vector<unsigned short> xlen(2 * 65536, 0); // [0]: lengths 4..7 by the last four bytes, [1]: 8..16 by the last eight
         for (auto &p : t->pats_h)
         {
             X x{};
@@ -445,7 +445,10 @@ int ac_anchor_prepare(AcTables *t, const uint8_t *d_text, size_t text_len, size_
                 }
             if (!dup)
                 xs.push_back(x);
-            xlen[ac_xlen_slot(x.w[3])] |= (unsigned short)(1u << (x.len - 4));
+            if (x.len < 8)
+                xlen[ac_xlen_slot(x.w[3])] |= (unsigned short)(1u << (x.len - 4));
+            else
+                xlen[65536u + ac_xlen_slot8(x.w[2], x.w[3])] |= (unsigned short)(1u << (x.len - 4));
         }
         static const u32 xmuls[] = {0x9E3779B1u, 0x7FEB352Du, 0x846CA68Bu, 0x2C1B3C6Du, 0x297A2D39u, 0xB55A4F09u};
         std::vector<uint4> xt;

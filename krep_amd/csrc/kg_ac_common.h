@@ -62,7 +62,9 @@ struct AcArgs
     // stage 3 of the anchored scan for dictionaries of 4..16-byte patterns: which LENGTHS end in these four bytes (a hashed 16-bit mask per
     // final gram), and per length an exact entry {the pattern right-aligned in 16 bytes, length, copies} in buckets of two — every pattern
     // that ends at a marked position, longest first, without walking a trie (ac_exact_end)
-    const unsigned short *xlen; // [65536]: bit l - 4 set: a pattern of length l has a final 4-gram with this hash
+    const unsigned short *xlen; // [2][65536]: bit l - 4 set: a pattern of length l ends in these bytes — [0] lengths 4..7 by the hash of the
+                                //   last FOUR bytes, [1] lengths 8..16 by the hash of the last EIGHT (a word's last eight bytes are all but its
+                                //   own: one length, one probe; by the last four alone `tion` named nine lengths, nine round trips in turn)
     const uint4 *xtab;          // buckets of two 32-byte entries {w0..w3}{length, copies, 0, 0}
     u32 xmask, xmul;
 };
@@ -642,6 +644,11 @@ __host__ __device__ __forceinline__ u32 ac_xhash(u32 w0, u32 w1, u32 w2, u32 w3,
     return h ^ (h >> 14);
 }
 __host__ __device__ __forceinline__ u32 ac_xlen_slot(u32 last4) { return (last4 * kHashMul) >> 16; }
+__host__ __device__ __forceinline__ u32 ac_xlen_slot8(u32 w2, u32 w3)
+{
+    const u32 h = w3 * kHashMul + w2 * 0x85EBCA6Bu;
+    return (h ^ (h >> 15)) >> 16;
+}
 // depth mask of the patterns ending at i (i >= 15) from the exact dictionary; `multi` when one of them occurs more than once in the
 // dictionary (the caller then counts and emits through the level walk, which knows the copies)
 template <bool CI>
@@ -656,7 +663,7 @@ __device__ __forceinline__ u32 ac_exact_end(const AcArgs &a, u64 i, bool &multi)
         for (int w = 0; w < 4; ++w)
             T[w] = ac_fold4(T[w]);
     }
-    u32 lm = a.xlen[ac_xlen_slot(T[3])];
+    u32 lm = ((u32)a.xlen[ac_xlen_slot(T[3])] & 0xfu) | ((u32)a.xlen[65536u + ac_xlen_slot8(T[2], T[3])] & 0x1ff0u);
     u32 dm = 0;
     multi = false;
     while (lm)
