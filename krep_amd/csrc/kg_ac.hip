@@ -164,7 +164,9 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
         // bytes per lane.  Measured at 32 GiB on the 1000-pattern dictionary, in-kernel -c road: 9.90 ms without the prefetch,
         // 9.61 ms with it and 20 bytes of scratch, profiles/r05_line_counting.txt; texts of 32 MiB and more count their lines on the
         // record list, kg_scan.hip, at 6.8 ms); the rest of a prefetched round is requested here, at its start
-        constexpr int kRoll = LINES ? (STRIDE == 2 ? 0 : KG_AC_LINES_ROLL_CELLS) : kCells;
+        // (the anchored instantiations roll six of the eight cells: the last two are requested at the round's start and consumed last —
+        //  their eight registers are free while the two verify stages run, which otherwise spilled 12-20 bytes per lane)
+        constexpr int kRoll = LINES ? (STRIDE == 2 ? 0 : KG_AC_LINES_ROLL_CELLS) : (ANCH != 0 ? kCells - 2 : kCells);
         if (fast_now)
         {
 #pragma unroll
@@ -326,7 +328,8 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 u32 t[5];
                 t[1] = ac_pair(d[j].x); t[2] = ac_pair(d[j].y); t[3] = ac_pair(d[j].z); t[4] = ac_pair(d[j].w);
                 const u32 last = d[j].w;
-                d[j] = nsrc[j * kWave];
+                if (j < kRoll)
+                    d[j] = nsrc[j * kWave];
                 t[0] = (u32)__builtin_amdgcn_update_dpp((int)ac_pair(before), (int)t[4], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
                 before = __builtin_amdgcn_readlane(last, 63);
 #pragma unroll
@@ -782,6 +785,37 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                     dmA = mA; dmB = mB;
                     cA = (u32)__popc(mA); cB = (u32)__popc(mB);
                     simA = simB = true;
+                    if constexpr (!SHORT && ANCH == 0 && !CI) // (-i: eight bytes of scratch per lane in the BASELINE-shaped kernel for a path the anchored instantiations cover)
+                        if (a.xtab && !(a.flags & F_WW) && pos >= 15u && (slA || slB))
+                        {
+                            // an end the chain-compressed entry cannot answer (the trie branches behind its final gram): the exact dictionary
+                            // instead of the level walk, where there is one (a word-like text, patterns of 4..16 bytes)
+                            auto clipx = [&](u32 m, u64 end) -> u32 {
+                                if (LINES)
+                                    return m; // (-c owns by END)
+                                const u64 e = end + 1;
+                                if (e <= a.own_lo)
+                                    return 0u;
+                                if (e - a.own_lo < 32)
+                                    m &= (2u << (u32)(e - a.own_lo)) - 1u;
+                                if (e > a.own_hi)
+                                    m = (e - a.own_hi < 32) ? (m & ~((2u << (u32)(e - a.own_hi)) - 1u)) : 0u;
+                                return m;
+                            };
+                            bool mu = false;
+                            if (slA)
+                            {
+                                const u32 m = clipx(ac_exact_end<CI>(a, pos, mu), pos);
+                                if (!mu || !m) { mA = m; slA = false; }
+                            }
+                            if (slB)
+                            {
+                                const u32 m = clipx(ac_exact_end<CI>(a, pos + 1u, mu), pos + 1u);
+                                if (!mu || !m) { mB = m; slB = false; }
+                            }
+                            dmA = mA; dmB = mB;
+                            cA = (u32)__popc(mA); cB = (u32)__popc(mB);
+                        }
 #pragma unroll 1
                     for (int e = 0; e < 2; ++e) // the one call site of the level walk
                         if (e ? slB : slA)
@@ -1004,13 +1038,13 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
         a.anch_mask = t->anch_mask;
         a.anch_mul = t->anch_mul;
         a.anch_five = t->anch_five;
-        if (t->d_xtab && !getenv("KREP_GPU_AC_NO_EXACT"))
-        {
-            a.xlen = t->d_xlen;
-            a.xtab = t->d_xtab;
-            a.xmask = t->xmask;
-            a.xmul = t->xmul;
-        }
+    }
+    if (t->d_xtab && !getenv("KREP_GPU_AC_NO_EXACT")) // the exact dictionary: stage 3 of the anchored scan, the slow path of the others
+    {
+        a.xlen = t->d_xlen;
+        a.xtab = t->d_xtab;
+        a.xmask = t->xmask;
+        a.xmul = t->xmul;
     }
     a.s1 = t->d_s1; a.s2 = t->d_s2; a.s3 = t->d_s3;
     if (t->short_dup)

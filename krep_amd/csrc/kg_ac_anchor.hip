@@ -81,6 +81,93 @@ void ac_anchor_free(AcTables *t)
     t->d_xtab = nullptr;
 }
 
+// The length-keyed exact dictionary (kg_ac_common.h ac_exact_end) of a dictionary whose patterns all have 4..16 bytes: what answers an end
+// where the chain-compressed entries cannot (the reversed trie branches behind the final gram) — stage 3 of the anchored scan, and the
+// slow path of every other instantiation.  Built for texts on which the end grams are frequent (a word-like text and dictionary).
+static void build_exact_dictionary(AcTables *t, hipStream_t st)
+{
+    if (t->d_xtab || getenv("KREP_GPU_AC_NO_EXACT"))
+        return;
+    if (t->lmin >= 4 && t->lmax <= 16)
+    {
+        struct X { u32 w[4]; u32 len, copies; };
+        std::vector<X> xs;
+        std::vector<unsigned short> xlen(2 * 65536, 0); // [0]: lengths 4..7 by the last four bytes, [1]: 8..16 by the last eight
+        for (auto &p : t->pats_h)
+        {
+            X x{};
+            uint8_t b[16] = {0};
+            memcpy(b + (16 - p.size()), p.data(), p.size());
+            for (int w = 0; w < 4; ++w)
+                x.w[w] = (u32)b[4 * w] | ((u32)b[4 * w + 1] << 8) | ((u32)b[4 * w + 2] << 16) | ((u32)b[4 * w + 3] << 24);
+            x.len = (u32)p.size();
+            x.copies = 1;
+            bool dup = false;
+            for (auto &y : xs)
+                if (y.len == x.len && !memcmp(y.w, x.w, sizeof x.w))
+                {
+                    ++y.copies;
+                    dup = true;
+                    break;
+                }
+            if (!dup)
+                xs.push_back(x);
+            if (x.len < 8)
+                xlen[ac_xlen_slot(x.w[3])] |= (unsigned short)(1u << (x.len - 4));
+            else
+                xlen[65536u + ac_xlen_slot8(x.w[2], x.w[3])] |= (unsigned short)(1u << (x.len - 4));
+        }
+        static const u32 xmuls[] = {0x9E3779B1u, 0x7FEB352Du, 0x846CA68Bu, 0x2C1B3C6Du, 0x297A2D39u, 0xB55A4F09u};
+        std::vector<uint4> xt;
+        u32 xnb = 0, xm = 0;
+        for (u32 nb = 1024; nb <= (1u << 18) && !xnb; nb <<= 1)
+        {
+            if ((u64)nb * 2 < xs.size())
+                continue;
+            for (u32 mul : xmuls)
+            {
+                std::vector<uint8_t> fill(nb, 0);
+                bool fits = true;
+                for (auto &x : xs)
+                    if (++fill[ac_xhash(x.w[0], x.w[1], x.w[2], x.w[3], x.len, mul) & (nb - 1)] > 2)
+                    {
+                        fits = false;
+                        break;
+                    }
+                if (!fits)
+                    continue;
+                xt.assign(4 * (size_t)nb, make_uint4(0u, 0u, 0u, 0u));
+                std::fill(fill.begin(), fill.end(), 0);
+                for (auto &x : xs)
+                {
+                    const u32 b = ac_xhash(x.w[0], x.w[1], x.w[2], x.w[3], x.len, mul) & (nb - 1);
+                    const u32 way = fill[b]++;
+                    xt[4 * (size_t)b + 2 * way] = make_uint4(x.w[0], x.w[1], x.w[2], x.w[3]);
+                    xt[4 * (size_t)b + 2 * way + 1] = make_uint4(x.len, x.copies, 0u, 0u);
+                }
+                xnb = nb;
+                xm = mul;
+                break;
+            }
+        }
+        if (xnb && hipMalloc(&t->d_xlen, xlen.size() * sizeof(unsigned short)) == hipSuccess && hipMalloc(&t->d_xtab, xt.size() * sizeof(uint4)) == hipSuccess &&
+            hipMemcpyAsync(t->d_xlen, xlen.data(), xlen.size() * sizeof(unsigned short), hipMemcpyHostToDevice, st) == hipSuccess &&
+            hipMemcpyAsync(t->d_xtab, xt.data(), xt.size() * sizeof(uint4), hipMemcpyHostToDevice, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess)
+        {
+            t->xmask = xnb - 1;
+            t->xmul = xm;
+        }
+        else
+        {
+            (void)hipGetLastError();
+            if (t->d_xlen) (void)hipFree(t->d_xlen);
+            if (t->d_xtab) (void)hipFree(t->d_xtab);
+            t->d_xlen = nullptr;
+            t->d_xtab = nullptr; // (stage 3 then walks the trie as before)
+        }
+    }
+}
+
 // -> 0 (anch_state settled to 1 or 2), 2 on a HIP error (anch_state 1: the scan goes on with the end grams)
 int ac_anchor_prepare(AcTables *t, const uint8_t *d_text, size_t text_len, size_t own_lo, size_t own_hi, hipStream_t st)
 {
@@ -154,8 +241,6 @@ int ac_anchor_prepare(AcTables *t, const uint8_t *d_text, size_t text_len, size_
         }
     }
     t->anch_moved = moved;
-    if (!moved)
-        return 0;
     // ---- the two tables ----
     std::vector<u32> T20(kHistBins / 32, 0), E20(kHistBins / 32, 0);
     struct Anchor { u32 kmask = 0, ctx = 0, cmask = 0xffffffu; bool first = true; };
@@ -275,7 +360,8 @@ int ac_anchor_prepare(AcTables *t, const uint8_t *d_text, size_t text_len, size_
     t->anch_rate0 = rate_of(E20, false);
     t->anch_rate = rate_of(T20, true);
     // worth a second stage: at least a third fewer candidates with the noise-proof moves alone, and a rate that matters to begin with
-    const bool go = force || (t->anch_rate0 > 0.008 && t->anch_rate < 0.66 * t->anch_rate0);
+    bool go = force || (moved && t->anch_rate0 > 0.008 && t->anch_rate < 0.66 * t->anch_rate0);
+    const bool wordy = t->anch_rate0 > 0.008; // the end grams are frequent in this text: structure, not chance
     if (go && !force)
     {
         // ... then every pattern takes its rarest window (a choice among windows the sample hardly holds costs nothing if it is noise)
@@ -288,7 +374,7 @@ int ac_anchor_prepare(AcTables *t, const uint8_t *d_text, size_t text_len, size_
     if (getenv("KREP_GPU_DEBUG"))
         fprintf(stderr, "krep-gpu: anchors: %u of %zu patterns off their end (%u beyond sampling noise); candidates per tested position %.4f %% (end grams) -> %.4f %% (anchors), %zu anchor grams: %s\n",
                 t->anch_moved, t->pats_h.size(), moved, 100.0 * t->anch_rate0, 100.0 * t->anch_rate, keys.size(), go ? "anchored" : "end grams kept");
-    if (!go)
+    if (!go && !wordy)
         return 0;
     // ---- five classes per lookup?  A 6-byte window of a word is several times rarer than its rarest 5-byte one (word text, 1000 rare
     // words: 0.37 % against 2.6 % of the tested positions), at two more VALU per tested position.  Windows that reach in front of a
@@ -352,7 +438,7 @@ int ac_anchor_prepare(AcTables *t, const uint8_t *d_text, size_t text_len, size_
                 }
                 sum5 += best;
             }
-            const double rate4 = t->anch_rate;
+            const double rate4 = go ? t->anch_rate : t->anch_rate0; // (what the scan would run with otherwise)
             build(k5, true);
             u64 slots = 0;
             for (u32 w : T20)
@@ -365,6 +451,7 @@ int ac_anchor_prepare(AcTables *t, const uint8_t *d_text, size_t text_len, size_
                         K.size(), (unsigned long long)slots, 100.0 * rate5, 100.0 * rate4, five ? "taken" : "not taken");
             if (five || getenv("KREP_GPU_AC_ANCHOR5"))
             {
+                go = true;
                 t->anch_five = 1;
                 t->anch_rate = rate5;
                 t->anch_moved = 0;
@@ -374,6 +461,11 @@ int ac_anchor_prepare(AcTables *t, const uint8_t *d_text, size_t text_len, size_
             else
                 build(force ? ks : kfree, false); // (back to the four-class tables)
         }
+    }
+    if (!go)
+    {
+        build_exact_dictionary(t, st); // (the end grams stay, but their slow path need not walk the trie)
+        return 0;
     }
     // buckets of two 16-byte entries {key, 1 << 31 | offset mask, bytes in front, their mask}: no bucket overfull, one 32-byte probe
     static const u32 muls[] = {0x9E3779B1u, 0x85EBCA6Bu, 0xC2B2AE35u, 0x27D4EB2Fu, 0x165667B1u, 0xD3A2646Cu};
@@ -420,85 +512,7 @@ int ac_anchor_prepare(AcTables *t, const uint8_t *d_text, size_t text_len, size_
     t->anch_mask = nb_used - 1;
     t->anch_mul = mul_used;
     t->anch_state = 2;
-    // ---- stage 3's exact dictionary (kg_ac_common.h ac_exact_end): for dictionaries whose patterns all have 4..16 bytes ----
-    if (t->lmin >= 4 && t->lmax <= 16)
-    {
-        struct X { u32 w[4]; u32 len, copies; };
-        std::vector<X> xs;
-        std::vector<unsigned short> xlen(2 * 65536, 0); // [0]: lengths 4..7 by the last four bytes, [1]: 8..16 by the last eight
-        for (auto &p : t->pats_h)
-        {
-            X x{};
-            uint8_t b[16] = {0};
-            memcpy(b + (16 - p.size()), p.data(), p.size());
-            for (int w = 0; w < 4; ++w)
-                x.w[w] = (u32)b[4 * w] | ((u32)b[4 * w + 1] << 8) | ((u32)b[4 * w + 2] << 16) | ((u32)b[4 * w + 3] << 24);
-            x.len = (u32)p.size();
-            x.copies = 1;
-            bool dup = false;
-            for (auto &y : xs)
-                if (y.len == x.len && !memcmp(y.w, x.w, sizeof x.w))
-                {
-                    ++y.copies;
-                    dup = true;
-                    break;
-                }
-            if (!dup)
-                xs.push_back(x);
-            if (x.len < 8)
-                xlen[ac_xlen_slot(x.w[3])] |= (unsigned short)(1u << (x.len - 4));
-            else
-                xlen[65536u + ac_xlen_slot8(x.w[2], x.w[3])] |= (unsigned short)(1u << (x.len - 4));
-        }
-        static const u32 xmuls[] = {0x9E3779B1u, 0x7FEB352Du, 0x846CA68Bu, 0x2C1B3C6Du, 0x297A2D39u, 0xB55A4F09u};
-        std::vector<uint4> xt;
-        u32 xnb = 0, xm = 0;
-        for (u32 nb = 1024; nb <= (1u << 18) && !xnb; nb <<= 1)
-        {
-            if ((u64)nb * 2 < xs.size())
-                continue;
-            for (u32 mul : xmuls)
-            {
-                std::vector<uint8_t> fill(nb, 0);
-                bool fits = true;
-                for (auto &x : xs)
-                    if (++fill[ac_xhash(x.w[0], x.w[1], x.w[2], x.w[3], x.len, mul) & (nb - 1)] > 2)
-                    {
-                        fits = false;
-                        break;
-                    }
-                if (!fits)
-                    continue;
-                xt.assign(4 * (size_t)nb, make_uint4(0u, 0u, 0u, 0u));
-                std::fill(fill.begin(), fill.end(), 0);
-                for (auto &x : xs)
-                {
-                    const u32 b = ac_xhash(x.w[0], x.w[1], x.w[2], x.w[3], x.len, mul) & (nb - 1);
-                    const u32 way = fill[b]++;
-                    xt[4 * (size_t)b + 2 * way] = make_uint4(x.w[0], x.w[1], x.w[2], x.w[3]);
-                    xt[4 * (size_t)b + 2 * way + 1] = make_uint4(x.len, x.copies, 0u, 0u);
-                }
-                xnb = nb;
-                xm = mul;
-                break;
-            }
-        }
-        if (xnb && hipMalloc(&t->d_xlen, xlen.size() * sizeof(unsigned short)) == hipSuccess && hipMalloc(&t->d_xtab, xt.size() * sizeof(uint4)) == hipSuccess &&
-            hipMemcpyAsync(t->d_xlen, xlen.data(), xlen.size() * sizeof(unsigned short), hipMemcpyHostToDevice, st) == hipSuccess &&
-            hipMemcpyAsync(t->d_xtab, xt.data(), xt.size() * sizeof(uint4), hipMemcpyHostToDevice, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess)
-        {
-            t->xmask = xnb - 1;
-            t->xmul = xm;
-        }
-        else
-        {
-            (void)hipGetLastError();
-            if (t->d_xlen) (void)hipFree(t->d_xlen);
-            if (t->d_xtab) (void)hipFree(t->d_xtab);
-            t->d_xlen = nullptr;
-            t->d_xtab = nullptr; // (stage 3 then walks the trie as before)
-        }
-    }
+    build_exact_dictionary(t, st);
     return 0;
 }
 
