@@ -293,6 +293,11 @@ int krep_gpu_plan_ref_algo(const krep_gpu_plan_t *plan); /* enum krep_ref_algo t
  * call synchronises.  The kernels move 16 bytes per lane from d_text + a multiple of 16: a 16-byte aligned d_text (any
  * hipMalloc block) is the fast case; a slice at an odd offset is scanned correctly (gfx950 serves unaligned vector loads;
  * tests/test_gpu_fullsize.py scans such slices), an aligned block plus an ownership window is the better way to say it.
+ * Reads: d_text is never written, and no byte outside [0, text_len) can influence a result; the list-based -c of the
+ * multi-pattern scan reads whole ALIGNED 16-byte granules and so may touch up to 15 bytes behind text_len inside the granule
+ * that holds the last byte (the same page: safe for any allocation, worth knowing for a slice that ends an allocation).
+ * Placement: WHERE the driver puts a large allocation moves a 32-GiB read stream by 2-3 % and a scan that also writes GBs of
+ * records by ~10 % (two modes, one per allocation) — the library takes the buffers as the caller made them.
  * Returns 0 on success, non-zero on error (krep_gpu_last_error()). */
 int krep_gpu_scan_device(krep_gpu_plan_t *plan, const void *d_text, size_t text_len, size_t own_lo,
                          size_t own_hi, size_t global_base, match_position_t *d_positions,
