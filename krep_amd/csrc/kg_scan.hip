@@ -168,6 +168,11 @@ static int lit_pass(krep_gpu_plan *pl, const Window &w, const LitPass &ps, hipSt
         a.l0 = pl->l0; a.l1 = pl->l1;
         a.p2 = pl->p2; a.p3 = pl->p3; a.k2 = pl->k2; a.k3 = pl->k3; a.l2 = pl->l2; a.l3 = pl->l3;
     }
+    a.pat = pl->d_pat;
+    a.pat_chunks = pl->d_pat_chunks;
+    a.n_chunks = ps.first_byte ? 0 : pl->n_chunks;
+    a.ctr = pl->d_ctr;
+    a.flags = (pl->cs ? 0 : F_CI) | (ps.ww ? F_WW : 0) | (ps.lines ? F_LINES : 0) | (ps.sink != LitPass::COUNT ? F_POS : 0);
     {
         // kg_literal_dma.hip's prefilter: only for a first byte that text rarely holds (the blank and the dozen most frequent letters
         // of running text, either case, would pass nearly every 16-byte lane: the test would be paid for nothing)
@@ -179,18 +184,16 @@ static int lit_pass(krep_gpu_plan *pl, const Window &w, const LitPass &ps, hipSt
             rare = rare && b0 != (uint32_t)*q;
         a.prefilter = (rare && !ps.first_byte && !getenv("KREP_GPU_LIT_NO_PREFILTER")) ? 0x01010101u * b0 : 0u;
     }
-    a.pat = pl->d_pat;
-    a.pat_chunks = pl->d_pat_chunks;
-    a.n_chunks = ps.first_byte ? 0 : pl->n_chunks;
-    a.ctr = pl->d_ctr;
-    a.flags = (pl->cs ? 0 : F_CI) | (ps.ww ? F_WW : 0) | (ps.lines ? F_LINES : 0) | (ps.sink != LitPass::COUNT ? F_POS : 0);
     const bool chain = (a.flags & (F_POS | F_LINES)) != 0;
     const uint64_t n_units = a.num_tiles * kWavesPerBlk;
     // Dealing: from ~24 GiB on every wave draws tickets of 8 units (>= 24 tickets per resident wave, ~26 fetch-adds/us on the
     // ticket word); below that the static interleaved deal (upt = 0) is faster — measured at 8 GiB: 1.38 vs 1.41 ms with
     // offsets, 1.29 vs 1.37 ms counting; at 16 GiB 2.58 vs 2.63 ms; at 2 GiB 0.37 vs 0.48 ms (the ticket word becomes the limit
     // of a short scan); at 32 GiB tickets win: 5.20 vs 5.31 ms, and 7.1 vs 7.9 ms on the single-byte workload
-    a.upt = (a.rounds == kRoundsBig && n_units / ((uint64_t)pl->num_cu * 16) >= 192) ? 8 : 0;
+    // (the LDS-DMA kernel, kg_literal_dma.hip, wants tickets — a ticket is what it streams through without a seam — and is ahead with them
+    //  from ~8 GiB on: 8 GiB 1.339 against 1.362 ms for the register kernel's static deal, 16 GiB 2.610 against 2.639; round 6)
+    const bool dma_shape = m_scan >= 2 && m_scan <= 8 && !ps.lines && !ps.first_byte && a.prefilter != 0u && !getenv("KREP_GPU_LIT_NO_DMA");
+    a.upt = (a.rounds == kRoundsBig && n_units / ((uint64_t)pl->num_cu * 16) >= (dma_shape ? 64u : 192u)) ? 8 : 0;
     if (const char *e = getenv("KREP_GPU_LIT_UPT")) // measurement aid; only the values the kernel's parked-store bookkeeping
     {                                               // is built for (kPark = 240 must be a multiple)
         const int v = atoi(e);
