@@ -18,6 +18,9 @@ bool inject(int kind);                   // test hook: is failure `kind` being i
 
 // kg_literal.hip
 hipError_t launch_literal(const LitArgs &a, uint32_t num_cu, hipStream_t st); // grid = resident blocks of the variant x CUs
+// kg_runs.hip: the greedy families on a pattern of one repeated byte, counted without a list (1: a run too long for its look-back)
+int runs_count_greedy(const uint8_t *d_text, uint64_t text_len, uint64_t lo, uint64_t hi, uint32_t m, uint8_t byte, bool ci, int num_cu,
+                      unsigned long long *d_slots, unsigned long long *h_slots, hipStream_t st, uint64_t *total, uint64_t *end_p1);
 bool literal_dma_eligible(const LitArgs &a);                                       // kg_literal_dma.hip: 2..8-byte patterns, 32-KiB units, no -c
 hipError_t launch_literal_dma(const LitArgs &a, uint32_t num_cu, hipStream_t st);
 extern std::atomic<uint64_t> g_lit_dma_launches;                                   // launches of lit_scan_dma (test hook)

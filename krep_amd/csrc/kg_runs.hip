@@ -1,0 +1,227 @@
+// kg_runs.hip — the greedy families on a pattern of ONE repeated byte, counted (round 6).
+//
+// simd_sse42_search (krep.c:4839-4848: a hit advances by the pattern length) and kmp_search / boyer_moore_search under -o report
+// leftmost NON-overlapping occurrences.  For a pattern with a border the library resolves that on the ordered list of ALL
+// occurrences (kg_greedy.hip) — which for `  `, `--`, `==`, `aa` on real text means materialising hundreds of millions of them
+// before a single cluster is walked: `-c -o '  '` ran at 0.65 TB/s.  For a pattern that is m copies of one byte b the answer needs
+// no list: inside a maximal run of R bytes b the kept matches start at every m-th byte, floor(R / m) of them.  A kept match ENDS
+// where the number of b's of its run, counted from the run's start, is a multiple of m — a property of the position and of the run
+// length in front of it, which crosses lanes as a carry: per lane {is every byte b, trailing run length}, a wave scan, the round's
+// and the unit's carry in a scalar; a unit finds the run length in front of it by looking back (a run longer than 64 KiB in front
+// of a unit hands the scan back to the list road).  Counting only: with records wanted the list road stays.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdlib>
+#include "kg_common.h"
+#include "kg_internal.h"
+
+namespace kg {
+
+using u32 = uint32_t;
+using u64 = unsigned long long;
+
+namespace {
+constexpr u64 kRunUnit = (u64)kRoundsBig * kSegBytes; // 32 KiB per wave and step
+constexpr u64 kLookBack = 64u * 1024u;
+
+__device__ __forceinline__ u32 r_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ u32 r_eq16(const uint4 &v, u32 splat, u32 fold)
+{ // bit k: byte k of the lane's 16 equals b ((x | fold) == splat: fold = 0x20 per byte for a letter under -i)
+    auto eq = [&](u32 x) -> u32 {
+        const u32 y = (x | fold) ^ splat;
+        const u32 t = ~(((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y | 0x7f7f7f7fu);
+        return (((t >> 7) * 0x00204081u) >> 21) & 0xfu;
+    };
+    return eq(v.x) | (eq(v.y) << 4) | (eq(v.z) << 8) | (eq(v.w) << 12);
+}
+} // namespace
+
+// text[lo, hi): the window whose STARTS are owned, counted from lo (the reference's scan stands at lo: nothing in front of it belongs
+// to a run).  out[0] += kept matches, out[1] = max(out[1], end of the last kept match + 1), out[2] |= 1 when a unit gave up.
+__global__ __launch_bounds__(256) void run_count_kernel(const uint8_t *__restrict__ text, u64 text_len, u64 lo, u64 hi, u32 m, u32 splat, u32 fold,
+                                                        u64 n_units, unsigned long long *out)
+{
+    const u32 lane = r_lane();
+    const u64 anchor = lo & ~(u64)15;
+    const u64 end_lo = lo + m - 1, end_hi = (hi + m - 1 < text_len) ? hi + m - 1 : text_len; // ENDs of the owned matches
+    u64 total = 0, last_end = 0;
+    bool gave_up = false;
+    const u32 b = splat & 0xffu;
+    for (u64 unit = (u64)blockIdx.x * kWavesPerBlk + (threadIdx.x >> 6); unit < n_units; unit += (u64)gridDim.x * kWavesPerBlk)
+    {
+        const u64 ubase = anchor + unit * kRunUnit;
+        // ---- the run of b's in front of the unit (not in front of lo): 64 bytes per step, backwards
+        u32 carry = 0; // length of the run entering the next lane / cell, modulo m (uniform)
+        {
+            u64 q = ubase, run = 0;
+            while (q > lo)
+            {
+                const u64 p = q - 1 - lane;
+                const bool in = q >= lo + 1 + lane; // p >= lo
+                const u32 x = in ? text[p] : 0x100u;
+                const u64 ne = __ballot(!in || ((x | (fold & 0xffu)) != b)); // lanes whose byte ends the run (lane 0 = the byte right in front)
+                if (ne)
+                {
+                    run += (u64)__builtin_ctzll(ne);
+                    break;
+                }
+                run += 64;
+                q -= 64;
+                if (run >= kLookBack)
+                {
+                    gave_up = true;
+                    break;
+                }
+            }
+            carry = (u32)(run % m);
+        }
+#pragma unroll 1
+        for (int r = 0; r < kRoundsBig; ++r)
+        {
+            const u64 seg = ubase + (u64)r * kSegBytes;
+            if (seg >= end_hi)
+                break;
+            const bool fast = seg + kSegBytes <= text_len;
+            uint4 d[kCells];
+#pragma unroll
+            for (int j = 0; j < kCells; ++j)
+            {
+                const u64 off = seg + (u64)j * kCellBytes + (u64)lane * 16u;
+                if (fast)
+                {
+                    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+                    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(text + off));
+                    d[j] = make_uint4(v.x, v.y, v.z, v.w);
+                }
+                else
+                {
+                    u32 w[4] = {0, 0, 0, 0};
+                    for (int k = 0; k < 16; ++k) // (bytes behind the text stay 0: they are masked out of the run test below)
+                        if (off + k < text_len)
+                            w[k >> 2] |= (u32)text[off + k] << (8 * (k & 3));
+                    d[j] = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < kCells; ++j)
+            {
+                const u64 lbase = seg + (u64)j * kCellBytes + (u64)lane * 16u;
+                u32 e = r_eq16(d[j], splat, fold);
+                // positions in front of lo are not part of any run; positions at or behind the text's end neither
+                if (lbase < lo)
+                    e &= lo - lbase < 16 ? ~((1u << (u32)(lo - lbase)) - 1u) : 0u;
+                if (lbase + 16 > text_len)
+                    e &= lbase < text_len ? (1u << (u32)(text_len - lbase)) - 1u : 0u;
+                e &= 0xffffu;
+                const u64 any = __ballot(e != 0u);
+                if (!any)
+                {
+                    carry = 0;
+                    continue;
+                }
+                // the run entering each lane: {all b, trailing run length} scanned over the wave, the cell's carry in front of lane 0
+                const bool all = e == 0xffffu;
+                u32 len = all ? 16u : (u32)__builtin_clz(~(e << 16)); // trailing run = leading ones of the 16-bit mask
+                bool al = all;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1)
+                {
+                    const u32 pl = __shfl_up(len, o);
+                    const bool pa = __shfl_up((int)al, o) != 0;
+                    if (lane >= (u32)o && al)
+                    {
+                        len += pl;
+                        al = pa;
+                    }
+                }
+                // inclusive -> exclusive: what enters THIS lane is the left neighbour's inclusive result (lane 0: the carry)
+                u32 in_len = __shfl_up(len, 1);
+                bool in_all = __shfl_up((int)al, 1) != 0;
+                if (lane == 0)
+                {
+                    in_len = 0;
+                    in_all = true;
+                }
+                u32 rp = (in_len + (in_all ? carry : 0u)) % m; // b's of the current run in front of the lane, modulo m
+                u32 cnt = 0, lastk = 0xffu;
+                if (e)
+                {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k)
+                    {
+                        if ((e >> k) & 1u)
+                        {
+                            if (++rp == m)
+                            {
+                                rp = 0;
+                                const u64 p = lbase + (u64)k; // a kept match ENDS here
+                                if (p >= end_lo && p < end_hi)
+                                {
+                                    ++cnt;
+                                    lastk = (u32)k;
+                                }
+                            }
+                        }
+                        else
+                            rp = 0;
+                    }
+                }
+                // the carry leaving the cell: lane 63's inclusive scan result (+ the old carry when the whole cell was b)
+                const u32 l63 = __shfl(len, 63);
+                const bool a63 = __shfl((int)al, 63) != 0;
+                carry = (l63 + (a63 ? carry : 0u)) % m;
+                const u64 hit = __ballot(cnt != 0u);
+                if (hit)
+                {
+                    u32 c = cnt;
+#pragma unroll
+                    for (int o = 32; o >= 1; o >>= 1)
+                        c += __shfl_xor(c, o);
+                    total += c;
+                    const u32 top = 63u - (u32)__builtin_clzll(hit);
+                    const u32 tk = __shfl(lastk, top);
+                    last_end = seg + (u64)j * kCellBytes + (u64)top * 16u + tk + 1;
+                }
+            }
+        }
+    }
+    if (lane == 0)
+    {
+        if (total)
+        {
+            atomicAdd(&out[0], total);
+            atomicMax(&out[1], last_end);
+        }
+        if (gave_up)
+            atomicOr(&out[2], 1ull);
+    }
+}
+
+// -> 0 and *total / *end_p1 (buffer offset behind the last kept match, 0 if none), 1 when a run was too long for the look-back (the
+// caller takes the list road), 2 on a HIP error.  d_slots: three zeroable u64 in device memory, h_slots: their pinned mirror.
+int runs_count_greedy(const uint8_t *d_text, uint64_t text_len, uint64_t lo, uint64_t hi, uint32_t m, uint8_t byte, bool ci, int num_cu,
+                      unsigned long long *d_slots, unsigned long long *h_slots, hipStream_t st, uint64_t *total, uint64_t *end_p1)
+{
+    *total = 0;
+    *end_p1 = 0;
+    if (hi <= lo || text_len < m)
+        return 0;
+    const bool letter = ci && ((byte | 0x20) >= 'a' && (byte | 0x20) <= 'z');
+    const u32 splat = 0x01010101u * (u32)(letter ? (byte | 0x20) : byte), fold = letter ? 0x20202020u : 0u;
+    const u64 anchor = lo & ~(u64)15, end_hi = std::min<u64>(hi + m - 1, text_len);
+    const u64 n_units = (end_hi - anchor + kRunUnit - 1) / kRunUnit;
+    if (hipMemsetAsync(d_slots, 0, 3 * sizeof(unsigned long long), st) != hipSuccess)
+        return 2;
+    const u32 grid = (u32)std::min<u64>((n_units + kWavesPerBlk - 1) / kWavesPerBlk, (u64)num_cu * 4);
+    hipLaunchKernelGGL(run_count_kernel, dim3(grid ? grid : 1), dim3(kBlock), 0, st, d_text, (u64)text_len, (u64)lo, (u64)hi, m, splat, fold, n_units, d_slots);
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(h_slots, d_slots, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+        return 2;
+    if (h_slots[2])
+        return 1;
+    *total = h_slots[0];
+    *end_p1 = h_slots[1];
+    return 0;
+}
+
+} // namespace kg

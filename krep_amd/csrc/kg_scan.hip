@@ -995,13 +995,35 @@ static int scan_literal(krep_gpu_plan *pl, int algo, const Window &w, match_posi
         size_t lo_eff = w.own_lo;
         if (resume_in > w.global_base + w.own_lo)
             lo_eff = (size_t)std::min<uint64_t>(own_hi, resume_in - w.global_base);
+        uint64_t resume_out = 0;
+        // ---- a pattern of ONE repeated byte (`  `, `--`, `aa`), counted: inside a run of R such bytes the kept matches start at every
+        // m-th byte — no list of all occurrences (kg_runs.hip; round 6: `-c -o '  '` materialised 188 M occurrences at 0.65 TB/s)
+        bool runs_done = false;
+        if (!mshort_o && !pl->ww && !pl->lines && want == 0 && m >= 2 && !getenv("KREP_GPU_NO_RUNS"))
+        {
+            bool uniform = true;
+            for (uint32_t i = 1; i < m; ++i)
+                uniform = uniform && pl->pat_folded[i] == pl->pat_folded[0];
+            if (uniform)
+            {
+                uint64_t end_p1 = 0;
+                const int rc = runs_count_greedy(w.d_text, w.text_len, lo_eff, own_hi, m, pl->pat_folded[0], !pl->cs, pl->num_cu, &pl->d_ctr->pad[1],
+                                                 &pl->h_ctr->pad[1], st, &total, &end_p1);
+                if (rc == 2)
+                    return 2;
+                if (rc == 0)
+                {
+                    runs_done = true;
+                    resume_out = end_p1 ? w.global_base + end_p1 : 0;
+                }
+            }
+        }
         LitPass ps;
         ps.own_lo = lo_eff; ps.own_hi = own_hi; ps.sink = LitPass::OCC; ps.post = &pl->post;
         ps.first_byte = mshort_o;
         ps.ww = ww_first;
-        if (lit_pass(pl, w, ps, st, &lr))
+        if (!runs_done && lit_pass(pl, w, ps, st, &lr))
             return 2;
-        uint64_t resume_out = 0;
         WalkSpec ws{};
         ws.mode = mshort_o ? (pl->lines ? kWalkShortOLines : kWalkShortO) : kWalkGreedy;
         if (ws.mode == kWalkShortOLines && !whole)

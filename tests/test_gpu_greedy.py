@@ -120,3 +120,65 @@ def test_pointer_jumping_form_of_the_walks(gpu, oracle_engine, monkeypatch):
     finally:
         gpu.set_only_matching(False)
         oracle_engine.set_only_matching(False)
+
+
+def test_one_repeated_byte_counted_without_a_list(gpu, oracle_engine):
+    """kg_runs.hip (round 6): a pattern of m copies of one byte, count-only, through the greedy families — floor(R / m) kept matches per
+    maximal run, found from run lengths carried across lanes, cells and units (no list of all occurrences).  Against simd_sse42_search,
+    kmp_search and boyer_moore_search under -o of the compiled reference / the restatement: runs on every seam (16-byte lane, 1-KiB
+    cell, 8-KiB round, 32-KiB unit), a run longer than the 64-KiB look-back (the list road takes over), a text of nothing but the byte,
+    windows chained with krep_gpu_scan_device_seq (the boundary record is where the reference's scan stands), -i."""
+    import torch
+    rng = np.random.RandomState(2026)
+    kw = dict(count_lines=True, only_match=True)
+    for n in (7, 1000, 16 * 1024 + 3, 3 * 32768 + 77, 300_001):
+        for alpha, pats in ((b"a b", [b"aa", b"aaa", b"  ", b"aaaaaaa"]), (b"-=x\n", [b"--", b"==", b"----", b"=" * 16]), (b"a", [b"aa", b"aaaaa"])):
+            text = cases.rand_text(rng, n, alpha)
+            for s, ln in ((0, 40), (16 - 3, 9), (1024 - 5, 30), (8192 - 7, 20), (32768 - 9, 33), (2 * 32768 - 1, 3), (n - 25, 25), (40000, 70000)):
+                if 0 <= s and s + ln <= n:
+                    text[s:s + ln] = pats[0][0]
+            for pat in pats:
+                for level in (abi.REF_AVX2, abi.REF_SCALAR):
+                    if level == abi.REF_SCALAR:
+                        gpu.set_algo_override(abi.ALGO_KMP)
+                    try:
+                        _check(gpu, oracle_engine, text, pat, kw, level)
+                        _check(gpu, oracle_engine, text, pat, dict(max_count=3, **kw), level)
+                    finally:
+                        gpu.set_algo_override(abi.ALGO_AUTO)
+    # -i: a letter in either case is the same byte of the run (kmp_search folds; simd_sse42_search is case-sensitive only)
+    text = cases.rand_text(rng, 70_000, b"aAb ")
+    gpu.set_algo_override(abi.ALGO_KMP)
+    try:
+        _check(gpu, oracle_engine, text, b"aaa", dict(case_sensitive=False, **kw), abi.REF_SCALAR)
+        _check(gpu, oracle_engine, text, b"aA", dict(case_sensitive=False, **kw), abi.REF_SCALAR)
+    finally:
+        gpu.set_algo_override(abi.ALGO_AUTO)
+    # boyer_moore_search under -o (greedy as well, krep.c:1371)
+    gpu.set_only_matching(True)
+    oracle_engine.set_only_matching(True)
+    gpu.set_algo_override(abi.ALGO_BM)
+    try:
+        text = cases.rand_text(rng, 100_000, b"a b")
+        _check(gpu, oracle_engine, text, b"aa", kw, abi.REF_SCALAR)
+        _check(gpu, oracle_engine, text, b"   ", kw, abi.REF_SCALAR)
+    finally:
+        gpu.set_algo_override(abi.ALGO_AUTO)
+        gpu.set_only_matching(False)
+        oracle_engine.set_only_matching(False)
+    # pieces in text order: the greedy phase continues across a cut through the boundary record
+    gpu.set_reference_simd(abi.REF_AVX2)
+    n = 200_000
+    text = cases.rand_text(rng, n, b"a b")
+    text[50_000 - 30:50_000 + 45] = ord("a")
+    want = oracle_engine.call(abi.RA_SSE42, abi.Params([b"aaa"], **kw), text)[0]
+    buf = torch.from_numpy(np.ascontiguousarray(text)).cuda()
+    plan = gpu.plan(abi.Params([b"aaa"], **kw))
+    assert plan.scan(buf.data_ptr(), n).count == want
+    for cuts in ((0, 50_000, n), (0, 49_999, 50_001, 50_016, 123_457, n), (0, 16, 32768, n)):
+        carry, total = None, 0
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            o, carry = plan.scan_seq(buf.data_ptr(), n, lo, hi, carry_in=carry)
+            total += o.total_matches
+        assert total == want, (cuts, total, want)
+    plan.close()
