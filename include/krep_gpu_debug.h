@@ -47,6 +47,9 @@ uint64_t krep_gpu_debug_anchored_launches(void);
 /* test hook: launches of the LDS-DMA literal kernel (kg_literal_dma.hip: 2..8-byte patterns on 32-KiB units without -c) since the
  * process started; $KREP_GPU_LIT_NO_DMA=1 keeps such scans on the register-load kernel (kg_literal.hip) */
 uint64_t krep_gpu_debug_literal_dma_launches(void);
+/* test hook: launches of the run-length kernel (kg_runs.hip: the greedy families on a pattern of one repeated byte, count-only);
+ * $KREP_GPU_NO_RUNS=1 keeps such scans on the list road */
+uint64_t krep_gpu_debug_runs_launches(void);
 /* what that decision was for `plan`: state 0 not taken yet / 1 end grams kept / 2 anchored; patterns moved off their end; the
  * estimated candidates per tested position with the end grams and with the anchors.  Returns 0, or 2 for a single-literal plan. */
 int krep_gpu_debug_anchor_info(const krep_gpu_plan_t *plan, int *state, uint32_t *moved, double *rate_end_grams, double *rate_anchors);

@@ -276,4 +276,5 @@ std::atomic<uint64_t> g_ac_anchored_launches{0}; // launches of the multi-patter
 }
 extern "C" uint64_t krep_gpu_debug_anchored_launches(void) { return kg::g_ac_anchored_launches.load(); }
 extern "C" uint64_t krep_gpu_debug_literal_dma_launches(void) { return kg::g_lit_dma_launches.load(); }
+extern "C" uint64_t krep_gpu_debug_runs_launches(void) { return kg::g_runs_launches.load(); }
 

@@ -11,6 +11,7 @@
 // of a unit hands the scan back to the list road).  Counting only: with records wanted the list road stays.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include "kg_common.h"
 #include "kg_internal.h"
@@ -19,6 +20,7 @@ namespace kg {
 
 using u32 = uint32_t;
 using u64 = unsigned long long;
+std::atomic<uint64_t> g_runs_launches{0}; // (test hook: krep_gpu_debug_runs_launches)
 
 namespace {
 constexpr u64 kRunUnit = (u64)kRoundsBig * kSegBytes; // 32 KiB per wave and step
@@ -217,6 +219,7 @@ int runs_count_greedy(const uint8_t *d_text, uint64_t text_len, uint64_t lo, uin
     if (hipGetLastError() != hipSuccess || hipMemcpyAsync(h_slots, d_slots, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess)
         return 2;
+    g_runs_launches.fetch_add(1, std::memory_order_relaxed);
     if (h_slots[2])
         return 1;
     *total = h_slots[0];

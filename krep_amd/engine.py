@@ -122,6 +122,7 @@ class Engine:
         L.krep_gpu_debug_tiny_dense_launches.restype = C.c_uint64
         L.krep_gpu_debug_anchored_launches.restype = C.c_uint64
         L.krep_gpu_debug_literal_dma_launches.restype = C.c_uint64
+        L.krep_gpu_debug_runs_launches.restype = C.c_uint64
         L.krep_gpu_debug_anchor_info.restype = C.c_int
         L.krep_gpu_debug_anchor_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_uint32), C.POINTER(C.c_double),
                                                  C.POINTER(C.c_double)]
@@ -182,6 +183,9 @@ class Engine:
 
     def tiny_dense_launches(self) -> int:
         return int(self.lib.krep_gpu_debug_tiny_dense_launches())
+
+    def runs_launches(self) -> int:
+        return int(self.lib.krep_gpu_debug_runs_launches())
 
     def literal_dma_launches(self) -> int:
         return int(self.lib.krep_gpu_debug_literal_dma_launches())

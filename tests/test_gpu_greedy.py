@@ -131,6 +131,7 @@ def test_one_repeated_byte_counted_without_a_list(gpu, oracle_engine):
     import torch
     rng = np.random.RandomState(2026)
     kw = dict(count_lines=True, only_match=True)
+    launches = gpu.runs_launches()
     for n in (7, 1000, 16 * 1024 + 3, 3 * 32768 + 77, 300_001):
         for alpha, pats in ((b"a b", [b"aa", b"aaa", b"  ", b"aaaaaaa"]), (b"-=x\n", [b"--", b"==", b"----", b"=" * 16]), (b"a", [b"aa", b"aaaaa"])):
             text = cases.rand_text(rng, n, alpha)
@@ -182,3 +183,4 @@ def test_one_repeated_byte_counted_without_a_list(gpu, oracle_engine):
             total += o.total_matches
         assert total == want, (cuts, total, want)
     plan.close()
+    assert gpu.runs_launches() > launches + 100  # the run-length kernel is what answered
