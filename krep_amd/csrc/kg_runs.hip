@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256) void run_count_kernel(const uint8_t *__restric
     u64 total = 0, last_end = 0;
     bool gave_up = false;
     const u32 b = splat & 0xffu;
+    const u32 inv_m = (u32)(0x100000000ull / m) + 1u; // floor(x / m) == umulhi(x, inv_m) for x < 2^16
     for (u64 unit = (u64)blockIdx.x * kWavesPerBlk + (threadIdx.x >> 6); unit < n_units; unit += (u64)gridDim.x * kWavesPerBlk)
     {
         const u64 ubase = anchor + unit * kRunUnit;
@@ -84,6 +85,7 @@ __global__ __launch_bounds__(256) void run_count_kernel(const uint8_t *__restric
             if (seg >= end_hi)
                 break;
             const bool fast = seg + kSegBytes <= text_len;
+            const bool interior = seg >= end_lo && seg + kSegBytes <= end_hi && seg >= lo;
             uint4 d[kCells];
 #pragma unroll
             for (int j = 0; j < kCells; ++j)
@@ -121,19 +123,23 @@ __global__ __launch_bounds__(256) void run_count_kernel(const uint8_t *__restric
                     carry = 0;
                     continue;
                 }
-                // the run entering each lane: {all b, trailing run length} scanned over the wave, the cell's carry in front of lane 0
+                // the run entering each lane: {all b, trailing run length} scanned over the wave, the cell's carry in front of lane 0.
+                // A lane of sixteen b's is rare in text: without one, what enters a lane is its left neighbour's own trailing run.
                 const bool all = e == 0xffffu;
                 u32 len = all ? 16u : (u32)__builtin_clz(~(e << 16)); // trailing run = leading ones of the 16-bit mask
                 bool al = all;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1)
+                if (__ballot(all))
                 {
-                    const u32 pl = __shfl_up(len, o);
-                    const bool pa = __shfl_up((int)al, o) != 0;
-                    if (lane >= (u32)o && al)
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1)
                     {
-                        len += pl;
-                        al = pa;
+                        const u32 pl = __shfl_up(len, o);
+                        const bool pa = __shfl_up((int)al, o) != 0;
+                        if (lane >= (u32)o && al)
+                        {
+                            len += pl;
+                            al = pa;
+                        }
                     }
                 }
                 // inclusive -> exclusive: what enters THIS lane is the left neighbour's inclusive result (lane 0: the carry)
@@ -144,34 +150,40 @@ __global__ __launch_bounds__(256) void run_count_kernel(const uint8_t *__restric
                     in_len = 0;
                     in_all = true;
                 }
-                u32 rp = (in_len + (in_all ? carry : 0u)) % m; // b's of the current run in front of the lane, modulo m
-                u32 cnt = 0, lastk = 0xffu;
-                if (e)
+                const u32 x0 = in_len + (in_all ? carry : 0u);
+                const u32 rp0 = x0 - __umulhi(x0, inv_m) * m; // b's of the current run in front of the lane, modulo m (x0 < 2^12)
+                // run by run (a lane holds one to three): a run of L bytes entered with c b's already counted keeps floor((c + L) / m)
+                u32 cnt = 0, lastk = 0xffu, rest = e;
+                while (rest)
                 {
-#pragma unroll
-                    for (int k = 0; k < 16; ++k)
+                    const u32 s0 = (u32)__builtin_ctz(rest), L = (u32)__builtin_ctz(~(rest >> s0));
+                    const u32 c = s0 == 0u ? rp0 : 0u, tot = c + L, kq = __umulhi(tot, inv_m); // tot < 32: exact
+                    rest = L + s0 >= 32u ? 0u : rest & ~((1u << (L + s0)) - 1u);
+                    if (kq)
                     {
-                        if ((e >> k) & 1u)
+                        if (interior)
                         {
-                            if (++rp == m)
+                            cnt += kq;
+                            lastk = s0 + kq * m - c - 1u; // the last kept END of the run
+                        }
+                        else
+                            for (u32 i = 1; i <= kq; ++i) // (a boundary cell: every END against the owned window)
                             {
-                                rp = 0;
-                                const u64 p = lbase + (u64)k; // a kept match ENDS here
+                                const u32 k = s0 + i * m - c - 1u;
+                                const u64 p = lbase + (u64)k;
                                 if (p >= end_lo && p < end_hi)
                                 {
                                     ++cnt;
-                                    lastk = (u32)k;
+                                    lastk = k;
                                 }
                             }
-                        }
-                        else
-                            rp = 0;
                     }
                 }
                 // the carry leaving the cell: lane 63's inclusive scan result (+ the old carry when the whole cell was b)
                 const u32 l63 = __shfl(len, 63);
                 const bool a63 = __shfl((int)al, 63) != 0;
-                carry = (l63 + (a63 ? carry : 0u)) % m;
+                const u32 x63 = l63 + (a63 ? carry : 0u);
+                carry = x63 - __umulhi(x63, inv_m) * m;
                 const u64 hit = __ballot(cnt != 0u);
                 if (hit)
                 {

@@ -122,12 +122,27 @@ def test_pointer_jumping_form_of_the_walks(gpu, oracle_engine, monkeypatch):
         oracle_engine.set_only_matching(False)
 
 
+def _count_on_device(gpu, o, text, pat, kw, level):
+    """count-only through the device API (no record buffer: what kg_runs.hip takes) against the reference function's return value"""
+    import torch
+    gpu.set_reference_simd(level)
+    p = abi.Params([pat], **kw)
+    algo = gpu.mirror_select(p, text.size)
+    want = o.call(algo, abi.Params([pat], **kw), text)[0]
+    buf = torch.from_numpy(np.ascontiguousarray(text)).cuda()
+    plan = gpu.plan(p)
+    got = plan.scan(buf.data_ptr(), text.size).count
+    plan.close()
+    assert got == want, (abi.RA_NAMES[algo], pat, kw, text.size, got, want)
+
+
 def test_one_repeated_byte_counted_without_a_list(gpu, oracle_engine):
     """kg_runs.hip (round 6): a pattern of m copies of one byte, count-only, through the greedy families — floor(R / m) kept matches per
     maximal run, found from run lengths carried across lanes, cells and units (no list of all occurrences).  Against simd_sse42_search,
     kmp_search and boyer_moore_search under -o of the compiled reference / the restatement: runs on every seam (16-byte lane, 1-KiB
     cell, 8-KiB round, 32-KiB unit), a run longer than the 64-KiB look-back (the list road takes over), a text of nothing but the byte,
-    windows chained with krep_gpu_scan_device_seq (the boundary record is where the reference's scan stands), -i."""
+    windows chained with krep_gpu_scan_device_seq (the boundary record is where the reference's scan stands), -i, patterns longer than
+    a lane."""
     import torch
     rng = np.random.RandomState(2026)
     kw = dict(count_lines=True, only_match=True)
@@ -143,16 +158,18 @@ def test_one_repeated_byte_counted_without_a_list(gpu, oracle_engine):
                     if level == abi.REF_SCALAR:
                         gpu.set_algo_override(abi.ALGO_KMP)
                     try:
-                        _check(gpu, oracle_engine, text, pat, kw, level)
-                        _check(gpu, oracle_engine, text, pat, dict(max_count=3, **kw), level)
+                        _count_on_device(gpu, oracle_engine, text, pat, kw, level)
+                        _count_on_device(gpu, oracle_engine, text, pat, dict(max_count=3, **kw), level)
+                        _check(gpu, oracle_engine, text, pat, kw, level)  # (the host operator with records: the list road)
                     finally:
                         gpu.set_algo_override(abi.ALGO_AUTO)
-    # -i: a letter in either case is the same byte of the run (kmp_search folds; simd_sse42_search is case-sensitive only)
-    text = cases.rand_text(rng, 70_000, b"aAb ")
+    # patterns longer than a 16-byte lane (kmp_search: any length), -i: a letter in either case is the same byte of the run
+    text = cases.rand_text(rng, 120_000, b"aAb ")
+    text[5000:5400] = ord("a")
     gpu.set_algo_override(abi.ALGO_KMP)
     try:
-        _check(gpu, oracle_engine, text, b"aaa", dict(case_sensitive=False, **kw), abi.REF_SCALAR)
-        _check(gpu, oracle_engine, text, b"aA", dict(case_sensitive=False, **kw), abi.REF_SCALAR)
+        for pat, kk in ((b"aaa", dict(case_sensitive=False)), (b"aA", dict(case_sensitive=False)), (b"a" * 40, dict(case_sensitive=False)), (b"a" * 17, dict())):
+            _count_on_device(gpu, oracle_engine, text, pat, dict(**kk, **kw), abi.REF_SCALAR)
     finally:
         gpu.set_algo_override(abi.ALGO_AUTO)
     # boyer_moore_search under -o (greedy as well, krep.c:1371)
@@ -161,8 +178,8 @@ def test_one_repeated_byte_counted_without_a_list(gpu, oracle_engine):
     gpu.set_algo_override(abi.ALGO_BM)
     try:
         text = cases.rand_text(rng, 100_000, b"a b")
-        _check(gpu, oracle_engine, text, b"aa", kw, abi.REF_SCALAR)
-        _check(gpu, oracle_engine, text, b"   ", kw, abi.REF_SCALAR)
+        _count_on_device(gpu, oracle_engine, text, b"aa", kw, abi.REF_SCALAR)
+        _count_on_device(gpu, oracle_engine, text, b"   ", kw, abi.REF_SCALAR)
     finally:
         gpu.set_algo_override(abi.ALGO_AUTO)
         gpu.set_only_matching(False)
