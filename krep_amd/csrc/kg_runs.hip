@@ -8,11 +8,13 @@
 // where the number of b's of its run, counted from the run's start, is a multiple of m — a property of the position and of the run
 // length in front of it, which crosses lanes as a carry: per lane {is every byte b, trailing run length}, a wave scan, the round's
 // and the unit's carry in a scalar; a unit finds the run length in front of it by looking back (a run longer than 64 KiB in front
-// of a unit hands the scan back to the list road).  Counting only: with records wanted the list road stays.
+// of a unit switches to the two-level form: per-unit summaries, the carries from a prefix pass on the host).  Counting only: with
+// records wanted the list road stays.
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <vector>
 #include "kg_common.h"
 #include "kg_internal.h"
 
@@ -41,7 +43,7 @@ __device__ __forceinline__ u32 r_eq16(const uint4 &v, u32 splat, u32 fold)
 // text[lo, hi): the window whose STARTS are owned, counted from lo (the reference's scan stands at lo: nothing in front of it belongs
 // to a run).  out[0] += kept matches, out[1] = max(out[1], end of the last kept match + 1), out[2] |= 1 when a unit gave up.
 __global__ __launch_bounds__(256) void run_count_kernel(const uint8_t *__restrict__ text, u64 text_len, u64 lo, u64 hi, u32 m, u32 splat, u32 fold,
-                                                        u64 n_units, unsigned long long *out)
+                                                        u64 n_units, unsigned long long *out, const u32 *__restrict__ carries)
 {
     const u32 lane = r_lane();
     const u64 anchor = lo & ~(u64)15;
@@ -55,6 +57,9 @@ __global__ __launch_bounds__(256) void run_count_kernel(const uint8_t *__restric
         const u64 ubase = anchor + unit * kRunUnit;
         // ---- the run of b's in front of the unit (not in front of lo): 64 bytes per step, backwards
         u32 carry = 0; // length of the run entering the next lane / cell, modulo m (uniform)
+        if (carries)
+            carry = carries[unit]; // (the two-level form: a run in front of some unit was too long to look back over)
+        else
         {
             u64 q = ubase, run = 0;
             while (q > lo)
@@ -211,6 +216,63 @@ __global__ __launch_bounds__(256) void run_count_kernel(const uint8_t *__restric
     }
 }
 
+// The two-level form's first pass: per unit {is every owned byte b, length of the run of b's that ends the unit}
+__global__ __launch_bounds__(256) void run_summary_kernel(const uint8_t *__restrict__ text, u64 text_len, u64 lo, u32 splat, u32 fold, u64 n_units,
+                                                          uint2 *__restrict__ summ)
+{
+    const u32 lane = r_lane();
+    const u64 anchor = lo & ~(u64)15;
+    for (u64 unit = (u64)blockIdx.x * kWavesPerBlk + (threadIdx.x >> 6); unit < n_units; unit += (u64)gridDim.x * kWavesPerBlk)
+    {
+        const u64 ubase = anchor + unit * kRunUnit;
+        u32 trail = 0;
+        bool unit_all = true;
+        for (u64 cell = 0; cell < kRunUnit / kCellBytes; ++cell)
+        {
+            const u64 lbase = ubase + cell * kCellBytes + (u64)lane * 16u;
+            u32 w[4] = {0, 0, 0, 0};
+            if (lbase + 16 <= text_len)
+            {
+                const uint4 v = *reinterpret_cast<const uint4 *>(text + lbase);
+                w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+            }
+            else
+                for (int k = 0; k < 16; ++k)
+                    if (lbase + k < text_len)
+                        w[k >> 2] |= (u32)text[lbase + k] << (8 * (k & 3));
+            u32 e = r_eq16(make_uint4(w[0], w[1], w[2], w[3]), splat, fold);
+            if (lbase < lo)
+                e &= lo - lbase < 16 ? ~((1u << (u32)(lo - lbase)) - 1u) : 0u;
+            if (lbase + 16 > text_len)
+                e &= lbase < text_len ? (1u << (u32)(text_len - lbase)) - 1u : 0u;
+            e &= 0xffffu;
+            const bool all = e == 0xffffu;
+            u32 len = all ? 16u : (u32)__builtin_clz(~(e << 16));
+            bool al = all;
+            if (__ballot(all))
+            {
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1)
+                {
+                    const u32 pl = __shfl_up(len, o);
+                    const bool pa = __shfl_up((int)al, o) != 0;
+                    if (lane >= (u32)o && al)
+                    {
+                        len += pl;
+                        al = pa;
+                    }
+                }
+            }
+            const u32 l63 = __shfl(len, 63);
+            const bool a63 = __shfl((int)al, 63) != 0;
+            trail = a63 ? trail + l63 : l63;
+            unit_all = unit_all && a63;
+        }
+        if (lane == 0)
+            summ[unit] = make_uint2(trail, unit_all ? 1u : 0u);
+    }
+}
+
 // -> 0 and *total / *end_p1 (buffer offset behind the last kept match, 0 if none), 1 when a run was too long for the look-back (the
 // caller takes the list road), 2 on a HIP error.  d_slots: three zeroable u64 in device memory, h_slots: their pinned mirror.
 int runs_count_greedy(const uint8_t *d_text, uint64_t text_len, uint64_t lo, uint64_t hi, uint32_t m, uint8_t byte, bool ci, int num_cu,
@@ -227,13 +289,51 @@ int runs_count_greedy(const uint8_t *d_text, uint64_t text_len, uint64_t lo, uin
     if (hipMemsetAsync(d_slots, 0, 3 * sizeof(unsigned long long), st) != hipSuccess)
         return 2;
     const u32 grid = (u32)std::min<u64>((n_units + kWavesPerBlk - 1) / kWavesPerBlk, (u64)num_cu * 4);
-    hipLaunchKernelGGL(run_count_kernel, dim3(grid ? grid : 1), dim3(kBlock), 0, st, d_text, (u64)text_len, (u64)lo, (u64)hi, m, splat, fold, n_units, d_slots);
+    hipLaunchKernelGGL(run_count_kernel, dim3(grid ? grid : 1), dim3(kBlock), 0, st, d_text, (u64)text_len, (u64)lo, (u64)hi, m, splat, fold, n_units, d_slots,
+                       (const u32 *)nullptr);
     if (hipGetLastError() != hipSuccess || hipMemcpyAsync(h_slots, d_slots, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess)
         return 2;
     g_runs_launches.fetch_add(1, std::memory_order_relaxed);
     if (h_slots[2])
-        return 1;
+    {
+        // A run of more than 64 KiB in front of some unit (a text of `aaaa...`): the two-level form — every unit's {all b, trailing run},
+        // the carries from a prefix pass over the units on the host (one step per 32 KiB of text), then the count with the carries given.
+        uint2 *d_sum = nullptr;
+        u32 *d_car = nullptr;
+        std::vector<uint2> sum(n_units);
+        std::vector<u32> car(n_units, 0);
+        int rc = 2;
+        if (hipMalloc(&d_sum, n_units * sizeof(uint2)) == hipSuccess && hipMalloc(&d_car, n_units * sizeof(u32)) == hipSuccess)
+        {
+            hipLaunchKernelGGL(run_summary_kernel, dim3(grid ? grid : 1), dim3(kBlock), 0, st, d_text, (u64)text_len, (u64)lo, splat, fold, n_units, d_sum);
+            if (hipGetLastError() == hipSuccess && hipMemcpyAsync(sum.data(), d_sum, n_units * sizeof(uint2), hipMemcpyDeviceToHost, st) == hipSuccess &&
+                hipStreamSynchronize(st) == hipSuccess)
+            {
+                u64 run = 0; // b's in front of the unit, modulo m
+                for (u64 u = 0; u < n_units; ++u)
+                {
+                    car[u] = (u32)run;
+                    run = sum[u].y ? (run + sum[u].x) % m : sum[u].x % m;
+                }
+                if (hipMemcpyAsync(d_car, car.data(), n_units * sizeof(u32), hipMemcpyHostToDevice, st) == hipSuccess &&
+                    hipMemsetAsync(d_slots, 0, 3 * sizeof(unsigned long long), st) == hipSuccess)
+                {
+                    hipLaunchKernelGGL(run_count_kernel, dim3(grid ? grid : 1), dim3(kBlock), 0, st, d_text, (u64)text_len, (u64)lo, (u64)hi, m, splat, fold,
+                                       n_units, d_slots, (const u32 *)d_car);
+                    if (hipGetLastError() == hipSuccess &&
+                        hipMemcpyAsync(h_slots, d_slots, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st) == hipSuccess &&
+                        hipStreamSynchronize(st) == hipSuccess)
+                        rc = 0;
+                }
+            }
+        }
+        if (d_sum) (void)hipFree(d_sum);
+        if (d_car) (void)hipFree(d_car);
+        if (rc)
+            return (void)hipGetLastError(), 1; // (the list road, which says what it cannot hold)
+        g_runs_launches.fetch_add(2, std::memory_order_relaxed);
+    }
     *total = h_slots[0];
     *end_p1 = h_slots[1];
     return 0;
