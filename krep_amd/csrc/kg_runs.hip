@@ -7,7 +7,7 @@
 // no list: inside a maximal run of R bytes b the kept matches start at every m-th byte, floor(R / m) of them.  A kept match ENDS
 // where the number of b's of its run, counted from the run's start, is a multiple of m — a property of the position and of the run
 // length in front of it, which crosses lanes as a carry: per lane {is every byte b, trailing run length}, a wave scan, the round's
-// and the unit's carry in a scalar; a unit finds the run length in front of it by looking back (a run longer than 64 KiB in front
+// and the unit's carry in a scalar; a unit finds the run length in front of it by looking back (a run longer than 4 KiB in front
 // of a unit switches to the two-level form: per-unit summaries, the carries from a prefix pass on the host).  Counting only: with
 // records wanted the list road stays.
 #include <hip/hip_runtime.h>
@@ -26,7 +26,7 @@ std::atomic<uint64_t> g_runs_launches{0}; // (test hook: krep_gpu_debug_runs_lau
 
 namespace {
 constexpr u64 kRunUnit = (u64)kRoundsBig * kSegBytes; // 32 KiB per wave and step
-constexpr u64 kLookBack = 64u * 1024u;
+constexpr u64 kLookBack = 4u * 1024u; // (a run this long in front of a unit: the two-level form)
 
 __device__ __forceinline__ u32 r_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 __device__ __forceinline__ u32 r_eq16(const uint4 &v, u32 splat, u32 fold)
@@ -55,6 +55,8 @@ __global__ __launch_bounds__(256) void run_count_kernel(const uint8_t *__restric
     for (u64 unit = (u64)blockIdx.x * kWavesPerBlk + (threadIdx.x >> 6); unit < n_units; unit += (u64)gridDim.x * kWavesPerBlk)
     {
         const u64 ubase = anchor + unit * kRunUnit;
+        if (!carries && __hip_atomic_load(&out[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            break; // (some unit gave up: this launch's count is void, the two-level form follows)
         // ---- the run of b's in front of the unit (not in front of lo): 64 bytes per step, backwards
         u32 carry = 0; // length of the run entering the next lane / cell, modulo m (uniform)
         if (carries)
@@ -78,11 +80,15 @@ __global__ __launch_bounds__(256) void run_count_kernel(const uint8_t *__restric
                 if (run >= kLookBack)
                 {
                     gave_up = true;
+                    if (lane == 0)
+                        atomicOr(&out[2], 1ull); // (at once: the other waves stop at their next unit)
                     break;
                 }
             }
             carry = (u32)(run % m);
         }
+        if (gave_up)
+            break;
 #pragma unroll 1
         for (int r = 0; r < kRoundsBig; ++r)
         {

@@ -140,7 +140,7 @@ def test_one_repeated_byte_counted_without_a_list(gpu, oracle_engine):
     """kg_runs.hip (round 6): a pattern of m copies of one byte, count-only, through the greedy families — floor(R / m) kept matches per
     maximal run, found from run lengths carried across lanes, cells and units (no list of all occurrences).  Against simd_sse42_search,
     kmp_search and boyer_moore_search under -o of the compiled reference / the restatement: runs on every seam (16-byte lane, 1-KiB
-    cell, 8-KiB round, 32-KiB unit), a run longer than the 64-KiB look-back (the list road takes over), a text of nothing but the byte,
+    cell, 8-KiB round, 32-KiB unit), a run longer than the look-back (the two-level form takes over), a text of nothing but the byte,
     windows chained with krep_gpu_scan_device_seq (the boundary record is where the reference's scan stands), -i, patterns longer than
     a lane."""
     import torch
