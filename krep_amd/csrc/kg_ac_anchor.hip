@@ -512,6 +512,9 @@ int ac_anchor_prepare(AcTables *t, const uint8_t *d_text, size_t text_len, size_
     t->anch_mask = nb_used - 1;
     t->anch_mul = mul_used;
     t->anch_state = 2;
+    // (an anchored scan parks nothing — the END bitmap has the park area — so the 64-entry staging slot costs it nothing, and a word
+    //  dictionary's matches cluster: with 16 entries the FIRST scan of `uniform` re-scanned its overflowed units, 34.7 ms against 11.7)
+    t->stage_cap = std::max<u32>(t->stage_cap, 64u);
     build_exact_dictionary(t, st);
     return 0;
 }
