@@ -785,6 +785,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                     dmA = mA; dmB = mB;
                     cA = (u32)__popc(mA); cB = (u32)__popc(mB);
                     simA = simB = true;
+#ifndef KG_AC_NO_EXACT_SLOW // (A/B switch of krep_amd/build.py --variant)
                     if constexpr (!SHORT && ANCH == 0 && !CI) // (-i: eight bytes of scratch per lane in the BASELINE-shaped kernel for a path the anchored instantiations cover)
                         if (a.xtab && !(a.flags & F_WW) && pos >= 15u && (slA || slB))
                         {
@@ -816,6 +817,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                             dmA = mA; dmB = mB;
                             cA = (u32)__popc(mA); cB = (u32)__popc(mB);
                         }
+#endif
 #pragma unroll 1
                     for (int e = 0; e < 2; ++e) // the one call site of the level walk
                         if (e ? slB : slA)

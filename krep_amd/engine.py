@@ -120,12 +120,13 @@ class Engine:
         L.krep_gpu_debug_chain_fixups.restype = None
         L.krep_gpu_debug_chain_fixups.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.krep_gpu_debug_tiny_dense_launches.restype = C.c_uint64
-        L.krep_gpu_debug_anchored_launches.restype = C.c_uint64
-        L.krep_gpu_debug_literal_dma_launches.restype = C.c_uint64
-        L.krep_gpu_debug_runs_launches.restype = C.c_uint64
-        L.krep_gpu_debug_anchor_info.restype = C.c_int
-        L.krep_gpu_debug_anchor_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_uint32), C.POINTER(C.c_double),
-                                                 C.POINTER(C.c_double)]
+        if hasattr(L, "krep_gpu_debug_anchor_info"):  # (an older build of the library as an A/B partner, tools/ab_bench.py, lacks the round-6 hooks)
+            L.krep_gpu_debug_anchored_launches.restype = C.c_uint64
+            L.krep_gpu_debug_literal_dma_launches.restype = C.c_uint64
+            L.krep_gpu_debug_runs_launches.restype = C.c_uint64
+            L.krep_gpu_debug_anchor_info.restype = C.c_int
+            L.krep_gpu_debug_anchor_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_uint32), C.POINTER(C.c_double),
+                                                     C.POINTER(C.c_double)]
         L.krep_gpu_last_shard_info.restype = None
         L.krep_gpu_last_shard_info.argtypes = [C.POINTER(abi.ShardInfo)]
         L.krep_gpu_available.restype = C.c_int
