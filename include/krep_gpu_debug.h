@@ -47,12 +47,19 @@ uint64_t krep_gpu_debug_anchored_launches(void);
 /* test hook: launches of the LDS-DMA literal kernel (kg_literal_dma.hip: 2..8-byte patterns on 32-KiB units without -c) since the
  * process started; $KREP_GPU_LIT_NO_DMA=1 keeps such scans on the register-load kernel (kg_literal.hip) */
 uint64_t krep_gpu_debug_literal_dma_launches(void);
+/* what chose between that kernel and the register kernel for `plan`: has the text been sampled, is the kernel barred for it (the prefilter's
+ * byte occurs in more than 35 % of its 1-KiB cells; $KREP_GPU_LIT_DMA_MAX_PASS), the share last measured (sample or launch).
+ * $KREP_GPU_LIT_DMA_KEEP=1: no sample, no bar (measurement aid) */
+int krep_gpu_debug_literal_dma_state(const krep_gpu_plan_t *plan, int *looked, int *barred, double *pass_rate);
 /* test hook: launches of the run-length kernel (kg_runs.hip: the greedy families on a pattern of one repeated byte, count-only);
  * $KREP_GPU_NO_RUNS=1 keeps such scans on the list road */
 uint64_t krep_gpu_debug_runs_launches(void);
 /* what that decision was for `plan`: state 0 not taken yet / 1 end grams kept / 2 anchored; patterns moved off their end; the
  * estimated candidates per tested position with the end grams and with the anchors.  Returns 0, or 2 for a single-literal plan. */
 int krep_gpu_debug_anchor_info(const krep_gpu_plan_t *plan, int *state, uint32_t *moved, double *rate_end_grams, double *rate_anchors);
+/* what the last general-kernel scan of `plan` MEASURED (candidates per tested position, counted in the kernel), and how many times a
+ * measurement that contradicted the estimate re-opened the decision (at most 3; $KREP_GPU_AC_NO_RESAMPLE=1: never) */
+int krep_gpu_debug_anchor_measured(const krep_gpu_plan_t *plan, double *measured, int *resamples);
 
 #ifdef __cplusplus
 }

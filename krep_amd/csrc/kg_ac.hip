@@ -100,6 +100,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
     const bool emit_final = a.emit_mode != 0;
 
     u64 acc_total = 0;
+    u32 acc_cand = 0; // (wave-uniform, an SGPR: a wave's share of a text holds far fewer than 2^32 tested positions)
     __syncthreads(); // filter tables are in LDS from here on; the waves never synchronise again
 
     // Waves are autonomous: each draws its own ticket for a.upt consecutive 16-KiB units (128 KiB on large texts:
@@ -498,6 +499,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
             }
             const bool off = (a.flags & (1u << 31)) != 0u; // (ablation hook KREP_GPU_AC_NOVERIFY: filter cost only)
             const u32 n = off ? 0u : __shfl(incl, 63);
+            acc_cand += (u32)__builtin_amdgcn_readfirstlane((int)n);
             // an END lies up to 13 bytes behind the tested position that names it: the six tested positions in front of the unit
             // whose ends can fall into it are looked at again here (their own unit drops the ends beyond its last pair)
             const u32 n_x = (!off && useg >= 16u) ? 6u : 0u;
@@ -674,6 +676,8 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                     incl += t;
             }
             const u32 n = (a.flags & (1u << 31)) ? 0u : __shfl(incl, 63); // (ablation hook KREP_GPU_AC_NOVERIFY: filter cost only)
+            if (!ANCH)
+                acc_cand += (u32)__builtin_amdgcn_readfirstlane((int)n);
             constexpr bool pair = STRIDE == 2; // a candidate stands for the ends t and t + 1
             const u32 n_tot = n + ((XCAND && !(a.flags & (1u << 31)) && useg >= 1u) ? 1u : 0u); // rank n: the extra candidate
             for (u32 b0 = 0; b0 < n_tot; b0 += 64)
@@ -880,6 +884,8 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
     }
     if (lane == 0 && acc_total && !a.emit_mode)
         atomicAdd(&a.ctr->total, acc_total);
+    if (lane == 0 && acc_cand && !a.emit_mode)
+        atomicAdd(&a.ctr->candidates, (unsigned long long)acc_cand);
 }
 
 // ---------------------------------------------------------------------------------------------- host: launches and the scan driver
@@ -1301,6 +1307,26 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
     if (time_it) SCHK(hipEventRecord(ev1, st));
     SCHK(hipMemcpyAsync(h_ctr, d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, st));
     SCHK(hipStreamSynchronize(st));
+    // The anchor decision follows the TEXT, and a dictionary meets more than one: the kernel counts the positions its filter passed, and a
+    // scan whose measured rate is both one that matters (the decision's own 0.8 % bar) and more than twice what the decision estimated for
+    // the filter it chose re-opens the decision, so that the next scan samples the text it is given (an i.i.d. text first, a word-like
+    // one after it: 0.04 of the roofline without this, 0.49 with).  Matches are candidates too, so a text dense with matches can ask as
+    // well; the repeats are bounded, and a repeat on the same kind of text decides as before.
+    if (!tiny && !lines && a.stride == 2 && !a.emit_mode && own_hi > own_lo)
+    {
+        const double tested = 0.5 * (double)(own_hi - own_lo);
+        t->anch_measured = (double)h_ctr->candidates / tested;
+        const double est = t->anch_state == 2 ? t->anch_rate : t->anch_rate0;
+        if (t->anch_state != 0 && t->anch_resamples < kAnchResamples && text_len >= (1u << 20) && own_hi - own_lo >= (1u << 19) &&
+            t->anch_measured > 0.008 && t->anch_measured > 2.0 * est + 0.002 && !getenv("KREP_GPU_AC_ANCHOR") && !getenv("KREP_GPU_AC_NO_RESAMPLE"))
+        {
+            if (getenv("KREP_GPU_DEBUG"))
+                fprintf(stderr, "krep-gpu: anchors: measured %.3f %% candidates per tested position against %.3f %% estimated (%s): the next scan decides again\n",
+                        100.0 * t->anch_measured, 100.0 * est, t->anch_state == 2 ? "anchored" : "end grams");
+            t->anch_state = 0;
+            ++t->anch_resamples;
+        }
+    }
     if (want && !g_ac_force_stage_cap)
     {
         // a dense dictionary / text: the next scans stage 64 matches per unit — or, when most units of a tiny dictionary hold more

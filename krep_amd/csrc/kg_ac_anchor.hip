@@ -172,6 +172,13 @@ static void build_exact_dictionary(AcTables *t, hipStream_t st)
 int ac_anchor_prepare(AcTables *t, const uint8_t *d_text, size_t text_len, size_t own_lo, size_t own_hi, hipStream_t st)
 {
     t->anch_state = 1;
+    // (a repeated decision — kg_ac.hip ac_scan, when a later text's measured candidates contradict this one's estimate — drops the
+    //  anchor tables of the text before; the exact dictionary is the patterns' alone and stays)
+    if (t->d_filtera20) (void)hipFree(t->d_filtera20);
+    if (t->d_anch) (void)hipFree(t->d_anch);
+    t->d_filtera20 = nullptr;
+    t->d_anch = nullptr;
+    t->anch_five = 0;
     const bool force = getenv("KREP_GPU_AC_ANCHOR") != nullptr; // test hook: anchors by plain minimum, whatever the gain
     if (getenv("KREP_GPU_AC_NO_ANCHOR") || !t->d_filters20 || t->has1 || t->has2 || t->has3 || t->tiny.ok || t->pats_h.empty())
         return 0;

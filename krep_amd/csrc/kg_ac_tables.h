@@ -47,10 +47,13 @@ struct AcTables
     unsigned short *d_xlen = nullptr;         // stage 3's exact dictionary (AcArgs::xlen / xtab): dictionaries of 4..16-byte patterns
     uint4 *d_xtab = nullptr;
     u32 xmask = 0, xmul = 0;
+    int anch_resamples = 0;                   // decisions repeated because a later text's measured candidates contradicted the estimate (at most kAnchResamples)
+    double anch_measured = 0;                 // candidates per tested position the last general-kernel scan counted (Counters::candidates)
     double anch_rate0 = 0, anch_rate = 0;     // estimated candidates per tested position: end grams / anchor grams (diagnostic)
     u32 anch_moved = 0;                       // patterns whose anchor is not their end
 };
 // kg_ac_anchor.hip
+constexpr int kAnchResamples = 3; // (a session that alternates kinds of text settles on the last decision after three repeats)
 int ac_anchor_prepare(AcTables *t, const uint8_t *d_text, size_t text_len, size_t own_lo, size_t own_hi, hipStream_t st);
 void ac_anchor_free(AcTables *t);
 

@@ -50,6 +50,7 @@ struct Counters {
     unsigned long long overflow_units; // units whose hit count exceeded the staging capacity
     unsigned long long max_unit_count; // largest per-unit hit count seen
     unsigned long long pad[4];       // scratch slots of the small tail kernels (pad[0]: one value; pad[1..3]: the newline-pattern walk)
+    unsigned long long candidates;   // multi-pattern scan: tested positions its LDS filter passed (what its time follows; round 6)
 };
 
 // Parameters of a literal scan launch.

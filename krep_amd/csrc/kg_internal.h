@@ -23,6 +23,7 @@ int runs_count_greedy(const uint8_t *d_text, uint64_t text_len, uint64_t lo, uin
                       unsigned long long *d_slots, unsigned long long *h_slots, hipStream_t st, uint64_t *total, uint64_t *end_p1);
 bool literal_dma_eligible(const LitArgs &a);                                       // kg_literal_dma.hip: 2..8-byte patterns, 32-KiB units, no -c
 hipError_t launch_literal_dma(const LitArgs &a, uint32_t num_cu, hipStream_t st);
+hipError_t launch_dma_byte_look(const uint8_t *text, uint64_t lo, uint32_t n_cells, uint32_t prefilter, bool ci, unsigned long long *out, hipStream_t st); // 1-KiB cells of a sample that hold the prefilter's byte
 extern std::atomic<uint64_t> g_runs_launches;                                      // launches of run_count_kernel (kg_runs.hip, test hook)
 extern std::atomic<uint64_t> g_lit_dma_launches;                                   // launches of lit_scan_dma (test hook)
 

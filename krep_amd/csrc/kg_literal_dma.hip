@@ -144,6 +144,7 @@ __global__ __launch_bounds__(kBlock, 2) void lit_scan_dma(const LitArgs a)
     };
 
     u64 acc_total = 0;
+    u32 pf_cells = 0; // 1-KiB cells the prefilter let through (uniform; Counters::candidates — what the host's choice of kernel follows)
     u32 wcnt = 0; // hits of the unit being scanned (uniform)
     // a hit at unit-relative offset `rel` of `unit`, ranked idx: staged (parked or in the unit's slot)
     auto stage_hit = [&](u64 unit, u32 idx, u32 rel) __attribute__((always_inline)) {
@@ -342,6 +343,7 @@ __global__ __launch_bounds__(kBlock, 2) void lit_scan_dma(const LitArgs a)
                     }
                     if (!__ballot((z & 0x80808080u) != 0u))
                         continue;
+                    ++pf_cells;
                 }
                 bool c[16];
                 u64 any = 0;
@@ -455,6 +457,39 @@ __global__ __launch_bounds__(kBlock, 2) void lit_scan_dma(const LitArgs a)
         flush_parked();
     if (lane == 0 && acc_total)
         atomicAdd(&a.ctr->total, acc_total);
+    if (lane == 0 && pf_cells)
+        atomicAdd(&a.ctr->candidates, (u64)pf_cells);
+}
+
+// The look before the first launch (kg_scan.hip lit_pass): in how many 1-KiB cells of a sample does the prefilter's byte occur at all?
+// A cell that holds it costs lit_scan_dma the full 16-position compare, and at two workgroups per CU that work is not hidden; the register
+// kernel (kg_literal.hip, more waves per SIMD) is the faster one from ~4 cells in 10 on (measured: kg_scan.hip lit_pass).  One wave per cell, 16 B per lane.
+__global__ __launch_bounds__(256) void dma_byte_look(const uint8_t *text, u64 lo, u32 n_cells, u32 b4, u32 fold, unsigned long long *out)
+{
+    const u32 lane = d_lane();
+    const u32 wave = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
+    u32 cnt = 0;
+    for (u32 c = wave; c < n_cells; c += n_waves)
+    {
+        const uint4 v = *reinterpret_cast<const uint4 *>(text + lo + (u64)c * kCellBytes + lane * 16u);
+        const u32 d[4] = {v.x, v.y, v.z, v.w};
+        u32 z = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+        {
+            const u32 y = (d[w] | fold) ^ b4;
+            z |= (y - 0x01010101u) & ~y;
+        }
+        if (__ballot((z & 0x80808080u) != 0u))
+            ++cnt;
+    }
+    if (lane == 0 && cnt)
+        atomicAdd(out, (u64)cnt);
+}
+hipError_t launch_dma_byte_look(const uint8_t *text, uint64_t lo, uint32_t n_cells, uint32_t prefilter, bool ci, unsigned long long *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(dma_byte_look, dim3(256), dim3(256), 0, st, text, (u64)lo, n_cells, prefilter, ci ? 0x20202020u : 0u, out);
+    return hipGetLastError();
 }
 
 // ---- launcher ----------------------------------------------------------------------------------

@@ -38,6 +38,13 @@ struct krep_gpu_plan
     uint32_t sparse_cap = 16; // staging entries per 32 KiB unit of the sparse literal kinds: 16, raised to 64 after a scan whose
                               // units overflowed (see lit_pass); one 32-byte slot per unit keeps the store stream dense
     uint32_t ac_cap = 16;     // the same for the multi-pattern scan (16 KiB units)
+    // lit_pass, the LDS-DMA literal kernel (kg_literal_dma.hip): chosen by what the TEXT holds — the share of 1-KiB cells its prefilter lets
+    // through, sampled before the plan's first eligible launch and counted by every launch of the kernel itself
+    bool dma_look_done = false;   // the sample has been taken
+    bool dma_off = false;         // too many cells pass: the register kernel takes this plan's scans (looked at again when the text changes)
+    const void *dma_off_text = nullptr; // ... the text that said so
+    size_t dma_off_len = 0;
+    double dma_pass_rate = 0;     // last share measured (sample or launch)
     bool first_look_done = false; // lit_pass: the density of the plan's first large text has been sampled (road / ring shape / slot from it)
     bool fused1_ok = true;    // single byte with records: the one-pass kernel (kg_single.hip) until a scan proves too dense for it
     bool fusedk_on = false;   // a 2..8-byte literal with records: the same kernel's MULTI instantiations, switched on by a two-pass scan that

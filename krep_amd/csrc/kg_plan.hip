@@ -201,6 +201,23 @@ extern "C" void krep_gpu_plan_destroy(krep_gpu_plan_t *pl)
     delete pl;
 }
 extern "C" int krep_gpu_plan_ref_algo(const krep_gpu_plan_t *pl) { return pl ? pl->ref_algo : KREP_RA_NONE; }
+extern "C" int krep_gpu_debug_literal_dma_state(const krep_gpu_plan_t *pl, int *looked, int *barred, double *pass_rate)
+{
+    if (!pl)
+        return 2;
+    if (looked) *looked = pl->dma_look_done;
+    if (barred) *barred = pl->dma_off;
+    if (pass_rate) *pass_rate = pl->dma_pass_rate;
+    return 0;
+}
+extern "C" int krep_gpu_debug_anchor_measured(const krep_gpu_plan_t *pl, double *measured, int *resamples)
+{
+    if (!pl || !pl->ac)
+        return 2;
+    if (measured) *measured = pl->ac->anch_measured;
+    if (resamples) *resamples = pl->ac->anch_resamples;
+    return 0;
+}
 extern "C" int krep_gpu_debug_anchor_info(const krep_gpu_plan_t *pl, int *state, uint32_t *moved, double *rate_end_grams, double *rate_anchors)
 {
     if (!pl || !pl->ac)

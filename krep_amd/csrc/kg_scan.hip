@@ -192,8 +192,41 @@ static int lit_pass(krep_gpu_plan *pl, const Window &w, const LitPass &ps, hipSt
     // of a short scan); at 32 GiB tickets win: 5.20 vs 5.31 ms, and 7.1 vs 7.9 ms on the single-byte workload
     // (the LDS-DMA kernel, kg_literal_dma.hip, wants tickets — a ticket is what it streams through without a seam — and is ahead with them
     //  from ~8 GiB on: 8 GiB 1.339 against 1.362 ms for the register kernel's static deal, 16 GiB 2.610 against 2.639; round 6)
-    const bool dma_shape = m_scan >= 2 && m_scan <= 8 && !ps.lines && !ps.first_byte && a.prefilter != 0u && !getenv("KREP_GPU_LIT_NO_DMA");
-    a.upt = (a.rounds == kRoundsBig && n_units / ((uint64_t)pl->num_cu * 16) >= (dma_shape ? 64u : 192u)) ? 8 : 0;
+    bool dma_shape = m_scan >= 2 && m_scan <= 8 && !ps.lines && !ps.first_byte && a.prefilter != 0u && !getenv("KREP_GPU_LIT_NO_DMA");
+    auto tickets_for = [&](bool dma) { return (a.rounds == kRoundsBig && n_units / ((uint64_t)pl->num_cu * 16) >= (dma ? 64u : 192u)) ? 8u : 0u; };
+    a.upt = tickets_for(dma_shape);
+    // ... and wants a TEXT in which the prefilter's byte is rare: a 1-KiB cell that holds it pays the full compare, which two workgroups per CU
+    // do not hide.  32 GiB, offsets produced, by the share of cells that hold the byte (profiles/r06_ldsdma_byte_rate.txt): 10 % 5.08 ms,
+    // 27 % 5.08, 46 % 5.23, 68 % 5.75, 96 % 6.49 — against 5.19-5.20 ms of the register kernel throughout.  The static rule above only bars
+    // the letters that running text is made of; what THIS text holds is sampled once (two 2-MiB windows, one wave per cell) before the plan's
+    // first such launch, and counted by every launch of the kernel (Counters::candidates).  A plan barred by one text looks again at the next.
+    static const double kDmaMaxPass = [] { const char *e = getenv("KREP_GPU_LIT_DMA_MAX_PASS"); return e ? atof(e) : 0.35; }();
+    const bool dma_keep = getenv("KREP_GPU_LIT_DMA_KEEP") != nullptr; // measurement aid: no look, no bar
+    if (dma_shape && (a.upt >= 4 || getenv("KREP_GPU_LIT_DMA_ALL")) && a.rounds == kRoundsBig && !dma_keep && hi_match - a.anchor >= (64ull << 20) &&
+        (!pl->dma_look_done || (pl->dma_off && (pl->dma_off_text != (const void *)w.d_text || pl->dma_off_len != w.text_len))))
+    {
+        pl->dma_look_done = true;
+        const uint64_t span = hi_match - a.anchor, win = 2ull << 20;
+        HIPCHK(hipMemsetAsync(pl->d_ctr, 0, sizeof(Counters), st));
+        for (int q = 0; q < 2; ++q)
+            HIPCHK(launch_dma_byte_look(w.d_text, (a.anchor + span / 4 * (2 * q + 1)) & ~(uint64_t)15, (uint32_t)(win / kCellBytes), a.prefilter,
+                                        !pl->cs, &pl->d_ctr->candidates, st));
+        HIPCHK(hipMemcpyAsync(pl->h_ctr, pl->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        pl->dma_pass_rate = (double)pl->h_ctr->candidates / (double)(2 * win / kCellBytes);
+        pl->dma_off = pl->dma_pass_rate > kDmaMaxPass;
+        pl->dma_off_text = w.d_text;
+        pl->dma_off_len = w.text_len;
+        if (getenv("KREP_GPU_DEBUG"))
+            fprintf(stderr, "krep-gpu: literal scan: the prefilter's byte 0x%02x occurs in %.1f %% of the sampled 1-KiB cells -> %s kernel\n", a.prefilter & 0xffu,
+                    100.0 * pl->dma_pass_rate, pl->dma_off ? "register" : "LDS-DMA");
+    }
+    if (pl->dma_off && !dma_keep)
+    {
+        a.prefilter = 0u; // (kg_literal_dma.hip literal_dma_eligible: the register kernel)
+        dma_shape = false;
+        a.upt = tickets_for(false);
+    }
     if (const char *e = getenv("KREP_GPU_LIT_UPT")) // measurement aid; only the values the kernel's parked-store bookkeeping
     {                                               // is built for (kPark = 240 must be a multiple)
         const int v = atoi(e);
@@ -359,6 +392,19 @@ static int lit_pass(krep_gpu_plan *pl, const Window &w, const LitPass &ps, hipSt
         if (ps.ev_end) HIPCHK(hipEventRecord(ps.ev_end, st));
         HIPCHK(hipMemcpyAsync(pl->h_ctr, pl->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
+        if (literal_dma_eligible(a) && hi_match - a.anchor >= (64ull << 20))
+        {
+            // what the LDS-DMA kernel itself counted on this text: its later scans go by it
+            pl->dma_pass_rate = (double)pl->h_ctr->candidates / ((double)(hi_match - a.anchor) / kCellBytes);
+            if (pl->dma_pass_rate > kDmaMaxPass && !dma_keep)
+            {
+                pl->dma_off = true;
+                pl->dma_off_text = w.d_text;
+                pl->dma_off_len = w.text_len;
+                if (getenv("KREP_GPU_DEBUG"))
+                    fprintf(stderr, "krep-gpu: literal scan: the prefilter passed %.1f %% of the 1-KiB cells -> the register kernel from the next scan on\n", 100.0 * pl->dma_pass_rate);
+            }
+        }
         if ((a.flags & F_POS) && m_scan != 1 && a.rounds == kRoundsBig && pl->h_ctr->overflow_units * 64 > n_units && !fsc)
         {
             // a dense input: the next scans of this plan stage 64 hits per unit — and if more than 1 unit in 64 overflows that as

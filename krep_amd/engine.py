@@ -127,6 +127,12 @@ class Engine:
             L.krep_gpu_debug_anchor_info.restype = C.c_int
             L.krep_gpu_debug_anchor_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_uint32), C.POINTER(C.c_double),
                                                      C.POINTER(C.c_double)]
+        if hasattr(L, "krep_gpu_debug_literal_dma_state"):
+            L.krep_gpu_debug_literal_dma_state.restype = C.c_int
+            L.krep_gpu_debug_literal_dma_state.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]
+        if hasattr(L, "krep_gpu_debug_anchor_measured"):
+            L.krep_gpu_debug_anchor_measured.restype = C.c_int
+            L.krep_gpu_debug_anchor_measured.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.krep_gpu_last_shard_info.restype = None
         L.krep_gpu_last_shard_info.argtypes = [C.POINTER(abi.ShardInfo)]
         L.krep_gpu_available.restype = C.c_int
@@ -414,6 +420,20 @@ class Plan:
         if self.eng.lib.krep_gpu_debug_anchor_info(self.h, C.byref(st), C.byref(mv), C.byref(r0), C.byref(r1)):
             return None
         return int(st.value), int(mv.value), float(r0.value), float(r1.value)
+
+    def literal_dma_state(self):
+        """(text sampled?, LDS-DMA kernel barred for it?, share of 1-KiB cells its prefilter passed) — kg_scan.hip lit_pass"""
+        a, b, r = C.c_int(0), C.c_int(0), C.c_double(0)
+        if self.eng.lib.krep_gpu_debug_literal_dma_state(self.h, C.byref(a), C.byref(b), C.byref(r)):
+            return None
+        return bool(a.value), bool(b.value), float(r.value)
+
+    def anchor_measured(self):
+        """(candidates per tested position the last general-kernel scan counted, decisions re-opened so far)"""
+        m, r = C.c_double(0), C.c_int(0)
+        if self.eng.lib.krep_gpu_debug_anchor_measured(self.h, C.byref(m), C.byref(r)):
+            return None
+        return float(m.value), int(r.value)
 
     def scan_seq(self, d_text: int, text_len: int, own_lo, own_hi, global_base=0, d_positions: int = 0, capacity: int = 0,
                  global_len=0, carry_in: "abi.SeqCarry | None" = None):

@@ -153,6 +153,56 @@ def test_decision_keeps_end_grams_on_iid_text_and_anchors_word_text(gpu, oracle_
     assert np.array_equal(rec, want.astype(np.int64))
 
 
+def test_decision_follows_the_text_a_plan_meets_later(gpu, oracle_engine):
+    """One plan, two kinds of text.  The decision is taken on the first text of >= 1 MiB: i.i.d. letters here, on which a word
+    dictionary's end grams are as rare as any (state 1).  The word text after it passes ~40x the candidates the estimate named; the
+    kernel counts them (Counters::candidates), the scan that measured them re-opens the decision and the NEXT scan samples the word
+    text and anchors.  Same records as aho_corasick_search (/root/reference/aho_corasick.c:328-437) before, at and after the switch;
+    $KREP_GPU_AC_NO_RESAMPLE=1 keeps the first decision."""
+    import torch
+    w = wordlist.word_list()
+    wp = wordlist.dictionary(w, "rare")
+    rng = np.random.RandomState(77)
+    iid = cases.rand_text(rng, 3 << 20, bytes(range(97, 123)) + b"  \n")
+    wtext = np.frombuffer(gpu.generate_host(3 << 20, 0, 5, 20260930, wordlist.pack(w), 80), dtype=np.uint8).copy()
+    want_iid = oracle_engine.call(abi.RA_AHO_CORASICK, abi.Params(wp), iid)[1].astype(np.int64)
+    want_w = oracle_engine.call(abi.RA_AHO_CORASICK, abi.Params(wp), wtext)[1].astype(np.int64)
+    for resample in (True, False):
+        if not resample:
+            os.environ["KREP_GPU_AC_NO_RESAMPLE"] = "1"
+        try:
+            plan = gpu.plan(abi.Params(wp))
+            cap = max(len(want_w), len(want_iid)) + 16
+            pos = torch.empty(2 * cap, dtype=torch.int64, device="cuda")
+
+            def scan(text):
+                d = torch.from_numpy(text).cuda()
+                out = plan.scan(d.data_ptr(), len(text), 0, len(text), 0, pos.data_ptr(), cap)
+                return pos[: 2 * out.stored].view(-1, 2).cpu().numpy().copy()
+
+            assert np.array_equal(scan(iid), want_iid)
+            assert plan.anchor_info()[0] == 1 and plan.anchor_measured()[1] == 0
+            low = plan.anchor_measured()[0]
+            assert np.array_equal(scan(wtext), want_w)  # (still the end grams: this scan is the one that measures)
+            high, n = plan.anchor_measured()
+            assert high > 0.008 and high > 10 * low, (low, high)
+            assert n == (1 if resample else 0) and plan.anchor_info()[0] == (0 if resample else 1)
+            before = gpu.anchored_launches()
+            assert np.array_equal(scan(wtext), want_w)
+            assert plan.anchor_info()[0] == (2 if resample else 1)
+            assert (gpu.anchored_launches() > before) == resample
+            if resample:
+                est = plan.anchor_info()[3]
+                got = plan.anchor_measured()[0]
+                assert got < 0.5 * high and got < 2.0 * est + 0.002, (got, est, high)  # the estimate holds on the text it was taken on
+                assert np.array_equal(scan(iid), want_iid)  # anchored tables on the other text: same records, few candidates, no repeat
+                assert np.array_equal(scan(wtext), want_w)
+                assert plan.anchor_measured()[1] == 1 and plan.anchor_info()[0] == 2
+            plan.close()
+        finally:
+            os.environ.pop("KREP_GPU_AC_NO_RESAMPLE", None)
+
+
 def test_end_owned_window_that_starts_on_a_16_byte_boundary(gpu, oracle_engine):
     """Multi-pattern -c on the record-list road owns a match by its END.  A window whose first owned byte is 16-byte aligned starts
     a scan unit there, and a unit verifies the ends BEHIND its first byte (its first byte is the last end of the unit in front):

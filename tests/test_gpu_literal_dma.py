@@ -108,3 +108,52 @@ def test_windows_and_overflowing_slots(gpu, oracle_engine, dma):
         plan.close()
     finally:
         gpu.set_algo_override(abi.ALGO_AUTO)
+
+
+def test_kernel_choice_follows_the_first_byte_in_the_text(gpu, oracle_engine, dma):
+    """The kernel is chosen by what the TEXT holds (kg_scan.hip lit_pass): a sample before the plan's first eligible launch, and the
+    kernel's own count of the 1-KiB cells its prefilter let through.  Text A does not hold the pattern's first byte outside the plants;
+    in text B it is 1 byte in 100 (every cell holds it).  Same records as the compiled reference whichever kernel runs; a plan barred
+    by B looks again when it is handed A."""
+    import torch
+    rng = np.random.RandomState(90 + int(dma))
+    n = (72 << 20) + 4321
+    pat = b"Qwerty"
+    m = len(pat)
+    A = cases.rand_text(rng, n, bytes(range(97, 123)) + b"  \n")
+    for s in list(rng.randint(0, n - m, 300)) + [0, n - m, 8 * 32768 - 3]:
+        A[s:s + m] = np.frombuffer(pat, dtype=np.uint8)
+    B = A.copy()
+    B[rng.rand(n) < 0.01] = ord("Q")
+    algo = gpu.mirror_select(abi.Params([pat]), n)
+    want = {id(t): oracle_engine.call(algo, abi.Params([pat]), t)[1].astype(np.int64) for t in (A, B)}
+    dA, dB = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
+    cap = 4096
+    pos = torch.empty(2 * cap, dtype=torch.int64, device="cuda")
+
+    def scan(plan, d, host):
+        before = gpu.literal_dma_launches()
+        out = plan.scan(d.data_ptr(), n, 0, n, 0, pos.data_ptr(), cap)
+        assert np.array_equal(pos[: 2 * out.stored].view(-1, 2).cpu().numpy(), want[id(host)])
+        return gpu.literal_dma_launches() - before
+
+    plan = gpu.plan(abi.Params([pat]))
+    assert scan(plan, dA, A) == 1
+    looked, barred, rate = plan.literal_dma_state()
+    assert looked and not barred and rate < 0.01, (looked, barred, rate)
+    assert scan(plan, dB, B) == 1          # not barred yet: this launch is the one that counts B's cells
+    looked, barred, rate = plan.literal_dma_state()
+    assert barred and rate > 0.9, (barred, rate)
+    assert scan(plan, dB, B) == 0          # the register kernel
+    assert scan(plan, dA, A) == 1          # another text: sampled again, the bar is lifted
+    assert not plan.literal_dma_state()[1]
+    plan.close()
+    plan = gpu.plan(abi.Params([pat]))     # a fresh plan on B: the sample bars the kernel before its first launch
+    assert scan(plan, dB, B) == 0
+    assert plan.literal_dma_state()[:2] == (True, True)
+    os.environ["KREP_GPU_LIT_DMA_KEEP"] = "1"
+    try:
+        assert scan(plan, dB, B) == 1      # (the measurement aid: no sample, no bar; same records)
+    finally:
+        os.environ.pop("KREP_GPU_LIT_DMA_KEEP", None)
+    plan.close()

@@ -87,7 +87,11 @@ for tname, gen in texts:
         kw = dict(whole_word=True) if name.endswith("-w") else {}
         try:
             t_c, _, oc = timed(pats, dict(count_lines=True, only_match=True, **kw), False)
-            t_p, f_p, op = timed(pats, kw, True)
+            try:
+                t_p, f_p, op = timed(pats, kw, True)
+            except AssertionError:  # more records than this tool's list holds (a frequent single byte): counted only
+                print(f"{name:38s} {oc.count:12d} matches  count {n / t_c / 1e6:6.0f} GB/s ({t_c:.2f} ms)  (offsets: more records than the tool's {cap}-record list)", flush=True)
+                continue
             chk = check_windows(pats, op) if not kw else "-"
             print(f"{name:38s} {oc.count:12d} matches  count {n / t_c / 1e6:6.0f}  offsets {n / t_p / 1e6:6.0f} GB/s ({t_p:.2f} ms, first {f_p:.2f})  {chk}", flush=True)
         except Exception as ex:
@@ -107,3 +111,26 @@ for tname, gen in texts:
                   f"-c {n / t_l / 1e6:6.0f} ({ol_.count} lines)  {chk}", flush=True)
         except Exception as ex:
             print(f"1000 words, {name:32s} failed: {ex!r}", flush=True)
+
+# One plan that meets BOTH texts (round 6, kg_ac.hip ac_scan: the kernel counts its candidates, and a measurement that contradicts the
+# estimate re-opens the anchor decision): the i.i.d. text first (decision: end grams), then the word text three times.
+print("## one plan, i.i.d. text first, word text after (count-only kernel ms per scan; state = anchor decision after the scan)", flush=True)
+for name, pats in dicts[:2]:
+    for env in ({}, {"KREP_GPU_AC_NO_RESAMPLE": "1"}):
+        os.environ.update(env)
+        try:
+            plan = e.plan(abi.Params(pats, count_lines=True, only_match=True))
+            texts[1][1]()
+            torch.cuda.synchronize()
+            o = plan.scan(buf.data_ptr(), n, 0, n, 0, 0, 0, time_it=True)
+            row = [f"i.i.d. {o.kernel_ms:.2f} ms (state {plan.anchor_info()[0]})"]
+            texts[0][1]()
+            torch.cuda.synchronize()
+            for i in range(4):
+                o = plan.scan(buf.data_ptr(), n, 0, n, 0, 0, 0, time_it=True)
+                row.append(f"words #{i + 1} {o.kernel_ms:.2f} ms = {n / o.kernel_ms / 1e6:.0f} GB/s (state {plan.anchor_info()[0]}, measured {100 * plan.anchor_measured()[0]:.2f} %)")
+            plan.close()
+            print(f"1000 words, {name:8s} {'first decision kept ($KREP_GPU_AC_NO_RESAMPLE)' if env else 'decision follows the text':48s} " + "; ".join(row), flush=True)
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
