@@ -16,12 +16,13 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT, PROF = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
-DOMINANT = {"literal8": "kg::lit_scan", "memchr1": "kg::single_fused", "ac1000": "kg::ac_scan_kernel"}
+DOMINANT = {"literal8": "kg::lit_scan", "memchr1": "kg::single_fused", "ac1000": "kg::ac_scan_kernel", "words1000": "kg::ac_scan_kernel"}
 # the kernels of one step besides the dominant one (launched once per step: their bytes are added per step)
-POST = {"literal8": ("kg::post_",), "memchr1": (), "ac1000": ("kg::post_",)}
+POST = {"literal8": ("kg::post_",), "memchr1": (), "ac1000": ("kg::post_",), "words1000": ("kg::post_",)}
 # the sources whose change makes a workload's traffic figure stale (bench.py checks the hash before it quotes the figure)
 KERNEL_SOURCES = {"literal8": ["kg_literal_dma.hip", "kg_literal.hip", "kg_post.hip", "kg_common.h"], "memchr1": ["kg_single.hip", "kg_tickets.h", "kg_common.h"],
-                  "ac1000": ["kg_ac.hip", "kg_ac_common.h", "kg_ac_tables.h", "kg_post.hip", "kg_common.h"]}
+                  "ac1000": ["kg_ac.hip", "kg_ac_common.h", "kg_ac_tables.h", "kg_post.hip", "kg_common.h"],
+                  "words1000": ["kg_ac.hip", "kg_ac_anchor.hip", "kg_ac_common.h", "kg_ac_tables.h", "kg_post.hip", "kg_common.h"]}
 
 
 def sources_sha(workload):

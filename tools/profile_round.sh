@@ -17,7 +17,7 @@ for w in $WL; do
     timeout 600 rocprofv3 --pmc $c --output-format csv -d $O/${TAG}_${w}_$c -o pmc -- \
         python $R/bench.py --workload $w --steps 2 --warmup 1 --no-cpu-baseline --no-extra > $O/${TAG}_${w}_$c.log 2>&1
   done
-  if [ "$w" = "ac1000" ]; then
+  if [ "$w" = "ac1000" ] || [ "$w" = "words1000" ]; then
     # the filter alone (ablation hook): its streamed reads are the part of FETCH_SIZE that has to be doubled; the verify
     # stage's gathers are counted exactly (profiles/r03_fetch_size_calibration.txt)
     KREP_GPU_AC_NOVERIFY=1 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_${w}_FETCH_SIZE_filter -o pmc -- \
