@@ -563,14 +563,12 @@ def main():
     ap.add_argument("--workload", default="literal8", choices=sorted(WORKLOADS))
     ap.add_argument("--gib", type=float, default=32.0, help="haystack GiB per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    # Both default to 1 since round 6: the reported number is the one a user's single allocation
-    # gets.  Physical placement moves the 8-byte literal by 2-3 % and the single byte with records by ~10 %; values > 1
-    # draw again outside every timed region, keep the fastest candidate and say so under the line's top-level `placement` key —
-    # a development aid (A/B runs on a fixed placement), not the protocol of the headline.
-    ap.add_argument("--haystack-tries", type=int, default=1,
-                    help="candidate haystack allocations (physical placement moves every workload by 2-3 %%; 1 = take the first)")
+    # 1 since round 6: the reported number is the one a user's single allocation gets.  Physical
+    # placement moves the 8-byte literal by 2-3 % and the single byte with records by ~10 %; values > 1 let the library's
+    # placed allocator draw (outside every timed region) and say so under the line's top-level `placement` key — not the protocol of
+    # the headline.
     ap.add_argument("--placement-tries", type=int, default=1,
-                    help="candidate record buffers to draw from (1 = take the first allocation as it comes)")
+                    help="candidate blocks (haystack + record buffer) krep_gpu_alloc_placed() draws from (1 = the first allocation as it comes)")
     ap.add_argument("--no-extra", action="store_true", help="N = 1: do not measure the other two BASELINE workloads")
     ap.add_argument("--cpu-sample-gib", type=float, default=4.0)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo = CPU dry run of the plumbing")
@@ -625,78 +623,34 @@ def main():
     global SCAN_STREAM
     SCAN_STREAM = torch.cuda.Stream(device=dev)
     n = int(args.gib * (1 << 30))
-    buf = torch.empty(n + 64, dtype=torch.uint8, device=dev)
-    # The haystack's own placement (round 5, profiles/r05_run_to_run.txt): consecutive fresh processes alternate STRICTLY between two
-    # modes 2-3 % apart for all three workloads (literal8 5.19-5.21 / 5.32-5.39 ms) — a process gets the 32 GiB its predecessor just
-    # freed back in the other of two physical layouts.  Same remedy as for the record buffer below: up to --haystack-tries
-    # candidate haystacks are allocated, the 8-byte-literal scan (with its records) is timed on each, outside every timed region,
-    # the fastest is kept and the others are returned to the driver.  `config.placement.haystack_draws_ms` says what was drawn.
-    hay_draws = None
-    if args.haystack_tries > 1 and n >= (4 << 30):
-        from krep_amd import abi
-        wl2 = workload("literal8")
-        cap2 = positions_capacity("literal8", n)
-        probe_pos = torch.empty(2 * cap2, dtype=torch.int64, device=dev)
-        probe = eng.plan(abi.Params(wl2["patterns"]), device=local)
-        cands, hay_draws = [buf], []
-        for i in range(args.haystack_tries):
-            free_b, _ = torch.cuda.mem_get_info(dev)
-            if i and free_b < 2 * (n + (8 << 30)):
-                break  # (keep room for the record buffers drawn below)
-            if i:
-                cands.append(torch.empty(n + 64, dtype=torch.uint8, device=dev))
-            c = cands[-1]
-            eng.generate(c.data_ptr(), n, rank * n, wl2["kind"], SEED, wl2["plant"], wl2["period"])
-            ms = sorted(probe.scan(c.data_ptr(), n, 0, n, 0, probe_pos.data_ptr(), cap2, time_it=True).kernel_ms for _ in range(4))[1]
-            hay_draws.append(round(ms, 3))
-        probe.close()
-        kept_h = min(range(len(hay_draws)), key=lambda i: hay_draws[i])
-        buf = cands[kept_h]
-        del cands, c, probe_pos
-        torch.cuda.empty_cache()
-    # ONE record buffer for every workload of this run.  Where the driver places a buffer physically decides, per ALLOCATION and
-    # bimodally, how fast the scans that write many records run (profiles/r04_placement.txt: the single-byte workload draws
-    # ~6.57 or ~7.25 ms for the same bytes, whether text and records share one allocation or not, whatever their offsets inside
-    # it; the 8-byte literal moves by 1 %).  An application can only draw again: up to kPlacementTries candidate record buffers
-    # are allocated, the single-byte scan is timed on each (3 launches, outside every timed region), and the first one that runs
-    # within 1.32x of the count-only scan of the same text — the fast mode sits at 1.28x, the slow one at 1.41x — is kept, else
-    # the fastest seen.  `config.placement` says what was drawn.
     names = [args.workload] + ([w for w in ("literal8", "memchr1", "ac1000", "words1000") if w != args.workload]
                                if (world == 1 and not args.no_extra) else [])
     pos_words = 2 * max(positions_capacity(w, n) for w in names)
+    # ONE haystack and ONE record buffer for every workload of this run, taken as the driver places their first allocation.  Where a
+    # buffer lies physically decides, per ALLOCATION and in two modes, how fast the scans over it run (a 32-GiB read stream 2-3 %, the
+    # single-byte workload with its 5 GB of records ~10 %: profiles/r04_placement.txt, r05_run_to_run.txt).  Rounds 3-5 drew candidates
+    # HERE; since round 6 the remedy is the library's (krep_gpu_alloc_placed, kg_place.hip: up to k candidate blocks, the single-byte
+    # workload timed on each, the fastest kept) and --placement-tries k > 1 calls it — outside every timed region, reported under the
+    # line's top-level `placement` key.  The default is 1: the first allocation, no draw.
     placement = None
+    placed_block = None
     if args.placement_tries > 1 and n >= (4 << 30):
-        from krep_amd import abi
-        wl1 = workload("memchr1")
-        eng.generate(buf.data_ptr(), n, rank * n, wl1["kind"], SEED, wl1["plant"], wl1["period"])
-        cnt_plan = eng.plan(abi.Params(wl1["patterns"], count_lines=True, only_match=True), device=local)
-        base_ms = min(cnt_plan.scan(buf.data_ptr(), n, time_it=True).kernel_ms for _ in range(3))
-        cnt_plan.close()
-        rec_plan = eng.plan(abi.Params(wl1["patterns"]), device=local)
-        cap1 = positions_capacity("memchr1", n)
-        cands, draws = [], []
-        for _ in range(args.placement_tries):
-            cand = torch.empty(max(pos_words, 2 * cap1), dtype=torch.int64, device=dev)
-            ms = sorted(rec_plan.scan(buf.data_ptr(), n, 0, n, 0, cand.data_ptr(), cap1, time_it=True).kernel_ms for _ in range(3))[1]
-            cands.append(cand)
-            draws.append(round(ms, 3))
-            if ms <= 1.32 * base_ms:
-                break
-        rec_plan.close()
-        best = min(range(len(draws)), key=lambda i: draws[i])
-        pos = cands[best]
-        del cands, cand
-        torch.cuda.empty_cache()
-        placement = dict(record_buffer_draws_ms=draws, kept=best, count_only_ms=round(base_ms, 3),
-                         rule="first candidate whose single-byte record scan runs within 1.32x of the count-only scan, else the fastest")
-        if hay_draws:
-            placement.update(haystack_draws_ms=hay_draws, haystack_kept=kept_h,
-                             haystack_rule="the candidate haystack on which the 8-byte-literal scan (records included) runs fastest")
+        d_text, d_rec, info = eng.alloc_placed(n, pos_words * 8, args.placement_tries, local)
+        placed_block = d_text  # (the views below live as long as the process: never freed)
+
+        class _Raw:  # (zero-copy torch views of the library's block)
+            def __init__(self, ptr, nbytes, typestr):
+                self.__cuda_array_interface__ = {"shape": (nbytes // int(typestr[-1]),), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+        buf = torch.as_tensor(_Raw(d_text, n + 64, "|u1"), device=dev)
+        pos = torch.as_tensor(_Raw(d_rec, pos_words * 8, "<i8"), device=dev)
+        placement = dict(policy="krep_gpu_alloc_placed (include/krep_gpu.h): the library's placed allocator, text and records in one block",
+                         tries=int(info.tries), kept=int(info.kept),
+                         records_ms=[round(float(x), 3) for x in info.records_ms[:info.tries]],
+                         count_only_ms=[round(float(x), 3) for x in info.count_only_ms[:info.tries]])
     else:
+        buf = torch.empty(n + 64, dtype=torch.uint8, device=dev)
         pos = torch.empty(pos_words, dtype=torch.int64, device=dev)
-        if hay_draws:
-            placement = dict(haystack_draws_ms=hay_draws, haystack_kept=kept_h,
-                             haystack_rule="the candidate haystack on which the 8-byte-literal scan (records included) runs fastest")
 
     res = run_workload(args.workload, args, eng, buf, pos, dev, rank, world, local, use_dist)
     line = None
@@ -712,8 +666,7 @@ def main():
             "verified": res["verified"], "verified_how": res["verified_how"],
         }
         # (top level and short, so that it survives a truncating reader of `config`)
-        line["placement"] = placement or {"haystack_tries": 1, "record_buffer_tries": 1,
-                                          "policy": "the first allocation of each buffer, as the driver places it"}
+        line["placement"] = placement or {"tries": 1, "policy": "the first allocation of each buffer, as the driver places it"}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(wl, min(n, int(args.cpu_sample_gib * (1 << 30))), buf)

@@ -297,12 +297,33 @@ int krep_gpu_plan_ref_algo(const krep_gpu_plan_t *plan); /* enum krep_ref_algo t
  * multi-pattern scan reads whole ALIGNED 16-byte granules and so may touch up to 15 bytes behind text_len inside the granule
  * that holds the last byte (the same page: safe for any allocation, worth knowing for a slice that ends an allocation).
  * Placement: WHERE the driver puts a large allocation moves a 32-GiB read stream by 2-3 % and a scan that also writes GBs of
- * records by ~10 % (two modes, one per allocation) — the library takes the buffers as the caller made them.
+ * records by ~10 % (two modes, one per allocation) — the library takes the buffers as the caller made them;
+ * krep_gpu_alloc_placed() below makes them with the placement drawn for.
  * Returns 0 on success, non-zero on error (krep_gpu_last_error()). */
 int krep_gpu_scan_device(krep_gpu_plan_t *plan, const void *d_text, size_t text_len, size_t own_lo,
                          size_t own_hi, size_t global_base, match_position_t *d_positions,
                          uint64_t position_capacity, void *stream, int time_it,
                          krep_gpu_scan_out_t *out);
+
+/* Device memory for a text and the records of its scans whose PLACEMENT has been drawn for (kg_place.hip).  Allocates up to `tries`
+ * (1..8) candidate blocks of text_bytes (+ 64 bytes of slack) followed by record_bytes on `device`, times the single-byte workload of
+ * BASELINE config 3 on each (the generator's 1 %-density text in the candidate's text area; counting only, and with the records written
+ * into the candidate's record area), keeps the candidate whose record-writing scan ran fastest — the first one that runs within 1.32x of
+ * its own counting scan is taken at once — and frees the others.  *d_text receives the block (hipMalloc alignment), *d_records (may be NULL
+ * when record_bytes == 0) the record area inside the same block, 256-byte aligned; `info` (may be NULL) what was drawn.  The text area
+ * comes back holding the probe's bytes.  tries <= 1, a text of less than 1 GiB or a record area of less than 16 bytes per 64 bytes of the
+ * first GiB: one plain allocation, nothing timed.  Cost per draw at 32 GiB + 8 GiB: the allocation + ~50 ms of probe scans.
+ * Free with krep_gpu_free_placed(device, *d_text).  Returns 0, or 2 (krep_gpu_last_error()). */
+typedef struct krep_gpu_placement
+{
+    uint32_t tries;          /* candidates drawn                                  */
+    uint32_t kept;           /* index of the one returned                         */
+    float count_only_ms[8];  /* per draw: kernel time of the counting scan        */
+    float records_ms[8];     /* per draw: median of three record-writing scans    */
+} krep_gpu_placement_t;
+int krep_gpu_alloc_placed(int device, size_t text_bytes, size_t record_bytes, int tries, void **d_text, void **d_records,
+                          krep_gpu_placement_t *info);
+int krep_gpu_free_placed(int device, void *d_text);
 
 /* The same for a device buffer that is a SLICE [global_base, global_base + text_len) of a text of global_len bytes
  * (global_len == 0: the buffer ends the text).  The reference functions place some of their behaviour by the length of

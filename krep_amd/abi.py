@@ -99,6 +99,11 @@ SEARCH_FUNC = C.CFUNCTYPE(C.c_uint64, C.POINTER(SearchParams), C.c_char_p, C.c_s
                           C.POINTER(MatchResult))
 
 
+class Placement(C.Structure):
+    """krep_gpu_placement_t (include/krep_gpu.h): what krep_gpu_alloc_placed() drew"""
+    _fields_ = [("tries", C.c_uint32), ("kept", C.c_uint32), ("count_only_ms", C.c_float * 8), ("records_ms", C.c_float * 8)]
+
+
 class Params:
     """Owns the Python-side buffers a search_params_t points into."""
 

@@ -116,6 +116,26 @@ struct Arena
         HIPCHK(hipSetDevice(device));
         if (kg::inject(1))
             return kg::fail("injected failure: device allocation of %zu bytes", total);
+        // $KREP_GPU_PLACE_TRIES=k (2..8): an arena of >= 4 GiB is drawn for (kg_place.hip krep_gpu_alloc_placed: up to k candidates, the
+        // single-byte workload timed on each, the fastest kept).  Off by default: the host path stages its text over PCIe at <= 55 GB/s, next
+        // to which the 2-10 % of a scan that placement moves are not visible, and every draw costs an allocation + ~50 ms of probe scans.
+        static const int place_tries = [] { const char *e = getenv("KREP_GPU_PLACE_TRIES"); return e ? atoi(e) : 1; }();
+        if (place_tries > 1 && total >= ((size_t)4 << 30))
+        {
+            void *t = nullptr, *r = nullptr;
+            // (the arena's layout: n text buffers in a row, the record area behind them — the probe treats the row as one text)
+            if (krep_gpu_alloc_placed(device, (size_t)n * want_each - 64, want_pos, place_tries, &t, &r, nullptr) == 0)
+            {
+                base = (uint8_t *)t;
+                cap = total;
+                ntext = n;
+                text_each = want_each;
+                pos_bytes = want_pos;
+                dev = device;
+                return 0;
+            }
+            krep_gpu_clear_error(); // (the plain allocation below is tried before anything is reported)
+        }
         if (hipMalloc(&base, total) != hipSuccess)
         {
             base = nullptr;

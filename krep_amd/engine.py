@@ -127,6 +127,12 @@ class Engine:
             L.krep_gpu_debug_anchor_info.restype = C.c_int
             L.krep_gpu_debug_anchor_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_uint32), C.POINTER(C.c_double),
                                                      C.POINTER(C.c_double)]
+        if hasattr(L, "krep_gpu_alloc_placed"):
+            L.krep_gpu_alloc_placed.restype = C.c_int
+            L.krep_gpu_alloc_placed.argtypes = [C.c_int, C.c_size_t, C.c_size_t, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                                C.POINTER(abi.Placement)]
+            L.krep_gpu_free_placed.restype = C.c_int
+            L.krep_gpu_free_placed.argtypes = [C.c_int, C.c_void_p]
         if hasattr(L, "krep_gpu_debug_literal_dma_state"):
             L.krep_gpu_debug_literal_dma_state.restype = C.c_int
             L.krep_gpu_debug_literal_dma_state.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]
@@ -196,6 +202,17 @@ class Engine:
 
     def literal_dma_launches(self) -> int:
         return int(self.lib.krep_gpu_debug_literal_dma_launches())
+
+    def alloc_placed(self, text_bytes: int, record_bytes: int, tries: int = 3, device: int = 0):
+        """krep_gpu_alloc_placed(): (d_text, d_records, abi.Placement) — one block, its placement drawn for; free_placed(d_text)"""
+        t, r, info = C.c_void_p(0), C.c_void_p(0), abi.Placement()
+        if self.lib.krep_gpu_alloc_placed(device, text_bytes, record_bytes, tries, C.byref(t), C.byref(r), C.byref(info)):
+            raise KrepGpuError("krep_gpu_alloc_placed failed: " + self.last_error())
+        return int(t.value), int(r.value or 0), info
+
+    def free_placed(self, d_text: int, device: int = 0):
+        if self.lib.krep_gpu_free_placed(device, C.c_void_p(d_text)):
+            raise KrepGpuError("krep_gpu_free_placed failed: " + self.last_error())
 
     def anchored_launches(self) -> int:
         return int(self.lib.krep_gpu_debug_anchored_launches())
