@@ -601,8 +601,47 @@ __global__ __launch_bounds__(kBlock, (KIND == 1 && LINES && R == 4) ? KG_LIT1_LI
                         m16 = 0;
                     }
                 }
-                // rare refinement on candidate lanes: verify the pattern tail (m > 8) and -w
-                if (KIND != 10 && (KIND == 9 || ww) && __ballot(m16 != 0u))
+                // -w for m <= 8 (round 6): both neighbours of every start position of the lane lie in registers — the 24-byte window and,
+                // for position 0, the last byte of the lane below (one shuffle per cell that holds a candidate) — and are picked out of
+                // them by a select chain: ~35 VALU per candidate, no memory access (lane 0's position 0 excepted: the byte in front of
+                // the cell).  The loop used to pay two dependent byte loads per candidate: `-w the` on word text (a candidate
+                // every 130 bytes) counted at 2.5 TB/s where `tion` counts at 6.5.
+                if (KIND != 10 && KIND != 9 && ww && __ballot(m16 != 0u))
+                {
+                    u32 d4 = D[4], d5 = D[5];
+                    if (KIND == 1 && fast) // (the single-byte kinds do not build the window's tail: byte 16 is the lane above's first)
+                    {
+                        const u32 n0 = __shfl_down(D[0], 1);
+                        const u32 e0 = (j + 1 < kCells) ? __builtin_amdgcn_readfirstlane(d[(j + 1 < kCells) ? j + 1 : j].x) : after.x;
+                        d4 = (lane == 63u) ? e0 : n0;
+                        d5 = 0u;
+                    }
+                    const u32 below = __shfl_up(D[3], 1); // byte 3: the byte in front of this lane's position 0
+                    // byte i of the 28-byte sequence [below | D0 D1 D2 D3 | d4 d5]: the left neighbour of position k is byte k + 3, the right
+                    // one byte k + m + 4
+                    auto pick = [&](u32 i) -> u32 {
+                        const u32 q = i >> 2;
+                        const u32 w = q == 0u ? below : q == 1u ? D[0] : q == 2u ? D[1] : q == 3u ? D[2] : q == 4u ? D[3] : q == 5u ? d4 : d5;
+                        return (w >> (8u * (i & 3u))) & 0xffu;
+                    };
+                    u32 rest = m16;
+                    while (rest)
+                    {
+                        const u32 k = __builtin_ctz(rest);
+                        rest &= rest - 1u;
+                        const u64 p = lbase + k;
+                        bool left = is_wordc(pick(k + 3u));
+                        if (lane == 0u && k == 0u)
+                            left = p > 0 && is_wordc(a.text[p - 1]);
+                        if (p == a.ww_exempt_left) // (the first byte of a scalar tail call has no left neighbour: krep.c:5059-5097)
+                            left = false;
+                        // (a right neighbour behind the text reads as 0 in the guarded window, and a full round has its 8 bytes)
+                        if (left || is_wordc(pick(k + a.m + 4u)))
+                            m16 &= ~(1u << k);
+                    }
+                }
+                // rare refinement on candidate lanes: verify the pattern tail (m > 8) and its -w
+                if (KIND == 9 && __ballot(m16 != 0u))
                 {
                     // (wave-uniform branch) the next lane's bytes 8..15 for the in-register verify of m = 9..16
                     const bool inreg = KIND == 9 && fast && a.m <= 16u;

@@ -375,12 +375,27 @@ __global__ __launch_bounds__(kBlock, 2) void lit_scan_dma(const LitArgs a)
                 }
                 if (ww && __ballot(m16 != 0u))
                 {
+                    // -w in registers (kg_literal.hip): the neighbours picked out of the lane's window and the lane below's last dword; the
+                    // byte in front of lane 0 and the bytes behind a DMA round (lane 63 of its last cell) come from memory
+                    const u32 below = __shfl_up(D[3], 1);
+                    auto pick = [&](u32 i) -> u32 {
+                        const u32 q = i >> 2;
+                        const u32 w = q == 0u ? below : q == 1u ? D[0] : q == 2u ? D[1] : q == 3u ? D[2] : q == 4u ? D[3] : q == 5u ? D[4] : D[5];
+                        return (w >> (8u * (i & 3u))) & 0xffu;
+                    };
+                    const bool edge = dma_cur && j == kCells - 1 && lane == 63u;
                     u32 rest = m16;
                     while (rest)
                     {
                         const u32 k = __builtin_ctz(rest);
                         rest &= rest - 1u;
-                        if (!word_ok(lbase + k))
+                        const u64 p = lbase + k;
+                        bool bad;
+                        if (edge || (lane == 0u && k == 0u))
+                            bad = !word_ok(p);
+                        else
+                            bad = (p != a.ww_exempt_left && d_wordc(pick(k + 3u))) || d_wordc(pick(k + a.m + 4u));
+                        if (bad)
                             m16 &= ~(1u << k);
                     }
                 }

@@ -299,7 +299,7 @@ static int lit_pass(krep_gpu_plan *pl, const Window &w, const LitPass &ps, hipSt
                 pl->fused1_shape = shape;
             }
         }
-        else if (m_scan <= 8 && !ps.ww && !pl->fusedk_never && per_unit >= fusedk_min_hits_per_unit() &&
+        else if (m_scan <= 8 && !pl->fusedk_never && per_unit >= fusedk_min_hits_per_unit() &&
                  density <= single_fused_max_density(kFusedShapeMax))
         {
             int shape = 0;
@@ -317,7 +317,8 @@ static int lit_pass(krep_gpu_plan *pl, const Window &w, const LitPass &ps, hipSt
             a.stage_cap = a.rounds == kRoundsBig ? (m_scan == 1 ? 512u : pl->sparse_cap) : a.stage_cap;
     }
     const bool fusedk = m_scan >= 2 && m_scan <= 8 && pl->fusedk_on;
-    if ((m_scan == 1 ? pl->fused1_ok : fusedk) && ps.sink == LitPass::RECORDS && !ps.ww && !ps.lines && !ps.first_byte &&
+    // (-w: the 2..8-byte instantiations test it in registers since round 6; the single-byte ones do not build the window it needs)
+    if ((m_scan == 1 ? pl->fused1_ok : fusedk) && ps.sink == LitPass::RECORDS && !(ps.ww && m_scan == 1) && !ps.lines && !ps.first_byte &&
         a.rounds == kRoundsBig && fsc == 0 && ps.excl_lo == ps.excl_hi && w.text_len >= 2 * (size_t)kSegBytes &&
         !getenv("KREP_GPU_NO_FUSED1"))
     {
@@ -416,7 +417,7 @@ static int lit_pass(krep_gpu_plan *pl, const Window &w, const LitPass &ps, hipSt
             pl->sparse_cap = std::max(pl->sparse_cap, want);
         }
         if ((a.flags & F_POS) && m_scan >= 2 && m_scan <= 8 && a.rounds == kRoundsBig && !fsc && !pl->fusedk_never &&
-            ps.sink == LitPass::RECORDS && !ps.ww && !ps.lines && hi_match > a.anchor)
+            ps.sink == LitPass::RECORDS && !ps.lines && hi_match > a.anchor)
         {
             // dense enough for the one-pass record writer (kg_single.hip, MULTI)?  Its shape from the density just counted.
             const double density = (double)pl->h_ctr->total / (double)(hi_match - a.anchor);

@@ -106,6 +106,8 @@ __device__ __noinline__ uint4 s_load16_guarded(const uint8_t *text, u64 text_len
 // stands; a wave at the barrier holds nothing unpublished.  The resolver's own workgroup cannot use the barrier (its wave 0 never
 // gets there): its other three waves keep drawing one ticket each from the same counter — any mix of draws leaves a prefix — so a
 // device that runs a single workgroup of the grid still makes progress.
+__device__ __forceinline__ bool s_wordc(u32 c) { return (c - '0' < 10u) || ((c | 0x20u) - 'a' < 26u) || c == '_'; }
+
 template <bool CI, u32 kUpt, u32 kRing, int WPE, bool SET, bool MULTI = false, bool BDRAW = false>
 __global__ __launch_bounds__(kBlock, WPE) void single_fused(const LitArgs a, u64 *__restrict__ agg, u64 *__restrict__ pref,
                                                             const u64 n_tickets)
@@ -281,6 +283,32 @@ __global__ __launch_bounds__(kBlock, WPE) void single_fused(const LitArgs a, u64
                     for (int k = 0; k < 16; ++k)
                         if ((((CI ? (A(k + 4) | a.l1) : A(k + 4)) ^ a.p1) & a.k1) != 0u)
                             m16 &= ~(1u << k);
+                }
+                // -w (round 6; is_whole_word_match krep.h:312-319): both neighbours of a start position lie in the 24-byte window or — position
+                // 0 — in the lane below's last dword, and are picked out of registers (kg_literal.hip); only lane 0's position 0 asks memory
+                if ((a.flags & F_WW) && __ballot(m16 != 0u))
+                {
+                    const u32 below = __shfl_up(D[3], 1);
+                    const u64 lb = seg + (u64)j * kCellBytes + (u64)lane * 16u;
+                    auto pick = [&](u32 i) -> u32 {
+                        const u32 q = i >> 2;
+                        const u32 w = q == 0u ? below : q == 1u ? W[0] : q == 2u ? W[1] : q == 3u ? W[2] : q == 4u ? W[3] : q == 5u ? W[4] : W[5];
+                        return (w >> (8u * (i & 3u))) & 0xffu;
+                    };
+                    u32 rest = m16;
+                    while (rest)
+                    {
+                        const u32 k = __builtin_ctz(rest);
+                        rest &= rest - 1u;
+                        const u64 p = lb + k;
+                        bool left = s_wordc(pick(k + 3u));
+                        if (lane == 0u && k == 0u)
+                            left = p > 0 && s_wordc(a.text[p - 1]);
+                        if (p == a.ww_exempt_left)
+                            left = false;
+                        if (left || s_wordc(pick(k + a.m + 4u)))
+                            m16 &= ~(1u << k);
+                    }
                 }
             }
             else if (SET)

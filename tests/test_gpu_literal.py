@@ -448,3 +448,55 @@ def test_dense_short_literals_take_the_one_pass_record_writer(gpu, oracle_engine
 def plan_is_all_occurrence(gpu, p, n):
     """the literal kernels with a RECORDS sink serve the all-occurrence functions directly; greedy families go through the walk"""
     return gpu.mirror_select(p, n) in (abi.RA_BMH, abi.RA_MEMCHR_SHORT, abi.RA_MEMCHR)
+
+
+def test_dense_short_literals_whole_word_in_one_pass(gpu, oracle_engine):
+    """-w on the one-pass record writer and in the two-pass kernels (round 6): the neighbours of a start position are taken from the
+    lane's registers — the 24-byte window, the lane below's last dword — not from memory.  Texts made of the pattern as a word, the
+    pattern inside words, and every neighbour class is_whole_word_match (krep.h:312-319) tells apart (letters, digits, '_', blank,
+    punctuation, bytes >= 0x80), with occurrences on every seam: lane 0 of a cell (the byte in front comes from the lane above the
+    seam or, for lane 0 of a cell, from memory), cells, rounds, units, the first and the last bytes of the text."""
+    import torch
+    rng = np.random.RandomState(4242)
+    n = 5 * (1 << 20) + 777
+    gpu.force_rounds(4)
+    try:
+        for pat in (b"the", b"ab", b"word", b"hello", b"Sherloc", b"a1b2c3d4"):
+            m = len(pat)
+            toks = [pat, pat, pat + b"s", b"x" + pat, b"_" + pat, pat + b"9", b"\xc3" + pat, pat + b"\xa9", b" ", b" ", b"\n", b",", b".", b"-", b"(", b")",
+                    b"qq", b" "] * 2
+            dense = np.frombuffer(b"".join(toks[i] for i in rng.randint(0, len(toks), n))[:n], dtype=np.uint8).copy()
+            assert len(dense) == n
+            for at in (0, 16, 1024, 1024 - m, 8192, 8192 - 1, 32768, 32768 - m + 1, 131072, 3 * 131072 - 2, n - m, n - m - 1):
+                dense[at:at + m] = np.frombuffer(pat, dtype=np.uint8)
+                if at:
+                    dense[at - 1] = rng.choice(np.frombuffer(b" a_7.\xe9", dtype=np.uint8))
+                if at + m < n:
+                    dense[at + m] = rng.choice(np.frombuffer(b" z_0,\x80", dtype=np.uint8))
+            sparse = cases.rand_text(rng, n, bytes(range(65, 91)) * 4 + b"  ")
+            for kw in (dict(whole_word=True), dict(whole_word=True, case_sensitive=False)):
+                p = abi.Params([pat], **kw)
+                algo = gpu.mirror_select(p, n)
+                want_dense = oracle_engine.call(algo, abi.Params([pat], **kw), dense)
+                assert want_dense[0] > n // 400, (pat, kw, want_dense[0])
+                plan = gpu.plan(abi.Params([pat], **kw))
+                launches = []
+                for ti, text in enumerate((dense, dense, dense, sparse, dense, dense)):
+                    want = want_dense if text is dense else oracle_engine.call(algo, abi.Params([pat], **kw), text)
+                    d = torch.from_numpy(text).cuda()
+                    cap = int(want[0]) + 3
+                    pos = torch.zeros(2 * cap, dtype=torch.int64, device="cuda")
+                    before = gpu.single_launches()
+                    out = plan.scan(d.data_ptr(), n, 0, n, 0, pos.data_ptr(), cap)
+                    launches.append(gpu.single_launches() - before)
+                    assert out.count == want[0] and not out.overflow, (pat, kw, ti, out.count, want[0])
+                    got = pos[:2 * out.count].cpu().numpy().astype(np.uint64).reshape(-1, 2)
+                    assert np.array_equal(got, want[1]), (pat, kw, ti)
+                    # counting only (the two-pass kernels without their stores) agrees
+                    assert plan.scan(d.data_ptr(), n).count == want[0]
+                    del d, pos
+                plan.close()
+                if plan_is_all_occurrence(gpu, p, n):
+                    assert launches[0] == 0 and launches[1] >= 1 and launches[5] >= 1, (pat, kw, launches)
+    finally:
+        gpu.force_rounds(0)
