@@ -748,10 +748,15 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                         {
                             // stage 3 through the length-keyed exact dictionary (kg_ac_common.h ac_exact_end): no trie, no chain
                             bool muA = false, muB = false;
+#ifndef KG_AC_EXACT_SERIAL // (A/B switch of krep_amd/build.py --variant: the two ends one behind the other, as first built)
+                            if (liveA || liveB)
+                                ac_exact_end2<CI>(a, pos, liveA, liveB, mA, mB, muA, muB);
+#else
                             if (liveA)
                                 mA = ac_exact_end<CI>(a, pos, muA);
                             if (liveB)
                                 mB = ac_exact_end<CI>(a, pos + 1u, muB);
+#endif
                             // start ownership (the same clip as ac_eval_entry's)
                             auto clip = [&](u32 m, u64 end) -> u32 {
                                 const u64 e = end + 1;

@@ -692,6 +692,87 @@ __device__ __forceinline__ u32 ac_exact_end(const AcArgs &a, u64 i, bool &multi)
     return dm;
 }
 
+// The same for BOTH ends of a marked pair, i and i + 1 (stage 3 of the anchored scan), interleaved: one 17-byte window, the four length
+// masks requested together, then per step the longest remaining length of EACH end — both buckets in flight at once.  Two calls of
+// ac_exact_end run their round trips one behind the other (2 + nA, then 2 + nB); this runs 2 + max(nA, nB).
+template <bool CI>
+__device__ __forceinline__ void ac_exact_end2(const AcArgs &a, u64 i, bool liveA, bool liveB, u32 &dmA, u32 &dmB, bool &multiA, bool &multiB)
+{
+    struct __attribute__((packed)) U32p { u32 v; };
+    const U32p *q = reinterpret_cast<const U32p *>(a.text + (i - 15));
+    u32 TA[4] = {q[0].v, q[1].v, q[2].v, q[3].v};
+    const u32 nxt = liveB ? (u32)a.text[i + 1] : 0u; // (a live end i + 1 lies inside the text)
+    u32 TB[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+        TB[w] = __builtin_amdgcn_alignbyte(w < 3 ? TA[w < 3 ? w + 1 : 3] : nxt, TA[w], 1u);
+    if (CI)
+    {
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+        {
+            TA[w] = ac_fold4(TA[w]);
+            TB[w] = ac_fold4(TB[w]);
+        }
+    }
+    const u32 a4 = a.xlen[ac_xlen_slot(TA[3])], a8 = a.xlen[65536u + ac_xlen_slot8(TA[2], TA[3])];
+    const u32 b4 = a.xlen[ac_xlen_slot(TB[3])], b8 = a.xlen[65536u + ac_xlen_slot8(TB[2], TB[3])];
+    u32 lmA = liveA ? ((a4 & 0xfu) | (a8 & 0x1ff0u)) : 0u, lmB = liveB ? ((b4 & 0xfu) | (b8 & 0x1ff0u)) : 0u;
+    dmA = dmB = 0;
+    multiA = multiB = false;
+    auto keep = [](const u32 (&T)[4], u32 len, u32 (&M)[4]) { // the last `len` bytes of the 16, the bytes in front zeroed
+        const u32 drop = 16u - len;
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+        {
+            const u32 lo = 4u * (u32)w;
+            M[w] = drop >= lo + 4u ? 0u : drop <= lo ? T[w] : (T[w] & (0xffffffffu << (8u * (drop - lo))));
+        }
+    };
+    while (lmA | lmB)
+    {
+        const bool doA = lmA != 0u, doB = lmB != 0u;
+        const u32 bA = doA ? 31u - (u32)__builtin_clz(lmA) : 0u, bB = doB ? 31u - (u32)__builtin_clz(lmB) : 0u;
+        const u32 lenA = bA + 4u, lenB = bB + 4u;
+        lmA &= ~(1u << bA);
+        lmB &= ~(1u << bB);
+        u32 MA[4], MB[4];
+        keep(TA, lenA, MA);
+        keep(TB, lenB, MB);
+        const uint4 *bkA = a.xtab + 4u * (size_t)(ac_xhash(MA[0], MA[1], MA[2], MA[3], lenA, a.xmul) & a.xmask);
+        const uint4 *bkB = a.xtab + 4u * (size_t)(ac_xhash(MB[0], MB[1], MB[2], MB[3], lenB, a.xmul) & a.xmask);
+        uint4 eA0 = make_uint4(0, 0, 0, 0), mA0 = eA0, eA1 = eA0, mA1 = eA0, eB0 = eA0, mB0 = eA0, eB1 = eA0, mB1 = eA0;
+        if (doA)
+        {
+            eA0 = bkA[0]; mA0 = bkA[1]; eA1 = bkA[2]; mA1 = bkA[3];
+        }
+        if (doB)
+        {
+            eB0 = bkB[0]; mB0 = bkB[1]; eB1 = bkB[2]; mB1 = bkB[3];
+        }
+        if (doA)
+        {
+            const bool h0 = mA0.x == lenA && eA0.x == MA[0] && eA0.y == MA[1] && eA0.z == MA[2] && eA0.w == MA[3];
+            const bool h1 = mA1.x == lenA && eA1.x == MA[0] && eA1.y == MA[1] && eA1.z == MA[2] && eA1.w == MA[3];
+            if (h0 || h1)
+            {
+                dmA |= 1u << lenA;
+                multiA = multiA || (h0 ? mA0.y : mA1.y) != 1u;
+            }
+        }
+        if (doB)
+        {
+            const bool h0 = mB0.x == lenB && eB0.x == MB[0] && eB0.y == MB[1] && eB0.z == MB[2] && eB0.w == MB[3];
+            const bool h1 = mB1.x == lenB && eB1.x == MB[0] && eB1.y == MB[1] && eB1.z == MB[2] && eB1.w == MB[3];
+            if (h0 || h1)
+            {
+                dmB |= 1u << lenB;
+                multiB = multiB || (h0 ? mB0.y : mB1.y) != 1u;
+            }
+        }
+    }
+}
+
 constexpr u32 kAcUnitsPerTicketMax = 8; // fused kernel: up to 128 KiB per wave ticket (one cold round in 16), fewer on small texts
 constexpr int kAcRounds = 2;            // load rounds per unit: one candidate drain per 16 KiB (53 of 64 lanes busy)
 constexpr u32 kAcUnitBytes = kAcRounds * kSegBytes;
