@@ -122,6 +122,14 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
       uint4 d[kCells];
       bool have = false; // d[] holds (or is receiving) the round about to be processed (uniform)
       u32 carry = 0;     // the 4 bytes in front of that round (valid when have)
+      // ANCH, stage 3 DEFERRED over the ticket (round 6): a unit of word text marks ~6 END pairs — a verify batch of 6 lanes that waits
+      // for three dependent round trips (window, length masks, bucket) like a full one.  The marked pairs of the ticket's units are
+      // collected instead — one per lane in `pend` (unit of the ticket << 14 | pair), verified when 64 are there or the ticket ends —
+      // and the units' match counts wait in lanes 0..7 of `ucnt` until the ticket's info words are written.  Ranking and emission
+      // stay per unit, in END order: the pairs arrive unit by unit, ascending.
+      const bool defer = ANCH != 0 && !emit_final && a.xtab != nullptr && !(a.flags & (F_WW | (1u << 27) | (1u << 28) | (1u << 30) | (1u << 31))) &&
+                         a.upt <= kAcUnitsPerTicketMax;
+      u32 pend = 0, npend = 0, ucnt = 0;
       for (u64 unit = u_begin; unit < u_end; ++unit)
       {
         const u64 useg = a.anchor + unit * (u64)kAcUnitBytes; // the unit = kAcRounds load rounds of 8 KiB
@@ -415,6 +423,9 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
         //      select of the t-th set bit in the owner's block ------------------------------------------------
         // the matches of one batch (one END pair per lane: cA at pos, cB at pos + 1, depth masks or the level walk's verdict):
         // unit-local ranks by a wave prefix, then staging slots / final records / the -c hit bitmap, longest first at one end
+        // (what an emission refers to: this unit — or, for the deferred stage 3 of the anchored scan, the unit a pending pair belongs to)
+        u64 e_useg = useg, e_fbase = fbase;
+        u32 *e_slot = slot;
         auto rank_and_emit = [&](const u64 pos, const u32 cA, const u32 cB, const u64 dmA, const u64 dmB, const bool simA, const bool simB)
             __attribute__((always_inline)) {
             const u32 c = cA + cB;
@@ -435,7 +446,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 if (!ce)
                     continue;
                 const u64 pe = pos + (u64)e, dme = e ? dmB : dmA;
-                const u32 re = rank0 + (e ? cA : 0u), rele = (u32)(pe - useg); // the END's bit in the unit's hit bitmap
+                const u32 re = rank0 + (e ? cA : 0u), rele = (u32)(pe - e_useg); // the END's bit in the unit's hit bitmap
                 const bool sime = e ? simB : simA;
                 if (LINES)
                     atomicOr(&bitmap[rele >> 5], 1u << (rele & 31u));
@@ -445,11 +456,11 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                         if (do_stage)
                         {
                             if (at < a.stage_cap)
-                                slot[at] = ((u32)(s0 + 1024u - useg) << 11) | len; // start relative to the unit (>= -1023), length <= 1024
+                                e_slot[at] = ((u32)(s0 + 1024u - e_useg) << 11) | len; // start relative to the unit (>= -1023), length <= 1024
                         }
                         else
                         {
-                            const u64 g = fbase + at;
+                            const u64 g = e_fbase + at;
                             if (g < a.pos_cap)
                             {
                                 const u64 st = s0 + a.global_base, en = st + len;
@@ -643,10 +654,138 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 }
             }
         }
+        // the verification of ONE END pair per lane (ends pos and pos + 1): the number of matches at either end, their depth masks (or the
+        // level walk's verdict) — everything of a verify batch except its ranking and emission
+        auto verify_ends = [&](const u64 pos, const bool live, const bool isx, const u64 vuseg, u32 &cA, u32 &cB, u64 &dmA, u64 &dmB, bool &simA,
+                               bool &simB) __attribute__((always_inline)) {
+            bool liveA = live, liveB = false;
+            if (STRIDE == 2)
+                liveA = live && pos >= a.end_lo && pos < a.end_hi;
+            if (STRIDE == 2) // a candidate stands for the ends t and t + 1
+                liveB = (live || isx) && pos + 1 >= a.end_lo && pos + 1 < a.end_hi &&
+                        (!XCAND || pos + 1 < vuseg + kAcUnitBytes); // (-c: that end belongs to the next unit's extra candidate)
+            cA = cB = 0;
+            dmA = dmB = 0;
+            simA = simB = false;
+            if (STRIDE == 2)
+            {
+                bool slA = false, slB = false;
+                u32 mA = 0, mB = 0;
+#ifndef KG_AC_NO_BTEST // (A/B switches of krep_amd/build.py --variant)
+                constexpr bool kGram = PAIR && XB == 20 && !ANCH; // the probe asks the class table about both ends (kg_ac_common.h; ANCH: the table holds anchor grams, not end grams)
+#else
+                constexpr bool kGram = false;
+#endif
+#ifndef KG_AC_NO_STAGE
+                constexpr bool kStaged = kGram;
+#else
+                constexpr bool kStaged = false;
+#endif
+                bool exact_done = false;
+                if constexpr (ANCH != 0)
+                    if (a.xtab && !(a.flags & F_WW) && pos >= 15u)
+                    {
+                        // stage 3 through the length-keyed exact dictionary (kg_ac_common.h ac_exact_end): no trie, no chain
+                        bool muA = false, muB = false;
+#ifndef KG_AC_EXACT_SERIAL // (A/B switch of krep_amd/build.py --variant: the two ends one behind the other, as first built)
+                        if (liveA || liveB)
+                            ac_exact_end2<CI>(a, pos, liveA, liveB, mA, mB, muA, muB);
+#else
+                        if (liveA)
+                            mA = ac_exact_end<CI>(a, pos, muA);
+                        if (liveB)
+                            mB = ac_exact_end<CI>(a, pos + 1u, muB);
+#endif
+                        // start ownership (the same clip as ac_eval_entry's)
+                        auto clip = [&](u32 m, u64 end) -> u32 {
+                            const u64 e = end + 1;
+                            if (e <= a.own_lo)
+                                return 0u;
+                            if (e - a.own_lo < 32)
+                                m &= (2u << (u32)(e - a.own_lo)) - 1u;
+                            if (e > a.own_hi)
+                                m = (e - a.own_hi < 32) ? (m & ~((2u << (u32)(e - a.own_hi)) - 1u)) : 0u;
+                            return m;
+                        };
+                        mA = clip(mA, pos);
+                        mB = clip(mB, pos + 1u);
+                        slA = muA && mA != 0u; // (a pattern the dictionary holds twice: counted and emitted by the level walk)
+                        slB = muB && mB != 0u;
+                        exact_done = true;
+                    }
+                if (exact_done)
+                {
+                }
+                else if (!(a.flags & (1u << 30))) // (ablation hook KREP_GPU_AC_NOPROBE: candidate enumeration without the probes)
+                    ac_walk_probe2<CI, SHORT, kStaged>(a, pos, liveA, liveB, LINES, mA, slA, mB, slB, [&](u32 E) -> bool {
+                        if constexpr (kGram)
+                        {
+                            // the filter's own lookup for a gram that lies in one dword (cell_body, k = 3 mod 4)
+                            typedef __attribute__((address_space(3))) const u32 lds_u32;
+                            const u32 u = ac_pair(E);
+                            return ((*(lds_u32 *)(size_t)(((u >> 3) ^ (u >> 13)) & kTabMask) >> (u & 31u)) & 1u) != 0u;
+                        }
+                        else
+                            return true;
+                    });
+                else
+                    mA = liveA ? 1u : 0u; // ... and the count that comes back is the number of candidates
+                dmA = mA; dmB = mB;
+                cA = (u32)__popc(mA); cB = (u32)__popc(mB);
+                simA = simB = true;
+#ifndef KG_AC_NO_EXACT_SLOW // (A/B switch of krep_amd/build.py --variant)
+                if constexpr (!SHORT && ANCH == 0 && !CI) // (-i: eight bytes of scratch per lane in the BASELINE-shaped kernel for a path the anchored instantiations cover)
+                    if (a.xtab && !(a.flags & F_WW) && pos >= 15u && (slA || slB))
+                    {
+                        // an end the chain-compressed entry cannot answer (the trie branches behind its final gram): the exact dictionary
+                        // instead of the level walk, where there is one (a word-like text, patterns of 4..16 bytes)
+                        auto clipx = [&](u32 m, u64 end) -> u32 {
+                            if (LINES)
+                                return m; // (-c owns by END)
+                            const u64 e = end + 1;
+                            if (e <= a.own_lo)
+                                return 0u;
+                            if (e - a.own_lo < 32)
+                                m &= (2u << (u32)(e - a.own_lo)) - 1u;
+                            if (e > a.own_hi)
+                                m = (e - a.own_hi < 32) ? (m & ~((2u << (u32)(e - a.own_hi)) - 1u)) : 0u;
+                            return m;
+                        };
+                        bool mu = false;
+                        if (slA)
+                        {
+                            const u32 m = clipx(ac_exact_end<CI>(a, pos, mu), pos);
+                            if (!mu || !m) { mA = m; slA = false; }
+                        }
+                        if (slB)
+                        {
+                            const u32 m = clipx(ac_exact_end<CI>(a, pos + 1u, mu), pos + 1u);
+                            if (!mu || !m) { mB = m; slB = false; }
+                        }
+                        dmA = mA; dmB = mB;
+                        cA = (u32)__popc(mA); cB = (u32)__popc(mB);
+                    }
+#endif
+#pragma unroll 1
+                for (int e = 0; e < 2; ++e) // the one call site of the level walk
+                    if (e ? slB : slA)
+                    {
+                        u64 dm;
+                        bool sim;
+                        const u32 c = ac_walk_slow<CI, SHORT>(a, pos + (u64)e, LINES, dm, sim);
+                        if (e) { cB = c; dmB = dm; simB = sim; }
+                        else { cA = c; dmA = dm; simA = sim; }
+                    }
+            }
+            else if (liveA)
+                cA = ac_walk_fast<CI, SHORT>(a, pos, LINES, dmA, simA);
+        };
         // (ANCH: what follows is stage 3 — the same verify, over the END-pair bitmap instead of the candidate bitmap)
         const u32 *vbits = ANCH ? ebits : cbits;
-        if (ANCH && (a.flags & (1u << 28))) // (ablation hook KREP_GPU_AC_NOSTAGE3: the anchor stage alone; the count is the number of marked END pairs)
+        if constexpr (ANCH != 0)
         {
+          if (a.flags & (1u << 28)) // (ablation hook KREP_GPU_AC_NOSTAGE3: the anchor stage alone; the count is the number of marked END pairs)
+          {
             const uint4 m = *reinterpret_cast<const uint4 *>(ebits + lane * 4u);
             u32 c = (u32)(__popc(m.x) + __popc(m.y) + __popc(m.z) + __popc(m.w));
 #pragma unroll
@@ -654,8 +793,112 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 c += __shfl_xor(c, o);
             wcnt += c;
             *reinterpret_cast<uint4 *>(ebits + lane * 4u) = make_uint4(0u, 0u, 0u, 0u);
+          }
+          else if (!(a.flags & (1u << 30)))
+          {
+            // ---- the unit's marked pairs join the pending ones; 64 pending pairs are a verify batch.  Deferred: what is left waits for the
+            //      ticket's next unit; otherwise (emit mode, -w, no exact dictionary) it is verified here, at the unit's end ----
+            // (registers: nothing of the collection below lives across a batch, and a pair's position is re-derived from its `pend` word —
+            //  kept live they cost the anchored instantiations 20-28 B/lane of scratch, whose reloads drain the text prefetch)
+            auto pos_of = [&]() -> u64 { // (bit b of a unit's END bitmap <-> the pair 2b + 1, 2b + 2)
+                return a.anchor + (u_begin + (u64)(pend >> 14)) * (u64)kAcUnitBytes + ((pend & 0x3fffu) << 1) + 1u;
+            };
+            auto flush = [&](const u32 cnt) __attribute__((always_inline)) {
+                const bool live = lane < cnt;
+                u32 cA, cB;
+                u64 dmA, dmB;
+                bool simA, simB;
+                verify_ends(pos_of(), live, false, 0ull, cA, cB, dmA, dmB, simA, simB);
+                const u32 cc = cA | (cB << 8);
+                const u32 v0 = (u32)__builtin_amdgcn_readfirstlane((int)(pend >> 14)), v1 = (u32)__builtin_amdgcn_readlane((int)(pend >> 14), (int)(cnt - 1u));
+                for (u32 v = v0; v <= v1; ++v) // (uniform: the units the batch spans, ascending; not deferred: this unit)
+                {
+                    const bool in = live && (pend >> 14) == v;
+                    if (!__ballot(in))
+                        continue;
+                    if (defer)
+                    {
+                        e_useg = a.anchor + (u_begin + (u64)v) * (u64)kAcUnitBytes;
+                        e_slot = reinterpret_cast<u32 *>(a.stage) + (u_begin + (u64)v) * (u64)a.stage_cap;
+                        wcnt = (u32)__builtin_amdgcn_readlane((int)ucnt, (int)v);
+                    }
+                    rank_and_emit(pos_of(), in ? (cc & 0xffu) : 0u, in ? (cc >> 8) : 0u, dmA, dmB, simA, simB);
+                    if (defer && lane == v)
+                        ucnt = wcnt;
+                }
+                if (defer)
+                    wcnt = 0;
+            };
+            const u32 uv = (u32)(unit - u_begin);
+            u32 n = 0, mycnt = 0, incl = 0;
+            auto recount = [&]() { // the marked pairs per lane (four dwords of the bitmap each) and their inclusive prefix
+                const uint4 lo = *reinterpret_cast<const uint4 *>(ebits + lane * 4u);
+                mycnt = (u32)(__popc(lo.x) + __popc(lo.y) + __popc(lo.z) + __popc(lo.w));
+                incl = mycnt;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1)
+                {
+                    const u32 t = __shfl_up(incl, o);
+                    if (lane >= (u32)o)
+                        incl += t;
+                }
+                n = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+            };
+            recount();
+            u32 taken = 0;
+            do // (ONE call site of the verify batch: it is inlined, and two copies cost the anchored instantiations 12-20 B/lane of scratch)
+            {
+                const u32 room = 64u - npend, take = room < n - taken ? room : n - taken;
+                const bool mine = lane >= npend && lane < npend + take;
+                const u32 qi = mine ? taken + (lane - npend) : 0u;
+                u32 own = 0;
+#pragma unroll
+                for (u32 step = 32; step; step >>= 1)
+                {
+                    const u32 t = __shfl(incl, (own + step - 1u) & 63u);
+                    if (t <= qi)
+                        own += step;
+                }
+                own &= 63u;
+                const u32 oincl = __shfl(incl, own), ocnt = __shfl(mycnt, own);
+                if (mine)
+                {
+                    u32 t = qi - (oincl - ocnt); // the t-th set bit of the owner's four dwords
+                    const u32 *blk = ebits + own * 4u;
+                    u32 w = 0, word = blk[0];
+                    for (;;)
+                    {
+                        const u32 c = (u32)__popc(word);
+                        if (t < c)
+                            break;
+                        t -= c;
+                        word = blk[++w];
+                    }
+                    for (; t; --t)
+                        word &= word - 1u;
+                    pend = (uv << 14) | (own * 128u + w * 32u + (u32)__builtin_ctz(word));
+                }
+                npend += take;
+                taken += take;
+                if (npend == 64u || (taken >= n && npend && (!defer || unit + 1 == u_end)))
+                {
+                    flush(npend);
+                    npend = 0;
+                    if (taken < n)
+                        recount(); // (see flush)
+                }
+            } while (taken < n);
+            if (n) // (wave-uniform) the END-pair bitmap is the next unit's again
+            {
+                // (the zeros are made HERE: as a loop-invariant uint4 they were kept in four registers from the kernel's start, spilled,
+                //  and reloaded in front of this store — a scratch load whose wait drained the text prefetch once per unit)
+                u32 z;
+                asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+                *reinterpret_cast<uint4 *>(ebits + lane * 4u) = make_uint4(z, z, z, z);
+            }
+          }
         }
-        else if (!(ANCH && (a.flags & (1u << 30))))
+        else
         {
             u32 mycnt = 0;
             {
@@ -719,127 +962,10 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 }
                 // pair layout: bit j of the bitmap is tested position j + 1
                 const u64 pos = isx ? useg - 1u : useg + rel + (PAIR ? 1u : 0u);
-                bool liveA = live, liveB = false;
-                if (STRIDE == 2)
-                    liveA = live && pos >= a.end_lo && pos < a.end_hi;
-                if (pair)
-                    liveB = (live || isx) && pos + 1 >= a.end_lo && pos + 1 < a.end_hi &&
-                            (!XCAND || pos + 1 < useg + kAcUnitBytes); // (-c: that end belongs to the next unit's extra candidate)
-                u32 cA = 0, cB = 0;
-                u64 dmA = 0, dmB = 0;
-                bool simA = false, simB = false;
-                if (STRIDE == 2)
-                {
-                    bool slA = false, slB = false;
-                    u32 mA = 0, mB = 0;
-#ifndef KG_AC_NO_BTEST // (A/B switches of krep_amd/build.py --variant)
-                    constexpr bool kGram = PAIR && XB == 20 && !ANCH; // the probe asks the class table about both ends (kg_ac_common.h; ANCH: the table holds anchor grams, not end grams)
-#else
-                    constexpr bool kGram = false;
-#endif
-#ifndef KG_AC_NO_STAGE
-                    constexpr bool kStaged = kGram;
-#else
-                    constexpr bool kStaged = false;
-#endif
-                    bool exact_done = false;
-                    if constexpr (ANCH != 0)
-                        if (a.xtab && !(a.flags & F_WW) && pos >= 15u)
-                        {
-                            // stage 3 through the length-keyed exact dictionary (kg_ac_common.h ac_exact_end): no trie, no chain
-                            bool muA = false, muB = false;
-#ifndef KG_AC_EXACT_SERIAL // (A/B switch of krep_amd/build.py --variant: the two ends one behind the other, as first built)
-                            if (liveA || liveB)
-                                ac_exact_end2<CI>(a, pos, liveA, liveB, mA, mB, muA, muB);
-#else
-                            if (liveA)
-                                mA = ac_exact_end<CI>(a, pos, muA);
-                            if (liveB)
-                                mB = ac_exact_end<CI>(a, pos + 1u, muB);
-#endif
-                            // start ownership (the same clip as ac_eval_entry's)
-                            auto clip = [&](u32 m, u64 end) -> u32 {
-                                const u64 e = end + 1;
-                                if (e <= a.own_lo)
-                                    return 0u;
-                                if (e - a.own_lo < 32)
-                                    m &= (2u << (u32)(e - a.own_lo)) - 1u;
-                                if (e > a.own_hi)
-                                    m = (e - a.own_hi < 32) ? (m & ~((2u << (u32)(e - a.own_hi)) - 1u)) : 0u;
-                                return m;
-                            };
-                            mA = clip(mA, pos);
-                            mB = clip(mB, pos + 1u);
-                            slA = muA && mA != 0u; // (a pattern the dictionary holds twice: counted and emitted by the level walk)
-                            slB = muB && mB != 0u;
-                            exact_done = true;
-                        }
-                    if (exact_done)
-                    {
-                    }
-                    else if (!(a.flags & (1u << 30))) // (ablation hook KREP_GPU_AC_NOPROBE: candidate enumeration without the probes)
-                        ac_walk_probe2<CI, SHORT, kStaged>(a, pos, liveA, liveB, LINES, mA, slA, mB, slB, [&](u32 E) -> bool {
-                            if constexpr (kGram)
-                            {
-                                // the filter's own lookup for a gram that lies in one dword (cell_body, k = 3 mod 4)
-                                typedef __attribute__((address_space(3))) const u32 lds_u32;
-                                const u32 u = ac_pair(E);
-                                return ((*(lds_u32 *)(size_t)(((u >> 3) ^ (u >> 13)) & kTabMask) >> (u & 31u)) & 1u) != 0u;
-                            }
-                            else
-                                return true;
-                        });
-                    else
-                        mA = liveA ? 1u : 0u; // ... and the count that comes back is the number of candidates
-                    dmA = mA; dmB = mB;
-                    cA = (u32)__popc(mA); cB = (u32)__popc(mB);
-                    simA = simB = true;
-#ifndef KG_AC_NO_EXACT_SLOW // (A/B switch of krep_amd/build.py --variant)
-                    if constexpr (!SHORT && ANCH == 0 && !CI) // (-i: eight bytes of scratch per lane in the BASELINE-shaped kernel for a path the anchored instantiations cover)
-                        if (a.xtab && !(a.flags & F_WW) && pos >= 15u && (slA || slB))
-                        {
-                            // an end the chain-compressed entry cannot answer (the trie branches behind its final gram): the exact dictionary
-                            // instead of the level walk, where there is one (a word-like text, patterns of 4..16 bytes)
-                            auto clipx = [&](u32 m, u64 end) -> u32 {
-                                if (LINES)
-                                    return m; // (-c owns by END)
-                                const u64 e = end + 1;
-                                if (e <= a.own_lo)
-                                    return 0u;
-                                if (e - a.own_lo < 32)
-                                    m &= (2u << (u32)(e - a.own_lo)) - 1u;
-                                if (e > a.own_hi)
-                                    m = (e - a.own_hi < 32) ? (m & ~((2u << (u32)(e - a.own_hi)) - 1u)) : 0u;
-                                return m;
-                            };
-                            bool mu = false;
-                            if (slA)
-                            {
-                                const u32 m = clipx(ac_exact_end<CI>(a, pos, mu), pos);
-                                if (!mu || !m) { mA = m; slA = false; }
-                            }
-                            if (slB)
-                            {
-                                const u32 m = clipx(ac_exact_end<CI>(a, pos + 1u, mu), pos + 1u);
-                                if (!mu || !m) { mB = m; slB = false; }
-                            }
-                            dmA = mA; dmB = mB;
-                            cA = (u32)__popc(mA); cB = (u32)__popc(mB);
-                        }
-#endif
-#pragma unroll 1
-                    for (int e = 0; e < 2; ++e) // the one call site of the level walk
-                        if (e ? slB : slA)
-                        {
-                            u64 dm;
-                            bool sim;
-                            const u32 c = ac_walk_slow<CI, SHORT>(a, pos + (u64)e, LINES, dm, sim);
-                            if (e) { cB = c; dmB = dm; simB = sim; }
-                            else { cA = c; dmA = dm; simA = sim; }
-                        }
-                }
-                else if (liveA)
-                    cA = ac_walk_fast<CI, SHORT>(a, pos, LINES, dmA, simA);
+                u32 cA, cB;
+                u64 dmA, dmB;
+                bool simA, simB;
+                verify_ends(pos, live, isx, useg, cA, cB, dmA, dmB, simA, simB);
                 rank_and_emit(pos, cA, cB, dmA, dmB, simA, simB);
             }
             if (ANCH && n) // (wave-uniform) the END-pair bitmap is the next unit's again
@@ -857,8 +983,8 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 bitmap[w] = 0u;
         }
 
-        acc_total += wcnt;
-        if (chain && !emit_final && lane == 0)
+        acc_total += wcnt; // (deferred stage 3: zero here — the ticket's counts are added below)
+        if (chain && !emit_final && lane == 0 && !(ANCH != 0 && defer))
         {
             u64 info = (u64)wcnt;
             if (LINES)
@@ -874,6 +1000,28 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
             {
                 atomicAdd(&a.ctr->overflow_units, 1ull);
                 atomicMax(&a.ctr->max_unit_count, (u64)wcnt);
+            }
+        }
+      }
+      if (ANCH != 0 && defer)
+      {
+        // the ticket's units: their counts from `ucnt`, their info words in one store
+        const u32 nun = (u32)(u_end - u_begin);
+        const u32 c = lane < nun ? ucnt : 0u;
+        u32 sum = c;
+#pragma unroll
+        for (int o = 4; o >= 1; o >>= 1) // (lanes 0..7 hold the counts)
+            sum += __shfl_xor(sum, o);
+        acc_total += (u32)__builtin_amdgcn_readfirstlane((int)sum);
+        if (chain && lane < nun)
+        {
+            u32 l2 = lane;
+            asm volatile("" : "+v"(l2)); // (the address is formed here, not kept — and spilled — from the kernel's start)
+            a.unitinfo[u_begin + l2] = (u64)c | (c ? (kLnHead | kLnTail) : 0ull);
+            if (want_pos && c > a.stage_cap)
+            {
+                atomicAdd(&a.ctr->overflow_units, 1ull);
+                atomicMax(&a.ctr->max_unit_count, (u64)c);
             }
         }
       }
@@ -1024,6 +1172,8 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
         a.flags |= 1u << 31;
     if (getenv("KREP_GPU_AC_NOSTAGE3")) // measurement hook (anchored scan): candidates -> END pairs, no verify; a count-only scan returns the number of marked pairs
         a.flags |= 1u << 28;
+    if (getenv("KREP_GPU_AC_NODEFER")) // A/B hook (anchored scan): stage 3 at every unit's end, as first built
+        a.flags |= 1u << 27;
     if (getenv("KREP_GPU_AC_NOPROBE")) // measurement hook: filter + candidate enumeration, no probes: a count-only scan returns the number of candidates
         a.flags |= 1u << 30;
     a.lmax = t->lmax;
