@@ -127,8 +127,16 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
       // collected instead — one per lane in `pend` (unit of the ticket << 14 | pair), verified when 64 are there or the ticket ends —
       // and the units' match counts wait in lanes 0..7 of `ucnt` until the ticket's info words are written.  Ranking and emission
       // stay per unit, in END order: the pairs arrive unit by unit, ascending.
-      const bool defer = ANCH != 0 && !emit_final && a.xtab != nullptr && !(a.flags & (F_WW | (1u << 27) | (1u << 28) | (1u << 30) | (1u << 31))) &&
-                         a.upt <= kAcUnitsPerTicketMax;
+      // (The end-gram kernel with the pipelined pair filter can do the same with its CANDIDATES — -DKG_AC_DEFER_GENERIC — and is slower with
+      //  it: BASELINE config 4 holds ~40 candidates per unit, its batches are two thirds full already, and a batch that spans two units
+      //  ranks and emits twice: 6.45-6.54 ms against 6.32-6.40 in alternating runs on one box.  Off.)
+#ifdef KG_AC_DEFER_GENERIC
+      constexpr bool kPend = ANCH != 0 || (PIPE && !SHORT);
+#else
+      constexpr bool kPend = ANCH != 0;
+#endif
+      const bool defer = kPend && !emit_final && !(a.flags & ((1u << 27) | (1u << 28) | (1u << 30) | (1u << 31))) && a.upt <= kAcUnitsPerTicketMax &&
+                         (ANCH == 0 || (a.xtab != nullptr && !(a.flags & F_WW)));
       u32 pend = 0, npend = 0, ucnt = 0;
       for (u64 unit = u_begin; unit < u_end; ++unit)
       {
@@ -782,9 +790,9 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
         };
         // (ANCH: what follows is stage 3 — the same verify, over the END-pair bitmap instead of the candidate bitmap)
         const u32 *vbits = ANCH ? ebits : cbits;
-        if constexpr (ANCH != 0)
+        if constexpr (kPend)
         {
-          if (a.flags & (1u << 28)) // (ablation hook KREP_GPU_AC_NOSTAGE3: the anchor stage alone; the count is the number of marked END pairs)
+          if (ANCH != 0 && (a.flags & (1u << 28))) // (ablation hook KREP_GPU_AC_NOSTAGE3: the anchor stage alone; the count is the number of marked END pairs)
           {
             const uint4 m = *reinterpret_cast<const uint4 *>(ebits + lane * 4u);
             u32 c = (u32)(__popc(m.x) + __popc(m.y) + __popc(m.z) + __popc(m.w));
@@ -794,9 +802,9 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
             wcnt += c;
             *reinterpret_cast<uint4 *>(ebits + lane * 4u) = make_uint4(0u, 0u, 0u, 0u);
           }
-          else if (!(a.flags & (1u << 30)))
+          else if (ANCH == 0 || !(a.flags & (1u << 30)))
           {
-            // ---- the unit's marked pairs join the pending ones; 64 pending pairs are a verify batch.  Deferred: what is left waits for the
+            // ---- the unit's marked pairs (end-gram kernel: its candidates) join the pending ones; 64 pending pairs are a verify batch.  Deferred: what is left waits for the
             //      ticket's next unit; otherwise (emit mode, -w, no exact dictionary) it is verified here, at the unit's end ----
             // (registers: nothing of the collection below lives across a batch, and a pair's position is re-derived from its `pend` word —
             //  kept live they cost the anchored instantiations 20-28 B/lane of scratch, whose reloads drain the text prefetch)
@@ -819,7 +827,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                     if (defer)
                     {
                         e_useg = a.anchor + (u_begin + (u64)v) * (u64)kAcUnitBytes;
-                        e_slot = reinterpret_cast<u32 *>(a.stage) + (u_begin + (u64)v) * (u64)a.stage_cap;
+                        e_slot = parked ? park_slots + v * 16u : reinterpret_cast<u32 *>(a.stage) + (u_begin + (u64)v) * (u64)a.stage_cap;
                         wcnt = (u32)__builtin_amdgcn_readlane((int)ucnt, (int)v);
                     }
                     rank_and_emit(pos_of(), in ? (cc & 0xffu) : 0u, in ? (cc >> 8) : 0u, dmA, dmB, simA, simB);
@@ -832,19 +840,14 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
             const u32 uv = (u32)(unit - u_begin);
             u32 n = 0, mycnt = 0, incl = 0;
             auto recount = [&]() { // the marked pairs per lane (four dwords of the bitmap each) and their inclusive prefix
-                const uint4 lo = *reinterpret_cast<const uint4 *>(ebits + lane * 4u);
+                const uint4 lo = *reinterpret_cast<const uint4 *>(vbits + lane * 4u);
                 mycnt = (u32)(__popc(lo.x) + __popc(lo.y) + __popc(lo.z) + __popc(lo.w));
-                incl = mycnt;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1)
-                {
-                    const u32 t = __shfl_up(incl, o);
-                    if (lane >= (u32)o)
-                        incl += t;
-                }
-                n = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+                incl = ac_wave_scan_incl(mycnt);
+                n = (a.flags & (1u << 31)) ? 0u : (u32)__builtin_amdgcn_readlane((int)incl, 63); // (ablation hook KREP_GPU_AC_NOVERIFY: filter cost only)
             };
             recount();
+            if (ANCH == 0)
+                acc_cand += n;
             u32 taken = 0;
             do // (ONE call site of the verify batch: it is inlined, and two copies cost the anchored instantiations 12-20 B/lane of scratch)
             {
@@ -864,7 +867,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 if (mine)
                 {
                     u32 t = qi - (oincl - ocnt); // the t-th set bit of the owner's four dwords
-                    const u32 *blk = ebits + own * 4u;
+                    const u32 *blk = vbits + own * 4u;
                     u32 w = 0, word = blk[0];
                     for (;;)
                     {
@@ -888,7 +891,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                         recount(); // (see flush)
                 }
             } while (taken < n);
-            if (n) // (wave-uniform) the END-pair bitmap is the next unit's again
+            if (ANCH != 0 && n) // (wave-uniform) the END-pair bitmap is the next unit's again
             {
                 // (the zeros are made HERE: as a loop-invariant uint4 they were kept in four registers from the kernel's start, spilled,
                 //  and reloaded in front of this store — a scratch load whose wait drained the text prefetch once per unit)
@@ -984,7 +987,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
         }
 
         acc_total += wcnt; // (deferred stage 3: zero here — the ticket's counts are added below)
-        if (chain && !emit_final && lane == 0 && !(ANCH != 0 && defer))
+        if (chain && !emit_final && lane == 0 && !(kPend && defer))
         {
             u64 info = (u64)wcnt;
             if (LINES)
@@ -1003,7 +1006,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
             }
         }
       }
-      if (ANCH != 0 && defer)
+      if (kPend && defer)
       {
         // the ticket's units: their counts from `ucnt`, their info words in one store
         const u32 nun = (u32)(u_end - u_begin);
@@ -1017,7 +1020,11 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
         {
             u32 l2 = lane;
             asm volatile("" : "+v"(l2)); // (the address is formed here, not kept — and spilled — from the kernel's start)
-            a.unitinfo[u_begin + l2] = (u64)c | (c ? (kLnHead | kLnTail) : 0ull);
+            const u64 info = (u64)c | (c ? (kLnHead | kLnTail) : 0ull);
+            if (PIPE && !ANCH && a.stage_cap == 16u) // (parked: written with the ticket's slots below)
+                park_info[l2] = info;
+            else
+                a.unitinfo[u_begin + l2] = info;
             if (want_pos && c > a.stage_cap)
             {
                 atomicAdd(&a.ctr->overflow_units, 1ull);
@@ -1029,10 +1036,12 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
       {
         // the ticket's parked info words and slots (consecutive units: one contiguous 64-byte-per-unit region), two stores
         const u32 nun = (u32)(u_end - u_begin);
-        if (lane < nun)
-            a.unitinfo[u_begin + lane] = park_info[lane];
-        if (want_pos && lane < nun * 4u)
-            reinterpret_cast<uint4 *>(reinterpret_cast<u32 *>(a.stage) + u_begin * 16u)[lane] = reinterpret_cast<const uint4 *>(park_slots)[lane];
+        u32 l3 = lane;
+        asm volatile("" : "+v"(l3)); // (the two addresses are formed here, not kept — and spilled — from the kernel's start)
+        if (l3 < nun)
+            a.unitinfo[u_begin + l3] = park_info[l3];
+        if (want_pos && l3 < nun * 4u)
+            reinterpret_cast<uint4 *>(reinterpret_cast<u32 *>(a.stage) + u_begin * 16u)[l3] = reinterpret_cast<const uint4 *>(park_slots)[l3];
       }
     }
     if (lane == 0 && acc_total && !a.emit_mode)

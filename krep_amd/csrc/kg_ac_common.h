@@ -105,6 +105,19 @@ __device__ __forceinline__ u64 ac_rfl64(u64 v)
 {
     return ((u64)__builtin_amdgcn_readfirstlane((u32)(v >> 32)) << 32) | __builtin_amdgcn_readfirstlane((u32)v);
 }
+// inclusive prefix sum over the 64 lanes on the DPP network: four row shifts inside the rows of 16, then lane 15 of rows 0 / 2 into rows
+// 1 / 3 and lane 31 into rows 2 and 3 — six v_add with a DPP modifier, no LDS traffic and no per-lane address registers (the shuffle
+// version keeps six of them alive for as long as it is loop-invariant)
+__device__ __forceinline__ u32 ac_wave_scan_incl(u32 x)
+{
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x112 /* row_shr:2 */, 0xf, 0xf, true);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114 /* row_shr:4 */, 0xf, 0xf, true);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118 /* row_shr:8 */, 0xf, 0xf, true);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x142 /* row_bcast:15 */, 0xa, 0xf, false);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x143 /* row_bcast:31 */, 0xc, 0xf, false);
+    return x;
+}
 __device__ __forceinline__ u32 ac_fold4(u32 x)
 {
     u32 t = x & 0x7f7f7f7fu;
