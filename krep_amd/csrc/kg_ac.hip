@@ -1441,6 +1441,12 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
     // ticket size by text size: >= ~4 tickets per resident wave before tickets grow (small host buffers keep every
     // CU busy), 8 units (128 KiB) on large texts
     a.upt = (u32)std::min<u64>(kAcUnitsPerTicketMax, std::max<u64>(1, a.num_tiles / ((u64)num_cu * waves * 4)));
+    if (const char *e = getenv("KREP_GPU_AC_UPT")) // test hook: the ticket size large texts get (the anchored scan defers its verify stage over a ticket's units)
+    {
+        const int v = atoi(e);
+        if (v >= 1 && v <= (int)kAcUnitsPerTicketMax)
+            a.upt = (u32)v;
+    }
     const u64 n_tickets = (a.num_tiles + a.upt - 1) / a.upt;
     const u32 grid = (u32)std::min<u64>((n_tickets + waves - 1) / waves, (u64)num_cu * per_cu);
     auto launch = [&](const AcArgs &args) { return tiny ? ac_tiny_launch(args, t->tiny, n_tickets, (u32)num_cu, st) : ac_launch(args, grid, lds, st); };

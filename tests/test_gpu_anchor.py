@@ -24,17 +24,26 @@ def gpu():
     return e
 
 
-@pytest.fixture(params=["four classes", "five classes"])
+@pytest.fixture(params=["four classes", "five classes", "five classes, tickets of 8 units", "four classes, tickets of 3 units",
+                        "five classes, tickets of 8 units, verify at every unit's end"])
 def forced(request):
     """$KREP_GPU_AC_ANCHOR: anchors whatever the gain; + $KREP_GPU_AC_ANCHOR5: the five-class index (ac_scan_kernel<.., ANCH = 2>) whatever
-    the number of table slots it takes (4- and 5-byte patterns leave classes free: 32 or 1024 slots each)."""
+    the number of table slots it takes (4- and 5-byte patterns leave classes free: 32 or 1024 slots each).  $KREP_GPU_AC_UPT: the tickets of
+    several units that only large texts get by themselves — the verify stage is deferred over a ticket (its marked END pairs collected one
+    per lane, 64 per batch, a batch spanning units); $KREP_GPU_AC_NODEFER: not deferred, as first built."""
     os.environ["KREP_GPU_AC_ANCHOR"] = "1"
-    if request.param == "five classes":
+    if "five classes" in request.param:
         os.environ["KREP_GPU_AC_ANCHOR5"] = "1"
     else:
         os.environ["KREP_GPU_AC_NO_ANCHOR5"] = "1"
+    if "tickets of 8" in request.param:
+        os.environ["KREP_GPU_AC_UPT"] = "8"
+    if "tickets of 3" in request.param:
+        os.environ["KREP_GPU_AC_UPT"] = "3"
+    if "every unit" in request.param:
+        os.environ["KREP_GPU_AC_NODEFER"] = "1"
     yield request.param
-    for k in ("KREP_GPU_AC_ANCHOR", "KREP_GPU_AC_ANCHOR5", "KREP_GPU_AC_NO_ANCHOR5"):
+    for k in ("KREP_GPU_AC_ANCHOR", "KREP_GPU_AC_ANCHOR5", "KREP_GPU_AC_NO_ANCHOR5", "KREP_GPU_AC_UPT", "KREP_GPU_AC_NODEFER"):
         os.environ.pop(k, None)
 
 

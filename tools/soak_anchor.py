@@ -9,7 +9,7 @@ from krep_amd import abi
 
 gpu = krep_amd.load(); o = ol.checker()
 W = wordlist.word_list(); blob = wordlist.pack(W)
-SW = ("KREP_GPU_AC_ANCHOR", "KREP_GPU_AC_ANCHOR5", "KREP_GPU_AC_NO_ANCHOR5", "KREP_GPU_AC_NO_EXACT", "KREP_GPU_AC_NO_ANCHOR")
+SW = ("KREP_GPU_AC_ANCHOR", "KREP_GPU_AC_ANCHOR5", "KREP_GPU_AC_NO_ANCHOR5", "KREP_GPU_AC_NO_EXACT", "KREP_GPU_AC_NO_ANCHOR", "KREP_GPU_AC_UPT", "KREP_GPU_AC_NODEFER")
 COMBOS = ({}, {"KREP_GPU_AC_ANCHOR": "1", "KREP_GPU_AC_NO_ANCHOR5": "1"}, {"KREP_GPU_AC_ANCHOR": "1", "KREP_GPU_AC_ANCHOR5": "1"},
           {"KREP_GPU_AC_ANCHOR": "1", "KREP_GPU_AC_ANCHOR5": "1", "KREP_GPU_AC_NO_EXACT": "1"}, {"KREP_GPU_AC_NO_ANCHOR5": "1"}, {"KREP_GPU_AC_NO_EXACT": "1"})
 bad = n = 0
@@ -44,7 +44,11 @@ for seed in range(7000, 7000 + (int(sys.argv[1]) if len(sys.argv) > 1 else 20)):
         kw["max_count"] = kw["max_count"][rng.randint(0, 5)]
         if rng.rand() < 0.25:
             kw.update(count_lines=True, only_match=True)
-        env = COMBOS[rng.randint(0, len(COMBOS))]
+        env = dict(COMBOS[rng.randint(0, len(COMBOS))])
+        if rng.rand() < 0.6:  # tickets of several units (what large texts get): the deferred verify stage, batches that span units
+            env["KREP_GPU_AC_UPT"] = str([2, 3, 5, 8][rng.randint(0, 4)])
+        if rng.rand() < 0.15:
+            env["KREP_GPU_AC_NODEFER"] = "1"
         os.environ.update(env)
         try:
             want = o.call(abi.RA_AHO_CORASICK, abi.Params(pats, **kw), text)
