@@ -136,7 +136,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
       constexpr bool kPend = ANCH != 0;
 #endif
       const bool defer = kPend && !emit_final && !(a.flags & ((1u << 27) | (1u << 28) | (1u << 30) | (1u << 31))) && a.upt <= kAcUnitsPerTicketMax &&
-                         (ANCH == 0 || (a.xtab != nullptr && !(a.flags & F_WW)));
+                         (ANCH == 0 || a.xtab != nullptr);
       u32 pend = 0, npend = 0, ucnt = 0;
       for (u64 unit = u_begin; unit < u_end; ++unit)
       {
@@ -691,7 +691,11 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
 #endif
                 bool exact_done = false;
                 if constexpr (ANCH != 0)
+#ifndef KG_AC_EXACT_SERIAL
+                    if (a.xtab && pos >= 15u) // (-w: tested inside ac_exact_end2, on the window's own bytes)
+#else
                     if (a.xtab && !(a.flags & F_WW) && pos >= 15u)
+#endif
                     {
                         // stage 3 through the length-keyed exact dictionary (kg_ac_common.h ac_exact_end): no trie, no chain
                         bool muA = false, muB = false;

@@ -712,13 +712,19 @@ template <bool CI>
 __device__ __forceinline__ void ac_exact_end2(const AcArgs &a, u64 i, bool liveA, bool liveB, u32 &dmA, u32 &dmB, bool &multiA, bool &multiB)
 {
     struct __attribute__((packed)) U32p { u32 v; };
+    const bool ww = (a.flags & F_WW) != 0u; // -w (is_whole_word_match krep.h:312-319): a match needs a non-word byte (or the text's edge) on either side
     const U32p *q = reinterpret_cast<const U32p *>(a.text + (i - 15));
     u32 TA[4] = {q[0].v, q[1].v, q[2].v, q[3].v};
-    const u32 nxt = liveB ? (u32)a.text[i + 1] : 0u; // (a live end i + 1 lies inside the text)
+    const u32 nxt = ((liveB || ww) && i + 1 < a.text_len) ? (u32)a.text[i + 1] : 0u; // (a live end i + 1 lies inside the text)
+    // -w: the byte behind end i + 1, and the byte in front of a 16-byte pattern that ends at i (the other neighbours are in the window)
+    const u32 nxt2 = (ww && liveB && i + 2 < a.text_len) ? (u32)a.text[i + 2] : 0u;
+    const u32 prv = (ww && liveA && i >= 16u) ? (u32)a.text[i - 16] : 0u;
     u32 TB[4];
 #pragma unroll
     for (int w = 0; w < 4; ++w)
         TB[w] = __builtin_amdgcn_alignbyte(w < 3 ? TA[w < 3 ? w + 1 : 3] : nxt, TA[w], 1u);
+    const u32 firstA = TA[0] & 0xffu; // (text[i - 15]: the byte in front of a 16-byte pattern that ends at i + 1; before any fold)
+    // (the neighbour tests read the unfolded window's classes: folding maps letters to letters, so either copy will do; the folded one is at hand)
     if (CI)
     {
 #pragma unroll
@@ -731,6 +737,13 @@ __device__ __forceinline__ void ac_exact_end2(const AcArgs &a, u64 i, bool liveA
     const u32 a4 = a.xlen[ac_xlen_slot(TA[3])], a8 = a.xlen[65536u + ac_xlen_slot8(TA[2], TA[3])];
     const u32 b4 = a.xlen[ac_xlen_slot(TB[3])], b8 = a.xlen[65536u + ac_xlen_slot8(TB[2], TB[3])];
     u32 lmA = liveA ? ((a4 & 0xfu) | (a8 & 0x1ff0u)) : 0u, lmB = liveB ? ((b4 & 0xfu) | (b8 & 0x1ff0u)) : 0u;
+    if (ww)
+    { // a word character behind the end: no pattern ends here as a whole word
+        if (ac_wordc(nxt))
+            lmA = 0u;
+        if (ac_wordc(nxt2))
+            lmB = 0u;
+    }
     dmA = dmB = 0;
     multiA = multiB = false;
     auto keep = [](const u32 (&T)[4], u32 len, u32 (&M)[4]) { // the last `len` bytes of the 16, the bytes in front zeroed
@@ -741,6 +754,15 @@ __device__ __forceinline__ void ac_exact_end2(const AcArgs &a, u64 i, bool liveA
             const u32 lo = 4u * (u32)w;
             M[w] = drop >= lo + 4u ? 0u : drop <= lo ? T[w] : (T[w] & (0xffffffffu << (8u * (drop - lo))));
         }
+    };
+    // -w: is the byte in front of a pattern of `len` bytes that ends the window a word character?  (byte 15 - len of the window; a pattern of
+    // 16 bytes: `far`, the byte in front of the window — 0 where the text starts there)
+    auto left_is_word = [](const u32 (&T)[4], u32 len, u32 far) -> bool {
+        if (len >= 16u)
+            return ac_wordc(far);
+        const u32 at = 15u - len, w = at >> 2;
+        const u32 word = w == 0u ? T[0] : w == 1u ? T[1] : w == 2u ? T[2] : T[3];
+        return ac_wordc((word >> (8u * (at & 3u))) & 0xffu);
     };
     while (lmA | lmB)
     {
@@ -767,7 +789,7 @@ __device__ __forceinline__ void ac_exact_end2(const AcArgs &a, u64 i, bool liveA
         {
             const bool h0 = mA0.x == lenA && eA0.x == MA[0] && eA0.y == MA[1] && eA0.z == MA[2] && eA0.w == MA[3];
             const bool h1 = mA1.x == lenA && eA1.x == MA[0] && eA1.y == MA[1] && eA1.z == MA[2] && eA1.w == MA[3];
-            if (h0 || h1)
+            if ((h0 || h1) && !(ww && left_is_word(TA, lenA, prv)))
             {
                 dmA |= 1u << lenA;
                 multiA = multiA || (h0 ? mA0.y : mA1.y) != 1u;
@@ -777,7 +799,7 @@ __device__ __forceinline__ void ac_exact_end2(const AcArgs &a, u64 i, bool liveA
         {
             const bool h0 = mB0.x == lenB && eB0.x == MB[0] && eB0.y == MB[1] && eB0.z == MB[2] && eB0.w == MB[3];
             const bool h1 = mB1.x == lenB && eB1.x == MB[0] && eB1.y == MB[1] && eB1.z == MB[2] && eB1.w == MB[3];
-            if (h0 || h1)
+            if ((h0 || h1) && !(ww && left_is_word(TB, lenB, firstA)))
             {
                 dmB |= 1u << lenB;
                 multiB = multiB || (h0 ? mB0.y : mB1.y) != 1u;
