@@ -523,7 +523,9 @@ __device__ __forceinline__ void ac_walk_probe2(const AcArgs &a, u64 i, bool live
 {
     dmA = dmB = 0;
     slowA = slowB = false;
-    if (i < 15 || (a.flags & (F_WW | (SHORT ? F_AC_SHORT_DUP : 0u))))
+    // (-w no longer sends every candidate to the level walk, round 6: the depth masks the entries answer with are filtered by the matches'
+    //  neighbours at the end of this function — BASELINE config 4 with -w: 15.0 ms for 32 GiB where the plain scan takes 6.5)
+    if (i < 15 || (a.flags & (SHORT ? (F_WW | F_AC_SHORT_DUP) : 0u)))
     {
         slowA = liveA;
         slowB = liveB;
@@ -640,6 +642,39 @@ __device__ __forceinline__ void ac_walk_probe2(const AcArgs &a, u64 i, bool live
 #endif
     if (liveB)
         ac_eval_entry(a, foundB, TB, b0, b1, sbB, i + 1, own_by_end, dmB, slowB);
+    if (!SHORT && (a.flags & F_WW))
+    {
+        // -w (is_whole_word_match krep.h:312-319) on what matched: bit d of a mask is a pattern of d bytes ending here — the byte behind the
+        // end decides for all of them, the byte in front of each is byte 15 - d of the window (d >= 16: one load).  An end that takes the
+        // level walk (slow) is filtered there.
+        auto wwf = [&](u32 m, const u32 (&T)[4], u64 e) -> u32 {
+            if (!m)
+                return 0u;
+            if (e + 1 < a.text_len && ac_wordc(a.text[e + 1]))
+                return 0u;
+            u32 r = m;
+            for (u32 rest = m; rest;)
+            {
+                const u32 d = 31u - (u32)__builtin_clz(rest);
+                rest &= ~(1u << d);
+                u32 c = 0;
+                if (d <= 15u)
+                {
+                    const u32 at = 15u - d, w = at >> 2;
+                    c = ((w == 0u ? T[0] : w == 1u ? T[1] : w == 2u ? T[2] : T[3]) >> (8u * (at & 3u))) & 0xffu;
+                }
+                else if (e >= d)
+                    c = a.text[e - d];
+                if (ac_wordc(c))
+                    r &= ~(1u << d);
+            }
+            return r;
+        };
+        if (!slowA)
+            dmA = wwf(dmA, TA, i);
+        if (!slowB)
+            dmB = wwf(dmB, TB, i + 1);
+    }
 }
 
 // ---- the length-keyed exact dictionary (stage 3 of the anchored scan, kg_ac_anchor.hip) ----

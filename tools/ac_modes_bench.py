@@ -16,7 +16,8 @@ cap = n // 1500
 pos = torch.empty(2 * cap, dtype=torch.int64, device="cuda")
 for name, kw, want_pos in (("positions", {}, True), ("-c (lines)", dict(count_lines=True), False),
                            ("-c -o (matches)", dict(count_lines=True, only_match=True), False),
-                           ("-i positions", dict(case_sensitive=False), True)):
+                           ("-i positions", dict(case_sensitive=False), True), ("-w positions", dict(whole_word=True), True),
+                           ("-w -c -o", dict(whole_word=True, count_lines=True, only_match=True), False)):
     plan = e.plan(abi.Params(pats, **kw))
     best = 1e9
     for _ in range(4):
