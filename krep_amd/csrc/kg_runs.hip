@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void run_count_kernel(const uint8_t *__restric
     const u32 lane = r_lane();
     const u64 anchor = lo & ~(u64)15;
     const u64 end_lo = lo + m - 1, end_hi = (hi + m - 1 < text_len) ? hi + m - 1 : text_len; // ENDs of the owned matches
-    u64 total = 0, last_end = 0;
+    u64 total = 0, last_end = 0; // (per LANE: summed / maximised over the wave once, when the kernel ends)
     bool gave_up = false;
     const u32 b = splat & 0xffu;
     const u32 inv_m = (u32)(0x100000000ull / m) + 1u; // floor(x / m) == umulhi(x, inv_m) for x < 2^16
@@ -153,18 +153,30 @@ __global__ __launch_bounds__(256) void run_count_kernel(const uint8_t *__restric
                         }
                     }
                 }
-                // inclusive -> exclusive: what enters THIS lane is the left neighbour's inclusive result (lane 0: the carry)
-                u32 in_len = __shfl_up(len, 1);
-                bool in_all = __shfl_up((int)al, 1) != 0;
-                if (lane == 0)
-                {
-                    in_len = 0;
-                    in_all = true;
-                }
-                const u32 x0 = in_len + (in_all ? carry : 0u);
+                // inclusive -> exclusive: what enters THIS lane is the left neighbour's inclusive result (lane 0: the carry) — one DPP
+                // wave shift of {length | all << 31}
+                const u32 packed = len | (al ? 0x80000000u : 0u);
+                const u32 inp = (u32)__builtin_amdgcn_update_dpp((int)0x80000000u, (int)packed, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+                const u32 x0 = (inp & 0x7fffffffu) + ((inp >> 31) ? carry : 0u);
                 const u32 rp0 = x0 - __umulhi(x0, inv_m) * m; // b's of the current run in front of the lane, modulo m (x0 < 2^12)
-                // run by run (a lane holds one to three): a run of L bytes entered with c b's already counted keeps floor((c + L) / m)
                 u32 cnt = 0, lastk = 0xffu, rest = e;
+                if (m == 2u && interior) // (uniform) `  `, `--`, `==`, `aa`: the kept ENDs of every run of the lane at once, no loop
+                {
+                    // a kept match ends at every byte whose b-count from its run's start is even: odd OFFSETS inside the run — even ones in
+                    // the run that enters the lane with one b already counted.  Runs that start at an even bit index: adding their start
+                    // bits to e ripples through exactly those runs.
+                    const u32 starts = e & ~(e << 1);
+                    const u32 re = e & ~(e + (starts & 0x5555u));        // the runs that start at an even index
+                    const u32 evenoff = (re & 0x5555u) | (e & ~re & 0xaaaau); // bytes at an even offset inside their run
+                    const u32 r0 = (e & 1u) ? (e & ~(e + 1u)) : 0u;       // the run that contains the lane's first byte
+                    const u32 flip = rp0 ? r0 : 0u;
+                    const u32 kept = ((e & ~evenoff) ^ flip) & e & 0xffffu; // (inside r0 with rp0: even offsets are the kept ones)
+                    cnt = (u32)__popc(kept);
+                    if (kept)
+                        lastk = 31u - (u32)__builtin_clz(kept);
+                    rest = 0;
+                }
+                // run by run (a lane holds one to three): a run of L bytes entered with c b's already counted keeps floor((c + L) / m)
                 while (rest)
                 {
                     const u32 s0 = (u32)__builtin_ctz(rest), L = (u32)__builtin_ctz(~(rest >> s0));
@@ -191,24 +203,23 @@ __global__ __launch_bounds__(256) void run_count_kernel(const uint8_t *__restric
                     }
                 }
                 // the carry leaving the cell: lane 63's inclusive scan result (+ the old carry when the whole cell was b)
-                const u32 l63 = __shfl(len, 63);
-                const bool a63 = __shfl((int)al, 63) != 0;
-                const u32 x63 = l63 + (a63 ? carry : 0u);
+                const u32 p63 = (u32)__builtin_amdgcn_readlane((int)packed, 63);
+                const u32 x63 = (p63 & 0x7fffffffu) + ((p63 >> 31) ? carry : 0u);
                 carry = x63 - __umulhi(x63, inv_m) * m;
-                const u64 hit = __ballot(cnt != 0u);
-                if (hit)
+                if (cnt) // (per lane: a lane's later cells lie behind its earlier ones)
                 {
-                    u32 c = cnt;
-#pragma unroll
-                    for (int o = 32; o >= 1; o >>= 1)
-                        c += __shfl_xor(c, o);
-                    total += c;
-                    const u32 top = 63u - (u32)__builtin_clzll(hit);
-                    const u32 tk = __shfl(lastk, top);
-                    last_end = seg + (u64)j * kCellBytes + (u64)top * 16u + tk + 1;
+                    total += cnt;
+                    last_end = lbase + lastk + 1;
                 }
             }
         }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1)
+    {
+        total += ((u64)(u32)__shfl_xor((int)(u32)(total >> 32), o) << 32 | (u32)__shfl_xor((int)(u32)total, o));
+        const u64 other = (u64)(u32)__shfl_xor((int)(u32)(last_end >> 32), o) << 32 | (u32)__shfl_xor((int)(u32)last_end, o);
+        last_end = other > last_end ? other : last_end;
     }
     if (lane == 0)
     {
