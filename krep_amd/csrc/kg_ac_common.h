@@ -824,20 +824,22 @@ __device__ __forceinline__ void ac_exact_end2(const AcArgs &a, u64 i, bool liveA
         {
             const bool h0 = mA0.x == lenA && eA0.x == MA[0] && eA0.y == MA[1] && eA0.z == MA[2] && eA0.w == MA[3];
             const bool h1 = mA1.x == lenA && eA1.x == MA[0] && eA1.y == MA[1] && eA1.z == MA[2] && eA1.w == MA[3];
-            if ((h0 || h1) && !(ww && left_is_word(TA, lenA, prv)))
+            const bool mu = (h0 ? mA0.y : mA1.y) != 1u; // (copies != 1: the level walk answers this end, -w included — the entry may be a longer pattern's tail)
+            if ((h0 || h1) && (mu || !(ww && left_is_word(TA, lenA, prv))))
             {
                 dmA |= 1u << lenA;
-                multiA = multiA || (h0 ? mA0.y : mA1.y) != 1u;
+                multiA = multiA || mu;
             }
         }
         if (doB)
         {
             const bool h0 = mB0.x == lenB && eB0.x == MB[0] && eB0.y == MB[1] && eB0.z == MB[2] && eB0.w == MB[3];
             const bool h1 = mB1.x == lenB && eB1.x == MB[0] && eB1.y == MB[1] && eB1.z == MB[2] && eB1.w == MB[3];
-            if ((h0 || h1) && !(ww && left_is_word(TB, lenB, firstA)))
+            const bool mu = (h0 ? mB0.y : mB1.y) != 1u;
+            if ((h0 || h1) && (mu || !(ww && left_is_word(TB, lenB, firstA))))
             {
                 dmB |= 1u << lenB;
-                multiB = multiB || (h0 ? mB0.y : mB1.y) != 1u;
+                multiB = multiB || mu;
             }
         }
     }
