@@ -54,6 +54,9 @@ int krep_gpu_debug_literal_dma_state(const krep_gpu_plan_t *plan, int *looked, i
 /* test hook: launches of the run-length kernel (kg_runs.hip: the greedy families on a pattern of one repeated byte, count-only);
  * $KREP_GPU_NO_RUNS=1 keeps such scans on the list road */
 uint64_t krep_gpu_debug_runs_launches(void);
+/* a multi-pattern plan whose dictionary holds 1..3-byte patterns beside >= 8 longer ones: 0 not decided yet, 1 scanned as one dictionary, 2 split
+ * (the long part anchored, the short part on its own, the record lists merged: kg_scan.hip scan_ac_split); $KREP_GPU_AC_NO_SPLIT=1: never */
+int krep_gpu_debug_split_state(const krep_gpu_plan_t *plan);
 /* what that decision was for `plan`: state 0 not taken yet / 1 end grams kept / 2 anchored; patterns moved off their end; the
  * estimated candidates per tested position with the end grams and with the anchors.  Returns 0, or 2 for a single-literal plan. */
 int krep_gpu_debug_anchor_info(const krep_gpu_plan_t *plan, int *state, uint32_t *moved, double *rate_end_grams, double *rate_anchors);

@@ -248,14 +248,22 @@ using namespace kg;
 
 // max_offset: an upper bound of every start offset in the list — the length of the WHOLE text when the records carry a
 // global_base (the radix key is sized from it)
+// stable sort of a record list keyed on `start` (by_end = false) or on `end` (true); max_offset bounds the key
+namespace kg {
+int order_records(match_position_t *d_positions, uint64_t n, size_t max_offset, hipStream_t st, bool by_end);
+} // namespace kg
 extern "C" int krep_gpu_order_by_start(match_position_t *d_positions, uint64_t n, size_t max_offset, void *stream)
+{
+    return kg::order_records(d_positions, n, max_offset, (hipStream_t)stream, false);
+}
+namespace kg {
+int order_records(match_position_t *d_positions, uint64_t n, size_t max_offset, hipStream_t st, bool by_end)
 {
     const size_t text_len = max_offset;
     if (n < 2)
         return 0;
     if (n > 0x7fffffffull) // the vendor's device radix sort counts its items in an int: 2^31-1 records = 34 GB of match_position_t
         return fail("krep_gpu_order_by_start: %llu records exceed the device sort's 2^31-1 item limit", (unsigned long long)n);
-    hipStream_t st = (hipStream_t)stream;
     std::lock_guard<std::mutex> lk(g_fmt_mu);
     int rc = 0;
     int bits = 1;
@@ -272,15 +280,17 @@ extern "C" int krep_gpu_order_by_start(match_position_t *d_positions, uint64_t n
         u64 *k0 = (u64 *)base, *k1 = k0 + n, *v0 = k0 + 2 * n, *v1 = k0 + 3 * n;
         void *tmp = (uint8_t *)base + ((keys + 255) & ~(size_t)255);
         const u32 grid = (u32)((n + 255) / 256);
-        hipLaunchKernelGGL(fmt_split, dim3(grid), dim3(256), 0, st, (const u64 *)d_positions, (u64)n, k0, v0);
+        // (keyed on `end`: the two columns change roles on the way in and on the way out)
+        hipLaunchKernelGGL(fmt_split, dim3(grid), dim3(256), 0, st, (const u64 *)d_positions, (u64)n, by_end ? v0 : k0, by_end ? k0 : v0);
         FCHK(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, k0, k1, v0, v1, (int)n, 0, bits, st));
-        hipLaunchKernelGGL(fmt_merge, dim3(grid), dim3(256), 0, st, (const u64 *)k1, (const u64 *)v1, (u64)n, (u64 *)d_positions);
+        hipLaunchKernelGGL(fmt_merge, dim3(grid), dim3(256), 0, st, (const u64 *)(by_end ? v1 : k1), (const u64 *)(by_end ? k1 : v1), (u64)n, (u64 *)d_positions);
         FCHK(hipGetLastError());
         FCHK(hipStreamSynchronize(st));
     }
 done:
     return rc;
 }
+} // namespace kg
 
 extern "C" int krep_gpu_line_numbers(const void *d_text, size_t text_len, const match_position_t *d_positions, uint64_t n,
                                      uint64_t *d_lines, void *stream)

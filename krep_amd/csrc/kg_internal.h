@@ -103,6 +103,7 @@ int tail_count_newlines(const uint8_t *d_text, uint64_t lo, uint64_t hi, unsigne
 int tail_run_replay(const ReplayIn &r, unsigned long long *d_slot, unsigned long long *h_slot, hipStream_t st, uint64_t *lines);
 
 // kg_ac.hip — multi-pattern scan
+int order_records(match_position_t *d_positions, uint64_t n, size_t max_offset, hipStream_t st, bool by_end); // kg_format.hip: stable radix sort of a record list by start / by end
 struct AcTables;
 AcTables *ac_build(const search_params_t &sp, int device);
 void ac_free(AcTables *t);

@@ -33,6 +33,12 @@ struct krep_gpu_plan
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // multi-pattern
     kg::AcTables *ac = nullptr;
+    // a dictionary with 1..3-byte patterns beside many longer ones, on a text where the longer ones gain from anchors (kg_scan.hip
+    // scan_ac_split, round 6): the two parts as dictionaries of their own, scanned one after the other, their record lists merged
+    kg::AcTables *ac_long = nullptr, *ac_short = nullptr;
+    int ac_split = 0; // 0: not decided, 1: the whole dictionary in one scan, 2: split
+    match_position_t *d_split_rec = nullptr; // under max_count: both parts' first max_count records, merged here before the first max_count go out
+    uint64_t split_cap = 0;
     bool ac_has_newline = false; // some pattern of the set contains '\n' (-c then counts emission-order line changes)
     kg::PostScratch post; // ordering post-pass / sequential-family scratch of the main pass
     uint32_t sparse_cap = 16; // staging entries per 32 KiB unit of the sparse literal kinds: 16, raised to 64 after a scan whose

@@ -194,6 +194,9 @@ extern "C" void krep_gpu_plan_destroy(krep_gpu_plan_t *pl)
     if (pl->ev0) DBGFREE(hipEventDestroy(pl->ev0));
     if (pl->ev1) DBGFREE(hipEventDestroy(pl->ev1));
     if (pl->ac) ac_free(pl->ac);
+    if (pl->ac_long) ac_free(pl->ac_long);
+    if (pl->ac_short) ac_free(pl->ac_short);
+    if (pl->d_split_rec) DBGFREE(hipFree(pl->d_split_rec));
     if (pl->d_nl_rec) DBGFREE(hipFree(pl->d_nl_rec));
     if (pl->d_nl_ln) DBGFREE(hipFree(pl->d_nl_ln));
     post_free(pl->post);
@@ -201,6 +204,7 @@ extern "C" void krep_gpu_plan_destroy(krep_gpu_plan_t *pl)
     delete pl;
 }
 extern "C" int krep_gpu_plan_ref_algo(const krep_gpu_plan_t *pl) { return pl ? pl->ref_algo : KREP_RA_NONE; }
+extern "C" int krep_gpu_debug_split_state(const krep_gpu_plan_t *pl) { return pl ? pl->ac_split : -1; }
 extern "C" int krep_gpu_debug_literal_dma_state(const krep_gpu_plan_t *pl, int *looked, int *barred, double *pass_rate)
 {
     if (!pl)

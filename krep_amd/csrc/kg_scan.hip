@@ -21,6 +21,7 @@
 #include "kg_internal.h"
 #include "kg_plan.h"
 #include "kg_replay.h"
+#include "kg_ac_tables.h"
 
 using namespace kg;
 
@@ -1249,6 +1250,140 @@ static int scan_ac_newline_lines(krep_gpu_plan *pl, const Window &w, hipStream_t
 // their END (last byte in [own_lo, own_hi)) on both roads, so neighbouring pieces may take different roads (ac_scan).
 // Returns 1 when the text turns out to be too dense for the list (the caller takes the in-kernel road), 2 on error.
 constexpr size_t kAcLinesOnListMin = (size_t)32 << 20;
+// ---- a dictionary with SHORT patterns beside many longer ones on a word-like text (round 6) ----------------------------------
+// The anchored scan (kg_ac_anchor.hip) is what makes a word dictionary fast on word text — 20x — and it is refused when the dictionary
+// holds a 1..3-byte pattern: the pair filter's wildcard entries for such a pattern pass a 2-gram's worth of positions, and the exact
+// anchor buckets are keyed on four bytes.  One `the` or `of` in a list of a thousand words sent the whole scan back to 0.027 of the
+// roofline.  Here the two parts are dictionaries of their own: the patterns of >= 4 bytes (anchored), the 1..3-byte ones (the tiny
+// register-compare kernel when they qualify, the general kernel otherwise); their counts add, and their record lists — each in
+// aho_corasick_search's order, END ascending and longest first (aho_corasick.c:383-437), patterns of different lengths never produce the
+// same record — are merged by two stable radix sorts, by start and then by END.  Decided once per plan, on its first text of >= 1 MiB,
+// by sampling that text with the long part (ac_anchor_prepare): split only where the long part anchors.  Returns 1: not applicable.
+static int scan_ac_split(krep_gpu_plan *pl, const uint8_t *d_text, size_t text_len, size_t own_lo, size_t own_hi, size_t global_base,
+                         match_position_t *d_pos, uint64_t cap, hipStream_t st, int time_it, krep_gpu_scan_out_t *out)
+{
+    kg::AcTables *t = pl->ac;
+    if (pl->ac_split == 1 || !t || t->has_empty || !(t->has1 || t->has2 || t->has3) || pl->max_count == 0 || getenv("KREP_GPU_AC_NO_SPLIT"))
+        return 1;
+    const size_t hi = std::min(own_hi, text_len);
+    if (pl->ac_split == 0)
+    {
+        if (text_len < (1u << 20) || hi <= own_lo || hi - own_lo < (1u << 19))
+            return 1; // (too small to sample: decided by a later text)
+        std::vector<const char *> pl_long, pl_short;
+        std::vector<size_t> ln_long, ln_short;
+        for (size_t i = 0; i < pl->sp.num_patterns; ++i)
+        {
+            const bool is_long = pl->sp.pattern_lens[i] >= 4;
+            (is_long ? pl_long : pl_short).push_back(pl->sp.patterns[i]);
+            (is_long ? ln_long : ln_short).push_back(pl->sp.pattern_lens[i]);
+        }
+        pl->ac_split = 1;
+        if (pl_long.size() < 8 || pl_short.empty())
+            return 1;
+        search_params_t sub = pl->sp;
+        sub.patterns = pl_long.data();
+        sub.pattern_lens = ln_long.data();
+        sub.num_patterns = pl_long.size();
+        sub.pattern = nullptr;
+        sub.pattern_len = 0;
+        pl->ac_long = kg::ac_build(sub, pl->device);
+        if (!pl->ac_long)
+        {
+            krep_gpu_clear_error();
+            return 1;
+        }
+        HIPCHK(hipSetDevice(pl->device));
+        if (kg::ac_anchor_prepare(pl->ac_long, d_text, text_len, own_lo, hi, st) == 2)
+            (void)hipGetLastError();
+        if (pl->ac_long->anch_state != 2)
+        { // the long part gains nothing from anchors on this text: one scan of the whole dictionary, as always
+            kg::ac_free(pl->ac_long);
+            pl->ac_long = nullptr;
+            return 1;
+        }
+        sub.patterns = pl_short.data();
+        sub.pattern_lens = ln_short.data();
+        sub.num_patterns = pl_short.size();
+        pl->ac_short = kg::ac_build(sub, pl->device);
+        if (!pl->ac_short)
+        {
+            krep_gpu_clear_error();
+            kg::ac_free(pl->ac_long);
+            pl->ac_long = nullptr;
+            return 1;
+        }
+        pl->ac_split = 2;
+        if (getenv("KREP_GPU_DEBUG"))
+            fprintf(stderr, "krep-gpu: multi-pattern scan split: %zu patterns of >= 4 bytes (anchored) + %zu of 1..3 bytes, lists merged by (end, start)\n", pl_long.size(),
+                    pl_short.size());
+    }
+    // Under a max_count smaller than the caller's list the result is the first max_count records of the MERGED list: either part may
+    // contribute all of them, so both parts' first max_count records go to a scratch list of the plan, are merged there, and the first
+    // max_count are copied out.  Without such a limit the caller's list holds everything (or overflows, as always).
+    const bool want = d_pos && pl->track;
+    const bool limited = want && (uint64_t)pl->max_count < cap;
+    match_position_t *dst = d_pos;
+    uint64_t room = cap;
+    if (limited)
+    {
+        const uint64_t need = 2 * (uint64_t)pl->max_count;
+        if (need > pl->split_cap)
+        {
+            if (pl->d_split_rec) (void)hipFree(pl->d_split_rec);
+            pl->d_split_rec = nullptr;
+            pl->split_cap = 0;
+            if (hipMalloc(&pl->d_split_rec, need * sizeof(match_position_t)) != hipSuccess)
+            {
+                (void)hipGetLastError();
+                return 1; // (no room for the scratch list: one scan of the whole dictionary)
+            }
+            pl->split_cap = need;
+        }
+        dst = pl->d_split_rec;
+        room = need;
+    }
+    krep_gpu_scan_out_t o1, o2;
+    int rc = kg::ac_scan(pl->ac_long, pl->d_ctr, pl->h_ctr, pl->post, pl->num_cu, d_text, text_len, own_lo, own_hi, global_base, want ? dst : nullptr,
+                         want ? (limited ? (uint64_t)pl->max_count : room) : 0, pl->ww, false, pl->track, pl->max_count, st, time_it, pl->ev0, pl->ev1, &o1);
+    if (rc)
+        return rc;
+    const uint64_t s1 = want ? o1.stored : 0;
+    match_position_t *d2 = (want && room > s1) ? dst + s1 : nullptr; // (no room behind the first list: the second part is counted, and the sum overflows)
+    rc = kg::ac_scan(pl->ac_short, pl->d_ctr, pl->h_ctr, pl->post, pl->num_cu, d_text, text_len, own_lo, own_hi, global_base, d2,
+                     d2 ? (limited ? (uint64_t)pl->max_count : room - s1) : 0, pl->ww, false, pl->track, pl->max_count, st, time_it, pl->ev0, pl->ev1, &o2);
+    if (rc)
+        return rc;
+    memset(out, 0, sizeof *out);
+    const uint64_t total = o1.total_matches + o2.total_matches;
+    out->total_matches = total;
+    out->count = std::min<uint64_t>(total, (uint64_t)pl->max_count);
+    out->head_line_hit = out->tail_line_hit = total != 0;
+    out->kernel_ms = o1.kernel_ms + o2.kernel_ms;
+    if (want)
+    {
+        const uint64_t s2 = d2 ? o2.stored : 0, n = s1 + s2;
+        out->overflow = out->count > cap;
+        if (!out->overflow)
+        {
+            // (start, then END: records with one END come out longest first — the smaller start)
+            if (s1 && s2 &&
+                (kg::order_records(dst, n, global_base + text_len + 1, st, false) || kg::order_records(dst, n, global_base + text_len + 1, st, true)))
+                return 2;
+            out->stored = std::min<uint64_t>(n, out->count);
+            if (limited && out->stored)
+            {
+                HIPCHK(hipMemcpyAsync(d_pos, dst, out->stored * sizeof(match_position_t), hipMemcpyDeviceToDevice, st));
+                HIPCHK(hipStreamSynchronize(st));
+            }
+        }
+    }
+    // (a later text on which the long part no longer anchors — its decision follows the text, kg_ac.hip — ends the split)
+    if (pl->ac_long->anch_state == 1)
+        pl->ac_split = 1;
+    return 0;
+}
+
 static int scan_ac_lines_on_list(krep_gpu_plan *pl, const Window &w, hipStream_t st, int time_it, krep_gpu_scan_out_t *out)
 {
     memset(out, 0, sizeof *out);
@@ -1376,6 +1511,12 @@ static int scan_device_impl(krep_gpu_plan_t *pl, const void *d_text, size_t text
         // (small texts keep the in-kernel road: the list road ends with a few host round trips, ~0.1 ms)
         Window w{(const uint8_t *)d_text, text_len, own_lo, own_hi, global_base, global_len};
         const int rc = scan_ac_lines_on_list(pl, w, st, time_it, out);
+        if (rc != 1)
+            return rc;
+    }
+    if (pl->ref_algo == KREP_RA_AHO_CORASICK && !pl->lines)
+    {
+        const int rc = scan_ac_split(pl, (const uint8_t *)d_text, text_len, own_lo, own_hi, global_base, d_positions, position_capacity, st, time_it, out);
         if (rc != 1)
             return rc;
     }

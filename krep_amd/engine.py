@@ -445,6 +445,13 @@ class Plan:
             return None
         return bool(a.value), bool(b.value), float(r.value)
 
+    def split_state(self) -> int:
+        """0 undecided / 1 one dictionary / 2 split into a >= 4-byte part and a 1..3-byte part (kg_scan.hip scan_ac_split)"""
+        f = self.eng.lib.krep_gpu_debug_split_state
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p]
+        return int(f(self.h))
+
     def anchor_measured(self):
         """(candidates per tested position the last general-kernel scan counted, decisions re-opened so far)"""
         m, r = C.c_double(0), C.c_int(0)

@@ -7,6 +7,7 @@ staging slots carry the load."""
 import numpy as np
 import pytest
 
+import cases
 import wordlist
 from krep_amd import abi
 
@@ -119,4 +120,58 @@ def test_word_dictionary_device_windows_with_global_base(gpu, oracle_engine, wor
     # window order across them — sort both sides by (end, start) to compare as sets with multiplicity
     key = lambda a: a[np.lexsort((a[:, 0], a[:, 1]))]
     assert np.array_equal(key(cat), key(want))
+    plan.close()
+
+
+def test_word_dictionary_with_short_words_is_split_and_merged(gpu, oracle_engine, words):
+    """A word list that also holds 1..3-byte words (`of`, `the`, a rare three-letter word ...) gets no anchors as one dictionary; on word
+    text the plan scans its >= 4-byte part anchored and its short part on its own and merges the two record lists (kg_scan.hip
+    scan_ac_split).  The merged list must be aho_corasick_search's, record for record: END ascending, longest first at one END
+    (/root/reference/aho_corasick.c:383-437), under -i, -w and max_count; counting adds the two counts; -c (lines) keeps one scan."""
+    import torch
+    words, blob = words
+    n = 3 * (1 << 20) + 4567
+    text = gpu.generate_host(n, 0, 5, SEED, blob, LINE)
+    long_part = wordlist.dictionary(words, "rare", n=300) + wordlist.dictionary(words, "common", n=40, seed=3)
+    short = [w for w in words if len(w) <= 3]
+    assert len(short) >= 6
+    pats = long_part + short[:3] + short[-3:] + [b"of", b"th"]
+    d = torch.from_numpy(np.ascontiguousarray(text)).cuda()
+    for kw in (dict(), dict(case_sensitive=False), dict(whole_word=True), dict(max_count=1000), dict(max_count=3),
+               dict(count_lines=True, only_match=True), dict(count_lines=True)):
+        want = oracle_engine.call(abi.RA_AHO_CORASICK, abi.Params(pats, **kw), text)
+        plan = gpu.plan(abi.Params(pats, **kw))
+        cap = int(want[0]) + 8
+        pos = torch.zeros(2 * cap, dtype=torch.int64, device="cuda")
+        for rep in range(2):
+            out = plan.scan(d.data_ptr(), n, 0, n, 0, pos.data_ptr(), cap)
+            assert out.count == want[0], (kw, rep, out.count, want[0])
+            if len(want[1]):
+                got = pos[: 2 * out.stored].view(-1, 2).cpu().numpy().astype(np.uint64)
+                assert np.array_equal(got, want[1]), (kw, rep, got[:6], want[1][:6])
+        # (-c counts lines over ONE list: the split is never asked for, the state stays undecided)
+        assert plan.split_state() == (0 if kw.get("count_lines") and not kw.get("only_match") else 2), (kw, plan.split_state())
+        # ownership windows with a global base: the windows' lists concatenate to the whole list
+        if not kw:
+            base = (3 << 32) + 77
+            parts = []
+            for lo, hi in ((0, 1 << 20), (1 << 20, (2 << 20) + 17), ((2 << 20) + 17, n)):
+                out = plan.scan(d.data_ptr(), n, lo, hi, base, pos.data_ptr(), cap)
+                parts.append(pos[: 2 * out.stored].view(-1, 2).cpu().numpy().astype(np.uint64) - base)
+            assert np.array_equal(np.concatenate(parts), want[1])
+            # a list that does not fit is reported as such, with the right count
+            out = plan.scan(d.data_ptr(), n, 0, n, 0, pos.data_ptr(), 1000)
+            assert out.overflow and out.count == want[0]
+        plan.close()
+    # on i.i.d. text the long part gains nothing: one scan
+    rng = np.random.RandomState(3)
+    iid = cases.rand_text(rng, n, bytes(range(97, 123)) + b"  \n")
+    plan = gpu.plan(abi.Params(pats))
+    want = oracle_engine.call(abi.RA_AHO_CORASICK, abi.Params(pats), iid)
+    di = torch.from_numpy(iid).cuda()
+    cap = int(want[0]) + 8
+    pos = torch.zeros(2 * cap, dtype=torch.int64, device="cuda")
+    out = plan.scan(di.data_ptr(), n, 0, n, 0, pos.data_ptr(), cap)
+    assert out.count == want[0] and np.array_equal(pos[: 2 * out.stored].view(-1, 2).cpu().numpy().astype(np.uint64), want[1])
+    assert plan.split_state() == 1
     plan.close()
