@@ -28,6 +28,9 @@ for seed in range(7000, 7000 + (int(sys.argv[1]) if len(sys.argv) > 1 else 20)):
                 w = bytearray(pats[j]); w[rng.randint(0, len(w))] = 97 + rng.randint(0, 26); pats.append(bytes(w))
             pats += [pats[0][1:] if len(pats[0]) > 4 else pats[0], b"tion", b"ness", b"ation"][: rng.randint(0, 5)]
             pats = [p for p in pats if len(p) >= 4]
+            if rng.rand() < 0.35:  # a few 1..3-byte words beside them: the plan scans the two parts on their own and merges the lists (kg_scan.hip scan_ac_split)
+                shorts = [w for w in W if len(w) <= 3]
+                pats += [shorts[rng.randint(0, len(shorts))] for _ in range(rng.randint(1, 4))] + [b"of", b"a"][: rng.randint(0, 3)]
         else:
             alpha = [b"ab", b"abcdefgh \n", bytes(range(97, 123)) + b"  \n", b"abAB -\n"][rng.randint(0, 4)]
             text = cases.rand_text(rng, size, alpha)
