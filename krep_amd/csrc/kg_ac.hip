@@ -54,9 +54,13 @@ namespace kg {
 // ANCH == 2: the filter's index holds FIVE classes — the class of the byte in front of the 4-gram is multiplied out over the class
 // fields of the pair register (ac_mix5) before the slot address is formed, three VALU per tested position — for dictionaries (almost)
 // without patterns of 4 or 5 bytes: a 5-gram window of a word is several times rarer than its rarest 4-gram (kg_ac_anchor.hip).
-template <bool CI, bool LINES, bool SHORT, int STRIDE, int ANCH = 0>
+template <bool CI, bool LINES, bool SHORT, int STRIDE, int ANCH = 0, bool WW = false>
 __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
 {
+    // WW: -w with the neighbour filter of the depth masks compiled in (stride-2 instantiations without short patterns).  A flag tested at run
+    // time cost the plain scans 1.5-3 % — the filter's code in the verifier moved BASELINE config 4 from 6.27 to 6.38-6.46 ms in one process —
+    // so the eight instantiations it applies to exist twice; every other instantiation sends -w through the level walk as before.
+    static_assert(!WW || (STRIDE == 2 && !SHORT), "the -w filter of the depth masks: pair filter, no short patterns");
     static_assert(!ANCH || (STRIDE == 2 && !LINES && !SHORT), "anchored scan: pair filter, records / counts only");
     extern __shared__ __attribute__((aligned(16))) u32 s_mem[]; // filter table | per wave: candidate bitmap (+ hit and newline bitmaps for -c)
     const u32 lane = ac_lane();
@@ -508,14 +512,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 const uint4 lo = *reinterpret_cast<const uint4 *>(cbits + lane * kWPL);
                 mycnt = (u32)(__popc(lo.x) + __popc(lo.y) + __popc(lo.z) + __popc(lo.w));
             }
-            u32 incl = mycnt;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1)
-            {
-                const u32 t = __shfl_up(incl, o);
-                if (lane >= (u32)o)
-                    incl += t;
-            }
+            const u32 incl = ac_wave_scan_incl(mycnt); // (on the DPP network: the shuffle version's six address registers spilled in the -i -w instantiations)
             const bool off = (a.flags & (1u << 31)) != 0u; // (ablation hook KREP_GPU_AC_NOVERIFY: filter cost only)
             const u32 n = off ? 0u : __shfl(incl, 63);
             acc_cand += (u32)__builtin_amdgcn_readfirstlane((int)n);
@@ -692,7 +689,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 bool exact_done = false;
                 if constexpr (ANCH != 0)
 #ifndef KG_AC_EXACT_SERIAL
-                    if (a.xtab && pos >= 15u) // (-w: tested inside ac_exact_end2, on the window's own bytes)
+                    if (a.xtab && pos >= 15u && (WW || !(a.flags & F_WW))) // (-w: tested inside ac_exact_end2<.., WW>, on the window's own bytes)
 #else
                     if (a.xtab && !(a.flags & F_WW) && pos >= 15u)
 #endif
@@ -701,7 +698,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                         bool muA = false, muB = false;
 #ifndef KG_AC_EXACT_SERIAL // (A/B switch of krep_amd/build.py --variant: the two ends one behind the other, as first built)
                         if (liveA || liveB)
-                            ac_exact_end2<CI>(a, pos, liveA, liveB, mA, mB, muA, muB);
+                            ac_exact_end2<CI, WW>(a, pos, liveA, liveB, mA, mB, muA, muB);
 #else
                         if (liveA)
                             mA = ac_exact_end<CI>(a, pos, muA);
@@ -729,7 +726,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
                 {
                 }
                 else if (!(a.flags & (1u << 30))) // (ablation hook KREP_GPU_AC_NOPROBE: candidate enumeration without the probes)
-                    ac_walk_probe2<CI, SHORT, kStaged>(a, pos, liveA, liveB, LINES, mA, slA, mB, slB, [&](u32 E) -> bool {
+                    ac_walk_probe2<CI, SHORT, kStaged, WW>(a, pos, liveA, liveB, LINES, mA, slA, mB, slB, [&](u32 E) -> bool {
                         if constexpr (kGram)
                         {
                             // the filter's own lookup for a gram that lies in one dword (cell_body, k = 3 mod 4)
@@ -799,11 +796,8 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
           if (ANCH != 0 && (a.flags & (1u << 28))) // (ablation hook KREP_GPU_AC_NOSTAGE3: the anchor stage alone; the count is the number of marked END pairs)
           {
             const uint4 m = *reinterpret_cast<const uint4 *>(ebits + lane * 4u);
-            u32 c = (u32)(__popc(m.x) + __popc(m.y) + __popc(m.z) + __popc(m.w));
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1)
-                c += __shfl_xor(c, o);
-            wcnt += c;
+            const u32 c = (u32)(__popc(m.x) + __popc(m.y) + __popc(m.z) + __popc(m.w));
+            wcnt += (u32)__builtin_amdgcn_readlane((int)ac_wave_scan_incl(c), 63);
             *reinterpret_cast<uint4 *>(ebits + lane * 4u) = make_uint4(0u, 0u, 0u, 0u);
           }
           else if (ANCH == 0 || !(a.flags & (1u << 30)))
@@ -1015,11 +1009,7 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
         // the ticket's units: their counts from `ucnt`, their info words in one store
         const u32 nun = (u32)(u_end - u_begin);
         const u32 c = lane < nun ? ucnt : 0u;
-        u32 sum = c;
-#pragma unroll
-        for (int o = 4; o >= 1; o >>= 1) // (lanes 0..7 hold the counts)
-            sum += __shfl_xor(sum, o);
-        acc_total += (u32)__builtin_amdgcn_readfirstlane((int)sum);
+        acc_total += (u32)__builtin_amdgcn_readlane((int)ac_wave_scan_incl(c), 63); // (lanes 0..7 hold the counts; on the DPP network: no address registers)
         if (chain && lane < nun)
         {
             u32 l2 = lane;
@@ -1076,9 +1066,12 @@ static u32 ac_lds_bytes(u32 filter_words, bool lines)
 }
 
 constexpr u32 kAcMaxLds = 160u * 1024u; // LDS of a gfx950 CU: the most a launch of the scan kernel can ask for
-template <bool CI, bool LN, bool SHORT, int STRIDE, int ANCH = 0>
+template <bool CI, bool LN, bool SHORT, int STRIDE, int ANCH = 0, bool WW = false>
 static hipError_t ac_launch3(const AcArgs &a, u32 grid, u32 lds, hipStream_t st)
 {
+    if constexpr (!WW && STRIDE == 2 && !SHORT)
+        if (a.flags & F_WW)
+            return ac_launch3<CI, LN, SHORT, STRIDE, ANCH, true>(a, grid, lds, st);
     // more than 64 KiB of dynamic LDS has to be requested explicitly — once per instantiation and device, not on every launch
     // (the call sits on the latency path of small host buffers), and always for the MOST this kernel can ask for (the whole
     // 160 KiB of a CU), so that no later, larger request can find a stale grant.  Atomic flags: concurrent scans from several
@@ -1089,14 +1082,14 @@ static hipError_t ac_launch3(const AcArgs &a, u32 grid, u32 lds, hipStream_t st)
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= kMaxDev || !granted[dev].load(std::memory_order_acquire))
     {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ac_scan_kernel<CI, LN, SHORT, STRIDE, ANCH>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ac_scan_kernel<CI, LN, SHORT, STRIDE, ANCH, WW>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAcMaxLds);
         if (e != hipSuccess)
             return e;
         if (dev >= 0 && dev < kMaxDev)
             granted[dev].store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((ac_scan_kernel<CI, LN, SHORT, STRIDE, ANCH>), dim3(grid), dim3(kAcBlock), lds, st, a);
+    hipLaunchKernelGGL((ac_scan_kernel<CI, LN, SHORT, STRIDE, ANCH, WW>), dim3(grid), dim3(kAcBlock), lds, st, a);
     return hipGetLastError();
 }
 template <bool CI, bool LN>

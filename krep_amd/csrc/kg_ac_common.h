@@ -517,7 +517,7 @@ __device__ __forceinline__ u32 ac_walk_fast(const AcArgs &a, u64 i, bool own_by_
 // STAGED (the caller has a real gtest): the eight bytes i - 6 .. i + 1 come first — ONE request per candidate, and all that both
 // gram tests need; the 16-byte window in front of them is fetched only by the lanes an end survives in, together with their
 // buckets (the same two dependent round trips as before, a third of the requests).
-template <bool CI, bool SHORT, bool STAGED, typename GTest>
+template <bool CI, bool SHORT, bool STAGED, bool WW, typename GTest>
 __device__ __forceinline__ void ac_walk_probe2(const AcArgs &a, u64 i, bool liveA, bool liveB, bool own_by_end,
                                                u32 &dmA, bool &slowA, u32 &dmB, bool &slowB, GTest gtest)
 {
@@ -525,7 +525,8 @@ __device__ __forceinline__ void ac_walk_probe2(const AcArgs &a, u64 i, bool live
     slowA = slowB = false;
     // (-w no longer sends every candidate to the level walk, round 6: the depth masks the entries answer with are filtered by the matches'
     //  neighbours at the end of this function — BASELINE config 4 with -w: 15.0 ms for 32 GiB where the plain scan takes 6.5)
-    if (i < 15 || (a.flags & (SHORT ? (F_WW | F_AC_SHORT_DUP) : 0u)))
+    // (WW: a template parameter of the kernel, not the run-time flag — see ac_scan_kernel)
+    if (i < 15 || (a.flags & ((WW ? 0u : F_WW) | (SHORT ? F_AC_SHORT_DUP : 0u))))
     {
         slowA = liveA;
         slowB = liveB;
@@ -642,7 +643,7 @@ __device__ __forceinline__ void ac_walk_probe2(const AcArgs &a, u64 i, bool live
 #endif
     if (liveB)
         ac_eval_entry(a, foundB, TB, b0, b1, sbB, i + 1, own_by_end, dmB, slowB);
-    if (!SHORT && (a.flags & F_WW))
+    if constexpr (WW)
     {
         // -w (is_whole_word_match krep.h:312-319) on what matched: bit d of a mask is a pattern of d bytes ending here — the byte behind the
         // end decides for all of them, the byte in front of each is byte 15 - d of the window (d >= 16: one load).  An end that takes the
@@ -743,11 +744,11 @@ __device__ __forceinline__ u32 ac_exact_end(const AcArgs &a, u64 i, bool &multi)
 // The same for BOTH ends of a marked pair, i and i + 1 (stage 3 of the anchored scan), interleaved: one 17-byte window, the four length
 // masks requested together, then per step the longest remaining length of EACH end — both buckets in flight at once.  Two calls of
 // ac_exact_end run their round trips one behind the other (2 + nA, then 2 + nB); this runs 2 + max(nA, nB).
-template <bool CI>
+template <bool CI, bool WW>
 __device__ __forceinline__ void ac_exact_end2(const AcArgs &a, u64 i, bool liveA, bool liveB, u32 &dmA, u32 &dmB, bool &multiA, bool &multiB)
 {
     struct __attribute__((packed)) U32p { u32 v; };
-    const bool ww = (a.flags & F_WW) != 0u; // -w (is_whole_word_match krep.h:312-319): a match needs a non-word byte (or the text's edge) on either side
+    constexpr bool ww = WW; // -w (is_whole_word_match krep.h:312-319): a match needs a non-word byte (or the text's edge) on either side
     const U32p *q = reinterpret_cast<const U32p *>(a.text + (i - 15));
     u32 TA[4] = {q[0].v, q[1].v, q[2].v, q[3].v};
     const u32 nxt = ((liveB || ww) && i + 1 < a.text_len) ? (u32)a.text[i + 1] : 0u; // (a live end i + 1 lies inside the text)
