@@ -108,7 +108,7 @@ __device__ __noinline__ uint4 s_load16_guarded(const uint8_t *text, u64 text_len
 // device that runs a single workgroup of the grid still makes progress.
 __device__ __forceinline__ bool s_wordc(u32 c) { return (c - '0' < 10u) || ((c | 0x20u) - 'a' < 26u) || c == '_'; }
 
-template <bool CI, u32 kUpt, u32 kRing, int WPE, bool SET, bool MULTI = false, bool BDRAW = false>
+template <bool CI, u32 kUpt, u32 kRing, int WPE, bool SET, bool MULTI = false, bool BDRAW = false, bool WW = false>
 __global__ __launch_bounds__(kBlock, WPE) void single_fused(const LitArgs a, u64 *__restrict__ agg, u64 *__restrict__ pref,
                                                             const u64 n_tickets)
 {
@@ -286,7 +286,9 @@ __global__ __launch_bounds__(kBlock, WPE) void single_fused(const LitArgs a, u64
                 }
                 // -w (round 6; is_whole_word_match krep.h:312-319): both neighbours of a start position lie in the 24-byte window or — position
                 // 0 — in the lane below's last dword, and are picked out of registers (kg_literal.hip); only lane 0's position 0 asks memory
-                if ((a.flags & F_WW) && __ballot(m16 != 0u))
+                // (WW: a template parameter — behind a run-time flag this block cost the plain one-pass writer 1.3-1.6 %: ` a` 6.40 -> 6.49 ms
+                //  in one process, register allocation — so the -w instantiations are twins)
+                if (WW && __ballot(m16 != 0u))
                 {
                     const u32 below = __shfl_up(D[3], 1);
                     const u64 lb = seg + (u64)j * kCellBytes + (u64)lane * 16u;
@@ -463,7 +465,7 @@ __global__ __launch_bounds__(kBlock, WPE) void single_fused(const LitArgs a, u64
 
 int g_s1_force_grid = 0; // test hook: at most this many blocks (0 = auto)
 // grid = the resident blocks of the instantiation x CUs
-template <bool CI, u32 UPT, u32 RING, int WPE, bool SET, bool MULTI, bool BDRAW = false>
+template <bool CI, u32 UPT, u32 RING, int WPE, bool SET, bool MULTI, bool BDRAW = false, bool WW = false>
 static hipError_t launch_fused(const LitArgs &a, u64 *agg, u64 *pref, u64 n_tickets, u32 num_cu, hipStream_t st)
 {
     constexpr size_t kLds = (size_t)kWavesPerBlk * RING * sizeof(unsigned short) + (BDRAW ? 16u : 0u);
@@ -479,13 +481,13 @@ static hipError_t launch_fused(const LitArgs &a, u64 *agg, u64 *pref, u64 n_tick
     {
         if (kLds > 64 * 1024) // more than 64 KiB of dynamic LDS has to be asked for
         {
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&single_fused<CI, UPT, RING, WPE, SET, MULTI, BDRAW>),
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&single_fused<CI, UPT, RING, WPE, SET, MULTI, BDRAW, WW>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
             if (e != hipSuccess)
                 return e;
         }
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, single_fused<CI, UPT, RING, WPE, SET, MULTI, BDRAW>, kBlock, kLds) != hipSuccess || n < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, single_fused<CI, UPT, RING, WPE, SET, MULTI, BDRAW, WW>, kBlock, kLds) != hipSuccess || n < 1)
         {
             (void)hipGetLastError();
             n = 1;
@@ -498,7 +500,7 @@ static hipError_t launch_fused(const LitArgs &a, u64 *agg, u64 *pref, u64 n_tick
     u32 grid = (u32)std::max<u64>(1, std::min<u64>(want, (u64)num_cu * bpc));
     if (g_s1_force_grid > 0) // test hook: a starved grid (krep_gpu_debug_force_single_grid)
         grid = std::min<u32>(grid, (u32)g_s1_force_grid);
-    hipLaunchKernelGGL((single_fused<CI, UPT, RING, WPE, SET, MULTI, BDRAW>), dim3(grid), dim3(kBlock), kLds, st, a, agg, pref, n_tickets);
+    hipLaunchKernelGGL((single_fused<CI, UPT, RING, WPE, SET, MULTI, BDRAW, WW>), dim3(grid), dim3(kBlock), kLds, st, a, agg, pref, n_tickets);
     return hipGetLastError();
 }
 
@@ -521,22 +523,22 @@ double single_fused_max_density(int shape)
     return 0.4 * (double)shape_ring(shape) / ((double)shape_upt(shape) * (double)kUnitBytes1);
 }
 
-template <bool CI, bool SET, bool MULTI = false>
+template <bool CI, bool SET, bool MULTI = false, bool WW = false>
 static hipError_t launch_shape(const LitArgs &a, u64 *agg, u64 *pref, u64 n_tickets, u32 num_cu, int shape, hipStream_t st)
 {
     static_assert(kFusedShapeMax == 5, "six shapes");
-    if (shape == 0) return launch_fused<CI, kUptStd, kRingStd, 4, SET, MULTI>(a, agg, pref, n_tickets, num_cu, st);
-    if (shape == 1) return launch_fused<CI, 2u, kRingMid, 3, SET, MULTI>(a, agg, pref, n_tickets, num_cu, st);
-    if (shape == 2) return launch_fused<CI, 2u, kRingDense, 2, SET, MULTI>(a, agg, pref, n_tickets, num_cu, st);
+    if (shape == 0) return launch_fused<CI, kUptStd, kRingStd, 4, SET, MULTI, false, WW>(a, agg, pref, n_tickets, num_cu, st);
+    if (shape == 1) return launch_fused<CI, 2u, kRingMid, 3, SET, MULTI, false, WW>(a, agg, pref, n_tickets, num_cu, st);
+    if (shape == 2) return launch_fused<CI, 2u, kRingDense, 2, SET, MULTI, false, WW>(a, agg, pref, n_tickets, num_cu, st);
 #ifndef KG_S1_NO_BDRAW // (A/B switch)
     constexpr bool kB = true; // 32-KiB tickets: one draw per workgroup
 #else
     constexpr bool kB = false;
 #endif
-    if (shape == 3) return launch_fused<CI, 1u, kRingMid, 3, SET, MULTI, kB>(a, agg, pref, n_tickets, num_cu, st);
-    if (shape == 4) return launch_fused<CI, 1u, kRingDense, 2, SET, MULTI, kB>(a, agg, pref, n_tickets, num_cu, st);
+    if (shape == 3) return launch_fused<CI, 1u, kRingMid, 3, SET, MULTI, kB, WW>(a, agg, pref, n_tickets, num_cu, st);
+    if (shape == 4) return launch_fused<CI, 1u, kRingDense, 2, SET, MULTI, kB, WW>(a, agg, pref, n_tickets, num_cu, st);
     // (not the 32-KiB-ring shape: with ONE workgroup per CU its four waves would scan and flush in lock step — measured 959 against 1000 GB/s)
-    return launch_fused<CI, 1u, kRingDensest, 1, SET, MULTI, false>(a, agg, pref, n_tickets, num_cu, st);
+    return launch_fused<CI, 1u, kRingDensest, 1, SET, MULTI, false, WW>(a, agg, pref, n_tickets, num_cu, st);
 }
 
 hipError_t launch_single_fused(const LitArgs &a, unsigned long long *d_agg, unsigned long long *d_pref, uint64_t n_tickets,
@@ -547,6 +549,9 @@ hipError_t launch_single_fused(const LitArgs &a, unsigned long long *d_agg, unsi
     {
         if (a.m > 8u)
             return hipErrorInvalidValue;
+        if (a.flags & F_WW)
+            return ci ? launch_shape<true, false, true, true>(a, d_agg, d_pref, n_tickets, num_cu, shape, st)
+                      : launch_shape<false, false, true, true>(a, d_agg, d_pref, n_tickets, num_cu, shape, st);
         return ci ? launch_shape<true, false, true>(a, d_agg, d_pref, n_tickets, num_cu, shape, st)
                   : launch_shape<false, false, true>(a, d_agg, d_pref, n_tickets, num_cu, shape, st);
     }
