@@ -1259,65 +1259,69 @@ constexpr size_t kAcLinesOnListMin = (size_t)32 << 20;
 // aho_corasick_search's order, END ascending and longest first (aho_corasick.c:383-437), patterns of different lengths never produce the
 // same record — are merged by two stable radix sorts, by start and then by END.  Decided once per plan, on its first text of >= 1 MiB,
 // by sampling that text with the long part (ac_anchor_prepare): split only where the long part anchors.  Returns 1: not applicable.
+// the decision (once per plan, on its first text of >= 1 MiB): 2 = split, 1 = one dictionary; 0 = not decided yet (the text is too small to sample)
+static int ac_split_decide(krep_gpu_plan *pl, const uint8_t *d_text, size_t text_len, size_t own_lo, size_t own_hi, hipStream_t st)
+{
+    kg::AcTables *t = pl->ac;
+    if (pl->ac_split)
+        return pl->ac_split;
+    if (!t || t->has_empty || !(t->has1 || t->has2 || t->has3) || pl->max_count == 0 || getenv("KREP_GPU_AC_NO_SPLIT"))
+        return pl->ac_split = 1;
+    const size_t hi = std::min(own_hi, text_len);
+    if (text_len < (1u << 20) || hi <= own_lo || hi - own_lo < (1u << 19))
+        return 0; // (too small to sample: decided by a later text)
+    std::vector<const char *> pl_long, pl_short;
+    std::vector<size_t> ln_long, ln_short;
+    for (size_t i = 0; i < pl->sp.num_patterns; ++i)
+    {
+        const bool is_long = pl->sp.pattern_lens[i] >= 4;
+        (is_long ? pl_long : pl_short).push_back(pl->sp.patterns[i]);
+        (is_long ? ln_long : ln_short).push_back(pl->sp.pattern_lens[i]);
+    }
+    pl->ac_split = 1;
+    if (pl_long.size() < 8 || pl_short.empty())
+        return 1;
+    search_params_t sub = pl->sp;
+    sub.patterns = pl_long.data();
+    sub.pattern_lens = ln_long.data();
+    sub.num_patterns = pl_long.size();
+    sub.pattern = nullptr;
+    sub.pattern_len = 0;
+    pl->ac_long = kg::ac_build(sub, pl->device);
+    if (!pl->ac_long)
+    {
+        krep_gpu_clear_error();
+        return 1;
+    }
+    if (hipSetDevice(pl->device) != hipSuccess || kg::ac_anchor_prepare(pl->ac_long, d_text, text_len, own_lo, hi, st) == 2)
+        (void)hipGetLastError();
+    if (pl->ac_long->anch_state != 2)
+    { // the long part gains nothing from anchors on this text: one scan of the whole dictionary, as always
+        kg::ac_free(pl->ac_long);
+        pl->ac_long = nullptr;
+        return 1;
+    }
+    sub.patterns = pl_short.data();
+    sub.pattern_lens = ln_short.data();
+    sub.num_patterns = pl_short.size();
+    pl->ac_short = kg::ac_build(sub, pl->device);
+    if (!pl->ac_short)
+    {
+        krep_gpu_clear_error();
+        kg::ac_free(pl->ac_long);
+        pl->ac_long = nullptr;
+        return 1;
+    }
+    if (getenv("KREP_GPU_DEBUG"))
+        fprintf(stderr, "krep-gpu: multi-pattern scan split: %zu patterns of >= 4 bytes (anchored) + %zu of 1..3 bytes, lists merged by (end, start)\n", pl_long.size(),
+                pl_short.size());
+    return pl->ac_split = 2;
+}
 static int scan_ac_split(krep_gpu_plan *pl, const uint8_t *d_text, size_t text_len, size_t own_lo, size_t own_hi, size_t global_base,
                          match_position_t *d_pos, uint64_t cap, hipStream_t st, int time_it, krep_gpu_scan_out_t *out)
 {
-    kg::AcTables *t = pl->ac;
-    if (pl->ac_split == 1 || !t || t->has_empty || !(t->has1 || t->has2 || t->has3) || pl->max_count == 0 || getenv("KREP_GPU_AC_NO_SPLIT"))
+    if (ac_split_decide(pl, d_text, text_len, own_lo, own_hi, st) != 2)
         return 1;
-    const size_t hi = std::min(own_hi, text_len);
-    if (pl->ac_split == 0)
-    {
-        if (text_len < (1u << 20) || hi <= own_lo || hi - own_lo < (1u << 19))
-            return 1; // (too small to sample: decided by a later text)
-        std::vector<const char *> pl_long, pl_short;
-        std::vector<size_t> ln_long, ln_short;
-        for (size_t i = 0; i < pl->sp.num_patterns; ++i)
-        {
-            const bool is_long = pl->sp.pattern_lens[i] >= 4;
-            (is_long ? pl_long : pl_short).push_back(pl->sp.patterns[i]);
-            (is_long ? ln_long : ln_short).push_back(pl->sp.pattern_lens[i]);
-        }
-        pl->ac_split = 1;
-        if (pl_long.size() < 8 || pl_short.empty())
-            return 1;
-        search_params_t sub = pl->sp;
-        sub.patterns = pl_long.data();
-        sub.pattern_lens = ln_long.data();
-        sub.num_patterns = pl_long.size();
-        sub.pattern = nullptr;
-        sub.pattern_len = 0;
-        pl->ac_long = kg::ac_build(sub, pl->device);
-        if (!pl->ac_long)
-        {
-            krep_gpu_clear_error();
-            return 1;
-        }
-        HIPCHK(hipSetDevice(pl->device));
-        if (kg::ac_anchor_prepare(pl->ac_long, d_text, text_len, own_lo, hi, st) == 2)
-            (void)hipGetLastError();
-        if (pl->ac_long->anch_state != 2)
-        { // the long part gains nothing from anchors on this text: one scan of the whole dictionary, as always
-            kg::ac_free(pl->ac_long);
-            pl->ac_long = nullptr;
-            return 1;
-        }
-        sub.patterns = pl_short.data();
-        sub.pattern_lens = ln_short.data();
-        sub.num_patterns = pl_short.size();
-        pl->ac_short = kg::ac_build(sub, pl->device);
-        if (!pl->ac_short)
-        {
-            krep_gpu_clear_error();
-            kg::ac_free(pl->ac_long);
-            pl->ac_long = nullptr;
-            return 1;
-        }
-        pl->ac_split = 2;
-        if (getenv("KREP_GPU_DEBUG"))
-            fprintf(stderr, "krep-gpu: multi-pattern scan split: %zu patterns of >= 4 bytes (anchored) + %zu of 1..3 bytes, lists merged by (end, start)\n", pl_long.size(),
-                    pl_short.size());
-    }
     // Under a max_count smaller than the caller's list the result is the first max_count records of the MERGED list: either part may
     // contribute all of them, so both parts' first max_count records go to a scratch list of the plan, are merged there, and the first
     // max_count are copied out.  Without such a limit the caller's list holds everything (or overflows, as always).
@@ -1411,8 +1415,36 @@ static int scan_ac_lines_on_list(krep_gpu_plan *pl, const Window &w, hipStream_t
     krep_gpu_scan_out_t o1;
     for (int attempt = 0;; ++attempt)
     {
-        const int rc = ac_scan(pl->ac, pl->d_ctr, pl->h_ctr, pl->post, pl->num_cu, w.d_text, w.text_len, w.own_lo, own_hi, w.global_base,
-                               pl->d_nl_rec, pl->nl_cap, pl->ww, false, true, SIZE_MAX, st, 0, pl->ev0, pl->ev1, &o1, true);
+        int rc = 0;
+        if (ac_split_decide(pl, w.d_text, w.text_len, w.own_lo, own_hi, st) == 2)
+        {
+            // (a dictionary with short patterns on word-like text, scan_ac_split: the two parts' END-owned lists, merged into the order the
+            //  one list would have — END ascending, longest first —, the line gaps counted on the merged list below)
+            krep_gpu_scan_out_t oa, ob;
+            rc = ac_scan(pl->ac_long, pl->d_ctr, pl->h_ctr, pl->post, pl->num_cu, w.d_text, w.text_len, w.own_lo, own_hi, w.global_base, pl->d_nl_rec, pl->nl_cap,
+                         pl->ww, false, true, SIZE_MAX, st, 0, pl->ev0, pl->ev1, &oa, 2);
+            if (rc)
+                return rc;
+            const uint64_t sa = oa.stored;
+            match_position_t *d2 = pl->nl_cap > sa ? pl->d_nl_rec + sa : nullptr;
+            rc = ac_scan(pl->ac_short, pl->d_ctr, pl->h_ctr, pl->post, pl->num_cu, w.d_text, w.text_len, w.own_lo, own_hi, w.global_base, d2, d2 ? pl->nl_cap - sa : 0,
+                         pl->ww, false, true, SIZE_MAX, st, 0, pl->ev0, pl->ev1, &ob, 2);
+            if (rc)
+                return rc;
+            memset(&o1, 0, sizeof o1);
+            o1.total_matches = oa.total_matches + ob.total_matches;
+            o1.overflow = oa.overflow || ob.overflow || !d2 || o1.total_matches > pl->nl_cap;
+            o1.line_count = ~0ull; // (counted on the merged list below)
+            if (!o1.overflow && oa.stored && ob.stored &&
+                (kg::order_records(pl->d_nl_rec, o1.total_matches, w.global_base + w.text_len + 1, st, false) ||
+                 kg::order_records(pl->d_nl_rec, o1.total_matches, w.global_base + w.text_len + 1, st, true)))
+                return 2;
+            if (pl->ac_long->anch_state == 1)
+                pl->ac_split = 1;
+        }
+        else
+            rc = ac_scan(pl->ac, pl->d_ctr, pl->h_ctr, pl->post, pl->num_cu, w.d_text, w.text_len, w.own_lo, own_hi, w.global_base,
+                         pl->d_nl_rec, pl->nl_cap, pl->ww, false, true, SIZE_MAX, st, 0, pl->ev0, pl->ev1, &o1, true);
         if (rc)
             return rc;
         if (o1.total_matches > dense)

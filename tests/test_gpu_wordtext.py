@@ -175,3 +175,28 @@ def test_word_dictionary_with_short_words_is_split_and_merged(gpu, oracle_engine
     assert out.count == want[0] and np.array_equal(pos[: 2 * out.stored].view(-1, 2).cpu().numpy().astype(np.uint64), want[1])
     assert plan.split_state() == 1
     plan.close()
+
+
+def test_count_lines_of_a_split_dictionary_on_the_merged_list(gpu, oracle_engine, words):
+    """-c (distinct lines) of a word dictionary with short words, on a text large enough for the record-list road (>= 32 MiB): the two
+    parts' END-owned lists are merged and the line gaps counted on the merged list (kg_scan.hip scan_ac_lines_on_list); the same count
+    as aho_corasick_search's count_lines_mode (/root/reference/aho_corasick.c:353-431), also in two ownership windows whose line counts
+    combine (krep_gpu_combine_line_counts)."""
+    import torch
+    words, blob = words
+    n = (40 << 20) + 1234
+    text = gpu.generate_host(n, 0, 5, SEED, blob, LINE)
+    pats = wordlist.dictionary(words, "rare", n=300) + [w for w in words if len(w) <= 3][:4] + [b"of"]
+    d = torch.from_numpy(np.ascontiguousarray(text)).cuda()
+    for kw in (dict(count_lines=True), dict(count_lines=True, whole_word=True), dict(count_lines=True, case_sensitive=False, max_count=1000)):
+        want = oracle_engine.call(abi.RA_AHO_CORASICK, abi.Params(pats, **kw), text)[0]
+        plan = gpu.plan(abi.Params(pats, **kw))
+        for rep in range(2):
+            out = plan.scan(d.data_ptr(), n)
+            assert out.count == want, (kw, rep, out.count, want)
+        assert plan.split_state() == 2, (kw, plan.split_state())
+        if "max_count" not in kw:
+            cut = (17 << 20) + 40  # (inside a line)
+            outs = [plan.scan(d.data_ptr(), n, 0, cut), plan.scan(d.data_ptr(), n, cut, n)]
+            assert gpu.lib.krep_gpu_combine_line_counts((abi.ScanOut * 2)(*outs), 2) == want
+        plan.close()

@@ -31,8 +31,14 @@ for name, pats in SHAPES:
             ts.append(out.kernel_ms)
         info = plan.anchor_info()
         plan.close()
+        planc = e.plan(abi.Params(pats, count_lines=True))
+        tc = []
+        for i in range(4):
+            oc = planc.scan(buf.data_ptr(), n, time_it=True)
+            tc.append(oc.kernel_ms)
+        planc.close()
         t = statistics.median(ts[1:])
         print(f"{name:40s} {len(pats):5d} patterns {out.count:11d} matches   first {ts[0]:8.2f} ms | {t:8.2f} ms = {n / t / 1e6:6.0f} GB/s ({n / t / 8e9:.3f})"
-              f"{' OVERFLOW' if out.overflow else ''}   state {info[0] if info else '-'}", flush=True)
+              f"{' OVERFLOW' if out.overflow else ''}   state {info[0] if info else '-'}   -c (lines) {statistics.median(tc[1:]):8.2f} ms ({oc.count} lines)", flush=True)
     except Exception as ex:
         print(f"{name:40s} failed: {str(ex)[:120]}", flush=True)
