@@ -1259,6 +1259,7 @@ constexpr size_t kAcLinesOnListMin = (size_t)32 << 20;
 // aho_corasick_search's order, END ascending and longest first (aho_corasick.c:383-437), patterns of different lengths never produce the
 // same record — are merged by two stable radix sorts, by start and then by END.  Decided once per plan, on its first text of >= 1 MiB,
 // by sampling that text with the long part (ac_anchor_prepare): split only where the long part anchors.  Returns 1: not applicable.
+constexpr uint64_t kAcSplitMaxRecords = 1ull << 28; // (a merged list beyond this — a dense short part — is not worth two sorts with 32 bytes of scratch per record)
 // the decision (once per plan, on its first text of >= 1 MiB): 2 = split, 1 = one dictionary; 0 = not decided yet (the text is too small to sample)
 static int ac_split_decide(krep_gpu_plan *pl, const uint8_t *d_text, size_t text_len, size_t own_lo, size_t own_hi, hipStream_t st)
 {
@@ -1372,8 +1373,15 @@ static int scan_ac_split(krep_gpu_plan *pl, const uint8_t *d_text, size_t text_l
         {
             // (start, then END: records with one END come out longest first — the smaller start)
             if (s1 && s2 &&
-                (kg::order_records(dst, n, global_base + text_len + 1, st, false) || kg::order_records(dst, n, global_base + text_len + 1, st, true)))
-                return 2;
+                (n > kAcSplitMaxRecords || kg::order_records(dst, n, global_base + text_len + 1, st, false) ||
+                 kg::order_records(dst, n, global_base + text_len + 1, st, true)))
+            {
+                // (the sort's scratch — 32 bytes per record — did not fit, or the list exceeds the device sort's 2^31-1 items: a dictionary whose
+                //  short part is dense.  One scan of the whole dictionary, from now on.)
+                krep_gpu_clear_error();
+                pl->ac_split = 1;
+                return 1;
+            }
             out->stored = std::min<uint64_t>(n, out->count);
             if (limited && out->stored)
             {
@@ -1416,6 +1424,7 @@ static int scan_ac_lines_on_list(krep_gpu_plan *pl, const Window &w, hipStream_t
     for (int attempt = 0;; ++attempt)
     {
         int rc = 0;
+        bool merged = false; // (the list below is the two parts', merged)
         if (ac_split_decide(pl, w.d_text, w.text_len, w.own_lo, own_hi, st) == 2)
         {
             // (a dictionary with short patterns on word-like text, scan_ac_split: the two parts' END-owned lists, merged into the order the
@@ -1436,13 +1445,20 @@ static int scan_ac_lines_on_list(krep_gpu_plan *pl, const Window &w, hipStream_t
             o1.overflow = oa.overflow || ob.overflow || !d2 || o1.total_matches > pl->nl_cap;
             o1.line_count = ~0ull; // (counted on the merged list below)
             if (!o1.overflow && oa.stored && ob.stored &&
-                (kg::order_records(pl->d_nl_rec, o1.total_matches, w.global_base + w.text_len + 1, st, false) ||
+                (o1.total_matches > kAcSplitMaxRecords || kg::order_records(pl->d_nl_rec, o1.total_matches, w.global_base + w.text_len + 1, st, false) ||
                  kg::order_records(pl->d_nl_rec, o1.total_matches, w.global_base + w.text_len + 1, st, true)))
-                return 2;
-            if (pl->ac_long->anch_state == 1)
+            { // (no room for the sort's scratch: one scan of the whole dictionary, from now on — see scan_ac_split)
+                krep_gpu_clear_error();
                 pl->ac_split = 1;
+            }
+            else
+            {
+                merged = true;
+                if (pl->ac_long->anch_state == 1)
+                    pl->ac_split = 1;
+            }
         }
-        else
+        if (!merged)
             rc = ac_scan(pl->ac, pl->d_ctr, pl->h_ctr, pl->post, pl->num_cu, w.d_text, w.text_len, w.own_lo, own_hi, w.global_base,
                          pl->d_nl_rec, pl->nl_cap, pl->ww, false, true, SIZE_MAX, st, 0, pl->ev0, pl->ev1, &o1, true);
         if (rc)
