@@ -1259,7 +1259,8 @@ constexpr size_t kAcLinesOnListMin = (size_t)32 << 20;
 // aho_corasick_search's order, END ascending and longest first (aho_corasick.c:383-437), patterns of different lengths never produce the
 // same record — are merged by two stable radix sorts, by start and then by END.  Decided once per plan, on its first text of >= 1 MiB,
 // by sampling that text with the long part (ac_anchor_prepare): split only where the long part anchors.  Returns 1: not applicable.
-constexpr uint64_t kAcSplitMaxRecords = 1ull << 28; // (a merged list beyond this — a dense short part — is not worth two sorts with 32 bytes of scratch per record)
+// (a merged list beyond this — a dense short part — is not worth two sorts with 32 bytes of scratch per record; $KREP_GPU_AC_SPLIT_MAX: the tests' way to the fallback)
+static const uint64_t kAcSplitMaxRecords = [] { const char *e = getenv("KREP_GPU_AC_SPLIT_MAX"); return e && atoll(e) > 0 ? (uint64_t)atoll(e) : (1ull << 28); }();
 // the decision (once per plan, on its first text of >= 1 MiB): 2 = split, 1 = one dictionary; 0 = not decided yet (the text is too small to sample)
 static int ac_split_decide(krep_gpu_plan *pl, const uint8_t *d_text, size_t text_len, size_t own_lo, size_t own_hi, hipStream_t st)
 {

@@ -200,3 +200,12 @@ def test_count_lines_of_a_split_dictionary_on_the_merged_list(gpu, oracle_engine
             outs = [plan.scan(d.data_ptr(), n, 0, cut), plan.scan(d.data_ptr(), n, cut, n)]
             assert gpu.lib.krep_gpu_combine_line_counts((abi.ScanOut * 2)(*outs), 2) == want
         plan.close()
+
+
+def test_split_scan_falls_back_when_the_merged_list_is_too_long():
+    """A merged list beyond 2^28 records (a dense short part), or one whose sort finds no room, sends the plan back to ONE scan of the whole
+    dictionary — same records.  The limit is read at library load: a child process with $KREP_GPU_AC_SPLIT_MAX=1000."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "_split_fallback_child.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "split fallback ok [1, 2]" in r.stdout, (r.stdout[-400:], r.stderr[-800:])
