@@ -393,3 +393,62 @@ def test_one_pass_writers_8gib_properties(gpu):
             assert np.array_equal(got - lo, want), (pats, lo)
         plan.close()
         del pos
+
+
+@pytest.mark.parametrize("short_words", [False, True])
+def test_word_dictionary_8gib_of_word_text(gpu, short_words):
+    """The multi-pattern scan on WORD text at a size where its round-6 machinery is all in play (8 GiB: tickets of 8 units — the verify
+    stage deferred over the ticket —, anchors with the five-class index, the exact dictionary; with two short words in the list the
+    two-part scan and its merged record list, kg_scan.hip scan_ac_split):
+      * the whole list is in aho_corasick_search's emission order (/root/reference/aho_corasick.c:383-437: end ascending, longest first);
+      * its length equals the SUM of the single-literal all-occurrence counts of every word (an independent code path, at full size);
+      * exact (start, end) lists against the compiled reference's aho_corasick_search on 1-MiB windows, one of them above 4 GiB."""
+    import torch
+    import wordlist
+    n = 8 * GIB
+    free, _ = torch.cuda.mem_get_info()
+    if free < n + (6 << 30):
+        pytest.skip("not enough free HBM")
+    W = wordlist.word_list()
+    pats = wordlist.dictionary(W, "rare")
+    if short_words:
+        pats = pats + [w for w in W if len(w) == 3][:2] + [b"of"]
+    buf = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+    gpu.generate(buf.data_ptr(), n, 0, 5, 20260930, wordlist.pack(W), 80)
+    cap = n // (32 if short_words else 96)  # (the first three-letter words of the list are frequent ones: ~1e8 records)
+    pos = torch.empty(2 * cap, dtype=torch.int64, device="cuda")
+    before = gpu.anchored_launches()
+    plan = gpu.plan(abi.Params(pats))
+    out = plan.scan(buf.data_ptr(), n, 0, n, 0, pos.data_ptr(), cap)
+    out2 = plan.scan(buf.data_ptr(), n, 0, n, 0, pos.data_ptr(), cap)
+    assert not out.overflow and out.stored == out.total_matches == out.count == out2.count
+    assert gpu.anchored_launches() > before and plan.split_state() == (2 if short_words else 1)
+    plan.close()
+    rec = pos[: 2 * out.stored].view(-1, 2)
+    st, en = rec[:, 0], rec[:, 1]
+    assert bool(torch.all((en[1:] > en[:-1]) | ((en[1:] == en[:-1]) & (st[1:] >= st[:-1]))))
+    ln = en - st
+    assert int(ln.min().item()) >= (2 if short_words else 4) and int(ln.max().item()) <= 16 and int(st.min().item()) >= 0 and int(en.max().item()) <= n
+    gpu.set_algo_override(abi.ALGO_BM)
+    try:
+        total = 0
+        for p in pats:
+            pl = gpu.plan(abi.Params([p], count_lines=True, only_match=True))
+            total += pl.scan(buf.data_ptr(), n).count
+            pl.close()
+    finally:
+        gpu.set_algo_override(abi.ALGO_AUTO)
+    assert total == out.count, (total, out.count)
+    o = ol.checker()
+    order = torch.argsort(st, stable=True)
+    st_sorted = st[order]
+    for wlo in (0, 123457, 2 * GIB - (1 << 19), 4 * GIB + 4321, 7 * GIB + 99, n - (1 << 20)):
+        whi = min(n, wlo + (1 << 20))
+        b0, b1 = max(0, wlo - 16), min(n, whi + 16)
+        _, wpos = o.call(abi.RA_AHO_CORASICK, abi.Params(pats), buf[b0:b1].cpu().numpy())
+        wpos = wpos.astype(np.int64) + b0
+        want = wpos[(wpos[:, 0] >= wlo) & (wpos[:, 0] < whi)]
+        i0 = int(torch.searchsorted(st_sorted, torch.tensor([wlo], device="cuda")).item())
+        i1 = int(torch.searchsorted(st_sorted, torch.tensor([whi], device="cuda")).item())
+        got = rec[torch.sort(order[i0:i1]).values].cpu().numpy()
+        assert np.array_equal(got, want), (short_words, wlo, len(got), len(want))
