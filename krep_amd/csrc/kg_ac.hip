@@ -116,10 +116,15 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
         if (lane == 0)
             tk = __hip_atomic_fetch_add(&a.ctr->ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         tk = ac_rfl64(tk);
-        const u64 u_begin = tk * (u64)a.upt;
+        // (emit mode with a list: ticket k is the k-th unit that has to be scanned again — the launch no longer walks the info words of all
+        //  units, one dependent load each: 0.7 ms per 8 GiB whenever a single unit had overflowed its slot)
+        const bool listed = emit_final && a.redo_list != nullptr;
+        if (listed && tk >= (u64)a.n_redo)
+            break;
+        const u64 u_begin = listed ? (u64)a.redo_list[tk] : tk * (u64)a.upt;
         if (u_begin >= a.num_tiles)
             break;
-        const u64 u_end = (u_begin + a.upt < a.num_tiles) ? u_begin + a.upt : a.num_tiles;
+        const u64 u_end = listed ? u_begin + 1 : ((u_begin + a.upt < a.num_tiles) ? u_begin + a.upt : a.num_tiles);
       // Rolling prefetch: as soon as cell j of a round has been copied out of d[j], the same registers receive cell j
       // of the NEXT round (the rounds of a ticket are contiguous), so a wave always has 8 KiB in flight while it
       // filters and verifies — no second buffer (1024-thread blocks cap a wave at 128 VGPRs).
@@ -1044,6 +1049,18 @@ __global__ __launch_bounds__(kAcBlock) void ac_scan_kernel(const AcArgs a)
         atomicAdd(&a.ctr->candidates, (unsigned long long)acc_cand);
 }
 
+// the units of a scan whose matches did not fit their staging slot, compacted (any order: an emitted unit writes at its own offset)
+__global__ void ac_redo_list_kernel(const u64 *__restrict__ info, u64 n_units, u32 cap, u32 *__restrict__ list, u32 list_cap, unsigned long long *counter)
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_units && (u32)(info[i] & kUiCountMask) > cap)
+    {
+        const u64 at = atomicAdd(counter, 1ull);
+        if (at < list_cap)
+            list[at] = (u32)i;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- host: launches and the scan driver
 // (the tables: kg_ac_tables.h, built by kg_ac_build.hip)
 
@@ -1525,6 +1542,29 @@ int ac_scan(AcTables *t, Counters *d_ctr, Counters *h_ctr, PostScratch &post, in
         AcArgs e = a;
         e.emit_mode = 1;
         SCHK(hipMemsetAsync(&d_ctr->ticket, 0, sizeof(unsigned long long), st));
+        if (!tiny && !getenv("KREP_GPU_AC_NO_REDO_LIST"))
+        {
+            // the overflowed units as a list (their number is known: the scan counted them), one ticket each
+            const u64 n_over = h_ctr->overflow_units;
+            if (n_over > t->redo_cap)
+            {
+                if (t->d_redo) (void)hipFree(t->d_redo);
+                t->d_redo = nullptr;
+                t->redo_cap = 0;
+                if (hipMalloc(&t->d_redo, (n_over + n_over / 4 + 64) * sizeof(u32)) == hipSuccess)
+                    t->redo_cap = n_over + n_over / 4 + 64;
+                else
+                    (void)hipGetLastError();
+            }
+            if (t->d_redo && n_over <= 0xffffffffull)
+            {
+                SCHK(hipMemsetAsync(&d_ctr->pad[3], 0, sizeof(unsigned long long), st));
+                hipLaunchKernelGGL(ac_redo_list_kernel, dim3((u32)((n_units + 255) / 256)), dim3(256), 0, st, (const u64 *)a.unitinfo, n_units, a.stage_cap, t->d_redo,
+                                   (u32)t->redo_cap, &d_ctr->pad[3]);
+                e.redo_list = t->d_redo;
+                e.n_redo = (u32)n_over;
+            }
+        }
         SCHK(launch(e));
         if (time_it) SCHK(hipEventRecord(ev1, st));
         SCHK(hipStreamSynchronize(st));

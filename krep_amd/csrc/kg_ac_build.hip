@@ -415,6 +415,7 @@ void ac_free(AcTables *t)
     if (!t)
         return;
     (void)hipSetDevice(t->device);
+    if (t->d_redo) (void)hipFree(t->d_redo);
     if (t->d_s1) (void)hipFree(t->d_s1);
     if (t->d_s2) (void)hipFree(t->d_s2);
     if (t->d_s3) (void)hipFree(t->d_s3);

@@ -62,6 +62,8 @@ struct AcArgs
     // stage 3 of the anchored scan for dictionaries of 4..16-byte patterns: which LENGTHS end in these four bytes (a hashed 16-bit mask per
     // final gram), and per length an exact entry {the pattern right-aligned in 16 bytes, length, copies} in buckets of two — every pattern
     // that ends at a marked position, longest first, without walking a trie (ac_exact_end)
+    const u32 *redo_list;       // emit mode: the units to scan again (those whose matches did not fit their staging slot), one per ticket; NULL: every unit is looked at
+    u32 n_redo;
     const unsigned short *xlen; // [2][65536]: bit l - 4 set: a pattern of length l ends in these bytes — [0] lengths 4..7 by the hash of the
                                 //   last FOUR bytes, [1] lengths 8..16 by the hash of the last EIGHT (a word's last eight bytes are all but its
                                 //   own: one length, one probe; by the last four alone `tion` named nine lengths, nine round trips in turn)

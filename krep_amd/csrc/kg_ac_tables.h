@@ -25,6 +25,8 @@ struct AcTables
     uint4 *d_g4x = nullptr; // chain-compressed entries, same slots as d_gram4
     u32 g4mask = 0;
     u32 g4x_mode = 0, g4x_mask = 0, g4x_mul = 0;
+    u32 *d_redo = nullptr; // emit mode: the overflowed units of the scan just made, as a list (ac_scan)
+    uint64_t redo_cap = 0;
     u32 stage_cap = 16; // staged matches per unit (16, raised to 64 by a scan whose units overflowed; see ac_scan)
     AcTiny tiny{};      // ok: the dictionary runs in kg_ac_tiny.hip (every pattern <= 4 bytes, few of them)
     u32 tiny_dense_upt = 0;    // ... in its DENSE flavour, with tickets of this many units (0: not; set from the density a scan counted)
